@@ -1,0 +1,26 @@
+"""Shared test helpers: procedural state dicts built from the spec table (no reference needed)."""
+import torch
+
+from autonomous_driving_with_diffusion_model_amd.modeling.spec import unet_entries
+from autonomous_driving_with_diffusion_model_amd.utils import procedural as P
+
+IMG_SMALL = (64, 96)
+SCHED_KW = dict(num_train_timesteps=100, prediction_type="sample", beta_schedule="squaredcos_cap_v2",
+                beta_start=1e-4, beta_end=0.02)
+
+
+def oracle_sd(use_cond: str, seed: int = 0):
+    return P.procedural_state_dict(((e.key, e.shape) for e in unet_entries(use_cond)), seed)
+
+
+def uni(name, shape, seed=7, lo=-1.0, hi=1.0):
+    return P._uniform(name, seed, shape, lo, hi)
+
+
+def close(a, b, atol, rtol=0.0):
+    a = torch.as_tensor(a, dtype=torch.float32)
+    b = torch.as_tensor(b, dtype=torch.float32)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    assert bool((err <= tol).all()), f"max err {err.max().item():.3e} (atol {atol}, rtol {rtol})"

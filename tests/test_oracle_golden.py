@@ -1,0 +1,235 @@
+"""CPU: the oracle restatement against the golden vectors produced by the real reference
+(tests/golden/make_golden.py).  Tolerance: fp32, op-for-op restatement -> 2e-6 absolute on
+O(1) activations (same torch ops, different call grouping)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import diffusers_base as DB
+from oracle import guidance as G
+from oracle import resnet as R
+from oracle import sampling as S
+from oracle import schedulers as SCH
+from oracle import unet as U
+from autonomous_driving_with_diffusion_model_amd.modeling.spec import unet_entries
+from autonomous_driving_with_diffusion_model_amd.utils import procedural as P
+from helpers import IMG_SMALL, SCHED_KW, close, oracle_sd, uni
+
+ATOL = 2e-6
+
+
+def test_spec_matches_reference_state_dict():
+    spec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "state_spec.json")))
+    for g, ref in spec.items():
+        mine = unet_entries(g)
+        assert [e.key for e in mine] == [r[0] for r in ref["state_dict"]]
+        assert [list(e.shape) for e in mine] == [r[1] for r in ref["state_dict"]]
+        assert [e.key for e in mine if not e.is_buffer] == ref["parameters"]
+
+
+def test_ops(golden):
+    g = golden("ops")
+    sd = oracle_sd("CLASSIFIER_GUIDANCE")
+    x = uni("ops.x64", (2, 64, 16))
+    cond = uni("ops.cond", (2, 128))
+    close(U.conv1d_block(sd, "downs.0.1.blocks.0.", x), g["ops.conv1d_block"], ATOL)
+    close(U.residual_block(sd, "downs.0.1.", x, cond), g["ops.res_block_same"], ATOL)
+    close(U.residual_block(sd, "downs.1.0.", uni("ops.x64b", (2, 64, 8)), cond), g["ops.res_block_proj"], ATOL)
+    close(U.residual_block(sd, "downs.0.0.", uni("ops.x7", (2, 7, 16)), cond), g["ops.res_block_stem"], ATOL)
+    close(U.downsample(sd, "downs.0.3.", x), g["ops.downsample"], ATOL)
+    close(U.upsample(sd, "ups.0.3.", uni("ops.x256", (2, 256, 2))), g["ops.upsample"], ATOL)
+    t = torch.tensor([0, 37, 99], dtype=torch.int64)
+    close(U.sinusoidal_pos_emb(t, 64), g["ops.sinusoidal"], 0.0)
+    close(U.time_mlp(sd, t, 64), g["ops.time_mlp"], ATOL)
+    xb = uni("ops.xbb", (2, 64, 16, 24))
+    close(R.basic_block(sd, "perception.layer2.0.", xb, 2), g["ops.basic_block_down"], ATOL)
+    close(R.basic_block(sd, "perception.layer1.1.", xb, 1), g["ops.basic_block_same"], ATOL)
+    img = P.synthetic_batch(2, 16, image_hw=IMG_SMALL, seed=3)["imgs"]
+    close(R.resnet34_forward(sd, "perception.", img), g["ops.resnet34_small"], 2e-5)
+
+
+def test_resnet_full_size(golden):
+    sd = oracle_sd("CLASSIFIER_GUIDANCE")
+    img = P.synthetic_batch(1, 16, image_hw=(256, 900), seed=4)["imgs"]
+    close(R.resnet34_forward(sd, "perception.", img), golden("ops")["ops.resnet34_full"], 5e-5)
+
+
+def test_traj_predict_and_guidance(golden):
+    g = golden("ops")
+    sd = oracle_sd("CLASSIFIER_GUIDANCE")
+    a = uni("ops.action", (2, 15, 3)).requires_grad_()
+    te = uni("ops.te", (2, 64))
+    s = U.traj_predict(sd, "state_pred.", a, te)
+    close(s.detach(), g["ops.traj_predict"], 5e-6)
+    (ga,) = torch.autograd.grad((s * uni("ops.traj_w", (2, 15, 4))).sum(), [a])
+    close(ga, g["ops.traj_predict_dact"], 5e-6)
+    for tag, tgt in (("near", torch.tensor([0.05, -0.02])), ("far", torch.tensor([0.9, 0.7]))):
+        a1 = uni("ops.g_action." + tag, (1, 16, 3)).requires_grad_()
+        xg = U.state_from_action(sd, a1, uni("ops.g_te", (1, 64)))
+        close(G.target_guidance_loss(xg, tgt).detach(), g[f"ops.target_loss.{tag}"], 1e-6)
+        out = G.guidance_update(xg, a1, tgt, torch.tensor(1.5582221), 15.0, 1)
+        close(out, g[f"ops.guidance_loss.{tag}"], 5e-6)
+
+
+@pytest.mark.parametrize("H", [16, 32])
+def test_unet_forward(golden, H):
+    g = golden("unet")
+    d = P.synthetic_batch(2, H, image_hw=IMG_SMALL, seed=11)
+    t = torch.tensor([90, 3], dtype=torch.int64)
+    tol = 2e-5
+    sd = oracle_sd("NO_GUIDANCE")
+    close(U.unet_forward(sd, d["trajs"], d["imgs"], t), g[f"unet.no.h{H}"], tol)
+    close(U.unet_forward(sd, d["trajs"], d["imgs"], t[:1].repeat(2)), g[f"unet.no.h{H}.t1"], tol)
+    sd = oracle_sd("FREE_GUIDANCE")
+    kw = dict(use_cond=U.FREE_GUIDANCE)
+    close(U.unet_forward(sd, d["trajs"], d["imgs"], t, d["target"], **kw), g[f"unet.free.h{H}.cond"], tol)
+    close(U.unet_forward(sd, d["trajs"], d["imgs"], t, None, **kw), g[f"unet.free.h{H}.nocond"], tol)
+    x2 = torch.cat([d["trajs"], d["trajs"]], 0)
+    c2 = torch.cat([d["target"], torch.zeros_like(d["target"])], 0)
+    close(U.unet_forward(sd, x2, d["imgs"], t[:1], c2, **kw), g[f"unet.free.h{H}.cfg"], tol)
+    sd = oracle_sd("CLASSIFIER_GUIDANCE")
+    kw = dict(use_cond=U.CLASSIFIER_GUIDANCE)
+    close(U.unet_forward(sd, d["trajs"], d["imgs"], t, **kw), g[f"unet.cls.h{H}.full"], tol)
+    a, te = U.unet_forward(sd, d["trajs"], d["imgs"], t, return_action_and_time_only=True, **kw)
+    close(a, g[f"unet.cls.h{H}.action"], tol)
+    close(te, g[f"unet.cls.h{H}.time_embed"], tol)
+
+
+def test_diffusers_known_answers():
+    """SURVEY.md §8(c) restatement-derived known answers (N = 100, cosine)."""
+    s = DB.DDPMScheduler(**SCHED_KW)
+    ac = s.alphas_cumprod
+    assert abs(s.betas[0].item() - 6.31281582e-4) < 1e-12
+    for i, v in ((0, 0.999368727), (10, 0.966716647), (50, 0.47826457), (90, 0.0195443742), (98, 2.42857204e-4),
+                 (99, 2.42854071e-7)):
+        assert abs(ac[i].item() - v) <= 1e-7 * max(v, 1e-3), (i, ac[i].item())
+    assert abs(s.betas[99].item() - 0.999000013) < 1e-8
+    d = DB.DDIMScheduler(**SCHED_KW)
+    v = d._get_variance(98, 96)
+    assert abs(v.item() - 0.887090862) < 1e-7 and abs(torch.exp(0.5 * v).item() - 1.55822206) < 1e-6
+    for n, first, last in ((100, 99, 0), (50, 98, 0), (10, 90, 0), (2, 50, 0)):
+        d.set_timesteps(n)
+        assert d.timesteps.dtype == torch.int64 and len(d.timesteps) == n
+        assert d.timesteps[0].item() == first and d.timesteps[-1].item() == last
+    with pytest.raises(ValueError):
+        d.set_timesteps(101)
+
+
+def test_scheduler_steps(golden):
+    g = golden("sched")
+    for n in (100, 50, 10, 2):
+        s = SCH.GuidanceDDIM(**SCHED_KW)
+        s.set_timesteps(n)
+        assert np.array_equal(s.timesteps.numpy(), g[f"sched.timesteps.{n}"])  # integer tables: bit-exact
+    base = SCH.GuidanceDDIM(**SCHED_KW)
+    assert np.array_equal(base.betas.numpy(), g["sched.betas"])
+    assert np.array_equal(base.alphas_cumprod.numpy(), g["sched.alphas_cumprod"])
+    u = lambda n, lo=-1.5, hi=1.5: P._uniform(n, 21, (3, 16, 7), lo, hi)  # noqa: E731
+    mo, x = u("sched.mo"), u("sched.x")
+    z = P.step_noise(0, (3, 16, 7), seed=21)
+    tt, tm = u("sched.tt", -1, 1), (P._uniform("sched.tm", 21, (3, 16, 7), 0, 1) > 0.5).float()
+    tol = 0.0  # same scalar/elementwise op order as the reference -> bit-exact on CPU
+    for pt in ("sample", "epsilon", "v_prediction"):
+        kw = dict(SCHED_KW, prediction_type=pt)
+        for n, ts in ((50, (98, 50, 0)), (10, (90, 0)), (100, (99, 1, 0))):
+            for thr in (True, False):
+                s = SCH.GuidanceDDIM(thresholding=thr, **kw)
+                s.set_timesteps(n)
+                for t in ts:
+                    r = s.step(mo, torch.tensor(t), x)
+                    close(r.prev_sample, g[f"sched.ddim.{pt}.thr{int(thr)}.n{n}.t{t}.prev"], tol)
+                    close(r.pred_original_sample, g[f"sched.ddim.{pt}.thr{int(thr)}.n{n}.t{t}.x0"], tol)
+            s = SCH.GuidanceDDIM(thresholding=True, **kw)
+            s.set_timesteps(n)
+            s2 = SCH.GuidanceDDPM(thresholding=False, **kw)
+            s2.set_timesteps(n)
+            s3 = SCH.InpaintingDDIM(**kw)
+            s3.set_timesteps(n)
+            s4 = SCH.InpaintingDDPM(**kw)
+            s4.set_timesteps(n)
+            for t in ts:
+                tt_ = torch.tensor(t)
+                close(s.step(mo, tt_, x, eta=0.5, variance_noise=z).prev_sample,
+                      g[f"sched.ddim.{pt}.eta.n{n}.t{t}.prev"], tol)
+                close(s2.step(mo, tt_, x, variance_noise=z).prev_sample, g[f"sched.ddpm.{pt}.n{n}.t{t}.prev"], tol)
+                close(s3.step(mo, tt_, x, variance_noise=z, target_traj=tt, target_mask=tm).prev_sample,
+                      g[f"sched.inp_ddim.{pt}.n{n}.t{t}.prev"], tol)
+                close(s3.step(mo, tt_, x, variance_noise=z).prev_sample, g[f"sched.inp_ddim.{pt}.n{n}.t{t}.plain"], tol)
+                close(s4.step(mo, tt_, x, variance_noise=z, target_traj=tt, target_mask=tm).prev_sample,
+                      g[f"sched.inp_ddpm.{pt}.n{n}.t{t}.prev"], tol)
+                close(s4.step(mo, tt_, x, variance_noise=z).prev_sample, g[f"sched.inp_ddpm.{pt}.n{n}.t{t}.plain"], tol)
+    close(base.add_noise(x, z, torch.tensor([0, 50, 99])), g["sched.add_noise"], 0.0)
+    # the reference's GuidanceDDPMScheduler(thresholding=True) raises NameError (np not imported)
+    assert int(g["sched.ddpm_threshold_raises"]) == 1
+
+
+def test_threshold_is_clamp():
+    """S5 is degenerate: sample_max_value = 1 => s == 1 => clamp(x, -1, 1)."""
+    x = P._uniform("thr", 5, (4, 32, 7), -3, 3)
+    assert torch.equal(SCH.threshold_sample(x), x.clamp(-1, 1))
+
+
+def test_loops(golden):
+    g = golden("loop")
+    H = 16
+    d = P.synthetic_batch(1, H, image_hw=IMG_SMALL, seed=31)
+    tgt = d["target"][0]
+    tol = 23.315 * 2e-5
+    for name, n, kw in (("NO_GUIDANCE", 10, {}), ("FREE_GUIDANCE", 10, dict(free_scale=7.5)),
+                        ("CLASSIFIER_GUIDANCE", 5, dict(classifier_scale=15.0))):
+        r = S.generate_traj(oracle_sd(name), d["imgs"], d["init_trajs"], None if name == "NO_GUIDANCE" else tgt,
+                            use_cond=name, n_steps=n, **kw)
+        close(r, g[f"loop.ddim.{name}"], tol)
+    # hoisting the perception pass out of the loop is exact in eval mode
+    r2 = S.generate_traj(oracle_sd("FREE_GUIDANCE"), d["imgs"], d["init_trajs"], tgt, use_cond="FREE_GUIDANCE",
+                         n_steps=10, free_scale=7.5, hoist_perception=True)
+    close(r2, g["loop.ddim.FREE_GUIDANCE"], tol)
+    r = S.generate_traj(oracle_sd("NO_GUIDANCE"), d["imgs"], d["init_trajs"], None, use_cond="NO_GUIDANCE",
+                        n_steps=10, scheduler="ddpm", sched_kw=dict(S.scheduler_kwargs(), thresholding=False),
+                        step_noise=lambda i, s: P.step_noise(i, s, seed=33))
+    close(r, g["loop.ddpm.NO_GUIDANCE"], tol)
+
+
+def test_loop_cfg3_shape(golden):
+    """50-step DDIM, FREE guidance, H = 32, batched targets (BASELINE cfg-3 at B = 2, small image)."""
+    d = P.synthetic_batch(2, 32, image_hw=IMG_SMALL, seed=32)
+    r = S.generate_traj(oracle_sd("FREE_GUIDANCE"), d["imgs"], d["init_trajs"], d["target"],
+                        use_cond="FREE_GUIDANCE", n_steps=50, free_scale=7.5, hoist_perception=True)
+    close(r, golden("loop")["loop.ddim50.FREE_GUIDANCE.h32"], 23.315 * 5e-5)
+
+
+def test_loop_cfg1_evaluate(golden):
+    d = P.synthetic_batch(8, 16, image_hw=IMG_SMALL, seed=34)
+    img = d["imgs"][:1].repeat(8, 1, 1, 1)
+    r = S.evaluate_loop(oracle_sd("NO_GUIDANCE"), img, d["init_trajs"], n_steps=10, hoist_perception=True,
+                        step_noise=lambda i, s: P.step_noise(i, s, seed=35))
+    close(r, golden("loop")["loop.evaluate.cfg1"], 2e-5)
+
+
+@pytest.mark.parametrize("name", ["NO_GUIDANCE", "FREE_GUIDANCE", "CLASSIFIER_GUIDANCE"])
+def test_training_step(golden, name):
+    g = golden("train")
+    d = P.synthetic_batch(2, 16, image_hw=IMG_SMALL, seed=41)
+    sd = oracle_sd(name)
+    entries = unet_entries(name)
+    for e in entries:
+        if not e.is_buffer:
+            sd[e.key].requires_grad_()
+    loss = S.training_loss(sd, d["imgs"], d["trajs"], d["target"], d["t"], d["noise"], use_cond=name)
+    close(loss.detach(), g[f"train.{name}.loss"], 2e-6)
+    loss.backward()
+    assert sum(sd[e.key].numel() for e in entries if not e.is_buffer) == int(g[f"train.{name}.n_params"])
+    assert len(entries) == int(g[f"train.{name}.n_state"])
+    for k in g.files:
+        pre = f"train.{name}.gradnorm."
+        if k.startswith(pre):
+            ref = float(g[k])
+            got = sd[k[len(pre):]].grad.norm().item()
+            assert abs(got - ref) <= 2e-4 * max(1.0, abs(ref)), (k, got, ref)
+    bias_key = [e.key for e in entries if e.key.endswith("_conv.1.bias")][0]
+    close(sd[bias_key].grad, g[f"train.{name}.grad.final_bias"], 2e-6)
+    # every parameter receives a gradient (DDP find_unused_parameters=False)
+    assert all(sd[e.key].grad is not None for e in entries if not e.is_buffer)
