@@ -1,0 +1,137 @@
+"""ctypes binding of libadx.so (C ABI declared in include/adx.h).
+
+There is NO fallback: if the shared library is missing every op raises, so a GPU box can
+never silently run an eager/PyTorch path instead of the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libadx.so")
+
+c_f32p = C.POINTER(C.c_float)
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class TConvDesc(C.Structure):
+    _fields_ = [("kind", i32), ("taps", i32), ("stride", i32), ("pad", i32), ("c0", i32), ("c1", i32),
+                ("cout", i32), ("lin", i32), ("lout", i32), ("groups", i32), ("eps", f32)]
+
+
+class TConvIO(C.Structure):
+    _fields_ = [("x0", vp), ("x0_sb", i64), ("x0_sc", i64), ("x0_sl", i64),
+                ("x1", vp), ("x1_sb", i64), ("x1_sc", i64), ("x1_sl", i64),
+                ("packed_w", vp), ("bias", vp), ("gamma", vp), ("beta", vp),
+                ("tbias", vp), ("tbias_stride", i64),
+                ("res", vp), ("res_sb", i64), ("res_sc", i64), ("res_sl", i64),
+                ("y", vp), ("y_sb", i64), ("y_sc", i64), ("y_sl", i64), ("batch", i32)]
+
+
+class EmbedWeights(C.Structure):
+    _fields_ = [(n, vp) for n in ("freqs", "w1", "b1", "w3", "b3", "cw0", "cb0", "cw2", "cb2")]
+
+
+class UnetConfig(C.Structure):
+    _fields_ = [("horizon", i32), ("transition_dim", i32), ("dim", i32), ("n_mults", i32),
+                ("dim_mults", i32 * 8), ("guidance", i32)]
+
+
+class UnetIO(C.Structure):
+    _fields_ = [("x", vp), ("img_feature", vp), ("feat_rows", i32), ("t", vp), ("t_rows", i32), ("cond", vp),
+                ("rows", i32), ("out", vp), ("time_embed", vp)]
+
+
+class StepCoef(C.Structure):
+    _fields_ = [("prediction_type", i32), ("clip", i32), ("clip_range", f32), ("sqrt_alpha_t", f32),
+                ("sqrt_beta_t", f32), ("c_x0", f32), ("c_dir", f32), ("c_x", f32), ("c_noise", f32),
+                ("add_noise", i32), ("use_clipped_model_output", i32), ("inpaint", i32), ("c_const", f32),
+                ("c_known", f32), ("c_known_noise", f32), ("known_noise", i32), ("cfg_combine", i32),
+                ("free_scale", f32), ("zero_first", i32)]
+
+
+_SIGS = {
+    "adx_version": (i32, []),
+    "adx_last_error": (C.c_char_p, []),
+    "adx_tconv_packed_bytes": (C.c_size_t, [C.POINTER(TConvDesc)]),
+    "adx_tconv_pack": (i32, [C.POINTER(TConvDesc), vp, vp, vp]),
+    "adx_tconv_forward": (i32, [C.POINTER(TConvDesc), C.POINTER(TConvIO), vp]),
+    "adx_embed_forward": (i32, [C.POINTER(EmbedWeights), i32, vp, i32, vp, vp, i32, i32, vp, vp, vp]),
+    "adx_unet_create": (i32, [C.POINTER(UnetConfig), C.POINTER(vp)]),
+    "adx_unet_destroy": (None, [vp]),
+    "adx_unet_num_params": (i32, [vp]),
+    "adx_unet_packed_bytes": (C.c_size_t, [vp]),
+    "adx_unet_pack": (i32, [vp, C.POINTER(vp), i32, vp, vp, vp]),
+    "adx_unet_workspace_bytes": (C.c_size_t, [vp, i32]),
+    "adx_unet_forward": (i32, [vp, vp, vp, C.POINTER(UnetIO), vp]),
+    "adx_resnet_create": (i32, [i32, C.POINTER(vp)]),
+    "adx_resnet_destroy": (None, [vp]),
+    "adx_resnet_num_tensors": (i32, [vp]),
+    "adx_resnet_packed_bytes": (C.c_size_t, [vp]),
+    "adx_resnet_pack": (i32, [vp, C.POINTER(vp), i32, vp, vp]),
+    "adx_resnet_workspace_bytes": (C.c_size_t, [vp, i32, i32, i32]),
+    "adx_resnet_forward": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp]),
+    "adx_ddim_step": (i32, [C.POINTER(StepCoef), vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "adx_ddpm_step": (i32, [C.POINTER(StepCoef), vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "adx_add_noise": (i32, [vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+_lib: Optional[C.CDLL] = None
+
+
+class AdxError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load libadx.so once; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AdxError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` (or autonomous_driving_with_diffusion_model_amd/csrc/build.sh). There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().adx_last_error().decode(errors="replace")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}" if what else msg)
+        raise AdxError(f"{what} failed (status {rc}): {msg}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_gpu_f32(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not t.is_cuda:
+        raise AdxError(f"{name} lives on {t.device}; the adx kernels only run on an MI355X (no CPU path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def ptr_array(tensors: Sequence[torch.Tensor]):
+    arr = (vp * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr

@@ -1,0 +1,66 @@
+// extern "C" surface of libadx.so (declared in include/adx.h): thin wrappers over the adx::
+// implementations plus the thread-local error string.
+#include <stdarg.h>
+
+#include "tconv.h"
+
+namespace adx {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int embed_forward(const adx_embed_weights* w, int dim, const int64_t* t, int t_rows, const float* cond,
+                  const float* feat, int feat_rows, int rows, float* time_embed, float* mish_cond, hipStream_t s);
+int ddim_step(const adx_step_coef* c, const float* mo, const float* x, const float* z, const float* tgt,
+              const float* mask, float* prev, float* x0, int b, int h, int d, hipStream_t s);
+int ddpm_step(const adx_step_coef* c, const float* mo, const float* x, const float* z, const float* tgt,
+              const float* mask, float* prev, float* x0, int b, int h, int d, hipStream_t s);
+int add_noise(const float* x, const float* n, const int64_t* t, const float* sa, const float* sb, int n_train,
+              float* out, int batch, int horizon, int dim, int zero_first, hipStream_t s);
+
+}  // namespace adx
+
+extern "C" {
+
+int adx_version(void) { return 1; }
+const char* adx_last_error(void) { return adx::g_err; }
+
+size_t adx_tconv_packed_bytes(const adx_tconv_desc* d) {
+  if (d == nullptr || adx::tconv_check(d) != ADX_OK) return 0;
+  return adx::tconv_packed_floats(d) * sizeof(float);
+}
+int adx_tconv_pack(const adx_tconv_desc* d, const float* w, float* packed, adx_stream s) {
+  return adx::tconv_pack(d, w, packed, (hipStream_t)s);
+}
+int adx_tconv_forward(const adx_tconv_desc* d, const adx_tconv_io* io, adx_stream s) {
+  return adx::tconv_forward(d, io, (hipStream_t)s);
+}
+int adx_embed_forward(const adx_embed_weights* w, int32_t dim, const int64_t* t, int32_t t_rows, const float* cond,
+                      const float* img_feature, int32_t feat_rows, int32_t rows, float* time_embed, float* mish_cond,
+                      adx_stream s) {
+  return adx::embed_forward(w, dim, t, t_rows, cond, img_feature, feat_rows, rows, time_embed, mish_cond,
+                            (hipStream_t)s);
+}
+int adx_ddim_step(const adx_step_coef* c, const float* model_output, const float* sample, const float* noise,
+                  const float* target, const float* mask, float* prev, float* x0, int32_t batch, int32_t horizon,
+                  int32_t dim, adx_stream s) {
+  return adx::ddim_step(c, model_output, sample, noise, target, mask, prev, x0, batch, horizon, dim, (hipStream_t)s);
+}
+int adx_ddpm_step(const adx_step_coef* c, const float* model_output, const float* sample, const float* noise,
+                  const float* target, const float* mask, float* prev, float* x0, int32_t batch, int32_t horizon,
+                  int32_t dim, adx_stream s) {
+  return adx::ddpm_step(c, model_output, sample, noise, target, mask, prev, x0, batch, horizon, dim, (hipStream_t)s);
+}
+int adx_add_noise(const float* x, const float* noise, const int64_t* t, const float* sqrt_ab, const float* sqrt_1mab,
+                  int32_t n_train, float* out, int32_t batch, int32_t horizon, int32_t dim, int32_t zero_first,
+                  adx_stream s) {
+  return adx::add_noise(x, noise, t, sqrt_ab, sqrt_1mab, n_train, out, batch, horizon, dim, zero_first, (hipStream_t)s);
+}
+
+}  // extern "C"

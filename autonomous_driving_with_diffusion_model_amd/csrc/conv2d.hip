@@ -1,0 +1,395 @@
+// ResNet-34 perception forward (eval mode) on the fp32 matrix cores of gfx950.
+//   modeling/resnet.py:56-102 (BasicBlock), :163-296 (ResNet), fc replaced by Linear(512, dim)
+//   at modeling/temporal.py:83-84.  This is 99.5 % of the FLOPs of one reference forward
+//   (34 GFLOP per 3x256x900 image).
+//
+// conv2d = implicit GEMM, C[cout][pixel] = sum_k W[cout][k] * X[k][pixel], k = (tap, cin):
+//   * v_mfma_f32_32x32x2_f32: A = weights (32 couts x 2 k), B = activations (2 k x 32 pixels),
+//     so a lane of the accumulator owns one pixel column -> NCHW stores are 128-byte rows and
+//     the tensors keep PyTorch's layout end to end (no layout conversion of the camera image);
+//   * one workgroup = 4 waves = 4 output rows x 32 output columns x 64 output channels; per
+//     16-channel chunk the zero-padded input patch and the [tap][cin][64] weight slab are staged
+//     in LDS (both read conflict-free: consecutive lanes = consecutive columns / channels);
+//   * epilogue fuses eval-mode BatchNorm as y = acc * scale[c] + shift[c] (the same
+//     alpha/beta form torch uses), the residual add and ReLU.
+#include <vector>
+
+#include "adx_common.h"
+
+namespace adx {
+
+constexpr int kTileH = 4;    // output rows per workgroup (one per wave)
+constexpr int kTileW = 32;   // output columns per workgroup (= MFMA N)
+constexpr int kCoutT = 64;   // output channels per workgroup (2 MFMA row blocks)
+constexpr size_t kMaxLds = 96 * 1024;
+
+struct Conv2dArgs {
+  const float* x;       // [N][Cin][H][W]
+  const float* w;       // packed [KH*KW][cin_pad][Cout]
+  const float* scale;   // [Cout] or null
+  const float* shift;   // [Cout] or null
+  const float* res;     // [N][Cout][OH][OW] or null
+  float* y;             // [N][Cout][OH][OW]
+  int N, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, relu;
+  int cin_pad, cc;      // channels padded to the chunk size, chunk size (16, or 4 for the stem)
+  int tiles_x, tiles_y, cout_tiles;
+  int PH, PW, PWp;      // staged patch rows, columns, padded row pitch
+};
+
+template <int STRIDE>
+__global__ void __launch_bounds__(256) conv2d_kernel(const Conv2dArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bid = blockIdx.x;
+  const int ct = bid % a.cout_tiles; bid /= a.cout_tiles;
+  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y; bid /= a.tiles_y;
+  const int n = bid;
+  const int oy0 = ty * kTileH, ox0 = tx * kTileW;
+  const int iy0 = oy0 * STRIDE - a.pad, ix0 = ox0 * STRIDE - a.pad;
+  const int cout0 = ct * kCoutT;
+  const int ntaps = a.KH * a.KW;
+  const int plane = a.PH * a.PWp;
+  float* patch = smem;                         // [cc][PH][PWp]
+  float* wl = smem + a.cc * plane;             // [ntaps][cc][64]
+  const int l31 = lane & 31, khalf = lane >> 5;
+
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+  const float* xin = a.x + (size_t)n * a.Cin * a.H * a.W;
+  for (int c0 = 0; c0 < a.cin_pad; c0 += a.cc) {
+    if (c0 > 0) __syncthreads();
+    // ---- stage the input patch: one wave per (channel, patch row), lanes along the row -------
+    const int nrows = a.cc * a.PH;
+    for (int rr = wave; rr < nrows; rr += 4) {
+      const int c = rr / a.PH, py = rr - c * a.PH;
+      const int ci = c0 + c, iy = iy0 + py;
+      const bool rok = ci < a.Cin && iy >= 0 && iy < a.H;
+      const float* src = xin + ((size_t)ci * a.H + iy) * a.W;
+      for (int px = lane; px < a.PWp; px += 64) {
+        const int ix = ix0 + px;
+        float v = 0.f;
+        if (rok && px < a.PW && ix >= 0 && ix < a.W) v = src[ix];
+        patch[rr * a.PWp + px] = v;
+      }
+    }
+    // ---- stage the weight slab [tap][cc][64] with 16-byte loads ------------------------------
+    const int nw4 = ntaps * a.cc * (kCoutT / 4);
+    for (int e = tid; e < nw4; e += 256) {
+      const int q = e & 15;              // float4 index within the 64 couts
+      const int row = e >> 4;            // tap * cc + c
+      const int tap = row / a.cc, c = row - tap * a.cc;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a.w + ((size_t)tap * a.cin_pad + c0 + c) * a.Cout + cout0 + 4 * q);
+      *reinterpret_cast<f32x4*>(wl + row * kCoutT + 4 * q) = v;
+    }
+    __syncthreads();
+    // ---- MFMA over (tap, channel pair) --------------------------------------------------------
+    const int ksteps = a.cc >> 1;
+    for (int kh = 0; kh < a.KH; ++kh) {
+      for (int kw = 0; kw < a.KW; ++kw) {
+        const int tap = kh * a.KW + kw;
+        const float* pb = patch + (wave * STRIDE + kh) * a.PWp + l31 * STRIDE + kw + khalf * plane;
+        const float* wa = wl + (tap * a.cc + khalf) * kCoutT + l31;
+        for (int ks = 0; ks < ksteps; ++ks) {
+          const float b = pb[2 * ks * plane];
+          const float a0 = wa[2 * ks * kCoutT];
+          const float a1 = wa[2 * ks * kCoutT + 32];
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: BN scale/shift, residual, ReLU; lane = pixel column, register = channel --------
+  const int oy = oy0 + wave, ox = ox0 + l31;
+  if (oy < a.OH && ox < a.OW) {
+    const size_t pix = (size_t)oy * a.OW + ox;
+    const size_t img = (size_t)n * a.Cout * a.OH * a.OW;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = cout0 + half * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        float v = half == 0 ? acc0[r] : acc1[r];
+        if (a.scale != nullptr) v = v * a.scale[c] + a.shift[c];
+        const size_t o = img + (size_t)c * a.OH * a.OW + pix;
+        if (a.res != nullptr) v += a.res[o];
+        if (a.relu) v = v > 0.f ? v : 0.f;
+        a.y[o] = v;
+      }
+    }
+  }
+}
+
+// [Cout][Cin][KH][KW] -> [KH*KW][cin_pad][Cout]
+__global__ void conv2d_pack_kernel(const float* __restrict__ w, float* __restrict__ p, int Cout, int Cin, int taps,
+                                   int cin_pad, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int co = idx % Cout;
+  const int ci = (idx / Cout) % cin_pad;
+  const int tap = idx / ((size_t)Cout * cin_pad);
+  p[idx] = ci < Cin ? w[((size_t)co * Cin + ci) * taps + tap] : 0.f;
+}
+
+// eval-mode BatchNorm2d as y = x * scale + shift (eps = 1e-5)
+__global__ void bn_fold_kernel(const float* g, const float* b, const float* mean, const float* var, float* scale,
+                               float* shift, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float s = g[c] / sqrtf(var[c] + 1e-5f);
+  scale[c] = s;
+  shift[c] = b[c] - mean[c] * s;
+}
+
+// MaxPool2d(kernel 3, stride 2, padding 1), modeling/resnet.py:197
+__global__ void __launch_bounds__(256) maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, int planes,
+                                                       int H, int W, int OH, int OW) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)planes * OH * OW;
+  if (idx >= total) return;
+  const int ox = idx % OW;
+  const int oy = (idx / OW) % OH;
+  const size_t pl = idx / ((size_t)OW * OH);
+  const float* src = x + pl * H * W;
+  float m = -INFINITY;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int iy = oy * 2 - 1 + dy;
+    if (iy < 0 || iy >= H) continue;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int ix = ox * 2 - 1 + dx;
+      if (ix < 0 || ix >= W) continue;
+      const float v = src[(size_t)iy * W + ix];
+      m = (v > m || v != v) ? v : m;  // NaN propagates like torch
+    }
+  }
+  y[idx] = m;
+}
+
+// AdaptiveAvgPool2d(1) + flatten + fc, modeling/resnet.py:288-290; one workgroup per image
+__global__ void __launch_bounds__(256) avgpool_fc_kernel(const float* __restrict__ x, const float* __restrict__ fw,
+                                                          const float* __restrict__ fb, float* __restrict__ out,
+                                                          int C, int HW, int out_dim) {
+  __shared__ float pooled[512];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* src = x + (size_t)n * C * HW;
+  const float inv = 1.0f / (float)HW;
+  for (int c = wave; c < C; c += 4) {
+    float s = 0.f;
+    for (int i = lane; i < HW; i += 64) s += src[(size_t)c * HW + i];
+    s = wave_sum(s);
+    if (lane == 0) pooled[c] = s * inv;
+  }
+  __syncthreads();
+  for (int j = wave; j < out_dim; j += 4) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += fw[(size_t)j * C + c] * pooled[c];
+    s = wave_sum(s);
+    if (lane == 0) out[(size_t)n * out_dim + j] = s + fb[j];
+  }
+}
+
+struct ConvSpec {
+  int cin, cout, k, stride, pad;
+  int t_w, t_g, t_b, t_m, t_v;           // tensor indices (weight, bn gamma, beta, mean, var)
+  size_t o_w, o_scale, o_shift;          // float offsets in the packed buffer
+  int cin_pad, cc;
+};
+
+}  // namespace adx
+
+struct adx_resnet {
+  int out_dim = 0;
+  std::vector<adx::ConvSpec> convs;      // execution order: stem, then per block conv1, conv2, [downsample]
+  std::vector<int> block_has_ds;         // per BasicBlock
+  int t_fcw = 0, t_fcb = 0, n_tensors = 0;
+  size_t o_fcw = 0, o_fcb = 0, packed_floats = 0;
+  bool packed_once = false;
+};
+
+namespace adx {
+
+static size_t align64f(size_t v) { return (v + 63) / 64 * 64; }
+
+static int conv_out(int h, int k, int s, int p) { return (h + 2 * p - k) / s + 1; }
+
+static int conv2d_launch(const ConvSpec& L, const float* base, const float* x, const float* res, float* y, int N, int H,
+                         int W, int relu, hipStream_t s) {
+  Conv2dArgs a;
+  a.x = x; a.w = base + L.o_w; a.scale = base + L.o_scale; a.shift = base + L.o_shift; a.res = res; a.y = y;
+  a.N = N; a.Cin = L.cin; a.H = H; a.W = W; a.Cout = L.cout;
+  a.OH = conv_out(H, L.k, L.stride, L.pad); a.OW = conv_out(W, L.k, L.stride, L.pad);
+  a.KH = L.k; a.KW = L.k; a.stride = L.stride; a.pad = L.pad; a.relu = relu;
+  a.cin_pad = L.cin_pad; a.cc = L.cc;
+  a.tiles_x = ceil_div(a.OW, kTileW); a.tiles_y = ceil_div(a.OH, kTileH); a.cout_tiles = L.cout / kCoutT;
+  a.PH = (kTileH - 1) * L.stride + L.k; a.PW = (kTileW - 1) * L.stride + L.k;
+  a.PWp = a.PW;
+  const size_t lds = sizeof(float) * ((size_t)a.cc * a.PH * a.PWp + (size_t)L.k * L.k * a.cc * kCoutT);
+  ADX_REQUIRE(lds <= kMaxLds, "conv2d: LDS %zu bytes too large", lds);
+  static bool attr_set = false;  // dynamic LDS above 64 KB must be opted into once per kernel
+  if (!attr_set) {
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_kernel<1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_kernel<2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+    attr_set = true;
+  }
+  const size_t grid = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y * N;
+  ADX_REQUIRE(grid < (1u << 31), "conv2d: grid too large");
+  if (L.stride == 1) conv2d_kernel<1><<<dim3((unsigned)grid), dim3(256), lds, s>>>(a);
+  else conv2d_kernel<2><<<dim3((unsigned)grid), dim3(256), lds, s>>>(a);
+  ADX_LAUNCH_CHECK();
+  return ADX_OK;
+}
+
+}  // namespace adx
+
+using namespace adx;
+
+extern "C" {
+
+int adx_resnet_create(int32_t out_dim, adx_resnet** out) {
+  ADX_REQUIRE(out != nullptr && out_dim >= 1 && out_dim <= 4096, "adx_resnet_create: bad argument");
+  adx_resnet* r = new adx_resnet();
+  r->out_dim = out_dim;
+  int t = 0;
+  size_t off = 0;
+  auto add = [&](int cin, int cout, int k, int stride, int pad) {
+    ConvSpec L;
+    L.cin = cin; L.cout = cout; L.k = k; L.stride = stride; L.pad = pad;
+    L.t_w = t++; L.t_g = t++; L.t_b = t++; L.t_m = t++; L.t_v = t++;
+    L.cc = cin >= 16 ? 16 : 4;
+    L.cin_pad = round_up(cin, L.cc);
+    L.o_w = off; off = align64f(off + (size_t)k * k * L.cin_pad * cout);
+    L.o_scale = off; off = align64f(off + cout);
+    L.o_shift = off; off = align64f(off + cout);
+    r->convs.push_back(L);
+  };
+  add(3, 64, 7, 2, 3);
+  const int planes[4] = {64, 128, 256, 512}, nblk[4] = {3, 4, 6, 3};
+  int inpl = 64;
+  for (int li = 0; li < 4; ++li)
+    for (int bi = 0; bi < nblk[li]; ++bi) {
+      const int stride = (li > 0 && bi == 0) ? 2 : 1;
+      add(inpl, planes[li], 3, stride, 1);
+      add(planes[li], planes[li], 3, 1, 1);
+      const int ds = (stride != 1 || inpl != planes[li]) ? 1 : 0;
+      if (ds) add(inpl, planes[li], 1, stride, 0);
+      r->block_has_ds.push_back(ds);
+      inpl = planes[li];
+    }
+  r->t_fcw = t++; r->t_fcb = t++;
+  r->n_tensors = t;
+  r->o_fcw = off; off = align64f(off + (size_t)out_dim * 512);
+  r->o_fcb = off; off = align64f(off + out_dim);
+  r->packed_floats = off;
+  *out = r;
+  return ADX_OK;
+}
+
+void adx_resnet_destroy(adx_resnet* r) { delete r; }
+int adx_resnet_num_tensors(const adx_resnet* r) { return r ? r->n_tensors : 0; }
+size_t adx_resnet_packed_bytes(const adx_resnet* r) { return r ? r->packed_floats * sizeof(float) : 0; }
+
+int adx_resnet_pack(adx_resnet* r, const float* const* T, int32_t n, void* packed, adx_stream stream) {
+  ADX_REQUIRE(r && T && packed, "adx_resnet_pack: null argument");
+  ADX_REQUIRE(n == r->n_tensors, "adx_resnet_pack: expected %d tensors, got %d", r->n_tensors, n);
+  for (int i = 0; i < n; ++i) ADX_REQUIRE(T[i] != nullptr, "adx_resnet_pack: tensor %d is null", i);
+  hipStream_t s = (hipStream_t)stream;
+  float* base = (float*)packed;
+  for (const ConvSpec& L : r->convs) {
+    const size_t total = (size_t)L.k * L.k * L.cin_pad * L.cout;
+    conv2d_pack_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(T[L.t_w], base + L.o_w, L.cout, L.cin,
+                                                                                L.k * L.k, L.cin_pad, total);
+    ADX_LAUNCH_CHECK();
+    bn_fold_kernel<<<dim3(ceil_div(L.cout, 256)), dim3(256), 0, s>>>(T[L.t_g], T[L.t_b], T[L.t_m], T[L.t_v],
+                                                                     base + L.o_scale, base + L.o_shift, L.cout);
+    ADX_LAUNCH_CHECK();
+  }
+  ADX_CHECK_HIP(hipMemcpyAsync(base + r->o_fcw, T[r->t_fcw], (size_t)r->out_dim * 512 * sizeof(float),
+                               hipMemcpyDeviceToDevice, s));
+  ADX_CHECK_HIP(hipMemcpyAsync(base + r->o_fcb, T[r->t_fcb], (size_t)r->out_dim * sizeof(float),
+                               hipMemcpyDeviceToDevice, s));
+  r->packed_once = true;
+  return ADX_OK;
+}
+
+// workspace: the stem output, then three rotating buffers sized for the post-maxpool map
+static void resnet_dims(int h, int w, int* h1, int* w1, int* h2, int* w2) {
+  *h1 = conv_out(h, 7, 2, 3); *w1 = conv_out(w, 7, 2, 3);
+  *h2 = conv_out(*h1, 3, 2, 1); *w2 = conv_out(*w1, 3, 2, 1);
+}
+
+size_t adx_resnet_workspace_bytes(const adx_resnet* r, int32_t batch, int32_t h, int32_t w) {
+  if (!r || batch < 1 || h < 32 || w < 32) return 0;
+  int h1, w1, h2, w2;
+  resnet_dims(h, w, &h1, &w1, &h2, &w2);
+  const size_t stem = align64f((size_t)batch * 64 * h1 * w1);
+  const size_t act = align64f((size_t)batch * 64 * h2 * w2);
+  return (stem + 3 * act) * sizeof(float);
+}
+
+int adx_resnet_forward(adx_resnet* r, const void* packed, void* workspace, const float* img, int32_t batch, int32_t h,
+                       int32_t w, float* feature, adx_stream stream) {
+  ADX_REQUIRE(r && packed && workspace && img && feature, "adx_resnet_forward: null argument");
+  if (!r->packed_once) {
+    set_error("adx_resnet_forward: weights were never packed (call adx_resnet_pack first)");
+    return ADX_ERR_STATE;
+  }
+  ADX_REQUIRE(batch >= 1 && h >= 32 && w >= 32, "adx_resnet_forward: image %dx%d (batch %d) too small", h, w, batch);
+  hipStream_t s = (hipStream_t)stream;
+  const float* base = (const float*)packed;
+  int h1, w1, h2, w2;
+  resnet_dims(h, w, &h1, &w1, &h2, &w2);
+  float* ws = (float*)workspace;
+  float* stem = ws;
+  const size_t act = align64f((size_t)batch * 64 * h2 * w2);
+  float* buf[3];
+  buf[0] = ws + align64f((size_t)batch * 64 * h1 * w1);
+  buf[1] = buf[0] + act;
+  buf[2] = buf[1] + act;
+
+  size_t ci = 0;
+  int rc = conv2d_launch(r->convs[ci++], base, img, nullptr, stem, batch, h, w, 1, s);
+  if (rc != ADX_OK) return rc;
+  {
+    const size_t total = (size_t)batch * 64 * h2 * w2;
+    maxpool_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(stem, buf[0], batch * 64, h1, w1, h2, w2);
+    ADX_LAUNCH_CHECK();
+  }
+  int cur = 0, H = h2, W = w2;
+  for (size_t b = 0; b < r->block_has_ds.size(); ++b) {
+    const ConvSpec& c1 = r->convs[ci++];
+    const ConvSpec& c2 = r->convs[ci++];
+    const int mid = (cur + 1) % 3, outb = (cur + 2) % 3;
+    const int OH = conv_out(H, 3, c1.stride, 1), OW = conv_out(W, 3, c1.stride, 1);
+    rc = conv2d_launch(c1, base, buf[cur], nullptr, buf[mid], batch, H, W, 1, s);  // conv1 + bn1 + relu
+    if (rc != ADX_OK) return rc;
+    const float* identity = buf[cur];
+    if (r->block_has_ds[b]) {
+      const ConvSpec& ds = r->convs[ci++];
+      rc = conv2d_launch(ds, base, buf[cur], nullptr, buf[outb], batch, H, W, 0, s);  // downsample conv + bn
+      if (rc != ADX_OK) return rc;
+      identity = buf[outb];
+    }
+    // conv2 + bn2 + identity + relu.  With a downsample the identity lives in buf[outb] and the result
+    // overwrites buf[cur] (the block input is dead by then); otherwise the result goes to buf[outb].
+    float* dst = r->block_has_ds[b] ? buf[cur] : buf[outb];
+    rc = conv2d_launch(c2, base, buf[mid], identity, dst, batch, OH, OW, 1, s);
+    if (rc != ADX_OK) return rc;
+    if (!r->block_has_ds[b]) cur = outb;
+    H = OH; W = OW;
+  }
+  avgpool_fc_kernel<<<dim3(batch), dim3(256), 0, s>>>(buf[cur], base + r->o_fcw, base + r->o_fcb, feature, 512, H * W,
+                                                      r->out_dim);
+  ADX_LAUNCH_CHECK();
+  return ADX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,28 @@
+// Temporal (1-D) convolution on fp32 MFMA — geometry shared by the op-level C ABI and the
+// UNet executor.
+#pragma once
+#include "adx_common.h"
+
+namespace adx {
+
+// Tiling derived from an adx_tconv_desc and the batch.  One workgroup (4 waves) owns
+// `bt` samples x `ct` output channels for ALL positions, so every GroupNorm group it
+// touches is complete inside the workgroup; the four waves split the K = taps*cin
+// reduction and are summed through LDS in the epilogue.
+struct TConvTile {
+  int cin, cin_pad, ncb, nkb;  // channels, padded to 16, 16-channel blocks, taps*ncb
+  int cout_pad;                // cout padded to 16
+  int bt, mf;                  // samples per workgroup, 16-row MFMA fragments (bt*lout = 16*mf)
+  int ct, nf;                  // channels per workgroup, 16-col fragments
+  int pl, lp, rs, ck;          // left zero pad, per-sample LDS pitch, LDS row stride, channels per LDS chunk
+  int ntiles;                  // workgroups along channels
+  size_t lds_bytes;
+};
+
+int tconv_check(const adx_tconv_desc* d);
+int tconv_tile(const adx_tconv_desc* d, int batch, TConvTile* t);
+size_t tconv_packed_floats(const adx_tconv_desc* d);
+int tconv_pack(const adx_tconv_desc* d, const float* w, float* packed, hipStream_t s);
+int tconv_forward(const adx_tconv_desc* d, const adx_tconv_io* io, hipStream_t s);
+
+}  // namespace adx

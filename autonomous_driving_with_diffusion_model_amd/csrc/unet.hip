@@ -1,0 +1,451 @@
+// Native executor for TemporalMapUnet.forward minus the perception pass
+// (modeling/temporal.py:204-245): one C call issues the whole launch sequence on a stream, so a
+// denoising loop has no Python between kernels and can be captured in a HIP graph.
+//
+// Topology (modeling/temporal.py:59-195): n levels of [ResBlock, ResBlock, Downsample (not on
+// the last)], two mid ResBlocks, n-1 levels of [cat(skip), ResBlock, ResBlock, Upsample (on ALL
+// of them)], then Conv1dBlock + 1x1 head.  A ResBlock (temporal.py:23-55) is
+//   h = Mish(GN(conv5(x))) + Linear(Mish(cond))[:, :, None];  y = Mish(GN(conv5(h))) + R(x)
+// and costs 2 launches (+1 when R is a 1x1 conv): GN, Mish, bias and both adds live in the
+// conv epilogues.  The 16 per-block Linears share their input, so they run up front as ONE
+// GEMM [rows, 2*dim] x [2*dim, sum(C)] through the same MFMA kernel (a length-1 "conv").
+#include <algorithm>
+#include <vector>
+
+#include "tconv.h"
+
+namespace adx {
+
+int embed_forward(const adx_embed_weights* w, int dim, const int64_t* t, int t_rows, const float* cond,
+                  const float* feat, int feat_rows, int rows, float* time_embed, float* mish_cond, hipStream_t s);
+
+struct ConvLayer {
+  adx_tconv_desc d{};
+  int p_w = -1, p_b = -1, p_g = -1, p_be = -1;      // indices into the parameter list
+  size_t o_w = 0, o_b = 0, o_g = 0, o_be = 0;       // float offsets into the packed buffer
+};
+
+struct ResBlock {
+  ConvLayer a, b, r;
+  bool has_r = false;
+  int p_tw = -1, p_tb = -1;  // time_mlp.1 weight / bias
+  int tb_off = 0;            // column offset in the fused time-bias matrix
+  int c0 = 0, c1 = 0, cout = 0, len = 0;
+};
+
+}  // namespace adx
+
+struct adx_unet {
+  adx_unet_config cfg{};
+  std::vector<adx::ResBlock> blocks;
+  std::vector<adx::ConvLayer> downs, ups;
+  adx::ConvLayer head0, head1, tlin;
+  int n_levels = 0, n_params = 0, sum_c = 0, out_ch = 0;
+  int p_t1w = 0, p_t1b = 0, p_t3w = 0, p_t3b = 0, p_c0w = -1, p_c0b = -1, p_c2w = -1, p_c2b = -1;
+  size_t o_freqs = 0, o_t1w = 0, o_t1b = 0, o_t3w = 0, o_t3b = 0, o_c0w = 0, o_c0b = 0, o_c2w = 0, o_c2b = 0;
+  size_t o_tlin_raw = 0, o_tlin_b = 0;  // concatenated [sum_c][2 dim] block-Linear weight (staging) and bias
+  size_t packed_floats = 0;
+  bool packed_once = false;
+};
+
+namespace adx {
+
+static adx_tconv_desc conv_desc(int kind, int taps, int stride, int pad, int c0, int c1, int cout, int lin, int lout,
+                                int groups) {
+  adx_tconv_desc d;
+  d.kind = kind; d.taps = taps; d.stride = stride; d.pad = pad;
+  d.c0 = c0; d.c1 = c1; d.cout = cout; d.lin = lin; d.lout = lout;
+  d.groups = groups; d.eps = 1e-5f;
+  return d;
+}
+
+static size_t align64(size_t v) { return (v + 63) / 64 * 64; }
+
+struct Builder {
+  adx_unet* u;
+  int next_param = 0;
+  size_t off = 0;
+  size_t take(size_t n) {
+    const size_t o = off;
+    off = align64(off + n);
+    return o;
+  }
+  // Conv1dBlock: conv weight, conv bias, GN weight, GN bias (modeling/helpers.py:103-109)
+  ConvLayer conv_block(int c0, int c1, int cout, int len) {
+    ConvLayer L;
+    L.d = conv_desc(0, 5, 1, 2, c0, c1, cout, len, len, 8);
+    L.p_w = next_param++; L.p_b = next_param++; L.p_g = next_param++; L.p_be = next_param++;
+    L.o_w = take(tconv_packed_floats(&L.d));
+    L.o_b = take(cout); L.o_g = take(cout); L.o_be = take(cout);
+    return L;
+  }
+  ConvLayer plain(int kind, int taps, int stride, int pad, int c0, int c1, int cout, int lin, int lout) {
+    ConvLayer L;
+    L.d = conv_desc(kind, taps, stride, pad, c0, c1, cout, lin, lout, 0);
+    L.p_w = next_param++; L.p_b = next_param++;
+    L.o_w = take(tconv_packed_floats(&L.d));
+    L.o_b = take(cout);
+    return L;
+  }
+  ResBlock res_block(int c0, int c1, int cout, int len) {
+    ResBlock B;
+    B.c0 = c0; B.c1 = c1; B.cout = cout; B.len = len;
+    B.a = conv_block(c0, c1, cout, len);
+    B.b = conv_block(cout, 0, cout, len);
+    B.p_tw = next_param++; B.p_tb = next_param++;
+    B.tb_off = u->sum_c;
+    u->sum_c += cout;
+    B.has_r = (c0 + c1) != cout;
+    if (B.has_r) B.r = plain(0, 1, 1, 0, c0, c1, cout, len, len);
+    return B;
+  }
+};
+
+static int build(adx_unet* u) {
+  const adx_unet_config& c = u->cfg;
+  ADX_REQUIRE(c.n_mults >= 1 && c.n_mults <= 8, "unet: n_mults %d out of range", c.n_mults);
+  ADX_REQUIRE(c.guidance >= 0 && c.guidance <= 2, "unet: guidance %d out of range", c.guidance);
+  ADX_REQUIRE(c.dim >= 16 && c.dim % 16 == 0, "unet: dim %d must be a multiple of 16", c.dim);
+  ADX_REQUIRE(c.transition_dim >= 4, "unet: transition_dim %d too small", c.transition_dim);
+  const int n = c.n_mults;
+  u->n_levels = n;
+  ADX_REQUIRE(c.horizon % (1 << (n - 1)) == 0, "unet: horizon %d not divisible by %d", c.horizon, 1 << (n - 1));
+  Builder B{u};
+  // parameter order == TemporalMapUnet.__init__ registration order (temporal.py:87-194)
+  if (c.guidance == 1) {
+    u->p_c0w = B.next_param++; u->p_c0b = B.next_param++; u->p_c2w = B.next_param++; u->p_c2b = B.next_param++;
+  }
+  u->p_t1w = B.next_param++; u->p_t1b = B.next_param++; u->p_t3w = B.next_param++; u->p_t3b = B.next_param++;
+  std::vector<int> dims(n + 1);
+  dims[0] = c.transition_dim;
+  for (int i = 0; i < n; ++i) dims[i + 1] = c.dim * c.dim_mults[i];
+  int len = c.horizon;
+  std::vector<int> level_len(n);
+  for (int i = 0; i < n; ++i) {
+    const int ci = dims[i], co = dims[i + 1];
+    level_len[i] = len;
+    u->blocks.push_back(B.res_block(ci, 0, co, len));
+    u->blocks.push_back(B.res_block(co, 0, co, len));
+    if (i < n - 1) {
+      u->downs.push_back(B.plain(0, 3, 2, 1, co, 0, co, len, len / 2));
+      len /= 2;
+    }
+  }
+  // ups are registered before the mid blocks (temporal.py:104-105,152-178) but run after them
+  std::vector<ResBlock> up_blocks;
+  std::vector<ConvLayer> up_convs;
+  int ulen = len;
+  for (int i = 0; i < n - 1; ++i) {
+    const int ci = dims[n - 1 - i], co = dims[n - i];  // reversed(in_out[1:])
+    up_blocks.push_back(B.res_block(co, co, ci, ulen));
+    up_blocks.push_back(B.res_block(ci, 0, ci, ulen));
+    up_convs.push_back(B.plain(1, 4, 2, 1, ci, 0, ci, ulen, ulen * 2));
+    ulen *= 2;
+  }
+  const int mid = dims[n];
+  // the time-bias column offsets follow execution order only by convention; keep the
+  // registration-order offsets assigned by res_block() above
+  ResBlock m1 = B.res_block(mid, 0, mid, len);
+  ResBlock m2 = B.res_block(mid, 0, mid, len);
+  u->blocks.push_back(m1);
+  u->blocks.push_back(m2);
+  for (auto& b : up_blocks) u->blocks.push_back(b);
+  u->ups = up_convs;
+  const int fin = n > 1 ? dims[1] : dims[n];
+  ADX_REQUIRE(ulen == c.horizon || n == 1, "unet: up path ends at length %d, expected %d", ulen, c.horizon);
+  u->head0 = B.conv_block(fin, 0, fin, ulen);
+  u->out_ch = c.guidance == 2 ? 3 : c.transition_dim;
+  u->head1 = B.plain(0, 1, 1, 0, fin, 0, u->out_ch, ulen, ulen);
+  u->n_params = B.next_param;
+  // the fused block-Linear: [rows, 2 dim] -> [rows, sum_c]
+  u->tlin.d = conv_desc(0, 1, 1, 0, 2 * c.dim, 0, u->sum_c, 1, 1, 0);
+  u->tlin.o_w = B.take(tconv_packed_floats(&u->tlin.d));
+  u->o_tlin_b = B.take(u->sum_c);
+  u->o_tlin_raw = B.take((size_t)u->sum_c * 2 * c.dim);
+  u->o_freqs = B.take(c.dim / 2);
+  u->o_t1w = B.take((size_t)4 * c.dim * c.dim); u->o_t1b = B.take(4 * c.dim);
+  u->o_t3w = B.take((size_t)4 * c.dim * c.dim); u->o_t3b = B.take(c.dim);
+  if (c.guidance == 1) {
+    u->o_c0w = B.take(2 * c.dim); u->o_c0b = B.take(c.dim);
+    u->o_c2w = B.take((size_t)c.dim * c.dim); u->o_c2b = B.take(c.dim);
+  }
+  u->packed_floats = B.off;
+  // validate every layer's geometry now so that forward() cannot fail on shape grounds
+  TConvTile t;
+  for (auto& b : u->blocks) {
+    int rc = tconv_tile(&b.a.d, 1, &t);
+    if (rc == ADX_OK) rc = tconv_tile(&b.b.d, 1, &t);
+    if (rc == ADX_OK && b.has_r) rc = tconv_tile(&b.r.d, 1, &t);
+    if (rc != ADX_OK) return rc;
+  }
+  for (auto& l : u->downs) { int rc = tconv_tile(&l.d, 1, &t); if (rc != ADX_OK) return rc; }
+  for (auto& l : u->ups) { int rc = tconv_tile(&l.d, 1, &t); if (rc != ADX_OK) return rc; }
+  int rc = tconv_tile(&u->head0.d, 1, &t);
+  if (rc == ADX_OK) rc = tconv_tile(&u->head1.d, 1, &t);
+  if (rc == ADX_OK) rc = tconv_tile(&u->tlin.d, 1, &t);
+  return rc;
+}
+
+static int copy_f(float* dst, const float* src, size_t n, hipStream_t s) {
+  ADX_CHECK_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return ADX_OK;
+}
+
+static int pack_layer(const ConvLayer& L, const float* const* P, float* base, hipStream_t s) {
+  int rc = tconv_pack(&L.d, P[L.p_w], base + L.o_w, s);
+  if (rc == ADX_OK && L.p_b >= 0) rc = copy_f(base + L.o_b, P[L.p_b], L.d.cout, s);
+  if (rc == ADX_OK && L.p_g >= 0) rc = copy_f(base + L.o_g, P[L.p_g], L.d.cout, s);
+  if (rc == ADX_OK && L.p_be >= 0) rc = copy_f(base + L.o_be, P[L.p_be], L.d.cout, s);
+  return rc;
+}
+
+static void fill_io(adx_tconv_io& io, const ConvLayer& L, const float* base) {
+  io.packed_w = base + L.o_w;
+  io.bias = L.p_b >= 0 ? base + L.o_b : nullptr;
+  io.gamma = L.p_g >= 0 ? base + L.o_g : nullptr;
+  io.beta = L.p_be >= 0 ? base + L.o_be : nullptr;
+}
+
+struct Act {  // an activation tensor [rows][c][len] with explicit strides
+  const float* p = nullptr;
+  int64_t sb = 0, sc = 0, sl = 0;
+};
+
+static Act dense(float* p, int c, int len) { return Act{p, (int64_t)c * len, (int64_t)len, 1}; }
+
+static int run_conv(const ConvLayer& L, const float* base, const Act& x0, const Act* x1, const float* tbias,
+                    int64_t tb_stride, const Act* res, float* y, int64_t y_sb, int64_t y_sc, int64_t y_sl, int rows,
+                    hipStream_t s) {
+  adx_tconv_io io;
+  memset(&io, 0, sizeof(io));
+  io.x0 = x0.p; io.x0_sb = x0.sb; io.x0_sc = x0.sc; io.x0_sl = x0.sl;
+  if (x1 != nullptr) { io.x1 = x1->p; io.x1_sb = x1->sb; io.x1_sc = x1->sc; io.x1_sl = x1->sl; }
+  fill_io(io, L, base);
+  io.tbias = tbias; io.tbias_stride = tb_stride;
+  if (res != nullptr) { io.res = res->p; io.res_sb = res->sb; io.res_sc = res->sc; io.res_sl = res->sl; }
+  io.y = y; io.y_sb = y_sb; io.y_sc = y_sc; io.y_sl = y_sl;
+  io.batch = rows;
+  return tconv_forward(&L.d, &io, s);
+}
+
+}  // namespace adx
+
+using namespace adx;
+
+extern "C" {
+
+int adx_unet_create(const adx_unet_config* cfg, adx_unet** out) {
+  ADX_REQUIRE(cfg != nullptr && out != nullptr, "adx_unet_create: null argument");
+  adx_unet* u = new adx_unet();
+  u->cfg = *cfg;
+  const int rc = build(u);
+  if (rc != ADX_OK) {
+    delete u;
+    return rc;
+  }
+  *out = u;
+  return ADX_OK;
+}
+
+void adx_unet_destroy(adx_unet* u) { delete u; }
+
+int adx_unet_num_params(const adx_unet* u) { return u ? u->n_params : 0; }
+
+size_t adx_unet_packed_bytes(const adx_unet* u) { return u ? u->packed_floats * sizeof(float) : 0; }
+
+int adx_unet_pack(adx_unet* u, const float* const* P, int32_t n_params, const float* freqs, void* packed,
+                  adx_stream stream) {
+  ADX_REQUIRE(u && P && freqs && packed, "adx_unet_pack: null argument");
+  // CLASSIFIER_GUIDANCE models carry TrajPredict's parameters after the head; they are not ours
+  ADX_REQUIRE(n_params >= u->n_params, "adx_unet_pack: expected at least %d parameter tensors, got %d", u->n_params,
+              n_params);
+  for (int i = 0; i < u->n_params; ++i) ADX_REQUIRE(P[i] != nullptr, "adx_unet_pack: parameter %d is null", i);
+  hipStream_t s = (hipStream_t)stream;
+  float* base = (float*)packed;
+  const int dim = u->cfg.dim;
+  int rc = ADX_OK;
+  for (auto& b : u->blocks) {
+    if (rc == ADX_OK) rc = pack_layer(b.a, P, base, s);
+    if (rc == ADX_OK) rc = pack_layer(b.b, P, base, s);
+    if (rc == ADX_OK && b.has_r) rc = pack_layer(b.r, P, base, s);
+    // concatenate the block's time_mlp Linear into the fused [sum_c][2 dim] matrix
+    if (rc == ADX_OK) rc = copy_f(base + u->o_tlin_raw + (size_t)b.tb_off * 2 * dim, P[b.p_tw], (size_t)b.cout * 2 * dim, s);
+    if (rc == ADX_OK) rc = copy_f(base + u->o_tlin_b + b.tb_off, P[b.p_tb], b.cout, s);
+  }
+  for (auto& l : u->downs) if (rc == ADX_OK) rc = pack_layer(l, P, base, s);
+  for (auto& l : u->ups) if (rc == ADX_OK) rc = pack_layer(l, P, base, s);
+  if (rc == ADX_OK) rc = pack_layer(u->head0, P, base, s);
+  if (rc == ADX_OK) rc = pack_layer(u->head1, P, base, s);
+  if (rc == ADX_OK) rc = tconv_pack(&u->tlin.d, base + u->o_tlin_raw, base + u->tlin.o_w, s);
+  if (rc == ADX_OK) rc = copy_f(base + u->o_freqs, freqs, dim / 2, s);
+  if (rc == ADX_OK) rc = copy_f(base + u->o_t1w, P[u->p_t1w], (size_t)4 * dim * dim, s);
+  if (rc == ADX_OK) rc = copy_f(base + u->o_t1b, P[u->p_t1b], 4 * dim, s);
+  if (rc == ADX_OK) rc = copy_f(base + u->o_t3w, P[u->p_t3w], (size_t)4 * dim * dim, s);
+  if (rc == ADX_OK) rc = copy_f(base + u->o_t3b, P[u->p_t3b], dim, s);
+  if (rc == ADX_OK && u->cfg.guidance == 1) {
+    rc = copy_f(base + u->o_c0w, P[u->p_c0w], 2 * dim, s);
+    if (rc == ADX_OK) rc = copy_f(base + u->o_c0b, P[u->p_c0b], dim, s);
+    if (rc == ADX_OK) rc = copy_f(base + u->o_c2w, P[u->p_c2w], (size_t)dim * dim, s);
+    if (rc == ADX_OK) rc = copy_f(base + u->o_c2b, P[u->p_c2b], dim, s);
+  }
+  if (rc == ADX_OK) u->packed_once = true;
+  return rc;
+}
+
+constexpr int kRing = 6;
+
+// workspace: time_embed, mish_cond, time-bias matrix, then kRing rotating activation buffers
+// and one skip per level, each rows*dim*horizon floats
+// (C*L is the same at every level: channels double as the length halves).
+static size_t act_floats(const adx_unet* u, int rows) {
+  size_t m = 0;
+  for (auto& b : u->blocks) m = std::max(m, (size_t)b.cout * b.len);
+  for (auto& l : u->ups) m = std::max(m, (size_t)l.d.cout * l.d.lout);
+  m = std::max(m, (size_t)u->head0.d.cout * u->head0.d.lout);
+  return align64(m * rows);
+}
+
+size_t adx_unet_workspace_bytes(const adx_unet* u, int32_t rows) {
+  if (!u || rows < 1) return 0;
+  const int dim = u->cfg.dim;
+  size_t f = align64((size_t)rows * dim) + align64((size_t)rows * 2 * dim) + align64((size_t)rows * u->sum_c);
+  f += act_floats(u, rows) * (size_t)(kRing + u->n_levels);
+  return f * sizeof(float);
+}
+
+int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx_unet_io* io, adx_stream stream) {
+  ADX_REQUIRE(u && packed && workspace && io, "adx_unet_forward: null argument");
+  if (!u->packed_once) {
+    set_error("adx_unet_forward: weights were never packed (call adx_unet_pack first)");
+    return ADX_ERR_STATE;
+  }
+  ADX_REQUIRE(io->x && io->img_feature && io->t && io->out, "adx_unet_forward: null tensor");
+  const int rows = io->rows, dim = u->cfg.dim, H = u->cfg.horizon, D = u->cfg.transition_dim;
+  ADX_REQUIRE(rows >= 1, "adx_unet_forward: rows must be >= 1");
+  ADX_REQUIRE(io->t_rows >= 1 && rows % io->t_rows == 0 && io->feat_rows >= 1 && rows % io->feat_rows == 0,
+              "adx_unet_forward: rows %d must be a multiple of t_rows %d and feat_rows %d", rows, io->t_rows,
+              io->feat_rows);
+  if (u->cfg.guidance != 1)
+    ADX_REQUIRE(io->t_rows == rows && io->feat_rows == rows,
+                "adx_unet_forward: time/img batch must equal the trajectory batch unless FREE_GUIDANCE "
+                "(the reference's torch.cat fails otherwise, temporal.py:213)");
+  hipStream_t s = (hipStream_t)stream;
+  const float* base = (const float*)packed;
+  float* ws = (float*)workspace;
+  size_t off = 0;
+  auto take = [&](size_t n) { float* p = ws + off; off += align64(n); return p; };
+  float* te = take((size_t)rows * dim);
+  float* mc = take((size_t)rows * 2 * dim);
+  float* tb = take((size_t)rows * u->sum_c);
+  const size_t af = act_floats(u, rows);
+  float* bufs[kRing];
+  for (auto& b : bufs) b = take(af);
+  std::vector<float*> skips(u->n_levels);
+  for (auto& p : skips) p = take(af);
+
+  adx_embed_weights ew;
+  memset(&ew, 0, sizeof(ew));
+  ew.freqs = base + u->o_freqs;
+  ew.w1 = base + u->o_t1w; ew.b1 = base + u->o_t1b; ew.w3 = base + u->o_t3w; ew.b3 = base + u->o_t3b;
+  if (u->cfg.guidance == 1) {
+    ew.cw0 = base + u->o_c0w; ew.cb0 = base + u->o_c0b; ew.cw2 = base + u->o_c2w; ew.cb2 = base + u->o_c2b;
+  }
+  int rc = embed_forward(&ew, dim, io->t, io->t_rows, u->cfg.guidance == 1 ? io->cond : nullptr, io->img_feature,
+                         io->feat_rows, rows, te, mc, s);
+  if (rc != ADX_OK) return rc;
+  {  // all 16 block Linears at once: tb[rows][sum_c] = mc @ Wcat^T + bcat
+    adx_tconv_io lio;
+    memset(&lio, 0, sizeof(lio));
+    lio.x0 = mc; lio.x0_sb = 2 * dim; lio.x0_sc = 1; lio.x0_sl = 0;
+    lio.packed_w = base + u->tlin.o_w; lio.bias = base + u->o_tlin_b;
+    lio.y = tb; lio.y_sb = u->sum_c; lio.y_sc = 1; lio.y_sl = 0;
+    lio.batch = rows;
+    rc = tconv_forward(&u->tlin.d, &lio, s);
+    if (rc != ADX_OK) return rc;
+  }
+
+  // x arrives as [rows][H][D]; the UNet works on [rows][D][H] (temporal.py:204): read with strides
+  Act cur{io->x, (int64_t)H * D, 1, (int64_t)D};
+  // Six activation buffers used strictly round-robin.  A buffer is overwritten six takes after it
+  // was handed out; the longest any tensor stays live is four takes (a block input is read by
+  // the last conv of the block, after h and the 1x1-residual buffers of that block were taken).
+  int nb = 0;
+  auto next_buf = [&]() { float* p = bufs[nb]; nb = (nb + 1) % kRing; return p; };
+  auto run_block = [&](const ResBlock& B, const Act& x0, const Act* x1, float* dst) -> int {
+    float* h = next_buf();
+    int r = run_conv(B.a, base, x0, x1, tb + B.tb_off, u->sum_c, nullptr, h, (int64_t)B.cout * B.len, B.len, 1, rows, s);
+    if (r != ADX_OK) return r;
+    Act res = x0;  // identity residual (cin == cout, never a concat)
+    if (B.has_r) {
+      float* rb = next_buf();
+      r = run_conv(B.r, base, x0, x1, nullptr, 0, nullptr, rb, (int64_t)B.cout * B.len, B.len, 1, rows, s);
+      if (r != ADX_OK) return r;
+      res = dense(rb, B.cout, B.len);
+    }
+    const Act hin = dense(h, B.cout, B.len);
+    return run_conv(B.b, base, hin, nullptr, nullptr, 0, &res, dst, (int64_t)B.cout * B.len, B.len, 1, rows, s);
+  };
+
+  size_t bi = 0;
+  const int n = u->n_levels;
+  for (int i = 0; i < n; ++i) {
+    const ResBlock& B0 = u->blocks[bi++];
+    const ResBlock& B1 = u->blocks[bi++];
+    float* y0 = next_buf();
+    rc = run_block(B0, cur, nullptr, y0);
+    if (rc != ADX_OK) return rc;
+    const Act a0 = dense(y0, B0.cout, B0.len);
+    rc = run_block(B1, a0, nullptr, skips[i]);  // the level output doubles as the skip (temporal.py:219)
+    if (rc != ADX_OK) return rc;
+    cur = dense(skips[i], B1.cout, B1.len);
+    if (i < n - 1) {
+      const ConvLayer& dn = u->downs[i];
+      float* y = next_buf();
+      rc = run_conv(dn, base, cur, nullptr, nullptr, 0, nullptr, y, (int64_t)dn.d.cout * dn.d.lout, dn.d.lout, 1, rows, s);
+      if (rc != ADX_OK) return rc;
+      cur = dense(y, dn.d.cout, dn.d.lout);
+    }
+  }
+  for (int k = 0; k < 2; ++k) {  // mid_block1, mid_block2
+    const ResBlock& B = u->blocks[bi++];
+    float* y = next_buf();
+    rc = run_block(B, cur, nullptr, y);
+    if (rc != ADX_OK) return rc;
+    cur = dense(y, B.cout, B.len);
+  }
+  for (int i = 0; i < n - 1; ++i) {
+    const ResBlock& B0 = u->blocks[bi++];
+    const ResBlock& B1 = u->blocks[bi++];
+    // h.pop(): the deepest skip first; h[0] is pushed but never popped (temporal.py:226-227)
+    const Act skip = dense(skips[n - 1 - i], B0.c1, B0.len);
+    float* y0 = next_buf();
+    rc = run_block(B0, cur, &skip, y0);
+    if (rc != ADX_OK) return rc;
+    const Act a0 = dense(y0, B0.cout, B0.len);
+    float* y1 = next_buf();
+    rc = run_block(B1, a0, nullptr, y1);
+    if (rc != ADX_OK) return rc;
+    const Act a1 = dense(y1, B1.cout, B1.len);
+    const ConvLayer& up = u->ups[i];
+    float* y2 = next_buf();
+    rc = run_conv(up, base, a1, nullptr, nullptr, 0, nullptr, y2, (int64_t)up.d.cout * up.d.lout, up.d.lout, 1, rows, s);
+    if (rc != ADX_OK) return rc;
+    cur = dense(y2, up.d.cout, up.d.lout);
+  }
+  {  // final_conv / act_conv: Conv1dBlock + 1x1, written back as [rows][H][out_ch] (temporal.py:233-235,243-244)
+    float* y = next_buf();
+    const ConvLayer& h0 = u->head0;
+    rc = run_conv(h0, base, cur, nullptr, nullptr, 0, nullptr, y, (int64_t)h0.d.cout * h0.d.lout, h0.d.lout, 1, rows, s);
+    if (rc != ADX_OK) return rc;
+    const Act a = dense(y, h0.d.cout, h0.d.lout);
+    rc = run_conv(u->head1, base, a, nullptr, nullptr, 0, nullptr, io->out, (int64_t)H * u->out_ch, 1, u->out_ch, rows, s);
+    if (rc != ADX_OK) return rc;
+  }
+  if (io->time_embed != nullptr) {
+    ADX_CHECK_HIP(hipMemcpyAsync(io->time_embed, te, (size_t)rows * dim * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+  (void)D;
+  return ADX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+"""ResNet-34 camera encoder (reference: modeling/resnet.py:163-296,325-333 with the fc replaced
+by Linear(512, dim) at modeling/temporal.py:83-84), executed by libadx.so.
+
+Eval mode only for now: BatchNorm uses running statistics and is folded into the conv epilogue at
+pack time.  Training (batch statistics + backward) is not implemented yet and raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .holders import populate
+from .spec import resnet34_entries
+
+
+class PerceptionResNet34(nn.Module):
+    def __init__(self, out_dim: int):
+        super().__init__()
+        self.out_dim = out_dim
+        self._entries = resnet34_entries("", out_dim)
+        populate(self, self._entries)
+        self._handle = None
+        self._packed = None
+        self._pack_key = None
+        self._ws = None
+
+    # -- native object management ------------------------------------------------------------
+    def _native(self):
+        if self._handle is None:
+            h = L.vp()
+            L.check(L.lib().adx_resnet_create(self.out_dim, C.byref(h)), "adx_resnet_create")
+            self._handle = h
+        return self._handle
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                L.lib().adx_resnet_destroy(self._handle)
+        except Exception:
+            pass
+
+    def _tensors(self):
+        sd = dict(self.named_parameters())
+        sd.update(dict(self.named_buffers()))
+        return [sd[e.key] for e in self._entries if e.dtype == "f32"]
+
+    def weights_key(self):
+        ts = self._tensors()
+        return (ts[0].data_ptr(), sum(t._version for t in ts), self.training)
+
+    def invalidate(self):
+        self._pack_key = None
+
+    def _ensure_packed(self):
+        key = self.weights_key()
+        if key == self._pack_key:
+            return
+        h = self._native()
+        ts = [L.require_gpu_f32(t.detach(), "perception tensor") for t in self._tensors()]
+        n = L.lib().adx_resnet_num_tensors(h)
+        assert n == len(ts), (n, len(ts))
+        nbytes = L.lib().adx_resnet_packed_bytes(h)
+        if self._packed is None or self._packed.numel() != nbytes or self._packed.device != ts[0].device:
+            self._packed = torch.empty(nbytes, dtype=torch.uint8, device=ts[0].device)
+        arr = L.ptr_array(ts)
+        L.check(L.lib().adx_resnet_pack(h, arr, n, self._packed.data_ptr(), L.stream_ptr(ts[0].device)),
+                "adx_resnet_pack")
+        self._pack_key = key
+
+    def forward(self, img: torch.Tensor) -> torch.Tensor:
+        if self.training:
+            raise NotImplementedError("perception: train-mode BatchNorm/backward kernels are not implemented yet; "
+                                      "call .eval()")
+        img = L.require_gpu_f32(img, "img")
+        if img.dim() != 4 or img.shape[1] != 3:
+            raise ValueError(f"img must be [B, 3, H, W], got {tuple(img.shape)}")
+        self._ensure_packed()
+        h = self._native()
+        B, _, H, W = img.shape
+        nbytes = L.lib().adx_resnet_workspace_bytes(h, B, H, W)
+        if nbytes == 0:
+            raise ValueError(f"image {H}x{W} too small for ResNet-34")
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != img.device:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=img.device)
+        out = torch.empty((B, self.out_dim), dtype=torch.float32, device=img.device)
+        L.check(L.lib().adx_resnet_forward(h, self._packed.data_ptr(), self._ws.data_ptr(), img.data_ptr(), B, H, W,
+                                           out.data_ptr(), L.stream_ptr(img.device)), "adx_resnet_forward")
+        return out

@@ -1,0 +1,213 @@
+"""`TemporalMapUnet` / `build_model` with the reference's call surface
+(modeling/temporal.py:58-258), executed by libadx.so on an MI355X.
+
+Same constructor arguments, `forward(x, img, time, cond=None, return_action_and_time_only=False)`,
+attributes `.perception`, `.state_pred`, `.magic_num`, state_dict keys and parameter order as the
+reference.  The nn.Module tree only HOLDS parameters (modeling/holders.py); one forward is
+  perception(img)  -> adx_resnet_forward   (memoised per image tensor in eval mode, see below)
+  everything else  -> adx_unet_forward     (one native call, ~45 fused kernel launches)
+
+Perception memoisation: the reference re-runs the ResNet-34 on the same image at every denoising
+step (modeling/temporal.py:203) although in eval mode the result cannot change.  In eval mode
+under no_grad the feature is cached against the *identity* of the image tensor object (weak
+reference + version counter + weight fingerprint), which makes the agents' sampling loops
+(interact.py:131-164) pay for one perception pass per scene without touching their code.  Set
+`model.cache_perception = False` for the reference-faithful per-step behaviour.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import weakref
+from typing import Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from ..misc.constant import GuidanceType
+from .holders import populate
+from .perception import PerceptionResNet34
+from .spec import unet_entries
+from .trajpredict import TrajPredict
+
+
+class TemporalMapUnet(nn.Module):
+    def __init__(self, horizon, transition_dim=2, attention=False, dim=128, dim_mults=(1, 2, 4, 8),
+                 diffuser_building_block="concat", use_cond=GuidanceType.NO_GUIDANCE):
+        super().__init__()
+        if diffuser_building_block != "concat":
+            raise NotImplementedError  # modeling/temporal.py:71-74
+        if attention:
+            # MODEL.USE_ATTN defaults to False and the reference's up path is broken with it
+            # (temporal.py:168 builds LinearAttention(dim_out) for a dim_in tensor)
+            raise NotImplementedError("USE_ATTN=True is not supported (it raises in the reference's up path too)")
+        self.horizon, self.transition_dim, self.dim = int(horizon), int(transition_dim), int(dim)
+        self.dim_mults = tuple(int(m) for m in dim_mults)
+        self.use_cond = use_cond
+        dims = [transition_dim, *[dim * m for m in self.dim_mults]]
+        if int(os.environ.get("LOCAL_RANK", "-1")) <= 0:
+            print(f"[ models/temporal ] Channel dimensions: {list(zip(dims[:-1], dims[1:]))}")
+
+        entries = unet_entries(use_cond.name, self.transition_dim, self.dim, self.dim_mults)
+        # registration order: perception, [cond_mlp], time_mlp, downs, ups, mid_block1, mid_block2, heads
+        self.perception = PerceptionResNet34(self.dim)
+        rest = [e for e in entries if not e.key.startswith("perception.")]
+        unet_side = [e for e in rest if not e.key.startswith("state_pred.")]
+        populate(self, unet_side)
+        if use_cond == GuidanceType.CLASSIFIER_GUIDANCE:
+            self.state_pred = TrajPredict(in_dim=3, out_dim=self.transition_dim - 3, pred_len=self.horizon - 1,
+                                          hidden_dim=64, num_layers=2)
+        self._unet_keys = [e.key for e in unet_side]
+        self.magic_num = 23.315
+        self.cache_perception = True
+        self._handle = None
+        self._packed = None
+        self._pack_key = None
+        self._ws = None
+        self._ws_rows = 0
+        self._freqs = None
+        self._feat_cache = None  # (weakref(img), img._version, weights_key, feature)
+
+    # -- native object management --------------------------------------------------------------
+    def _native(self):
+        if self._handle is None:
+            cfg = L.UnetConfig()
+            cfg.horizon, cfg.transition_dim, cfg.dim = self.horizon, self.transition_dim, self.dim
+            cfg.n_mults = len(self.dim_mults)
+            for i, m in enumerate(self.dim_mults):
+                cfg.dim_mults[i] = m
+            cfg.guidance = self.use_cond.value
+            h = L.vp()
+            L.check(L.lib().adx_unet_create(C.byref(cfg), C.byref(h)), "adx_unet_create")
+            self._handle = h
+        return self._handle
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                L.lib().adx_unet_destroy(self._handle)
+        except Exception:
+            pass
+
+    def _unet_params(self):
+        named = dict(self.named_parameters())
+        return [named[k] for k in self._unet_keys]
+
+    def _weights_key(self):
+        ps = self._unet_params()
+        return (ps[0].data_ptr(), sum(p._version for p in ps))
+
+    def refresh_weights(self):
+        """Force a re-pack of the HIP weight images (needed only after out-of-band `.data` writes)."""
+        self._pack_key = None
+        self.perception.invalidate()
+        self._feat_cache = None
+
+    def train(self, mode: bool = True):
+        if mode != self.training:
+            # EMAModel.copy_to / restore write through `.data` around evaluate() (train.py:307-318),
+            # which version counters do not see; a mode flip always brackets them
+            self.refresh_weights()
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **k):
+        self.refresh_weights()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self.refresh_weights()
+        return super().load_state_dict(*a, **k)
+
+    def _ensure_packed(self, device):
+        key = self._weights_key()
+        if key == self._pack_key:
+            return
+        h = self._native()
+        ps = [L.require_gpu_f32(p.detach(), "parameter") for p in self._unet_params()]
+        n = L.lib().adx_unet_num_params(h)
+        assert n == len(ps), (n, len(ps))
+        nbytes = L.lib().adx_unet_packed_bytes(h)
+        if self._packed is None or self._packed.numel() != nbytes or self._packed.device != device:
+            self._packed = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        if self._freqs is None or self._freqs.device != device:
+            # helpers.py:66-69, evaluated with torch on the host exactly as the reference does on CPU
+            half = self.dim // 2
+            scale = math.log(10000) / (half - 1)
+            self._freqs = torch.exp(torch.arange(half) * -scale).to(device=device, dtype=torch.float32)
+        L.check(L.lib().adx_unet_pack(h, L.ptr_array(ps), n, self._freqs.data_ptr(), self._packed.data_ptr(),
+                                      L.stream_ptr(device)), "adx_unet_pack")
+        self._pack_key = key
+
+    # -- perception with per-image memoisation -------------------------------------------------
+    def image_feature(self, img: torch.Tensor) -> torch.Tensor:
+        use_cache = self.cache_perception and not self.training and not torch.is_grad_enabled()
+        if use_cache and self._feat_cache is not None:
+            ref, ver, wkey, feat = self._feat_cache
+            if ref() is img and ver == img._version and wkey == self.perception.weights_key():
+                return feat
+        feat = self.perception(img)
+        self._feat_cache = (weakref.ref(img), img._version, self.perception.weights_key(), feat) if use_cache else None
+        return feat
+
+    # -- forward ---------------------------------------------------------------------------------
+    def forward(self, x, img, time, cond=None, return_action_and_time_only=False):
+        """x [B, T, D]; img [B or 1, 3, H, W]; time int64 [B or 1]; cond None or [B, 2]."""
+        if self.training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+                             and x.requires_grad):
+            raise NotImplementedError("TemporalMapUnet: the training/backward kernels are not implemented yet; use "
+                                      "model.eval() under torch.no_grad()/inference_mode()")
+        x = L.require_gpu_f32(x, "x")
+        if x.dim() != 3 or x.shape[1] != self.horizon or x.shape[2] != self.transition_dim:
+            raise ValueError(f"x must be [B, {self.horizon}, {self.transition_dim}], got {tuple(x.shape)}")
+        rows = x.shape[0]
+        feat = self.image_feature(img)
+        time = L.require_gpu_f32(time.reshape(-1), "time", torch.int64)
+        free = self.use_cond == GuidanceType.FREE_GUIDANCE
+        if cond is not None and free:
+            cond = L.require_gpu_f32(cond, "cond")
+            if tuple(cond.shape) != (rows, 2):
+                raise ValueError(f"cond must be [{rows}, 2], got {tuple(cond.shape)}")
+        else:
+            cond = None
+        if not free and (time.shape[0] != rows or feat.shape[0] != rows):
+            raise RuntimeError(f"Sizes of tensors must match: time {time.shape[0]}, img {feat.shape[0]}, x {rows} "
+                               "(torch.cat at modeling/temporal.py:213)")
+        self._ensure_packed(x.device)
+        h = self._native()
+        nbytes = L.lib().adx_unet_workspace_bytes(h, rows)
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != x.device:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        classifier = self.use_cond == GuidanceType.CLASSIFIER_GUIDANCE
+        out_ch = 3 if classifier else self.transition_dim
+        out = torch.empty((rows, self.horizon, out_ch), dtype=torch.float32, device=x.device)
+        te = torch.empty((rows, self.dim), dtype=torch.float32, device=x.device) if classifier else None
+        io = L.UnetIO()
+        io.x, io.img_feature, io.feat_rows = x.data_ptr(), feat.data_ptr(), feat.shape[0]
+        io.t, io.t_rows, io.cond, io.rows = time.data_ptr(), time.shape[0], L.ptr(cond), rows
+        io.out, io.time_embed = out.data_ptr(), L.ptr(te)
+        L.check(L.lib().adx_unet_forward(h, self._packed.data_ptr(), self._ws.data_ptr(), C.byref(io),
+                                         L.stream_ptr(x.device)), "adx_unet_forward")
+        if not classifier:
+            return out
+        action = out
+        if return_action_and_time_only:
+            return action, te
+        # temporal.py:238-242: state from the detached action, dummy zero first row, concat
+        state = self.state_pred(action.detach()[:, :-1], te)
+        state = torch.cat([torch.zeros_like(state[:, :1]), state], dim=1)
+        return torch.cat([state, action], dim=-1)
+
+
+def build_model(cfg) -> TemporalMapUnet:
+    """modeling/temporal.py:248-258."""
+    return TemporalMapUnet(
+        horizon=cfg.MODEL.HORIZON,
+        transition_dim=cfg.MODEL.TRANSITION_DIM,
+        attention=cfg.MODEL.USE_ATTN,
+        dim=cfg.MODEL.DIM,
+        dim_mults=cfg.MODEL.DIM_MULTS,
+        diffuser_building_block=cfg.MODEL.DIFFUSER_BUILDING_BLOCK,
+        use_cond=GuidanceType[cfg.TRAIN.USE_COND],
+    )

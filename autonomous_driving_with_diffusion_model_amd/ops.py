@@ -1,0 +1,89 @@
+"""Op-level Python entry points over the C ABI (one call = one kernel launch).  Used by the parity
+tests and available to callers who want a single fused op; the model itself goes through the
+native executors (adx_unet_forward / adx_resnet_forward)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+
+def _strides3(t: torch.Tensor):
+    return t.stride(0), t.stride(1), t.stride(2)
+
+
+def tconv(x0: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, x1: Optional[torch.Tensor] = None,
+          kind: int = 0, stride: int = 1, pad: int = 0, gn_weight: Optional[torch.Tensor] = None,
+          gn_bias: Optional[torch.Tensor] = None, groups: int = 0, eps: float = 1e-5,
+          tbias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
+          out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Temporal conv (+bias) [-> GroupNorm(groups) -> Mish] [+ tbias[:, :, None]] [+ res].
+
+    x0/x1: [B, C, L] views with arbitrary strides (x1 is concatenated after x0 along C);
+    weight: Conv1d [Cout, Cin, k] (kind 0) or ConvTranspose1d [Cin, Cout, k] (kind 1)."""
+    assert x0.is_cuda and x0.dtype == torch.float32 and x0.dim() == 3
+    B, c0, lin = x0.shape
+    c1 = 0 if x1 is None else x1.shape[1]
+    taps = weight.shape[2]
+    cout = weight.shape[0] if kind == 0 else weight.shape[1]
+    lout = (lin + 2 * pad - taps) // stride + 1 if kind == 0 else (lin - 1) * stride - 2 * pad + taps
+    d = L.TConvDesc(kind, taps, stride, pad, c0, c1, cout, lin, lout, groups, eps)
+    nbytes = L.lib().adx_tconv_packed_bytes(C.byref(d))
+    if nbytes == 0:
+        L.check(-1, "adx_tconv_packed_bytes")
+    packed = torch.empty(nbytes // 4, dtype=torch.float32, device=x0.device)
+    s = L.stream_ptr(x0.device)
+    w = weight.detach().contiguous()
+    L.check(L.lib().adx_tconv_pack(C.byref(d), w.data_ptr(), packed.data_ptr(), s), "adx_tconv_pack")
+    y = out if out is not None else torch.empty((B, cout, lout), dtype=torch.float32, device=x0.device)
+    io = L.TConvIO()
+    io.x0 = x0.data_ptr()
+    io.x0_sb, io.x0_sc, io.x0_sl = _strides3(x0)
+    if x1 is not None:
+        io.x1 = x1.data_ptr()
+        io.x1_sb, io.x1_sc, io.x1_sl = _strides3(x1)
+    io.packed_w = packed.data_ptr()
+    keep = [w, packed]
+    for name, t in (("bias", bias), ("gamma", gn_weight), ("beta", gn_bias)):
+        if t is not None:
+            tc = t.detach().contiguous()
+            keep.append(tc)
+            setattr(io, name, tc.data_ptr())
+    if tbias is not None:
+        assert tbias.dim() == 2 and tbias.stride(1) == 1
+        io.tbias, io.tbias_stride = tbias.data_ptr(), tbias.stride(0)
+    if res is not None:
+        io.res = res.data_ptr()
+        io.res_sb, io.res_sc, io.res_sl = _strides3(res)
+    io.y = y.data_ptr()
+    io.y_sb, io.y_sc, io.y_sl = _strides3(y)
+    io.batch = B
+    L.check(L.lib().adx_tconv_forward(C.byref(d), C.byref(io), s), "adx_tconv_forward")
+    return y
+
+
+def embed(freqs, w1, b1, w3, b3, t, img_feature, rows, cond=None, cond_mlp=None):
+    """time_embed [rows, dim], mish_cond [rows, 2 dim] (see adx_embed_forward in include/adx.h)."""
+    dim = w3.shape[0]
+    ew = L.EmbedWeights()
+    keep = []
+    for name, v in (("freqs", freqs), ("w1", w1), ("b1", b1), ("w3", w3), ("b3", b3)):
+        v = v.detach().contiguous()
+        keep.append(v)
+        setattr(ew, name, v.data_ptr())
+    if cond_mlp is not None:
+        for name, v in zip(("cw0", "cb0", "cw2", "cb2"), cond_mlp):
+            v = v.detach().contiguous()
+            keep.append(v)
+            setattr(ew, name, v.data_ptr())
+    te = torch.empty((rows, dim), dtype=torch.float32, device=t.device)
+    mc = torch.empty((rows, 2 * dim), dtype=torch.float32, device=t.device)
+    t = t.contiguous()
+    img_feature = img_feature.contiguous()
+    L.check(L.lib().adx_embed_forward(C.byref(ew), dim, t.data_ptr(), t.shape[0], L.ptr(cond), img_feature.data_ptr(),
+                                      img_feature.shape[0], rows, te.data_ptr(), mc.data_ptr(),
+                                      L.stream_ptr(t.device)), "adx_embed_forward")
+    return te, mc

@@ -1,0 +1,194 @@
+/*
+ * adx.h — C ABI of libadx.so, the MI355X (gfx950) implementation of the diffusion
+ * trajectory-denoising hot path of Justin900429/autonomous_driving_with_diffusion_model.
+ *
+ * The reference has no FFI layer: its boundary is the Python call surface
+ * (SURVEY.md §8b).  This header is the boundary one level below it: every entry point
+ * takes raw device pointers, plain sizes and a hipStream_t (passed as void*), returns an
+ * int status (0 = ok, <0 = error; adx_last_error() gives the message) and never allocates
+ * device memory — workspaces are sized by *_bytes() queries and owned by the caller.
+ * All tensors are fp32, contiguous row-major unless a stride is given; integer schedule
+ * indices are int64.  Each entry cites the reference code it replaces
+ * (paths relative to the reference checkout).
+ */
+#ifndef ADX_H
+#define ADX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADX_OK 0
+#define ADX_ERR_INVALID (-1)   /* bad argument / unsupported shape */
+#define ADX_ERR_HIP (-2)       /* a HIP runtime call failed */
+#define ADX_ERR_STATE (-3)     /* object used before it was initialised */
+
+typedef void* adx_stream;      /* hipStream_t */
+
+int adx_version(void);
+const char* adx_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Temporal stack, op level (each op is one kernel launch).
+ * -----------------------------------------------------------------------------------*/
+
+/* Geometry of one temporal convolution, y = epilogue(conv(x)).
+ *   kind 0: Conv1d(k=taps, stride, padding=pad)           modeling/helpers.py:80,104; temporal.py:40-44,192
+ *   kind 1: ConvTranspose1d(k=taps, stride=2, padding=1)  modeling/helpers.py:89
+ * The input may be the channel-concatenation of two tensors (skip connection,
+ * modeling/temporal.py:227): channels [0,c0) come from x0, [c0,c0+c1) from x1.
+ * Strides are in elements so that [B,H,D] trajectories can be read/written in place
+ * (the einops rearranges at modeling/temporal.py:204,243).                              */
+typedef struct adx_tconv_desc {
+  int32_t kind, taps, stride, pad;
+  int32_t c0, c1, cout;
+  int32_t lin, lout;
+  int32_t groups;            /* 0: no GroupNorm/Mish epilogue; 8: Conv1dBlock (helpers.py:95-112) */
+  float eps;
+} adx_tconv_desc;
+
+/* Size (bytes) of the packed weight image for a conv of this geometry. */
+size_t adx_tconv_packed_bytes(const adx_tconv_desc* d);
+
+/* Pack a PyTorch-layout weight ([cout][cin][taps] for kind 0, [cin][cout][taps] for kind 1)
+ * into the MFMA B-operand fragment order read by adx_tconv_forward. */
+int adx_tconv_pack(const adx_tconv_desc* d, const float* w, float* packed, adx_stream s);
+
+typedef struct adx_tconv_io {
+  const float* x0; int64_t x0_sb, x0_sc, x0_sl;   /* input 0 and its batch/channel/position strides */
+  const float* x1; int64_t x1_sb, x1_sc, x1_sl;   /* input 1 (NULL when c1 == 0) */
+  const float* packed_w;                          /* from adx_tconv_pack */
+  const float* bias;                              /* [cout] or NULL */
+  const float* gamma; const float* beta;          /* GroupNorm affine [cout] (groups > 0) */
+  const float* tbias; int64_t tbias_stride;       /* additive time bias [B][...] (temporal.py:53) or NULL */
+  const float* res; int64_t res_sb, res_sc, res_sl; /* residual added last (temporal.py:55) or NULL */
+  float* y; int64_t y_sb, y_sc, y_sl;
+  int32_t batch;
+} adx_tconv_io;
+
+/* Conv (+bias) [-> GroupNorm -> Mish] [+ time bias] [+ residual], fp32 MFMA.
+ * Replaces Conv1dBlock.forward / Downsample1d / Upsample1d / the 1x1 residual and head convs. */
+int adx_tconv_forward(const adx_tconv_desc* d, const adx_tconv_io* io, adx_stream s);
+
+/* SinusoidalPosEmb + time_mlp (+ cond_mlp) + cat(img_feature) + Mish:
+ * modeling/helpers.py:62-74, modeling/temporal.py:88-98,205-213.
+ * rows = effective batch; t has t_rows entries and img_feature feat_rows rows, both
+ * broadcast by `r % n` exactly like the reference's .repeat (temporal.py:208-211).
+ * Outputs: time_embed [rows][dim] (after the cond_mlp add) and
+ *          mish_cond  [rows][2*dim] = Mish(cat(time_embed, img_feature)).               */
+typedef struct adx_embed_weights {
+  const float* freqs;                    /* [dim/2] host-computed exp(-i*ln(1e4)/(dim/2-1)) */
+  const float* w1; const float* b1;      /* time_mlp.1: [4dim][dim] */
+  const float* w3; const float* b3;      /* time_mlp.3: [dim][4dim] */
+  const float* cw0; const float* cb0;    /* cond_mlp.0: [dim][2]   (NULL unless FREE_GUIDANCE) */
+  const float* cw2; const float* cb2;    /* cond_mlp.2: [dim][dim] */
+} adx_embed_weights;
+int adx_embed_forward(const adx_embed_weights* w, int32_t dim, const int64_t* t, int32_t t_rows,
+                      const float* cond /* [rows][2] or NULL (=> zeros) */,
+                      const float* img_feature, int32_t feat_rows, int32_t rows,
+                      float* time_embed, float* mish_cond, adx_stream s);
+
+/* ------------------------------------------------------------------------------------
+ * Whole-UNet executor (one call = TemporalMapUnet.forward without the perception pass,
+ * modeling/temporal.py:204-245).  Weights are handed over once in the reference's
+ * parameter registration order and packed into a caller-owned buffer.
+ * -----------------------------------------------------------------------------------*/
+typedef struct adx_unet adx_unet;
+
+typedef struct adx_unet_config {
+  int32_t horizon, transition_dim, dim;
+  int32_t n_mults; int32_t dim_mults[8];
+  int32_t guidance;          /* 0 NO_GUIDANCE, 1 FREE_GUIDANCE, 2 CLASSIFIER_GUIDANCE (misc/constant.py:17-20) */
+} adx_unet_config;
+
+int adx_unet_create(const adx_unet_config* cfg, adx_unet** out);
+void adx_unet_destroy(adx_unet* u);
+/* number of parameter tensors expected by adx_unet_pack (the non-perception parameters,
+ * in named_parameters() order; TrajPredict's are accepted but handled by adx_trajpred_*) */
+int adx_unet_num_params(const adx_unet* u);
+size_t adx_unet_packed_bytes(const adx_unet* u);
+int adx_unet_pack(adx_unet* u, const float* const* params, int32_t n_params, const float* freqs,
+                  void* packed, adx_stream s);
+size_t adx_unet_workspace_bytes(const adx_unet* u, int32_t rows);
+
+typedef struct adx_unet_io {
+  const float* x;             /* [rows][horizon][transition_dim] */
+  const float* img_feature; int32_t feat_rows;   /* perception output [feat_rows][dim] */
+  const int64_t* t; int32_t t_rows;
+  const float* cond;          /* [rows][2] or NULL */
+  int32_t rows;
+  float* out;                 /* [rows][horizon][transition_dim] (NO/FREE) or action [rows][horizon][3] (CLASSIFIER) */
+  float* time_embed;          /* [rows][dim] or NULL (CLASSIFIER: returned to the caller, temporal.py:236-237) */
+} adx_unet_io;
+int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx_unet_io* io, adx_stream s);
+
+/* ------------------------------------------------------------------------------------
+ * Perception: ResNet-34 forward (eval mode, BatchNorm folded at pack time),
+ * modeling/resnet.py:56-102,163-296 with fc = Linear(512, dim) (temporal.py:83-84).
+ * -----------------------------------------------------------------------------------*/
+typedef struct adx_resnet adx_resnet;
+int adx_resnet_create(int32_t out_dim, adx_resnet** out);
+void adx_resnet_destroy(adx_resnet* r);
+int adx_resnet_num_tensors(const adx_resnet* r);     /* state_dict entries excluding num_batches_tracked */
+size_t adx_resnet_packed_bytes(const adx_resnet* r);
+/* tensors: the perception.* state_dict entries in order, num_batches_tracked skipped
+ * (conv weight, bn weight, bn bias, bn running_mean, bn running_var, ..., fc weight, fc bias) */
+int adx_resnet_pack(adx_resnet* r, const float* const* tensors, int32_t n, void* packed, adx_stream s);
+size_t adx_resnet_workspace_bytes(const adx_resnet* r, int32_t batch, int32_t h, int32_t w);
+int adx_resnet_forward(adx_resnet* r, const void* packed, void* workspace, const float* img /* NCHW */,
+                       int32_t batch, int32_t h, int32_t w, float* feature /* [batch][out_dim] */, adx_stream s);
+
+/* ------------------------------------------------------------------------------------
+ * Scheduler step math.  The integer schedule and the fp32 scalar coefficients are computed
+ * by the host (the scheduler/ modules keep them as 0-dim CPU tensors) and passed by value.
+ * -----------------------------------------------------------------------------------*/
+#define ADX_PRED_EPSILON 0
+#define ADX_PRED_SAMPLE 1
+#define ADX_PRED_V 2
+
+typedef struct adx_step_coef {
+  int32_t prediction_type;     /* ADX_PRED_* */
+  int32_t clip;                /* 1: clamp x0 to [-clip_range, clip_range]; `thresholding=True` with the
+                                  diffusers default sample_max_value=1 is exactly clamp(-1, 1) */
+  float clip_range;
+  float sqrt_alpha_t, sqrt_beta_t;   /* abar_t ** 0.5, (1 - abar_t) ** 0.5 */
+  float c_x0;                  /* DDIM: abar_prev ** 0.5;  DDPM: pred_original_sample_coeff */
+  float c_dir;                 /* DDIM: (1 - abar_prev - std^2) ** 0.5 */
+  float c_x;                   /* DDPM: current_sample_coeff */
+  float c_noise;               /* DDIM: std_dev_t = eta * var ** 0.5;  DDPM: var ** 0.5 */
+  int32_t add_noise;           /* DDIM: eta > 0;  DDPM: t > 0 */
+  int32_t use_clipped_model_output;
+  /* inpainting schedulers only */
+  int32_t inpaint;             /* 1: Inpainting*Scheduler arithmetic */
+  float c_const;               /* inpainting DDIM quirk: the SCALAR variance is added to every element */
+  float c_known, c_known_noise;/* RePaint: known = c_known * target + (known_noise ? c_known_noise * z : 0) */
+  int32_t known_noise;         /* t > 0 */
+  /* classifier-free guidance combine fused in front of the step (interact.py:142-144):
+   * model_output = uncond + free_scale * (cond - uncond); rows [0,B) cond, [B,2B) uncond */
+  int32_t cfg_combine; float free_scale;
+  int32_t zero_first;          /* 1: prev[:, 0, :3] = 0 after the step (interact.py:164, train.py:88) */
+} adx_step_coef;
+
+/* S1/S3: GuidanceDDIMScheduler.step / InpaintingDDIMScheduler.step
+ *        scheduler/guidance_ddim_scheduler.py:60-173, inpainting_ddim_scheduler.py:10-153 */
+int adx_ddim_step(const adx_step_coef* c, const float* model_output, const float* sample, const float* noise,
+                  const float* target, const float* mask, float* prev, float* x0,
+                  int32_t batch, int32_t horizon, int32_t dim, adx_stream s);
+/* S2/S4: GuidanceDDPMScheduler.step / InpaintingDDPMScheduler.step / stock DDPMScheduler.step
+ *        scheduler/guidance_ddpm_scheduler.py:59-178, inpainting_ddpm_scheduler.py:10-146, train.py:87 */
+int adx_ddpm_step(const adx_step_coef* c, const float* model_output, const float* sample, const float* noise,
+                  const float* target, const float* mask, float* prev, float* x0,
+                  int32_t batch, int32_t horizon, int32_t dim, adx_stream s);
+/* add_noise (train.py:234) fused with the [...,0,:3] = 0 of train.py:235 when zero_first != 0.
+ * sqrt_ab / sqrt_1mab are the host tables sqrt(abar), sqrt(1-abar) of length n_train. */
+int adx_add_noise(const float* x, const float* noise, const int64_t* t, const float* sqrt_ab, const float* sqrt_1mab,
+                  int32_t n_train, float* out, int32_t batch, int32_t horizon, int32_t dim, int32_t zero_first,
+                  adx_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADX_H */
