@@ -46,6 +46,10 @@ class UnetIO(C.Structure):
                 ("rows", i32), ("out", vp), ("time_embed", vp)]
 
 
+class Conv2dDesc(C.Structure):
+    _fields_ = [("cin", i32), ("cout", i32), ("k", i32), ("stride", i32), ("pad", i32)]
+
+
 class StepCoef(C.Structure):
     _fields_ = [("prediction_type", i32), ("clip", i32), ("clip_range", f32), ("sqrt_alpha_t", f32),
                 ("sqrt_beta_t", f32), ("c_x0", f32), ("c_dir", f32), ("c_x", f32), ("c_noise", f32),
@@ -75,6 +79,9 @@ _SIGS = {
     "adx_resnet_pack": (i32, [vp, C.POINTER(vp), i32, vp, vp]),
     "adx_resnet_workspace_bytes": (C.c_size_t, [vp, i32, i32, i32]),
     "adx_resnet_forward": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp]),
+    "adx_conv2d_packed_bytes": (C.c_size_t, [C.POINTER(Conv2dDesc)]),
+    "adx_conv2d_pack": (i32, [C.POINTER(Conv2dDesc), vp, vp, vp]),
+    "adx_conv2d_forward": (i32, [C.POINTER(Conv2dDesc), vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "adx_ddim_step": (i32, [C.POINTER(StepCoef), vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "adx_ddpm_step": (i32, [C.POINTER(StepCoef), vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "adx_add_noise": (i32, [vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp]),

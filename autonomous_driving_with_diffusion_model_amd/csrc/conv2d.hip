@@ -219,10 +219,18 @@ static size_t align64f(size_t v) { return (v + 63) / 64 * 64; }
 
 static int conv_out(int h, int k, int s, int p) { return (h + 2 * p - k) / s + 1; }
 
+static int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const float* scale, const float* shift,
+                             const float* res, float* y, int N, int H, int W, int relu, hipStream_t s);
+
 static int conv2d_launch(const ConvSpec& L, const float* base, const float* x, const float* res, float* y, int N, int H,
                          int W, int relu, hipStream_t s) {
+  return conv2d_launch_raw(L, x, base + L.o_w, base + L.o_scale, base + L.o_shift, res, y, N, H, W, relu, s);
+}
+
+static int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const float* scale, const float* shift,
+                             const float* res, float* y, int N, int H, int W, int relu, hipStream_t s) {
   Conv2dArgs a;
-  a.x = x; a.w = base + L.o_w; a.scale = base + L.o_scale; a.shift = base + L.o_shift; a.res = res; a.y = y;
+  a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.res = res; a.y = y;
   a.N = N; a.Cin = L.cin; a.H = H; a.W = W; a.Cout = L.cout;
   a.OH = conv_out(H, L.k, L.stride, L.pad); a.OW = conv_out(W, L.k, L.stride, L.pad);
   a.KH = L.k; a.KW = L.k; a.stride = L.stride; a.pad = L.pad; a.relu = relu;
@@ -252,7 +260,50 @@ static int conv2d_launch(const ConvSpec& L, const float* base, const float* x, c
 
 using namespace adx;
 
+static int spec_from_desc(const adx_conv2d_desc* d, ConvSpec* L) {
+  ADX_REQUIRE(d != nullptr, "conv2d: null descriptor");
+  ADX_REQUIRE(d->cin >= 1 && d->cout >= 64 && d->cout % kCoutT == 0, "conv2d: cout %d must be a multiple of %d", d->cout,
+              kCoutT);
+  ADX_REQUIRE(d->k >= 1 && d->k <= 7 && (d->stride == 1 || d->stride == 2) && d->pad >= 0 && d->pad <= 3,
+              "conv2d: unsupported k/stride/pad %d/%d/%d", d->k, d->stride, d->pad);
+  memset(L, 0, sizeof(*L));
+  L->cin = d->cin; L->cout = d->cout; L->k = d->k; L->stride = d->stride; L->pad = d->pad;
+  L->cc = d->cin >= 16 ? 16 : 4;
+  L->cin_pad = round_up(d->cin, L->cc);
+  return ADX_OK;
+}
+
 extern "C" {
+
+size_t adx_conv2d_packed_bytes(const adx_conv2d_desc* d) {
+  ConvSpec L;
+  if (spec_from_desc(d, &L) != ADX_OK) return 0;
+  return sizeof(float) * (size_t)L.k * L.k * L.cin_pad * L.cout;
+}
+
+int adx_conv2d_pack(const adx_conv2d_desc* d, const float* w, float* packed, adx_stream stream) {
+  ConvSpec L;
+  int rc = spec_from_desc(d, &L);
+  if (rc != ADX_OK) return rc;
+  ADX_REQUIRE(w && packed, "adx_conv2d_pack: null pointer");
+  const size_t total = (size_t)L.k * L.k * L.cin_pad * L.cout;
+  conv2d_pack_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+      w, packed, L.cout, L.cin, L.k * L.k, L.cin_pad, total);
+  ADX_LAUNCH_CHECK();
+  return ADX_OK;
+}
+
+int adx_conv2d_forward(const adx_conv2d_desc* d, const float* x, const float* packed_w, const float* scale,
+                       const float* shift, const float* res, float* y, int32_t n, int32_t h, int32_t w, int32_t relu,
+                       adx_stream stream) {
+  ConvSpec L;
+  int rc = spec_from_desc(d, &L);
+  if (rc != ADX_OK) return rc;
+  ADX_REQUIRE(x && packed_w && y, "adx_conv2d_forward: null tensor");
+  ADX_REQUIRE((scale == nullptr) == (shift == nullptr), "adx_conv2d_forward: scale and shift go together");
+  ADX_REQUIRE(n >= 1 && h + 2 * d->pad >= d->k && w + 2 * d->pad >= d->k, "adx_conv2d_forward: input too small");
+  return conv2d_launch_raw(L, x, packed_w, scale, shift, res, y, n, h, w, relu, (hipStream_t)stream);
+}
 
 int adx_resnet_create(int32_t out_dim, adx_resnet** out) {
   ADX_REQUIRE(out != nullptr && out_dim >= 1 && out_dim <= 4096, "adx_resnet_create: bad argument");

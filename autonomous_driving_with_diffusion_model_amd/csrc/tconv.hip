@@ -20,6 +20,10 @@
 //   3. the 4 partial tiles are summed through LDS in the [sample][channel][pos] order of
 //      the output tensor, one wave per (sample, group) computes two-pass mean/variance with
 //      wavefront shuffles, applies affine + Mish + time bias + residual and stores coalesced.
+#include <array>
+#include <map>
+#include <mutex>
+
 #include "tconv.h"
 
 namespace adx {
@@ -336,18 +340,29 @@ int tconv_tile(const adx_tconv_desc* d, int batch, TConvTile* t) {
   }
   if (pr < 0) pr = 0;
   const int lp_min = t->pl + d->lin + pr;
-  int best_cost = 1 << 30, best_lp = lp_min, best_rs = t->bt * lp_min;
-  for (int lp = lp_min; lp <= lp_min + 16; ++lp)
-    for (int rs = t->bt * lp; rs <= t->bt * lp + 32; ++rs) {
-      const int cost = lds_conflict_cost(d, t->bt, t->mf, t->pl, lp, rs);
-      if (cost < best_cost || (cost == best_cost && rs < best_rs)) {
-        best_cost = cost;
-        best_lp = lp;
-        best_rs = rs;
-      }
+  // the pitch search costs ~1 ms of host time: memoise it per geometry (thread-safe)
+  {
+    const std::array<int, 8> key{d->kind, d->taps, d->stride, d->pad, d->lin, d->lout, t->bt, t->mf};
+    static std::mutex mu;
+    static std::map<std::array<int, 8>, std::pair<int, int>> memo;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = memo.find(key);
+    if (it == memo.end()) {
+      int best_cost = 1 << 30, best_lp = lp_min, best_rs = t->bt * lp_min;
+      for (int lp = lp_min; lp <= lp_min + 16; ++lp)
+        for (int rs = t->bt * lp; rs <= t->bt * lp + 32; ++rs) {
+          const int cost = lds_conflict_cost(d, t->bt, t->mf, t->pl, lp, rs);
+          if (cost < best_cost || (cost == best_cost && rs < best_rs)) {
+            best_cost = cost;
+            best_lp = lp;
+            best_rs = rs;
+          }
+        }
+      it = memo.emplace(key, std::make_pair(best_lp, best_rs)).first;
     }
-  t->lp = best_lp;
-  t->rs = best_rs;
+    t->lp = it->second.first;
+    t->rs = it->second.second;
+  }
   // keep the staged tile <= 64 KB so two workgroups fit a CU; chunk the channels otherwise
   int ck = (16384 / t->rs) / 16 * 16;
   if (ck < 16) ck = 16;

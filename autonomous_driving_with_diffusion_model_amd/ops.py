@@ -83,7 +83,31 @@ def embed(freqs, w1, b1, w3, b3, t, img_feature, rows, cond=None, cond_mlp=None)
     mc = torch.empty((rows, 2 * dim), dtype=torch.float32, device=t.device)
     t = t.contiguous()
     img_feature = img_feature.contiguous()
+    if cond is not None:
+        cond = cond.contiguous()
     L.check(L.lib().adx_embed_forward(C.byref(ew), dim, t.data_ptr(), t.shape[0], L.ptr(cond), img_feature.data_ptr(),
                                       img_feature.shape[0], rows, te.data_ptr(), mc.data_ptr(),
                                       L.stream_ptr(t.device)), "adx_embed_forward")
     return te, mc
+
+
+def conv2d(x: torch.Tensor, weight: torch.Tensor, *, stride: int = 1, pad: int = 0, scale=None, shift=None, res=None,
+           relu: bool = False, packed: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+    """NCHW conv2d with the fused BatchNorm(eval)/residual/ReLU epilogue of the perception encoder."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+    n, cin, h, w = x.shape
+    cout, _, k, _ = weight.shape
+    d = L.Conv2dDesc(cin, cout, k, stride, pad)
+    s = L.stream_ptr(x.device)
+    if packed is None:
+        nbytes = L.lib().adx_conv2d_packed_bytes(C.byref(d))
+        if nbytes == 0:
+            L.check(-1, "adx_conv2d_packed_bytes")
+        packed = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+        wc = weight.detach().contiguous()
+        L.check(L.lib().adx_conv2d_pack(C.byref(d), wc.data_ptr(), packed.data_ptr(), s), "adx_conv2d_pack")
+    oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    y = out if out is not None else torch.empty((n, cout, oh, ow), dtype=torch.float32, device=x.device)
+    L.check(L.lib().adx_conv2d_forward(C.byref(d), x.data_ptr(), packed.data_ptr(), L.ptr(scale), L.ptr(shift),
+                                       L.ptr(res), y.data_ptr(), n, h, w, int(relu), s), "adx_conv2d_forward")
+    return y, packed

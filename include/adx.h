@@ -141,6 +141,16 @@ size_t adx_resnet_workspace_bytes(const adx_resnet* r, int32_t batch, int32_t h,
 int adx_resnet_forward(adx_resnet* r, const void* packed, void* workspace, const float* img /* NCHW */,
                        int32_t batch, int32_t h, int32_t w, float* feature /* [batch][out_dim] */, adx_stream s);
 
+/* Op-level 2-D convolution used by the perception executor (one launch): NCHW fp32,
+ * y = [relu]( conv(x, w) * scale[c] + shift[c] [+ res] ); scale/shift = eval-mode BatchNorm2d
+ * (modeling/resnet.py:87-102).  cout must be a multiple of 64. */
+typedef struct adx_conv2d_desc { int32_t cin, cout, k, stride, pad; } adx_conv2d_desc;
+size_t adx_conv2d_packed_bytes(const adx_conv2d_desc* d);
+int adx_conv2d_pack(const adx_conv2d_desc* d, const float* w /* [cout][cin][k][k] */, float* packed, adx_stream s);
+int adx_conv2d_forward(const adx_conv2d_desc* d, const float* x, const float* packed_w, const float* scale,
+                       const float* shift, const float* res, float* y, int32_t n, int32_t h, int32_t w,
+                       int32_t relu, adx_stream s);
+
 /* ------------------------------------------------------------------------------------
  * Scheduler step math.  The integer schedule and the fp32 scalar coefficients are computed
  * by the host (the scheduler/ modules keep them as 0-dim CPU tensors) and passed by value.

@@ -42,7 +42,7 @@ def test_ops(golden):
     close(U.downsample(sd, "downs.0.3.", x), g["ops.downsample"], ATOL)
     close(U.upsample(sd, "ups.0.3.", uni("ops.x256", (2, 256, 2))), g["ops.upsample"], ATOL)
     t = torch.tensor([0, 37, 99], dtype=torch.int64)
-    close(U.sinusoidal_pos_emb(t, 64), g["ops.sinusoidal"], 0.0)
+    close(U.sinusoidal_pos_emb(t, 64), g["ops.sinusoidal"], 1e-6)
     close(U.time_mlp(sd, t, 64), g["ops.time_mlp"], ATOL)
     xb = uni("ops.xbb", (2, 64, 16, 24))
     close(R.basic_block(sd, "perception.layer2.0.", xb, 2), g["ops.basic_block_down"], ATOL)
@@ -131,7 +131,7 @@ def test_scheduler_steps(golden):
     mo, x = u("sched.mo"), u("sched.x")
     z = P.step_noise(0, (3, 16, 7), seed=21)
     tt, tm = u("sched.tt", -1, 1), (P._uniform("sched.tm", 21, (3, 16, 7), 0, 1) > 0.5).float()
-    tol = 0.0  # same scalar/elementwise op order as the reference -> bit-exact on CPU
+    tol = 3e-7  # same op order as the reference: bit-exact on the CPU that made the fixtures, 1 ulp on others
     for pt in ("sample", "epsilon", "v_prediction"):
         kw = dict(SCHED_KW, prediction_type=pt)
         for n, ts in ((50, (98, 50, 0)), (10, (90, 0)), (100, (99, 1, 0))):
@@ -161,7 +161,7 @@ def test_scheduler_steps(golden):
                 close(s4.step(mo, tt_, x, variance_noise=z, target_traj=tt, target_mask=tm).prev_sample,
                       g[f"sched.inp_ddpm.{pt}.n{n}.t{t}.prev"], tol)
                 close(s4.step(mo, tt_, x, variance_noise=z).prev_sample, g[f"sched.inp_ddpm.{pt}.n{n}.t{t}.plain"], tol)
-    close(base.add_noise(x, z, torch.tensor([0, 50, 99])), g["sched.add_noise"], 0.0)
+    close(base.add_noise(x, z, torch.tensor([0, 50, 99])), g["sched.add_noise"], 3e-7)
     # the reference's GuidanceDDPMScheduler(thresholding=True) raises NameError (np not imported)
     assert int(g["sched.ddpm_threshold_raises"]) == 1
 
