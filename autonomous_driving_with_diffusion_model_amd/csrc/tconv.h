@@ -16,6 +16,7 @@ struct TConvTile {
   int ct, nf;                  // channels per workgroup, 16-col fragments
   int pl, lp, rs, ck;          // left zero pad, per-sample LDS pitch, LDS row stride, channels per LDS chunk
   int ntiles;                  // workgroups along channels
+  int nw;                      // waves per workgroup (K-split factor): 4, 8 or 16
   size_t lds_bytes;
 };
 

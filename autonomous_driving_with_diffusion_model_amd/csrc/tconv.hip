@@ -36,6 +36,7 @@ struct TConvArgs {
   float eps;
   int ncb, nkb;
   int bt, ct, log2_ct, pl, lp, rs, ck, ntiles, cin_pad;
+  int dense;  // both inputs are plain [B][C][L] tensors with lin % 4 == 0: 16-byte staging loads
 };
 
 __device__ __forceinline__ int tconv_in_pos(int kind, int l, int tap, int stride, int pad, bool& ok) {
@@ -49,8 +50,27 @@ __device__ __forceinline__ int tconv_in_pos(int kind, int l, int tap, int stride
   return v >> 1;
 }
 
-template <int MF, int NF>
-__global__ void __launch_bounds__(256) tconv_kernel(const TConvArgs a) {
+template <int NW>
+struct KCursor {  // walks this wave's (tap, 16-channel block) pairs of one chunk: i = wave, wave + NW, ...
+  int tap, cb;
+  __device__ __forceinline__ void init(int wave, int ncbc) {
+    tap = 0;
+    cb = wave;
+    while (cb >= ncbc) { cb -= ncbc; ++tap; }
+  }
+  __device__ __forceinline__ void next(int ncbc) {
+    cb += NW;
+    while (cb >= ncbc) { cb -= ncbc; ++tap; }
+  }
+};
+
+// PF = depth of the register ring that keeps the packed-weight loads of the next PF K-blocks in
+// flight while the current block's MFMAs run (the weights come from L2 / Infinity Cache).
+// NW = waves per workgroup = K-split factor (4 for shallow layers, 16 where taps*cin/16 is large, so
+// that a CU holds 4 waves per SIMD and the MFMA pipe stays fed while other waves wait on loads).
+template <int MF, int NF, int PF, int NW>
+__global__ void __launch_bounds__(64 * NW) tconv_kernel(const TConvArgs a) {
+  constexpr int NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -74,46 +94,73 @@ __global__ void __launch_bounds__(256) tconv_kernel(const TConvArgs a) {
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.io.packed_w);
+  const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.io.packed_w) + (size_t)nt * NF * a.nkb * 64 + lane;
+  const int nq = a.rs >> 2;      // 16-byte quads per staged row (pl, lp, rs are multiples of 4)
+  const int lpq = max(a.lp >> 2, 1), plq = a.pl >> 2, linq = a.lin >> 2;  // used on the dense path only
+  const bool dense = a.dense != 0;
+  f32x4 bq[PF][NF];
 
   for (int c0 = 0; c0 < a.cin_pad; c0 += a.ck) {
     const int ckc = min(a.ck, a.cin_pad - c0);
+    const int ncbc = ckc >> 4;
+    const int nblk = a.taps * ncbc;
+    const int nbw = nblk > wave ? (nblk - wave + NW - 1) / NW : 0;  // K-blocks of this wave in this chunk
+    const int cb0 = c0 >> 4;
+    // ---- weight prefetch for the first PF blocks; in flight while the input tile is staged ----
+    KCursor<NW> lc;
+    lc.init(wave, ncbc);
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+      const int tp = min(lc.tap, a.taps - 1);  // past-the-end slots re-read a valid block and are never used
+      const f32x4* src = wp + (size_t)(tp * a.ncb + cb0 + lc.cb) * 64;
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) bq[s][nf] = src[(size_t)nf * a.nkb * 64];
+      lc.next(ncbc);
+    }
     if (c0 > 0) __syncthreads();
-    // ---- stage [ckc channels][rs columns] of the input, zero padded ------------------------
-    for (int col = lane; col < a.rs; col += 64) {
-      const int bl = col / a.lp;
-      const int ip = col - bl * a.lp - a.pl;
-      const int b = b0 + bl;
-      const bool ok = bl < a.bt && ip >= 0 && ip < a.lin && b < batch;
-      const int64_t off0 = (int64_t)b * a.io.x0_sb + (int64_t)ip * a.io.x0_sl;
-      const int64_t off1 = (int64_t)b * a.io.x1_sb + (int64_t)ip * a.io.x1_sl;
-      for (int cl = wave; cl < ckc; cl += 4) {
+    // ---- stage [ckc channels][rs columns], zero padded, one 16-byte quad per work item ---------
+    // every quad of a row is either all halo/pad (zeros) or 4 consecutive positions of one sample
+    {
+      const int items = ckc * nq;
+#pragma unroll 4
+      for (int it = tid; it < items; it += NT) {
+        const int cl = it / nq, qi = it - cl * nq;
         const int ci = c0 + cl;
-        float v = 0.f;
-        if (ok && ci < a.cin) {
-          v = ci < a.c0 ? a.io.x0[off0 + (int64_t)ci * a.io.x0_sc]
-                        : a.io.x1[off1 + (int64_t)(ci - a.c0) * a.io.x1_sc];
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ci < a.cin) {
+          const bool first = ci < a.c0;
+          const float* src = first ? a.io.x0 + (int64_t)ci * a.io.x0_sc : a.io.x1 + (int64_t)(ci - a.c0) * a.io.x1_sc;
+          const int64_t sb = first ? a.io.x0_sb : a.io.x1_sb;
+          if (dense) {
+            const int bl = qi / lpq, ql = qi - bl * lpq - plq;
+            const int b = b0 + bl;
+            if (bl < a.bt && ql >= 0 && ql < linq && b < batch)
+              v = *reinterpret_cast<const f32x4*>(src + (int64_t)b * sb + 4 * ql);
+          } else {
+            const int64_t sl = first ? a.io.x0_sl : a.io.x1_sl;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int col = 4 * qi + k;
+              const int bl = col / a.lp, ip = col - bl * a.lp - a.pl;
+              const int b = b0 + bl;
+              if (bl < a.bt && ip >= 0 && ip < a.lin && b < batch) v[k] = src[(int64_t)b * sb + (int64_t)ip * sl];
+            }
+          }
         }
-        smem[cl * a.rs + col] = v;
+        *reinterpret_cast<f32x4*>(smem + 4 * it) = v;
       }
     }
     __syncthreads();
-    // ---- K loop: this wave takes every 4th (tap, 16-channel block) -------------------------
-    const int ncbc = ckc >> 4;
-    const int nblk = a.taps * ncbc;
-    int tap = 0, cbl = wave;
-    while (cbl >= ncbc && tap < a.taps) { cbl -= ncbc; ++tap; }
-    for (int i = wave; i < nblk; i += 4) {
-      const int kb = tap * a.ncb + (c0 >> 4) + cbl;
-      f32x4 bv[NF];
-#pragma unroll
-      for (int nf = 0; nf < NF; ++nf) bv[nf] = wp[((size_t)(nt * NF + nf) * a.nkb + kb) * 64 + lane];
+    // ---- K loop over this wave's blocks, PF-deep weight ring -----------------------------------
+    KCursor<NW> cc;
+    cc.init(wave, ncbc);
+    auto compute = [&](const f32x4 (&bw)[NF], int tap, int cbl) {
       float av[MF][4];
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
         bool ok;
         const int ip = tconv_in_pos(a.kind, rowl[mf], tap, a.stride, a.pad, ok);
-        const int col = ok ? rowoff[mf] + ip : 0;  // column 0 is always a zero pad when a parity can be invalid
+        const int col = ok ? rowoff[mf] + ip : 0;  // column 0 is always a zero pad
         const float* xp = smem + (cbl * 16 + kk) * a.rs + col;
 #pragma unroll
         for (int j = 0; j < 4; ++j) av[mf][j] = xp[4 * j * a.rs];
@@ -124,15 +171,33 @@ __global__ void __launch_bounds__(256) tconv_kernel(const TConvArgs a) {
         for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
           for (int nf = 0; nf < NF; ++nf)
-            acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mf][j], bv[nf][j], acc[mf][nf], 0, 0, 0);
-      cbl += 4;
-      while (cbl >= ncbc) { cbl -= ncbc; ++tap; }
+            acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mf][j], bw[nf][j], acc[mf][nf], 0, 0, 0);
+    };
+    int j0 = 0;
+    for (; j0 + PF <= nbw; j0 += PF) {  // full groups: branch-free
+#pragma unroll
+      for (int s = 0; s < PF; ++s) {
+        compute(bq[s], cc.tap, cc.cb);
+        cc.next(ncbc);
+        const int tp = min(lc.tap, a.taps - 1);
+        const f32x4* src = wp + (size_t)(tp * a.ncb + cb0 + lc.cb) * 64;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) bq[s][nf] = src[(size_t)nf * a.nkb * 64];
+        lc.next(ncbc);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {      // tail group: its weights are already in the ring
+      if (j0 + s < nbw) {
+        compute(bq[s], cc.tap, cc.cb);
+        cc.next(ncbc);
+      }
     }
   }
 
   // ---- epilogue: sum the 4 K-partials through LDS, laid out [sample][channel][pos] ----------
   __syncthreads();
-  const int tile_elems = 256 * MF * NF;  // bt * ct * lout
+  constexpr int tile_elems = 256 * MF * NF;  // bt * ct * lout
   float* P = smem;
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf)
@@ -148,59 +213,97 @@ __global__ void __launch_bounds__(256) tconv_kernel(const TConvArgs a) {
     }
   __syncthreads();
   const int n0 = nt * a.ct;
-  float* T = smem;  // the sum overwrites partial 0 element by element
-  for (int e = tid; e < tile_elems; e += 256) {
-    float v = ((P[e] + P[e + tile_elems]) + P[e + 2 * tile_elems]) + P[e + 3 * tile_elems];
-    const int c = n0 + ((e >> a.log2_lout) & (a.ct - 1));
-    if (a.io.bias != nullptr && c < a.cout) v += a.io.bias[c];
-    T[e] = v;
+  // Every thread owns EPT elements e = tid + NT*k of the output tile; 64 consecutive elements (one
+  // wave's worth) always belong to the same (sample, GroupNorm group) pair when n % 64 == 0.
+  constexpr int EPT = (tile_elems + NT - 1) / NT;
+  float v[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int e = tid + NT * k;
+    v[k] = 0.f;
+    if (e < tile_elems) {
+      float sum = P[e];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) sum += P[e + w * tile_elems];  // fixed order: deterministic
+      const int c = n0 + ((e >> a.log2_lout) & (a.ct - 1));
+      if (a.io.bias != nullptr && c < a.cout) sum += a.io.bias[c];
+      v[k] = sum;
+    }
   }
-  __syncthreads();
-
-  if (a.groups > 0) {
-    // one wave per (sample, group): cg*lout contiguous floats of T
-    const int gpt = a.ct / a.cg;
-    const int npairs = a.bt * gpt;
-    const int n = a.cg << a.log2_lout;
+  const int n = a.cg << a.log2_lout;  // elements per (sample, group)
+  float* red = smem + NW * tile_elems; // 2 x (tile_elems / 64) partial sums, behind the K-partials
+  constexpr int NCH = tile_elems / 64;
+  const bool gn = a.groups > 0;
+  // issue every global load of the epilogue now; they land while the statistics are reduced
+  float gm[EPT], be[EPT], tb[EPT], rs_[EPT];
+  int64_t yoff[EPT];
+  bool live[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int e = tid + NT * k;
+    const int l = e & (a.lout - 1);
+    const int c = n0 + ((e >> a.log2_lout) & (a.ct - 1));
+    const int b = b0 + (e >> (a.log2_lout + a.log2_ct));
+    live[k] = e < tile_elems && b < batch && c < a.cout;
+    gm[k] = 1.f; be[k] = 0.f; tb[k] = 0.f; rs_[k] = 0.f; yoff[k] = 0;
+    if (live[k]) {
+      if (gn) { gm[k] = a.io.gamma[c]; be[k] = a.io.beta[c]; }
+      if (a.io.tbias != nullptr) tb[k] = a.io.tbias[(int64_t)b * a.io.tbias_stride + c];
+      if (a.io.res != nullptr)
+        rs_[k] = a.io.res[(int64_t)b * a.io.res_sb + (int64_t)c * a.io.res_sc + (int64_t)l * a.io.res_sl];
+      yoff[k] = (int64_t)b * a.io.y_sb + (int64_t)c * a.io.y_sc + (int64_t)l * a.io.y_sl;
+    }
+  }
+  if (gn) {
+    // two-pass mean / variance: wave shuffle, then the pair's n/64 wave partials through LDS
+    const int cpp = n >> 6;  // 64-element chunks per pair (n is a multiple of 64: checked on the host)
     const float inv_n = 1.0f / (float)n;
-    for (int pidx = wave; pidx < npairs; pidx += 4) {
-      const int bl = pidx / gpt, g = pidx - bl * gpt;
-      const int b = b0 + bl;
-      if (b >= batch) continue;
-      const float* tp = T + (((bl << a.log2_ct) + g * a.cg) << a.log2_lout);
+    float mean[EPT], rstd[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const float s = wave_sum(v[k]);
+      const int ch = wave + NW * k;
+      if (lane == 0 && ch < NCH) red[ch] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int ch = min(wave + NW * k, NCH - 1);
+      const int base = (ch / cpp) * cpp;
       float s = 0.f;
-      for (int e = lane; e < n; e += 64) s += tp[e];
-      const float mean = wave_sum(s) * inv_n;
+      for (int i = 0; i < cpp; ++i) s += red[base + i];
+      mean[k] = s * inv_n;
+      const float d = v[k] - mean[k];
+      const float q = wave_sum(d * d);
+      if (lane == 0 && wave + NW * k < NCH) red[NCH + wave + NW * k] = q;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int ch = min(wave + NW * k, NCH - 1);
+      const int base = (ch / cpp) * cpp;
       float q = 0.f;
-      for (int e = lane; e < n; e += 64) {
-        const float d = tp[e] - mean;
-        q += d * d;
-      }
-      const float var = wave_sum(q) * inv_n;
-      const float rstd = 1.0f / sqrtf(var + a.eps);
-      for (int e = lane; e < n; e += 64) {
-        const int c = n0 + g * a.cg + (e >> a.log2_lout);
-        const int l = e & (a.lout - 1);
-        const float sc = rstd * a.io.gamma[c];
-        float v = (tp[e] - mean) * sc + a.io.beta[c];
-        v = mish_f(v);
-        if (a.io.tbias != nullptr) v += a.io.tbias[(int64_t)b * a.io.tbias_stride + c];
-        if (a.io.res != nullptr)
-          v += a.io.res[(int64_t)b * a.io.res_sb + (int64_t)c * a.io.res_sc + (int64_t)l * a.io.res_sl];
-        a.io.y[(int64_t)b * a.io.y_sb + (int64_t)c * a.io.y_sc + (int64_t)l * a.io.y_sl] = v;
+      for (int i = 0; i < cpp; ++i) q += red[NCH + base + i];
+      rstd[k] = 1.0f / sqrtf(q * inv_n + a.eps);
+    }
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      if (live[k]) {
+        float o = (v[k] - mean[k]) * (rstd[k] * gm[k]) + be[k];
+        o = mish_f(o);
+        if (a.io.tbias != nullptr) o += tb[k];
+        if (a.io.res != nullptr) o += rs_[k];
+        a.io.y[yoff[k]] = o;
       }
     }
   } else {
-    for (int e = tid; e < tile_elems; e += 256) {
-      const int l = e & (a.lout - 1);
-      const int c = n0 + ((e >> a.log2_lout) & (a.ct - 1));
-      const int b = b0 + (e >> (a.log2_lout + a.log2_ct));
-      if (b < batch && c < a.cout) {
-        float v = T[e];
-        if (a.io.tbias != nullptr) v += a.io.tbias[(int64_t)b * a.io.tbias_stride + c];
-        if (a.io.res != nullptr)
-          v += a.io.res[(int64_t)b * a.io.res_sb + (int64_t)c * a.io.res_sc + (int64_t)l * a.io.res_sl];
-        a.io.y[(int64_t)b * a.io.y_sb + (int64_t)c * a.io.y_sc + (int64_t)l * a.io.y_sl] = v;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      if (live[k]) {
+        float o = v[k];
+        if (a.io.tbias != nullptr) o += tb[k];
+        if (a.io.res != nullptr) o += rs_[k];
+        a.io.y[yoff[k]] = o;
       }
     }
   }
@@ -225,6 +328,8 @@ __global__ void tconv_pack_kernel(const float* __restrict__ w, float* __restrict
     v = kind == 0 ? w[((size_t)n * cin + ci) * taps + tap] : w[((size_t)ci * cout + n) * taps + tap];
   packed[idx] = v;
 }
+
+constexpr size_t kMaxTconvLds = 132 * 1024;
 
 static int ilog2_exact(int v) {
   int l = 0;
@@ -252,6 +357,8 @@ int tconv_check(const adx_tconv_desc* d) {
     const int cg = d->cout / d->groups;
     ADX_REQUIRE(ilog2_exact(cg) >= 0 && cg <= 128, "tconv: group width %d must be a power of two <= 128", cg);
     ADX_REQUIRE(d->cout % 16 == 0, "tconv: GroupNorm convs need cout %% 16 == 0");
+    ADX_REQUIRE((cg * d->lout) % 64 == 0, "tconv: GroupNorm group of %d x %d elements must be a multiple of 64", cg,
+                d->lout);
   }
   return ADX_OK;
 }
@@ -339,7 +446,11 @@ int tconv_tile(const adx_tconv_desc* d, int batch, TConvTile* t) {
     pr = (d->lout - 1 + d->pad) / 2 - (d->lin - 1);
   }
   if (pr < 0) pr = 0;
-  const int lp_min = t->pl + d->lin + pr;
+  // 16-byte staging: when lin is a multiple of 4 keep every sample's data on quad boundaries
+  const bool quads = d->lin % 4 == 0;
+  const int step = quads ? 4 : 1;
+  if (quads) t->pl = round_up(t->pl, 4);
+  const int lp_min = round_up(t->pl + d->lin + pr, step);
   // the pitch search costs ~1 ms of host time: memoise it per geometry (thread-safe)
   {
     const std::array<int, 8> key{d->kind, d->taps, d->stride, d->pad, d->lin, d->lout, t->bt, t->mf};
@@ -348,9 +459,9 @@ int tconv_tile(const adx_tconv_desc* d, int batch, TConvTile* t) {
     std::lock_guard<std::mutex> lock(mu);
     auto it = memo.find(key);
     if (it == memo.end()) {
-      int best_cost = 1 << 30, best_lp = lp_min, best_rs = t->bt * lp_min;
-      for (int lp = lp_min; lp <= lp_min + 16; ++lp)
-        for (int rs = t->bt * lp; rs <= t->bt * lp + 32; ++rs) {
+      int best_cost = 1 << 30, best_lp = lp_min, best_rs = round_up(t->bt * lp_min, 4);
+      for (int lp = lp_min; lp <= lp_min + 16; lp += step)
+        for (int rs = round_up(t->bt * lp, 4); rs <= t->bt * lp + 36; rs += 4) {
           const int cost = lds_conflict_cost(d, t->bt, t->mf, t->pl, lp, rs);
           if (cost < best_cost || (cost == best_cost && rs < best_rs)) {
             best_cost = cost;
@@ -363,14 +474,19 @@ int tconv_tile(const adx_tconv_desc* d, int batch, TConvTile* t) {
     t->lp = it->second.first;
     t->rs = it->second.second;
   }
-  // keep the staged tile <= 64 KB so two workgroups fit a CU; chunk the channels otherwise
-  int ck = (16384 / t->rs) / 16 * 16;
-  if (ck < 16) ck = 16;
-  t->ck = ck < t->cin_pad ? ck : t->cin_pad;
+  // Staged tile: <= 64 KB when there are enough workgroups to co-schedule two per CU, up to 128 KB
+  // when the whole grid is a single wave of workgroups anyway (then one chunk = one staging phase);
+  // the channels are split into equal chunks beyond that.
+  const bool single_wave = (long)btiles * t->ntiles <= 320;
+  int ck_max = ((single_wave ? 32768 : 16384) / t->rs) / 16 * 16;
+  if (ck_max < 16) ck_max = 16;
+  const int nchunks = ceil_div(t->cin_pad, ck_max);
+  t->ck = round_up(ceil_div(t->cin_pad, nchunks), 16);
   const size_t stage = (size_t)t->ck * t->rs;
-  const size_t epi = (size_t)4 * 256 * t->mf * t->nf;
+  t->nw = t->nkb >= 64 ? 16 : (t->nkb >= 32 ? 8 : 4);   // waves per workgroup = K split
+  const size_t epi = (size_t)t->nw * 256 * t->mf * t->nf + 2 * 4 * t->mf * t->nf;  // K-partials + GN wave partials
   t->lds_bytes = sizeof(float) * (stage > epi ? stage : epi);
-  ADX_REQUIRE(t->lds_bytes <= 64 * 1024, "tconv: LDS tile of %zu bytes exceeds 64 KB", t->lds_bytes);
+  ADX_REQUIRE(t->lds_bytes <= kMaxTconvLds, "tconv: LDS tile of %zu bytes exceeds %zu", t->lds_bytes, kMaxTconvLds);
   return ADX_OK;
 }
 
@@ -393,8 +509,23 @@ int tconv_pack(const adx_tconv_desc* d, const float* w, float* packed, hipStream
 }
 
 template <int MF, int NF>
-static int launch(const TConvArgs& a, int grid, size_t lds, hipStream_t s) {
-  tconv_kernel<MF, NF><<<dim3(grid), dim3(256), lds, s>>>(a);
+static int launch(const TConvArgs& a, int grid, size_t lds, int nw, hipStream_t s) {
+  // ring depth: ~16 MFMAs (512 cycles) of work per slot x PF slots covers an L2 / Infinity Cache round trip
+  constexpr int PF = NF >= 8 ? 2 : ((MF * NF >= 4) ? 4 : 8);
+  constexpr int PF16 = NF >= 8 ? 2 : (MF * NF >= 8 ? 2 : 4);  // 1024-thread workgroups: <= 128 VGPRs per lane
+  static bool attr_set = false;  // dynamic LDS above 64 KB must be opted into once per kernel
+  if (!attr_set) {
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_kernel<MF, NF, PF16, 16>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxTconvLds));
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_kernel<MF, NF, PF, 8>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxTconvLds));
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_kernel<MF, NF, PF, 4>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxTconvLds));
+    attr_set = true;
+  }
+  if (nw == 16) tconv_kernel<MF, NF, PF16, 16><<<dim3(grid), dim3(1024), lds, s>>>(a);
+  else if (nw == 8) tconv_kernel<MF, NF, PF, 8><<<dim3(grid), dim3(512), lds, s>>>(a);
+  else tconv_kernel<MF, NF, PF, 4><<<dim3(grid), dim3(256), lds, s>>>(a);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
 }
@@ -416,18 +547,23 @@ int tconv_forward(const adx_tconv_desc* d, const adx_tconv_io* io, hipStream_t s
   a.ncb = t.ncb; a.nkb = t.nkb;
   a.bt = t.bt; a.ct = t.ct; a.log2_ct = ilog2_exact(t.ct); a.pl = t.pl; a.lp = t.lp; a.rs = t.rs; a.ck = t.ck;
   a.ntiles = t.ntiles; a.cin_pad = t.cin_pad;
+  auto dense_src = [&](const float* p, int64_t sb, int64_t sc, int64_t sl) {
+    return sl == 1 && sc == d->lin && sb % 4 == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+  };
+  a.dense = d->lin % 4 == 0 && t.pl % 4 == 0 && t.lp % 4 == 0 && dense_src(io->x0, io->x0_sb, io->x0_sc, io->x0_sl) &&
+            (d->c1 == 0 || dense_src(io->x1, io->x1_sb, io->x1_sc, io->x1_sl));
   const int grid = ceil_div(io->batch, t.bt) * t.ntiles;
   const int key = t.mf * 16 + t.nf;
   switch (key) {
-    case 1 * 16 + 1: return launch<1, 1>(a, grid, t.lds_bytes, s);
-    case 1 * 16 + 2: return launch<1, 2>(a, grid, t.lds_bytes, s);
-    case 1 * 16 + 4: return launch<1, 4>(a, grid, t.lds_bytes, s);
-    case 1 * 16 + 8: return launch<1, 8>(a, grid, t.lds_bytes, s);
-    case 2 * 16 + 1: return launch<2, 1>(a, grid, t.lds_bytes, s);
-    case 2 * 16 + 2: return launch<2, 2>(a, grid, t.lds_bytes, s);
-    case 2 * 16 + 4: return launch<2, 4>(a, grid, t.lds_bytes, s);
-    case 4 * 16 + 1: return launch<4, 1>(a, grid, t.lds_bytes, s);
-    case 4 * 16 + 2: return launch<4, 2>(a, grid, t.lds_bytes, s);
+    case 1 * 16 + 1: return launch<1, 1>(a, grid, t.lds_bytes, t.nw, s);
+    case 1 * 16 + 2: return launch<1, 2>(a, grid, t.lds_bytes, t.nw, s);
+    case 1 * 16 + 4: return launch<1, 4>(a, grid, t.lds_bytes, t.nw, s);
+    case 1 * 16 + 8: return launch<1, 8>(a, grid, t.lds_bytes, t.nw, s);
+    case 2 * 16 + 1: return launch<2, 1>(a, grid, t.lds_bytes, t.nw, s);
+    case 2 * 16 + 2: return launch<2, 2>(a, grid, t.lds_bytes, t.nw, s);
+    case 2 * 16 + 4: return launch<2, 4>(a, grid, t.lds_bytes, t.nw, s);
+    case 4 * 16 + 1: return launch<4, 1>(a, grid, t.lds_bytes, t.nw, s);
+    case 4 * 16 + 2: return launch<4, 2>(a, grid, t.lds_bytes, t.nw, s);
     default: break;
   }
   adx::set_error("tconv_forward: no kernel for %dx%d fragments", t.mf, t.nf);
