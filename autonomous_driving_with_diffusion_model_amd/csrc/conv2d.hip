@@ -36,9 +36,24 @@ struct Conv2dArgs {
   int PH, PW, PWp;      // staged patch rows, columns, padded row pitch
 };
 
-template <int STRIDE>
+// Software pipeline (register double buffer): the global loads of chunk i+1 (input patch + weight
+// slab) are issued before the MFMAs of chunk i and written to LDS after them, so HBM/L2 latency
+// hides behind ~9k cycles of matrix work per 16-channel chunk.
+template <int STRIDE, int K>
 __global__ void __launch_bounds__(256) conv2d_kernel(const Conv2dArgs a) {
+  constexpr int CC = (K == 7) ? 4 : 16;                   // channels per chunk
+  constexpr int PH = (kTileH - 1) * STRIDE + K;           // staged patch rows / columns
+  constexpr int PW = (kTileW - 1) * STRIDE + K;
+  constexpr int PLANE = PH * PW;
+  constexpr int NP = CC * PLANE;                          // patch floats per chunk
+  constexpr int PITEMS = (NP + 255) / 256;
+  constexpr int NTAPS = K * K;
+  constexpr int NW4 = NTAPS * CC * (kCoutT / 4);          // weight float4s per chunk
+  constexpr int WITEMS = (NW4 + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* patch = smem;                                    // [CC][PH][PW]
+  float* wl = smem + ((NP + 3) & ~3);                     // [NTAPS][CC][64]
+  float* ss = wl + NTAPS * CC * kCoutT;                   // scale[64], shift[64]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bid = blockIdx.x;
@@ -49,52 +64,73 @@ __global__ void __launch_bounds__(256) conv2d_kernel(const Conv2dArgs a) {
   const int oy0 = ty * kTileH, ox0 = tx * kTileW;
   const int iy0 = oy0 * STRIDE - a.pad, ix0 = ox0 * STRIDE - a.pad;
   const int cout0 = ct * kCoutT;
-  const int ntaps = a.KH * a.KW;
-  const int plane = a.PH * a.PWp;
-  float* patch = smem;                         // [cc][PH][PWp]
-  float* wl = smem + a.cc * plane;             // [ntaps][cc][64]
   const int l31 = lane & 31, khalf = lane >> 5;
+  const size_t hw = (size_t)a.H * a.W;
+  const float* xin = a.x + (size_t)n * a.Cin * hw;
+
+  // per-thread gather offsets of its patch elements, identical for every chunk (-1 = zero padding)
+  int goff[PITEMS];
+#pragma unroll
+  for (int k = 0; k < PITEMS; ++k) {
+    const int e = tid + 256 * k;
+    const int c = e / PLANE, rem = e - c * PLANE;
+    const int py = rem / PW, px = rem - py * PW;
+    const int iy = iy0 + py, ix = ix0 + px;
+    const bool ok = e < NP && c < a.Cin && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    goff[k] = ok ? (int)(c * hw + (size_t)iy * a.W + ix) : -1;
+  }
+  if (tid < 2 * kCoutT) {
+    const int c = cout0 + (tid & (kCoutT - 1));
+    ss[tid] = a.scale == nullptr ? (tid < kCoutT ? 1.f : 0.f) : (tid < kCoutT ? a.scale[c] : a.shift[c]);
+  }
 
   f32x16 acc0, acc1;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+  float pv[PITEMS];
+  f32x4 wv[WITEMS];
+  auto load_chunk = [&](int c0) {
+    const float* xc = xin + (size_t)c0 * hw;
+#pragma unroll
+    for (int k = 0; k < PITEMS; ++k) pv[k] = goff[k] >= 0 ? xc[goff[k]] : 0.f;
+#pragma unroll
+    for (int k = 0; k < WITEMS; ++k) {
+      const int e = tid + 256 * k;
+      const int q = e & 15, row = e >> 4;             // row = tap * CC + c
+      const int tap = row / CC, c = row - tap * CC;
+      wv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (e < NW4)
+        wv[k] = *reinterpret_cast<const f32x4*>(a.w + ((size_t)tap * a.cin_pad + c0 + c) * a.Cout + cout0 + 4 * q);
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int k = 0; k < PITEMS; ++k) {
+      const int e = tid + 256 * k;
+      if (e < NP) patch[e] = pv[k];
+    }
+#pragma unroll
+    for (int k = 0; k < WITEMS; ++k) {
+      const int e = tid + 256 * k;
+      if (e < NW4) *reinterpret_cast<f32x4*>(wl + 4 * e) = wv[k];
+    }
+  };
 
-  const float* xin = a.x + (size_t)n * a.Cin * a.H * a.W;
-  for (int c0 = 0; c0 < a.cin_pad; c0 += a.cc) {
-    if (c0 > 0) __syncthreads();
-    // ---- stage the input patch: one wave per (channel, patch row), lanes along the row -------
-    const int nrows = a.cc * a.PH;
-    for (int rr = wave; rr < nrows; rr += 4) {
-      const int c = rr / a.PH, py = rr - c * a.PH;
-      const int ci = c0 + c, iy = iy0 + py;
-      const bool rok = ci < a.Cin && iy >= 0 && iy < a.H;
-      const float* src = xin + ((size_t)ci * a.H + iy) * a.W;
-      for (int px = lane; px < a.PWp; px += 64) {
-        const int ix = ix0 + px;
-        float v = 0.f;
-        if (rok && px < a.PW && ix >= 0 && ix < a.W) v = src[ix];
-        patch[rr * a.PWp + px] = v;
-      }
-    }
-    // ---- stage the weight slab [tap][cc][64] with 16-byte loads ------------------------------
-    const int nw4 = ntaps * a.cc * (kCoutT / 4);
-    for (int e = tid; e < nw4; e += 256) {
-      const int q = e & 15;              // float4 index within the 64 couts
-      const int row = e >> 4;            // tap * cc + c
-      const int tap = row / a.cc, c = row - tap * a.cc;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(a.w + ((size_t)tap * a.cin_pad + c0 + c) * a.Cout + cout0 + 4 * q);
-      *reinterpret_cast<f32x4*>(wl + row * kCoutT + 4 * q) = v;
-    }
+  load_chunk(0);
+  for (int c0 = 0; c0 < a.cin_pad; c0 += CC) {
+    if (c0 > 0) __syncthreads();          // everyone finished reading the previous chunk
+    store_chunk();
     __syncthreads();
-    // ---- MFMA over (tap, channel pair) --------------------------------------------------------
-    const int ksteps = a.cc >> 1;
-    for (int kh = 0; kh < a.KH; ++kh) {
-      for (int kw = 0; kw < a.KW; ++kw) {
-        const int tap = kh * a.KW + kw;
-        const float* pb = patch + (wave * STRIDE + kh) * a.PWp + l31 * STRIDE + kw + khalf * plane;
-        const float* wa = wl + (tap * a.cc + khalf) * kCoutT + l31;
-        for (int ks = 0; ks < ksteps; ++ks) {
-          const float b = pb[2 * ks * plane];
+    if (c0 + CC < a.cin_pad) load_chunk(c0 + CC);   // in flight during the MFMAs below
+#pragma unroll 1
+    for (int kh = 0; kh < K; ++kh) {
+#pragma unroll 1
+      for (int kw = 0; kw < K; ++kw) {
+        const float* pb = patch + (wave * STRIDE + kh) * PW + l31 * STRIDE + kw + khalf * PLANE;
+        const float* wa = wl + ((kh * K + kw) * CC + khalf) * kCoutT + l31;
+#pragma unroll
+        for (int ks = 0; ks < CC / 2; ++ks) {
+          const float b = pb[2 * ks * PLANE];
           const float a0 = wa[2 * ks * kCoutT];
           const float a1 = wa[2 * ks * kCoutT + 32];
           acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
@@ -109,17 +145,23 @@ __global__ void __launch_bounds__(256) conv2d_kernel(const Conv2dArgs a) {
   if (oy < a.OH && ox < a.OW) {
     const size_t pix = (size_t)oy * a.OW + ox;
     const size_t img = (size_t)n * a.Cout * a.OH * a.OW;
+    const size_t plane_o = (size_t)a.OH * a.OW;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
+      float rv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int c = cout0 + half * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        const int cl = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        rv[r] = a.res != nullptr ? a.res[img + (size_t)(cout0 + cl) * plane_o + pix] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cl = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
         float v = half == 0 ? acc0[r] : acc1[r];
-        if (a.scale != nullptr) v = v * a.scale[c] + a.shift[c];
-        const size_t o = img + (size_t)c * a.OH * a.OW + pix;
-        if (a.res != nullptr) v += a.res[o];
+        v = v * ss[cl] + ss[kCoutT + cl];
+        v += rv[r];
         if (a.relu) v = v > 0.f ? v : 0.f;
-        a.y[o] = v;
+        a.y[img + (size_t)(cout0 + cl) * plane_o + pix] = v;
       }
     }
   }
@@ -238,20 +280,29 @@ static int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, 
   a.tiles_x = ceil_div(a.OW, kTileW); a.tiles_y = ceil_div(a.OH, kTileH); a.cout_tiles = L.cout / kCoutT;
   a.PH = (kTileH - 1) * L.stride + L.k; a.PW = (kTileW - 1) * L.stride + L.k;
   a.PWp = a.PW;
-  const size_t lds = sizeof(float) * ((size_t)a.cc * a.PH * a.PWp + (size_t)L.k * L.k * a.cc * kCoutT);
+  ADX_REQUIRE(L.cin % L.cc == 0 || L.cin < L.cc, "conv2d: cin %d must be < %d or a multiple of it", L.cin, L.cc);
+  ADX_REQUIRE((size_t)L.cin * H * W < (1u << 31), "conv2d: image plane too large for 32-bit gather offsets");
+  const size_t np = (size_t)a.cc * a.PH * a.PW;
+  const size_t lds = sizeof(float) * (((np + 3) & ~(size_t)3) + (size_t)L.k * L.k * a.cc * kCoutT + 2 * kCoutT);
   ADX_REQUIRE(lds <= kMaxLds, "conv2d: LDS %zu bytes too large", lds);
-  static bool attr_set = false;  // dynamic LDS above 64 KB must be opted into once per kernel
-  if (!attr_set) {
-    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_kernel<1>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
-    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_kernel<2>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
-    attr_set = true;
-  }
   const size_t grid = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y * N;
   ADX_REQUIRE(grid < (1u << 31), "conv2d: grid too large");
-  if (L.stride == 1) conv2d_kernel<1><<<dim3((unsigned)grid), dim3(256), lds, s>>>(a);
-  else conv2d_kernel<2><<<dim3((unsigned)grid), dim3(256), lds, s>>>(a);
+  static bool attr_set = false;  // dynamic LDS above 64 KB must be opted into once per kernel
+  if (!attr_set) {
+    const void* fns[4] = {reinterpret_cast<const void*>(&conv2d_kernel<1, 3>), reinterpret_cast<const void*>(&conv2d_kernel<2, 3>),
+                          reinterpret_cast<const void*>(&conv2d_kernel<2, 1>), reinterpret_cast<const void*>(&conv2d_kernel<2, 7>)};
+    for (const void* f : fns) ADX_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+    attr_set = true;
+  }
+  const dim3 g((unsigned)grid), blk(256);
+  if (L.stride == 1 && L.k == 3) conv2d_kernel<1, 3><<<g, blk, lds, s>>>(a);
+  else if (L.stride == 2 && L.k == 3) conv2d_kernel<2, 3><<<g, blk, lds, s>>>(a);
+  else if (L.stride == 2 && L.k == 1) conv2d_kernel<2, 1><<<g, blk, lds, s>>>(a);
+  else if (L.stride == 2 && L.k == 7) conv2d_kernel<2, 7><<<g, blk, lds, s>>>(a);
+  else {
+    set_error("conv2d: no kernel for k=%d stride=%d (ResNet-34 uses 3x3 s1, 3x3 s2, 1x1 s2, 7x7 s2)", L.k, L.stride);
+    return ADX_ERR_INVALID;
+  }
   ADX_LAUNCH_CHECK();
   return ADX_OK;
 }
