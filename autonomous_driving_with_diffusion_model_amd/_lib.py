@@ -82,6 +82,14 @@ _SIGS = {
     "adx_conv2d_packed_bytes": (C.c_size_t, [C.POINTER(Conv2dDesc)]),
     "adx_conv2d_pack": (i32, [C.POINTER(Conv2dDesc), vp, vp, vp]),
     "adx_conv2d_forward": (i32, [C.POINTER(Conv2dDesc), vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "adx_trajpred_create": (i32, [i32, C.POINTER(vp)]),
+    "adx_trajpred_destroy": (None, [vp]),
+    "adx_trajpred_num_params": (i32, [vp]),
+    "adx_trajpred_packed_bytes": (C.c_size_t, [vp]),
+    "adx_trajpred_pack": (i32, [vp, C.POINTER(vp), i32, vp, vp, vp]),
+    "adx_trajpred_forward": (i32, [vp, vp, vp, i64, i64, vp, vp, i32, i32, vp]),
+    "adx_trajpred_backward": (i32, [vp, vp, vp, i64, i64, vp, vp, vp, i32, i32, vp]),
+    "adx_guided_output": (i32, [vp, vp, vp, vp, vp, f32, f32, vp, vp, i32, i32, vp]),
     "adx_ddim_step": (i32, [C.POINTER(StepCoef), vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "adx_ddpm_step": (i32, [C.POINTER(StepCoef), vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "adx_add_noise": (i32, [vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp]),

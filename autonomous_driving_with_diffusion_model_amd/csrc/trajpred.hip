@@ -1,0 +1,668 @@
+// TrajPredict (state head of classifier guidance) forward and input-gradient, one workgroup per
+// sample, every activation of a layer resident in LDS.
+//   reference: modeling/helpers.py:22-59 (Linear(3,64) + SinusoidalPosEmb + time_embed ->
+//   2 x post-norm nn.TransformerEncoderLayer(d=64, 4 heads, ff=256, SiLU) -> LayerNorm -> Linear(64,4)),
+//   used at modeling/temporal.py:238-241 and interact.py:158-160; its input gradient is what
+//   GuidanceLoss asks autograd for (control/guidance.py:47-50).
+//
+// T = horizon-1 <= 31 rows x 64 features per sample is a 8 KB tile, so this is latency-bound
+// small-matrix work: plain fp32 FMA with the weight read coalesced (K-major copy for x @ W^T,
+// PyTorch layout for the transposed products of the backward pass) and the activation operand
+// broadcast from LDS, 8 rows per thread.  The backward kernel saves nothing from the forward:
+// it keeps the three layer inputs and recomputes each layer's internals right before
+// back-propagating through it (dropout is inactive: eval mode).
+//
+// The fused guidance kernel (adx_guided_output) additionally evaluates TargetGuidance
+// (control/guidance_loss.py:10-22) per sample, back-propagates its gradient to the action and
+// applies GuidanceLoss.forward's update + clip (control/guidance.py:51-59) in the same launch.
+#include "adx_common.h"
+
+namespace adx {
+
+constexpr int E = 64;        // hidden_dim (must equal MODEL.DIM)
+constexpr int NH = 4;        // heads
+constexpr int DH = 16;       // head dim
+constexpr int FF = 256;      // dim_feedforward
+constexpr int TP = 32;       // padded rows
+constexpr int RT = 8;        // rows per thread in the small GEMMs
+constexpr int NL = 2;        // encoder layers
+constexpr int IN_DIM = 3;
+
+// packed parameter block (floats), produced by trajpred_pack_kernel
+struct TPLayer {
+  int w_in_t, w_in, b_in;        // in_proj  [192][64]: K-major copy, original, bias
+  int w_out_t, w_out, b_out;     // out_proj [64][64]
+  int w1_t, w1, b1;              // linear1  [256][64]
+  int w2_t, w2, b2;              // linear2  [64][256]
+  int g1, be1, g2, be2;          // norm1 / norm2
+};
+struct TPLayout {
+  int w_ip, b_ip;                // input_proj [64][3], bias
+  TPLayer layer[NL];
+  int gf, bef;                   // final LayerNorm
+  int w_op, b_op;                // output_proj [out][64], bias
+  int freqs;                     // 32 sinusoidal frequencies (host-computed like helpers.py:66-69)
+  int total;
+  int out_dim;
+};
+
+static TPLayout make_layout(int out_dim) {
+  TPLayout L;
+  int o = 0;
+  auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
+  L.w_ip = take(E * IN_DIM); L.b_ip = take(E);
+  for (int l = 0; l < NL; ++l) {
+    TPLayer& y = L.layer[l];
+    y.w_in_t = take(3 * E * E); y.w_in = take(3 * E * E); y.b_in = take(3 * E);
+    y.w_out_t = take(E * E); y.w_out = take(E * E); y.b_out = take(E);
+    y.w1_t = take(FF * E); y.w1 = take(FF * E); y.b1 = take(FF);
+    y.w2_t = take(E * FF); y.w2 = take(E * FF); y.b2 = take(E);
+    y.g1 = take(E); y.be1 = take(E); y.g2 = take(E); y.be2 = take(E);
+  }
+  L.gf = take(E); L.bef = take(E);
+  L.w_op = take(out_dim * E); L.b_op = take(out_dim);
+  L.freqs = take(E / 2);
+  L.total = o;
+  L.out_dim = out_dim;
+  return L;
+}
+
+__global__ void transpose_copy_kernel(const float* __restrict__ w, float* __restrict__ wt, float* __restrict__ wc,
+                                      int rows, int cols) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * cols) return;
+  const int r = idx / cols, c = idx - r * cols;
+  const float v = w[idx];
+  wc[idx] = v;
+  wt[c * rows + r] = v;  // K-major: wt[k][n] = w[n][k]
+}
+
+// ---------------------------------------------------------------------------------------------
+// small GEMMs on an LDS-resident [TP][K] tile
+// out[t][n] = sum_k in[t][k] * wt[k][n] (+ bias[n]);  wt is K-major in global memory
+template <bool ACCUM>
+__device__ __forceinline__ void mm_fwd(float* out, int ldo, const float* in, int ldi, const float* __restrict__ wt,
+                                       const float* __restrict__ bias, int K, int N, int tid) {
+  for (int item = tid; item < N * (TP / RT); item += 256) {
+    const int n = item % N, tg = item / N;
+    float acc[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) acc[r] = 0.f;
+    const float* ip = in + tg * RT * ldi;
+#pragma unroll 4
+    for (int k = 0; k < K; ++k) {
+      const float w = wt[(size_t)k * N + n];
+#pragma unroll
+      for (int r = 0; r < RT; ++r) acc[r] += ip[r * ldi + k] * w;
+    }
+    const float b = bias != nullptr ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+      float* o = out + (tg * RT + r) * ldo + n;
+      *o = ACCUM ? *o + acc[r] + b : acc[r] + b;
+    }
+  }
+}
+
+__device__ __forceinline__ void layer_norm_rows(float* y, const float* x, int ld, const float* __restrict__ g,
+                                                const float* __restrict__ b, float* xhat, float* rstd_out, int T,
+                                                int tid) {
+  // one wave per row, 64 features = 64 lanes
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int t = wave; t < T; t += 4) {
+    const float v = x[t * ld + lane];
+    const float mean = wave_sum(v) * (1.0f / E);
+    const float d = v - mean;
+    const float var = wave_sum(d * d) * (1.0f / E);
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    const float xh = d * rstd;
+    if (xhat != nullptr) xhat[t * ld + lane] = xh;
+    if (rstd_out != nullptr && lane == 0) rstd_out[t] = rstd;
+    y[t * ld + lane] = xh * g[lane] + b[lane];
+  }
+}
+
+// dx = rstd * (dxh - mean(dxh) - xhat * mean(dxh * xhat)),  dxh = dy * gamma
+__device__ __forceinline__ void layer_norm_bwd_rows(float* dx, const float* dy, const float* xhat, const float* rstd,
+                                                    int ld, const float* __restrict__ g, int T, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int t = wave; t < T; t += 4) {
+    const float dxh = dy[t * ld + lane] * g[lane];
+    const float xh = xhat[t * ld + lane];
+    const float m1 = wave_sum(dxh) * (1.0f / E);
+    const float m2 = wave_sum(dxh * xh) * (1.0f / E);
+    dx[t * ld + lane] = rstd[t] * (dxh - m1 - xh * m2);
+  }
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float silu_grad(float x) {
+  const float s = 1.0f / (1.0f + expf(-x));
+  return s * (1.0f + x * (1.0f - s));
+}
+
+// LDS plan (floats).  X: layer input; QKV; P: attention probs [NH][TP][TP]; O: attention output,
+// later reused; Y: pre-norm sums / scratch; H1: norm1 output; F: feed-forward pre-activation;
+// XH1/XH2: normalised values for the LayerNorm backward; small per-row vectors at the end.
+struct Lds {
+  float* X; float* QKV; float* P; float* O; float* Y; float* H1; float* F; float* XH1; float* XH2; float* R1; float* R2;
+  float* INb;   // NL + 1 saved [TP][E] tiles (layer inputs + gradient scratch)
+  __device__ __forceinline__ float* IN(int i) const { return INb + i * TP * E; }
+};
+constexpr int kLdsFloats = TP * E * 6 + TP * 3 * E + NH * TP * TP + TP * FF + 2 * TP + (NL + 1) * TP * E;
+
+__device__ __forceinline__ Lds carve(float* s) {
+  Lds l;
+  l.X = s; s += TP * E;
+  l.QKV = s; s += TP * 3 * E;
+  l.P = s; s += NH * TP * TP;
+  l.O = s; s += TP * E;
+  l.Y = s; s += TP * E;
+  l.H1 = s; s += TP * E;
+  l.F = s; s += TP * FF;
+  l.XH1 = s; s += TP * E;
+  l.XH2 = s; s += TP * E;
+  l.R1 = s; s += TP;
+  l.R2 = s; s += TP;
+  l.INb = s;
+  return l;
+}
+
+// x0 = input_proj(action) + pos_emb(arange(T)) + time_embed   (helpers.py:52-57)
+__device__ __forceinline__ void embed_rows(float* X, const float* __restrict__ act, int64_t act_stride,
+                                           const float* __restrict__ te, const float* __restrict__ P,
+                                           const TPLayout& L, int T, int tid) {
+  for (int idx = tid; idx < TP * E; idx += 256) {
+    const int t = idx >> 6, j = idx & 63;
+    float v = 0.f;
+    if (t < T) {
+      const float* a = act + (int64_t)t * act_stride;
+      v = P[L.b_ip + j];
+#pragma unroll
+      for (int i = 0; i < IN_DIM; ++i) v += a[i] * P[L.w_ip + j * IN_DIM + i];
+      const int fi = j < 32 ? j : j - 32;
+      const float arg = (float)t * P[L.freqs + fi];
+      v += j < 32 ? sinf(arg) : cosf(arg);
+      v += te[j];
+    }
+    X[idx] = v;
+  }
+}
+
+// one encoder layer, forward; leaves every intermediate the backward needs in LDS
+__device__ __forceinline__ void layer_forward(const Lds& l, const float* __restrict__ P, const TPLayer& y, int T,
+                                              int tid) {
+  mm_fwd<false>(l.QKV, 3 * E, l.X, E, P + y.w_in_t, P + y.b_in, E, 3 * E, tid);
+  __syncthreads();
+  // scores + softmax: one thread per (head, query row)
+  for (int idx = tid; idx < NH * TP; idx += 256) {
+    const int h = idx / TP, t = idx - h * TP;
+    float* p = l.P + (h * TP + t) * TP;
+    if (t < T) {
+      const float* q = l.QKV + t * 3 * E + h * DH;
+      float mx = -INFINITY;
+      for (int s = 0; s < T; ++s) {
+        const float* k = l.QKV + s * 3 * E + E + h * DH;
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < DH; ++i) d += q[i] * k[i];
+        d *= 0.25f;  // 1 / sqrt(16)
+        p[s] = d;
+        mx = fmaxf(mx, d);
+      }
+      float sum = 0.f;
+      for (int s = 0; s < T; ++s) {
+        const float e = expf(p[s] - mx);
+        p[s] = e;
+        sum += e;
+      }
+      const float inv = 1.0f / sum;
+      for (int s = 0; s < T; ++s) p[s] *= inv;
+    }
+  }
+  __syncthreads();
+  // O = P @ V
+  for (int idx = tid; idx < TP * E; idx += 256) {
+    const int t = idx >> 6, c = idx & 63, h = c >> 4;
+    float acc = 0.f;
+    if (t < T) {
+      const float* p = l.P + (h * TP + t) * TP;
+      for (int s = 0; s < T; ++s) acc += p[s] * l.QKV[s * 3 * E + 2 * E + c];
+    }
+    l.O[idx] = acc;
+  }
+  __syncthreads();
+  // Y = X + out_proj(O)
+  for (int idx = tid; idx < TP * E; idx += 256) l.Y[idx] = l.X[idx];
+  __syncthreads();
+  mm_fwd<true>(l.Y, E, l.O, E, P + y.w_out_t, P + y.b_out, E, E, tid);
+  __syncthreads();
+  layer_norm_rows(l.H1, l.Y, E, P + y.g1, P + y.be1, l.XH1, l.R1, T, tid);
+  __syncthreads();
+  mm_fwd<false>(l.F, FF, l.H1, E, P + y.w1_t, P + y.b1, E, FF, tid);
+  __syncthreads();
+  // Y = H1 + linear2(silu(F));  O is reused as scratch for silu(F) in 64-column slabs
+  for (int idx = tid; idx < TP * E; idx += 256) l.Y[idx] = l.H1[idx];
+  __syncthreads();
+  {
+    // silu(F) @ W2^T, K = 256: accumulate directly, activation applied on the fly
+    for (int item = tid; item < E * (TP / RT); item += 256) {
+      const int n = item % E, tg = item / E;
+      float acc[RT];
+#pragma unroll
+      for (int r = 0; r < RT; ++r) acc[r] = 0.f;
+      const float* wt = P + y.w2_t;
+      for (int k = 0; k < FF; ++k) {
+        const float w = wt[(size_t)k * E + n];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[r] += silu_f(l.F[(tg * RT + r) * FF + k]) * w;
+      }
+      const float b = P[y.b2 + n];
+#pragma unroll
+      for (int r = 0; r < RT; ++r) l.Y[(tg * RT + r) * E + n] += acc[r] + b;
+    }
+  }
+  __syncthreads();
+  layer_norm_rows(l.X, l.Y, E, P + y.g2, P + y.be2, l.XH2, l.R2, T, tid);  // X becomes the layer output
+  __syncthreads();
+}
+
+// back-propagate through one layer: D (in/out, [TP][E]) holds d(layer output) on entry and
+// d(layer input) on exit.  Requires layer_forward() to have just run on this layer's input.
+__device__ __forceinline__ void layer_backward(const Lds& l, float* D, const float* __restrict__ P, const TPLayer& y,
+                                               int T, int tid) {
+  // norm2
+  layer_norm_bwd_rows(l.Y, D, l.XH2, l.R2, E, P + y.g2, T, tid);   // Y = d(y2) = d(h1 path) = d(ff)
+  __syncthreads();
+  // ds = dff @ W2  ([T][256]); dF = ds * silu'(F), stored over F
+  for (int item = tid; item < FF * (TP / RT); item += 256) {
+    const int n = item % FF, tg = item / FF;
+    float acc[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) acc[r] = 0.f;
+    const float* w = P + y.w2;  // [64][256]: row j, column n
+    for (int j = 0; j < E; ++j) {
+      const float wv = w[(size_t)j * FF + n];
+#pragma unroll
+      for (int r = 0; r < RT; ++r) acc[r] += l.Y[(tg * RT + r) * E + j] * wv;
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+      float* f = l.F + (tg * RT + r) * FF + n;
+      *f = acc[r] * silu_grad(*f);
+    }
+  }
+  __syncthreads();
+  // dH1 = dy2 + dF @ W1   (W1 is [256][64]: K = 256 rows, N = 64 contiguous)
+  mm_fwd<true>(l.Y, E, l.F, FF, P + y.w1, nullptr, FF, E, tid);
+  __syncthreads();
+  // norm1: D = d(y1)
+  layer_norm_bwd_rows(D, l.Y, l.XH1, l.R1, E, P + y.g1, T, tid);
+  __syncthreads();
+  // dO = dsa @ Wout  (Wout [64][64], row j = output feature)
+  mm_fwd<false>(l.Y, E, D, E, P + y.w_out, nullptr, E, E, tid);    // Y = dO
+  __syncthreads();
+  // dP[h][t][s] = sum_d dO[t][hd] V[s][hd];  dS = P * (dP - sum_s dP P), written into F (dead by now)
+  for (int idx = tid; idx < NH * TP; idx += 256) {
+    const int h = idx / TP, t = idx - h * TP;
+    if (t < T) {
+      const float* p = l.P + (h * TP + t) * TP;
+      float* dS = l.F + (h * TP + t) * TP;
+      const float* dO = l.Y + t * E + h * DH;
+      float dot = 0.f;
+      for (int s = 0; s < T; ++s) {
+        const float* v = l.QKV + s * 3 * E + 2 * E + h * DH;
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < DH; ++i) d += dO[i] * v[i];
+        dS[s] = d;
+        dot += d * p[s];
+      }
+      for (int s = 0; s < T; ++s) dS[s] = p[s] * (dS[s] - dot);
+    }
+  }
+  __syncthreads();
+  // dV[s][c] = sum_t P[h][t][s] dO[t][c];  dQ[t][c] = sum_s dS[t][s] K[s][c] / 4;  dK[s][c] = sum_t dS[t][s] Q[t][c] / 4
+  // written into O (dq), H1 (dk), XH1 (dv) -- all dead at this point
+  for (int idx = tid; idx < TP * E; idx += 256) {
+    const int t = idx >> 6, c = idx & 63, h = c >> 4;
+    float dq = 0.f, dk = 0.f, dv = 0.f;
+    if (t < T) {
+      const float* dS = l.F + (h * TP + t) * TP;
+      for (int s = 0; s < T; ++s) {
+        dq += dS[s] * l.QKV[s * 3 * E + E + c];
+        dk += l.F[(h * TP + s) * TP + t] * l.QKV[s * 3 * E + c];
+        dv += l.P[(h * TP + s) * TP + t] * l.Y[s * E + c];
+      }
+    }
+    l.O[idx] = dq * 0.25f;
+    l.H1[idx] = dk * 0.25f;
+    l.XH1[idx] = dv;
+  }
+  __syncthreads();
+  // dX = d(y1) + [dq dk dv] @ Win   (Win [192][64]); D already holds d(y1)
+  mm_fwd<true>(D, E, l.O, E, P + y.w_in, nullptr, E, E, tid);
+  mm_fwd<true>(D, E, l.H1, E, P + y.w_in + E * E, nullptr, E, E, tid);
+  mm_fwd<true>(D, E, l.XH1, E, P + y.w_in + 2 * E * E, nullptr, E, E, tid);
+  __syncthreads();
+}
+
+struct TrajArgs {
+  const float* P;            // packed parameters
+  TPLayout L;
+  const float* action;       // [B][T(+1)][3] rows with stride act_stride
+  int64_t act_sb, act_st;
+  const float* te;           // [B][64]
+  int B, T;
+  // forward
+  float* out; int64_t out_sb, out_st;         // [B][T][out_dim]
+  // backward
+  const float* gout; int64_t gout_sb, gout_st; // [B][T][out_dim]
+  float* gact; int64_t gact_sb, gact_st;       // [B][T][3]
+  // fused guidance
+  const float* target;       // [B][2]
+  float* xg;                 // [B][T+1][out_dim+3] guided output (state | action)
+  float grad_scale, scale;   // model_std, GUIDANCE.CLASSIFIER_SCALE
+  float* loss;               // [B] or null
+};
+
+// head: LayerNorm -> Linear(64, out_dim)
+__device__ __forceinline__ void head_forward(const Lds& l, const float* __restrict__ P, const TPLayout& L, int T,
+                                             int tid) {
+  layer_norm_rows(l.Y, l.X, E, P + L.gf, P + L.bef, l.XH2, l.R2, T, tid);
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) trajpred_forward_kernel(const TrajArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const Lds l = carve(smem);
+  const int b = blockIdx.x, tid = threadIdx.x;
+  embed_rows(l.X, a.action + (int64_t)b * a.act_sb, a.act_st, a.te + (int64_t)b * E, a.P, a.L, a.T, tid);
+  __syncthreads();
+  for (int li = 0; li < NL; ++li) layer_forward(l, a.P, a.L.layer[li], a.T, tid);
+  head_forward(l, a.P, a.L, a.T, tid);
+  const int od = a.L.out_dim;
+  for (int idx = tid; idx < a.T * od; idx += 256) {
+    const int t = idx / od, j = idx - t * od;
+    float acc = a.P[a.L.b_op + j];
+    for (int i = 0; i < E; ++i) acc += l.Y[t * E + i] * a.P[a.L.w_op + j * E + i];
+    a.out[(int64_t)b * a.out_sb + (int64_t)t * a.out_st + j] = acc;
+  }
+}
+
+// shared by the backward and the fused guidance kernels: forward with the layer inputs kept, then
+// back-propagation of d(out) [T][out_dim] (given by `dout(t, j)`) down to d(action) [T][3] in l.O.
+template <typename DOut>
+__device__ __forceinline__ void backward_core(const Lds& l, const TrajArgs& a, int b, int tid, DOut dout) {
+  const float* P = a.P;
+  const TPLayout& L = a.L;
+  const int T = a.T, od = L.out_dim;
+  embed_rows(l.X, a.action + (int64_t)b * a.act_sb, a.act_st, a.te + (int64_t)b * E, P, L, T, tid);
+  __syncthreads();
+  for (int li = 0; li < NL; ++li) {
+    for (int idx = tid; idx < TP * E; idx += 256) l.IN(li)[idx] = l.X[idx];
+    __syncthreads();
+    layer_forward(l, P, L.layer[li], T, tid);
+  }
+  head_forward(l, P, L, T, tid);   // XH2 / R2 now belong to the final norm
+  // d(normed) = dout @ Wop  -> H1
+  for (int idx = tid; idx < TP * E; idx += 256) {
+    const int t = idx >> 6, i = idx & 63;
+    float acc = 0.f;
+    if (t < T)
+      for (int j = 0; j < od; ++j) acc += dout(t, j) * P[L.w_op + j * E + i];
+    l.H1[idx] = acc;
+  }
+  __syncthreads();
+  float* D = l.IN(NL);
+  layer_norm_bwd_rows(D, l.H1, l.XH2, l.R2, E, P + L.gf, T, tid);
+  for (int idx = tid + 0; idx < TP * E; idx += 256)
+    if ((idx >> 6) >= T) D[idx] = 0.f;
+  __syncthreads();
+  for (int li = NL - 1; li >= 0; --li) {
+    for (int idx = tid; idx < TP * E; idx += 256) l.X[idx] = l.IN(li)[idx];
+    __syncthreads();
+    layer_forward(l, P, L.layer[li], T, tid);     // recompute this layer's internals
+    layer_backward(l, D, P, L.layer[li], T, tid);
+    for (int idx = tid; idx < TP * E; idx += 256)
+      if ((idx >> 6) >= T) D[idx] = 0.f;
+    __syncthreads();
+  }
+  // d(action)[t][i] = sum_j D[t][j] Wip[j][i]
+  for (int idx = tid; idx < TP * IN_DIM; idx += 256) {
+    const int t = idx / IN_DIM, i = idx - t * IN_DIM;
+    float acc = 0.f;
+    if (t < T)
+      for (int j = 0; j < E; ++j) acc += D[t * E + j] * P[L.w_ip + j * IN_DIM + i];
+    l.O[idx] = acc;
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) trajpred_backward_kernel(const TrajArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const Lds l = carve(smem);
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* g = a.gout + (int64_t)b * a.gout_sb;
+  const int64_t gst = a.gout_st;
+  backward_core(l, a, b, tid, [&](int t, int j) { return g[(int64_t)t * gst + j]; });
+  for (int idx = tid; idx < a.T * IN_DIM; idx += 256) {
+    const int t = idx / IN_DIM, i = idx - t * IN_DIM;
+    a.gact[(int64_t)b * a.gact_sb + (int64_t)t * a.gact_st + i] = l.O[idx];
+  }
+}
+
+// Fused classifier guidance for one sample (GUIDANCE.STEP = 1):
+//   x = cat([0; state_pred(action[:-1])], action);  choose h* by TargetGuidance's rule;
+//   g_x = 2 (x[h*, :2] - target) at (h*, :2);  g_a = d(state)/d(action)^T g_x[1:, :4];
+//   x[:, :4] -= scale/15 * std * g_x[:, :4];  x[:, 4:] -= scale * std * g_a;  clip(-1, 1)
+__global__ void __launch_bounds__(256) guided_output_kernel(const TrajArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const Lds l = carve(smem);
+  __shared__ float st[TP + 1][4];
+  __shared__ int hstar;
+  __shared__ float gxy[2];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int T = a.T, H = T + 1, od = a.L.out_dim;
+  const float* act = a.action + (int64_t)b * a.act_sb;
+  // forward to get the state rows
+  embed_rows(l.X, act, a.act_st, a.te + (int64_t)b * E, a.P, a.L, T, tid);
+  __syncthreads();
+  for (int li = 0; li < NL; ++li) layer_forward(l, a.P, a.L.layer[li], T, tid);
+  head_forward(l, a.P, a.L, T, tid);
+  for (int idx = tid; idx < H * od; idx += 256) {
+    const int h = idx / od, j = idx - h * od;
+    float acc = 0.f;
+    if (h > 0) {
+      acc = a.P[a.L.b_op + j];
+      for (int i = 0; i < E; ++i) acc += l.Y[(h - 1) * E + i] * a.P[a.L.w_op + j * E + i];
+    }
+    st[h][j] = acc;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float tx = a.target[2 * b], ty = a.target[2 * b + 1];
+    const float x0 = st[0][0], y0 = st[0][1];
+    const float t2a = sqrtf((tx - x0) * (tx - x0) + (ty - y0) * (ty - y0));
+    const float fx = st[H - 1][0] - x0, fy = st[H - 1][1] - y0;
+    const float f2a = sqrtf(fx * fx + fy * fy);
+    int best = 0;
+    if (!(f2a < t2a)) {
+      float bd = INFINITY;
+      for (int h = 0; h < H; ++h) {
+        const float dx = st[h][0] - tx, dy = st[h][1] - ty;
+        const float d = dx * dx + dy * dy;
+        if (d < bd) { bd = d; best = h; }   // first minimum, like torch.argmin
+      }
+    }
+    hstar = best;
+    const float dx = st[best][0] - tx, dy = st[best][1] - ty;
+    gxy[0] = 2.f * dx;
+    gxy[1] = 2.f * dy;
+    if (a.loss != nullptr) a.loss[b] = dx * dx + dy * dy;
+  }
+  __syncthreads();
+  const int hs = hstar;
+  const float g0 = gxy[0], g1 = gxy[1];
+  // gradient w.r.t. the action through the state path (row h* of x is state row h*-1; row 0 is the dummy zero)
+  if (hs > 0) {
+    backward_core(l, a, b, tid, [&](int t, int j) { return (t == hs - 1 && j < 2) ? (j == 0 ? g0 : g1) : 0.f; });
+  } else {
+    for (int idx = tid; idx < TP * IN_DIM; idx += 256) l.O[idx] = 0.f;
+    __syncthreads();
+  }
+  const int dims = od + IN_DIM;
+  const float s_state = a.scale / 15.f * a.grad_scale, s_act = a.scale * a.grad_scale;
+  float* xo = a.xg + (int64_t)b * H * dims;
+  for (int idx = tid; idx < H * dims; idx += 256) {
+    const int h = idx / dims, j = idx - h * dims;
+    float v;
+    if (j < od) {
+      v = st[h][j];
+      if (h == hs && j < 2) v -= s_state * (j == 0 ? g0 : g1);
+    } else {
+      v = act[(int64_t)h * a.act_st + (j - od)];
+      if (h < T) v -= s_act * l.O[h * IN_DIM + (j - od)];
+    }
+    xo[idx] = v < -1.f ? -1.f : (v > 1.f ? 1.f : v);
+  }
+}
+
+}  // namespace adx
+
+using namespace adx;
+
+struct adx_trajpred {
+  TPLayout L;
+  bool packed = false;
+};
+
+extern "C" {
+
+int adx_trajpred_create(int32_t out_dim, adx_trajpred** out) {
+  ADX_REQUIRE(out != nullptr && out_dim >= 2 && out_dim <= 4, "adx_trajpred_create: out_dim %d must be 2..4", out_dim);
+  adx_trajpred* t = new adx_trajpred();
+  t->L = make_layout(out_dim);
+  *out = t;
+  return ADX_OK;
+}
+void adx_trajpred_destroy(adx_trajpred* t) { delete t; }
+int adx_trajpred_num_params(const adx_trajpred* t) { return t ? 2 + NL * 12 + 2 + 2 : 0; }
+size_t adx_trajpred_packed_bytes(const adx_trajpred* t) { return t ? (size_t)t->L.total * sizeof(float) : 0; }
+
+// params: state_pred.* in named_parameters() order (input_proj w,b; per layer in_proj_weight,
+// in_proj_bias, out_proj w,b, linear1 w,b, linear2 w,b, norm1 w,b, norm2 w,b; final norm w,b;
+// output_proj w,b); freqs = exp(-i ln(1e4)/31), i < 32.
+int adx_trajpred_pack(adx_trajpred* t, const float* const* P, int32_t n, const float* freqs, void* packed,
+                      adx_stream stream) {
+  ADX_REQUIRE(t && P && freqs && packed, "adx_trajpred_pack: null argument");
+  ADX_REQUIRE(n == adx_trajpred_num_params(t), "adx_trajpred_pack: expected %d tensors, got %d",
+              adx_trajpred_num_params(t), n);
+  hipStream_t s = (hipStream_t)stream;
+  float* base = (float*)packed;
+  const TPLayout& L = t->L;
+  auto cp = [&](int off, const float* src, int cnt) -> int {
+    ADX_CHECK_HIP(hipMemcpyAsync(base + off, src, cnt * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return ADX_OK;
+  };
+  auto tr = [&](int off_t, int off_c, const float* src, int rows, int cols) -> int {
+    transpose_copy_kernel<<<dim3(ceil_div(rows * cols, 256)), dim3(256), 0, s>>>(src, base + off_t, base + off_c, rows, cols);
+    ADX_LAUNCH_CHECK();
+    return ADX_OK;
+  };
+  int i = 0, rc = ADX_OK;
+  rc = cp(L.w_ip, P[i++], E * IN_DIM); if (rc) return rc;
+  rc = cp(L.b_ip, P[i++], E); if (rc) return rc;
+  for (int l = 0; l < NL; ++l) {
+    const TPLayer& y = L.layer[l];
+    rc = tr(y.w_in_t, y.w_in, P[i++], 3 * E, E); if (rc) return rc;
+    rc = cp(y.b_in, P[i++], 3 * E); if (rc) return rc;
+    rc = tr(y.w_out_t, y.w_out, P[i++], E, E); if (rc) return rc;
+    rc = cp(y.b_out, P[i++], E); if (rc) return rc;
+    rc = tr(y.w1_t, y.w1, P[i++], FF, E); if (rc) return rc;
+    rc = cp(y.b1, P[i++], FF); if (rc) return rc;
+    rc = tr(y.w2_t, y.w2, P[i++], E, FF); if (rc) return rc;
+    rc = cp(y.b2, P[i++], E); if (rc) return rc;
+    rc = cp(y.g1, P[i++], E); if (rc) return rc;
+    rc = cp(y.be1, P[i++], E); if (rc) return rc;
+    rc = cp(y.g2, P[i++], E); if (rc) return rc;
+    rc = cp(y.be2, P[i++], E); if (rc) return rc;
+  }
+  rc = cp(L.gf, P[i++], E); if (rc) return rc;
+  rc = cp(L.bef, P[i++], E); if (rc) return rc;
+  rc = cp(L.w_op, P[i++], L.out_dim * E); if (rc) return rc;
+  rc = cp(L.b_op, P[i++], L.out_dim); if (rc) return rc;
+  rc = cp(L.freqs, freqs, E / 2); if (rc) return rc;
+  t->packed = true;
+  return ADX_OK;
+}
+
+static int tp_common(adx_trajpred* t, const void* packed, int batch, int T, TrajArgs* a) {
+  ADX_REQUIRE(t && packed, "trajpred: null argument");
+  if (!t->packed) {
+    set_error("trajpred: weights were never packed (call adx_trajpred_pack first)");
+    return ADX_ERR_STATE;
+  }
+  ADX_REQUIRE(batch >= 1 && T >= 1 && T < TP, "trajpred: batch %d / sequence length %d unsupported (T <= %d)", batch, T,
+              TP - 1);
+  memset(a, 0, sizeof(*a));
+  a->P = (const float*)packed;
+  a->L = t->L;
+  a->B = batch;
+  a->T = T;
+  static bool attr_set = false;
+  if (!attr_set) {
+    const void* fns[3] = {reinterpret_cast<const void*>(&trajpred_forward_kernel),
+                          reinterpret_cast<const void*>(&trajpred_backward_kernel),
+                          reinterpret_cast<const void*>(&guided_output_kernel)};
+    for (const void* f : fns)
+      ADX_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsFloats * sizeof(float))));
+    attr_set = true;
+  }
+  return ADX_OK;
+}
+
+int adx_trajpred_forward(adx_trajpred* t, const void* packed, const float* action, int64_t act_sb, int64_t act_st,
+                         const float* time_embed, float* out, int32_t batch, int32_t T, adx_stream stream) {
+  TrajArgs a;
+  int rc = tp_common(t, packed, batch, T, &a);
+  if (rc != ADX_OK) return rc;
+  ADX_REQUIRE(action && time_embed && out, "adx_trajpred_forward: null tensor");
+  a.action = action; a.act_sb = act_sb; a.act_st = act_st; a.te = time_embed;
+  a.out = out; a.out_sb = (int64_t)T * t->L.out_dim; a.out_st = t->L.out_dim;
+  trajpred_forward_kernel<<<dim3(batch), dim3(256), kLdsFloats * sizeof(float), (hipStream_t)stream>>>(a);
+  ADX_LAUNCH_CHECK();
+  return ADX_OK;
+}
+
+int adx_trajpred_backward(adx_trajpred* t, const void* packed, const float* action, int64_t act_sb, int64_t act_st,
+                          const float* time_embed, const float* grad_out, float* grad_action, int32_t batch, int32_t T,
+                          adx_stream stream) {
+  TrajArgs a;
+  int rc = tp_common(t, packed, batch, T, &a);
+  if (rc != ADX_OK) return rc;
+  ADX_REQUIRE(action && time_embed && grad_out && grad_action, "adx_trajpred_backward: null tensor");
+  a.action = action; a.act_sb = act_sb; a.act_st = act_st; a.te = time_embed;
+  a.gout = grad_out; a.gout_sb = (int64_t)T * t->L.out_dim; a.gout_st = t->L.out_dim;
+  a.gact = grad_action; a.gact_sb = (int64_t)T * IN_DIM; a.gact_st = IN_DIM;
+  trajpred_backward_kernel<<<dim3(batch), dim3(256), kLdsFloats * sizeof(float), (hipStream_t)stream>>>(a);
+  ADX_LAUNCH_CHECK();
+  return ADX_OK;
+}
+
+int adx_guided_output(adx_trajpred* t, const void* packed, const float* action /* [B][T+1][3] */,
+                      const float* time_embed, const float* target /* [B][2] */, float model_std, float scale,
+                      float* x_guided /* [B][T+1][out_dim+3] */, float* loss /* [B] or NULL */, int32_t batch, int32_t T,
+                      adx_stream stream) {
+  TrajArgs a;
+  int rc = tp_common(t, packed, batch, T, &a);
+  if (rc != ADX_OK) return rc;
+  ADX_REQUIRE(action && time_embed && target && x_guided, "adx_guided_output: null tensor");
+  a.action = action; a.act_sb = (int64_t)(T + 1) * IN_DIM; a.act_st = IN_DIM; a.te = time_embed;
+  a.target = target; a.xg = x_guided; a.grad_scale = model_std; a.scale = scale; a.loss = loss;
+  guided_output_kernel<<<dim3(batch), dim3(256), kLdsFloats * sizeof(float), (hipStream_t)stream>>>(a);
+  ADX_LAUNCH_CHECK();
+  return ADX_OK;
+}
+
+}  // extern "C"

@@ -64,10 +64,11 @@ def _init_tensor(e: Entry, all_keys) -> torch.Tensor:
     return torch.empty(shape).uniform_(-bound, bound)
 
 
-def populate(root: nn.Module, entries: Iterable[Entry], prefix: str = "") -> None:
-    """Attach every entry below `root`, creating intermediate containers in first-seen order."""
+def populate(root: nn.Module, entries: Iterable[Entry], prefix: str = "", init_prefix: str = "") -> None:
+    """Attach every entry below `root`, creating intermediate containers in first-seen order.
+    `init_prefix` is prepended to the keys only to select the initialisation rule."""
     entries = list(entries)
-    all_keys = {e.key: e.shape for e in entries}
+    all_keys = {init_prefix + e.key: e.shape for e in entries}
     for e in entries:
         assert e.key.startswith(prefix)
         parts = e.key[len(prefix):].split(".")
@@ -76,7 +77,7 @@ def populate(root: nn.Module, entries: Iterable[Entry], prefix: str = "") -> Non
             if p not in mod._modules:
                 mod.add_module(p, Node())
             mod = mod._modules[p]
-        value = _init_tensor(e, all_keys)
+        value = _init_tensor(Entry(init_prefix + e.key, e.shape, e.is_buffer, e.dtype), all_keys)
         if e.is_buffer:
             mod.register_buffer(parts[-1], value)
         else:

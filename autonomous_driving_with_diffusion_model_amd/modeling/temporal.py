@@ -104,6 +104,8 @@ class TemporalMapUnet(nn.Module):
         self._pack_key = None
         self.perception.invalidate()
         self._feat_cache = None
+        if hasattr(self, "state_pred"):
+            self.state_pred.invalidate()
 
     def train(self, mode: bool = True):
         if mode != self.training:

@@ -1,25 +1,122 @@
-"""`TrajPredict` state head used by classifier guidance (reference: modeling/helpers.py:22-59).
+"""`TrajPredict` state head used by classifier guidance (reference: modeling/helpers.py:22-59),
+executed by libadx.so (csrc/trajpred.hip).
 
 Parameter holder with the reference's keys (input_proj, encoder_traj.layers.N.*, encoder_traj.norm,
-output_proj).  The HIP forward + input-gradient kernels are the next hot-path row to land
-(SURVEY.md §8a M7/G1); until then calling it raises instead of falling back to torch ops.
+output_proj).  `forward(x, time_embed)` is an autograd node whose backward returns the gradient
+w.r.t. `x` (the action), which is what `GuidanceLoss` differentiates (control/guidance.py:47-50).
+Eval-mode semantics (no dropout); parameter gradients belong to the training row (not built yet).
 """
 from __future__ import annotations
+
+import ctypes as C
+import math
 
 import torch
 import torch.nn as nn
 
+from .. import _lib as L
 from .holders import populate
 from .spec import traj_predict_entries
+
+
+class _TrajPredictFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, action, time_embed, module):
+        action_c = L.require_gpu_f32(action.detach(), "action")
+        te = L.require_gpu_f32(time_embed.detach(), "time_embed")
+        B, T, _ = action_c.shape
+        out = torch.empty((B, T, module.out_dim), dtype=torch.float32, device=action_c.device)
+        h, packed = module._ensure_packed(action_c.device)
+        L.check(L.lib().adx_trajpred_forward(h, packed.data_ptr(), action_c.data_ptr(), action_c.stride(0),
+                                             action_c.stride(1), te.data_ptr(), out.data_ptr(), B, T,
+                                             L.stream_ptr(action_c.device)), "adx_trajpred_forward")
+        ctx.module = module
+        ctx.save_for_backward(action_c, te)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        action_c, te = ctx.saved_tensors
+        module = ctx.module
+        B, T, _ = action_c.shape
+        g = L.require_gpu_f32(grad_out, "grad_out")
+        ga = torch.empty((B, T, 3), dtype=torch.float32, device=g.device)
+        h, packed = module._ensure_packed(g.device)
+        L.check(L.lib().adx_trajpred_backward(h, packed.data_ptr(), action_c.data_ptr(), action_c.stride(0),
+                                              action_c.stride(1), te.data_ptr(), g.data_ptr(), ga.data_ptr(), B, T,
+                                              L.stream_ptr(g.device)), "adx_trajpred_backward")
+        return ga, None, None
 
 
 class TrajPredict(nn.Module):
     def __init__(self, in_dim: int = 3, out_dim: int = 3, pred_len: int = 16, hidden_dim: int = 256,
                  num_heads: int = 4, num_layers: int = 3):
         super().__init__()
+        if (in_dim, hidden_dim, num_heads, num_layers) != (3, 64, 4, 2):
+            raise NotImplementedError("TrajPredict kernels are built for in_dim 3, hidden 64, 4 heads, 2 layers "
+                                      "(the only configuration TemporalMapUnet instantiates, temporal.py:187-189)")
         self.in_dim, self.out_dim, self.pred_len = in_dim, out_dim, pred_len
         self.hidden_dim, self.num_heads, self.num_layers = hidden_dim, num_heads, num_layers
-        populate(self, traj_predict_entries("", in_dim, out_dim, hidden_dim, num_layers))
+        self._entries = traj_predict_entries("", in_dim, out_dim, hidden_dim, num_layers)
+        populate(self, self._entries, init_prefix="state_pred.")
+        self._handle = None
+        self._packed = None
+        self._pack_key = None
+        self._freqs = None
+
+    def _native(self):
+        if self._handle is None:
+            h = L.vp()
+            L.check(L.lib().adx_trajpred_create(self.out_dim, C.byref(h)), "adx_trajpred_create")
+            self._handle = h
+        return self._handle
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                L.lib().adx_trajpred_destroy(self._handle)
+        except Exception:
+            pass
+
+    def invalidate(self):
+        self._pack_key = None
+
+    def _ensure_packed(self, device):
+        named = dict(self.named_parameters())
+        ps = [named[e.key] for e in self._entries]
+        key = (ps[0].data_ptr(), sum(p._version for p in ps))
+        h = self._native()
+        if key != self._pack_key or self._packed is None or self._packed.device != device:
+            ts = [L.require_gpu_f32(p.detach(), "state_pred parameter") for p in ps]
+            n = L.lib().adx_trajpred_num_params(h)
+            assert n == len(ts), (n, len(ts))
+            self._packed = torch.empty(L.lib().adx_trajpred_packed_bytes(h), dtype=torch.uint8, device=device)
+            half = self.hidden_dim // 2
+            self._freqs = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1))).to(device=device,
+                                                                                           dtype=torch.float32)
+            L.check(L.lib().adx_trajpred_pack(h, L.ptr_array(ts), n, self._freqs.data_ptr(), self._packed.data_ptr(),
+                                              L.stream_ptr(device)), "adx_trajpred_pack")
+            self._pack_key = key
+        return h, self._packed
 
     def forward(self, x: torch.Tensor, time_embed: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError("TrajPredict: HIP forward/backward kernels not implemented yet")
+        if self.training:
+            raise NotImplementedError("TrajPredict: train-mode (dropout, parameter gradients) is not implemented yet")
+        if x.dim() != 3 or x.shape[2] != self.in_dim or x.shape[1] > 31:
+            raise ValueError(f"x must be [B, T <= 31, {self.in_dim}], got {tuple(x.shape)}")
+        return _TrajPredictFn.apply(x, time_embed, self)
+
+    def guided_output(self, action: torch.Tensor, time_embed: torch.Tensor, target: torch.Tensor, model_std: float,
+                      scale: float) -> torch.Tensor:
+        """Fused interact.py:153-160 + GuidanceLoss(STEP=1) + TargetGuidance for every sample:
+        returns the guided, clipped model output [B, H, out_dim + 3]."""
+        a = L.require_gpu_f32(action.detach(), "action")
+        te = L.require_gpu_f32(time_embed.detach(), "time_embed")
+        B, H, _ = a.shape
+        tg = L.require_gpu_f32(target.reshape(-1, 2).expand(B, 2) if target.numel() == 2 else target, "target")
+        out = torch.empty((B, H, self.out_dim + 3), dtype=torch.float32, device=a.device)
+        h, packed = self._ensure_packed(a.device)
+        L.check(L.lib().adx_guided_output(h, packed.data_ptr(), a.data_ptr(), te.data_ptr(), tg.data_ptr(),
+                                          float(model_std), float(scale), out.data_ptr(), None, B, H - 1,
+                                          L.stream_ptr(a.device)), "adx_guided_output")
+        return out

@@ -66,6 +66,13 @@ def generate_traj(model, scheduler, cfg, image: torch.Tensor, target: Optional[t
         elif use == GuidanceType.CLASSIFIER_GUIDANCE:
             with torch.no_grad():
                 action, time_embed = model(trajs, image, t.reshape(-1).repeat(B), return_action_and_time_only=True)
+            guided = getattr(scheduler, "use_classifier_guidance", False) and tgt is not None
+            if fuse and guided and scheduler.guidance_loss.guidance_step == 1:
+                # one launch: state_pred forward + TargetGuidance + its gradient through state_pred + update + clip
+                model_output = model.state_pred.guided_output(action, time_embed, tgt, scheduler.guidance_std(t),
+                                                              scheduler.guidance_loss.scale)
+                trajs = scheduler.step(model_output, t, trajs, zero_first=True, **extra).prev_sample
+                continue
             action = action.detach().requires_grad_()
             with torch.enable_grad():
                 state = model.state_pred(action[:, :-1], time_embed)

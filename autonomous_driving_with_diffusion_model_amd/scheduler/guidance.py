@@ -24,6 +24,12 @@ class GuidanceDDIMScheduler(DDIMScheduler):
             from ..control import GuidanceLoss
             self.guidance_loss = GuidanceLoss(cfg)
 
+    def guidance_std(self, timestep) -> float:
+        """model_std = exp(0.5 * variance) handed to GuidanceLoss (guidance_ddim_scheduler.py:87-91)."""
+        t = timestep_to_int(timestep)
+        prev_t = t - self.config.num_train_timesteps // self.num_inference_steps
+        return float(torch.exp(0.5 * self._get_variance(t, prev_t)))
+
     def step(self, model_output, timestep, sample, eta: float = 0.0, use_clipped_model_output: bool = False,
              generator=None, variance_noise=None, return_dict: bool = True, target=None, action=None,
              cfg_scale=None, zero_first: bool = False):
@@ -60,6 +66,10 @@ class GuidanceDDPMScheduler(DDPMScheduler):
         if self.use_classifier_guidance:
             from ..control import GuidanceLoss
             self.guidance_loss = GuidanceLoss(cfg)
+
+    def guidance_std(self, timestep) -> float:
+        """model_std = exp(0.5 * variance) handed to GuidanceLoss (guidance_ddpm_scheduler.py:94-99)."""
+        return float(torch.exp(0.5 * self._get_variance(timestep_to_int(timestep))))
 
     def step(self, model_output, timestep, sample, generator=None, return_dict: bool = True, target=None,
              action=None, variance_noise=None, cfg_scale=None, zero_first: bool = False):

@@ -152,6 +152,33 @@ int adx_conv2d_forward(const adx_conv2d_desc* d, const float* x, const float* pa
                        int32_t relu, adx_stream s);
 
 /* ------------------------------------------------------------------------------------
+ * Classifier guidance: TrajPredict state head (modeling/helpers.py:22-59; hidden 64, 4 heads,
+ * ff 256, 2 layers, eval mode) forward, input gradient, and the fused guidance update.
+ * -----------------------------------------------------------------------------------*/
+typedef struct adx_trajpred adx_trajpred;
+int adx_trajpred_create(int32_t out_dim, adx_trajpred** out);
+void adx_trajpred_destroy(adx_trajpred* t);
+int adx_trajpred_num_params(const adx_trajpred* t);       /* state_pred.* named_parameters() count (30) */
+size_t adx_trajpred_packed_bytes(const adx_trajpred* t);
+int adx_trajpred_pack(adx_trajpred* t, const float* const* params, int32_t n, const float* freqs, void* packed,
+                      adx_stream s);
+/* out[B][T][out_dim] = state_pred(action[B][T][3] (strides act_sb, act_st), time_embed[B][64]) */
+int adx_trajpred_forward(adx_trajpred* t, const void* packed, const float* action, int64_t act_sb, int64_t act_st,
+                         const float* time_embed, float* out, int32_t batch, int32_t T, adx_stream s);
+/* grad_action[B][T][3] = (d out / d action)^T grad_out[B][T][out_dim]; what torch.autograd.grad returns for
+ * `action` in control/guidance.py:47-50 through the state path */
+int adx_trajpred_backward(adx_trajpred* t, const void* packed, const float* action, int64_t act_sb, int64_t act_st,
+                          const float* time_embed, const float* grad_out, float* grad_action, int32_t batch,
+                          int32_t T, adx_stream s);
+/* One launch for interact.py:153-160 + GuidanceLoss.forward with STEP = 1 (control/guidance.py:35-59) +
+ * TargetGuidance (control/guidance_loss.py:10-22), per sample:
+ * x = cat([0; state_pred(action[:-1])], action); pick h*; x -= scaled gradient; clip(-1, 1). */
+int adx_guided_output(adx_trajpred* t, const void* packed, const float* action /* [B][T+1][3] */,
+                      const float* time_embed, const float* target /* [B][2] */, float model_std, float scale,
+                      float* x_guided /* [B][T+1][out_dim+3] */, float* loss /* [B] or NULL */, int32_t batch,
+                      int32_t T, adx_stream s);
+
+/* ------------------------------------------------------------------------------------
  * Scheduler step math.  The integer schedule and the fp32 scalar coefficients are computed
  * by the host (the scheduler/ modules keep them as 0-dim CPU tensors) and passed by value.
  * -----------------------------------------------------------------------------------*/
