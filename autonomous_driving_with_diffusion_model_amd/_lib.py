@@ -20,7 +20,8 @@ i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
 class TConvDesc(C.Structure):
     _fields_ = [("kind", i32), ("taps", i32), ("stride", i32), ("pad", i32), ("c0", i32), ("c1", i32),
-                ("cout", i32), ("lin", i32), ("lout", i32), ("groups", i32), ("eps", f32)]
+                ("cout", i32), ("lin", i32), ("lout", i32), ("groups", i32), ("eps", f32), ("w_layout", i32),
+                ("w_flip", i32)]
 
 
 class TConvIO(C.Structure):
@@ -29,7 +30,7 @@ class TConvIO(C.Structure):
                 ("packed_w", vp), ("bias", vp), ("gamma", vp), ("beta", vp),
                 ("tbias", vp), ("tbias_stride", i64),
                 ("res", vp), ("res_sb", i64), ("res_sc", i64), ("res_sl", i64),
-                ("y", vp), ("y_sb", i64), ("y_sc", i64), ("y_sl", i64), ("batch", i32)]
+                ("y", vp), ("y_sb", i64), ("y_sc", i64), ("y_sl", i64), ("batch", i32), ("pre", vp), ("stats", vp)]
 
 
 class EmbedWeights(C.Structure):
@@ -72,6 +73,14 @@ _SIGS = {
     "adx_unet_pack": (i32, [vp, C.POINTER(vp), i32, vp, vp, vp]),
     "adx_unet_workspace_bytes": (C.c_size_t, [vp, i32]),
     "adx_unet_forward": (i32, [vp, vp, vp, C.POINTER(UnetIO), vp]),
+    "adx_unet_tape_create": (i32, [C.POINTER(vp)]),
+    "adx_unet_tape_destroy": (None, [vp]),
+    "adx_unet_train_workspace_bytes": (C.c_size_t, [vp, i32]),
+    "adx_unet_forward_train": (i32, [vp, vp, vp, C.c_size_t, C.POINTER(UnetIO), vp, vp]),
+    "adx_unet_backward": (i32, [vp, vp, vp, C.c_size_t, vp, vp, vp, C.POINTER(vp), C.POINTER(vp), i32, vp]),
+    "adx_gn_mish_backward": (i32, [vp, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
+    "adx_tconv_wgrad": (i32, [C.POINTER(TConvDesc), C.POINTER(TConvIO), vp, vp, vp]),
+    "adx_bias_grad": (i32, [vp, vp, i32, i32, i32, vp]),
     "adx_resnet_create": (i32, [i32, C.POINTER(vp)]),
     "adx_resnet_destroy": (None, [vp]),
     "adx_resnet_num_tensors": (i32, [vp]),

@@ -228,6 +228,11 @@ __global__ void __launch_bounds__(64 * NW) tconv_kernel(const TConvArgs a) {
       const int c = n0 + ((e >> a.log2_lout) & (a.ct - 1));
       if (a.io.bias != nullptr && c < a.cout) sum += a.io.bias[c];
       v[k] = sum;
+      if (a.io.pre != nullptr) {
+        const int b = b0 + (e >> (a.log2_lout + a.log2_ct));
+        if (b < batch && c < a.cout)
+          a.io.pre[((int64_t)b * a.cout + c) * a.lout + (e & (a.lout - 1))] = sum;
+      }
     }
   }
   const int n = a.cg << a.log2_lout;  // elements per (sample, group)
@@ -285,6 +290,15 @@ __global__ void __launch_bounds__(64 * NW) tconv_kernel(const TConvArgs a) {
       float q = 0.f;
       for (int i = 0; i < cpp; ++i) q += red[NCH + base + i];
       rstd[k] = 1.0f / sqrtf(q * inv_n + a.eps);
+      if (a.io.stats != nullptr && lane == 0 && wave + NW * k < NCH && (ch % cpp) == 0) {
+        const int e0 = (wave + NW * k) * 64;  // first element of this (sample, group) pair
+        const int b = b0 + (e0 >> (a.log2_lout + a.log2_ct));
+        const int g = (n0 + ((e0 >> a.log2_lout) & (a.ct - 1))) / a.cg;
+        if (b < batch) {
+          a.io.stats[((int64_t)b * a.groups + g) * 2] = mean[k];
+          a.io.stats[((int64_t)b * a.groups + g) * 2 + 1] = rstd[k];
+        }
+      }
     }
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
@@ -311,8 +325,8 @@ __global__ void __launch_bounds__(64 * NW) tconv_kernel(const TConvArgs a) {
 
 // weight image: [cout_pad/16][nkb][64 lanes][4]; element j of lane l in block (tap, cb) is
 // W[n = 16*tile + (l & 15)][ci = 16*cb + 4*j + (l >> 4)][tap]  (B operand of 16x16x4, k = l >> 4)
-__global__ void tconv_pack_kernel(const float* __restrict__ w, float* __restrict__ packed, int kind, int taps,
-                                  int cin, int cout, int ncb, int nkb, size_t total) {
+__global__ void tconv_pack_kernel(const float* __restrict__ w, float* __restrict__ packed, int layout, int flip,
+                                  int taps, int cin, int cout, int ncb, int nkb, size_t total) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const int j = idx & 3;
@@ -324,8 +338,9 @@ __global__ void tconv_pack_kernel(const float* __restrict__ w, float* __restrict
   const int n = t16 * 16 + (lane & 15);
   const int ci = cb * 16 + 4 * j + (lane >> 4);
   float v = 0.f;
+  const int ts = flip ? taps - 1 - tap : tap;
   if (n < cout && ci < cin)
-    v = kind == 0 ? w[((size_t)n * cin + ci) * taps + tap] : w[((size_t)ci * cout + n) * taps + tap];
+    v = layout == 0 ? w[((size_t)n * cin + ci) * taps + ts] : w[((size_t)ci * cout + n) * taps + ts];
   packed[idx] = v;
 }
 
@@ -348,7 +363,9 @@ int tconv_check(const adx_tconv_desc* d) {
                 d->lout, d->lin);
   } else {
     ADX_REQUIRE(d->stride == 2, "tconv: transposed conv supports stride 2 only");
-    ADX_REQUIRE(d->lout == (d->lin - 1) * 2 - 2 * d->pad + d->taps, "tconv: transposed lout %d inconsistent", d->lout);
+    const int lo0 = (d->lin - 1) * 2 - 2 * d->pad + d->taps;  // output_padding 0 or 1
+    ADX_REQUIRE(d->lout == lo0 || d->lout == lo0 + 1, "tconv: transposed lout %d inconsistent", d->lout);
+    ADX_REQUIRE(d->w_layout == 0 || d->w_layout == 1, "tconv: bad w_layout");
     ADX_REQUIRE((d->taps - 1 - d->pad + 1) / 2 >= 1, "tconv: transposed conv needs a left halo");
   }
   ADX_REQUIRE(ilog2_exact(d->lout) >= 0 && d->lout <= 64, "tconv: lout must be a power of two <= 64, got %d", d->lout);
@@ -502,8 +519,8 @@ int tconv_pack(const adx_tconv_desc* d, const float* w, float* packed, hipStream
   const int cin = d->c0 + d->c1;
   const int ncb = round_up(cin, 16) / 16;
   const size_t total = tconv_packed_floats(d);
-  tconv_pack_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(w, packed, d->kind, d->taps, cin,
-                                                                             d->cout, ncb, d->taps * ncb, total);
+  tconv_pack_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
+      w, packed, d->kind == 1 ? 1 - d->w_layout : d->w_layout, d->w_flip, d->taps, cin, d->cout, ncb, d->taps * ncb, total);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
 }

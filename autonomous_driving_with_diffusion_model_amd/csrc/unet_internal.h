@@ -1,0 +1,40 @@
+// Shared between the inference executor (unet.hip) and the training executor (unet_train.hip).
+#pragma once
+#include <vector>
+
+#include "tconv.h"
+
+namespace adx {
+
+int embed_forward(const adx_embed_weights* w, int dim, const int64_t* t, int t_rows, const float* cond,
+                  const float* feat, int feat_rows, int rows, float* time_embed, float* mish_cond, hipStream_t s);
+
+struct ConvLayer {
+  adx_tconv_desc d{};
+  int p_w = -1, p_b = -1, p_g = -1, p_be = -1;      // indices into the parameter list
+  size_t o_w = 0, o_b = 0, o_g = 0, o_be = 0;       // float offsets into the packed buffer
+};
+
+struct ResBlock {
+  ConvLayer a, b, r;
+  bool has_r = false;
+  int p_tw = -1, p_tb = -1;  // time_mlp.1 weight / bias
+  int tb_off = 0;            // column offset in the fused time-bias matrix
+  int c0 = 0, c1 = 0, cout = 0, len = 0;
+};
+
+}  // namespace adx
+
+struct adx_unet {
+  adx_unet_config cfg{};
+  std::vector<adx::ResBlock> blocks;
+  std::vector<adx::ConvLayer> downs, ups;
+  adx::ConvLayer head0, head1, tlin;
+  int n_levels = 0, n_params = 0, sum_c = 0, out_ch = 0;
+  int p_t1w = 0, p_t1b = 0, p_t3w = 0, p_t3b = 0, p_c0w = -1, p_c0b = -1, p_c2w = -1, p_c2b = -1;
+  size_t o_freqs = 0, o_t1w = 0, o_t1b = 0, o_t3w = 0, o_t3b = 0, o_c0w = 0, o_c0b = 0, o_c2w = 0, o_c2b = 0;
+  size_t o_tlin_raw = 0, o_tlin_b = 0;  // concatenated [sum_c][2 dim] block-Linear weight (staging) and bias
+  size_t packed_floats = 0;
+  bool packed_once = false;
+};
+

@@ -33,6 +33,59 @@ from .spec import unet_entries
 from .trajpredict import TrajPredict
 
 
+class _UnetTrainFn(torch.autograd.Function):
+    """Temporal stack with gradients: adx_unet_forward_train keeps a tape in a per-call workspace,
+    adx_unet_backward turns d(out) into one gradient per parameter plus d(img_feature)."""
+
+    @staticmethod
+    def forward(ctx, x, feat, time, cond, module, *params):
+        h = module._native()
+        rows = x.shape[0]
+        module._ensure_packed(x.device)
+        nbytes = L.lib().adx_unet_train_workspace_bytes(h, rows)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        tape = L.vp()
+        L.check(L.lib().adx_unet_tape_create(C.byref(tape)), "adx_unet_tape_create")
+        out = torch.empty((rows, module.horizon, module.transition_dim), dtype=torch.float32, device=x.device)
+        feat_c = L.require_gpu_f32(feat.detach(), "img_feature")
+        io = L.UnetIO()
+        io.x, io.img_feature, io.feat_rows = x.data_ptr(), feat_c.data_ptr(), feat_c.shape[0]
+        io.t, io.t_rows, io.cond, io.rows = time.data_ptr(), time.shape[0], L.ptr(cond), rows
+        io.out, io.time_embed = out.data_ptr(), None
+        try:
+            L.check(L.lib().adx_unet_forward_train(h, module._packed.data_ptr(), ws.data_ptr(), nbytes, C.byref(io), tape,
+                                                   L.stream_ptr(x.device)), "adx_unet_forward_train")
+        except Exception:
+            L.lib().adx_unet_tape_destroy(tape)
+            raise
+        ctx.module, ctx.tape, ctx.ws, ctx.nbytes = module, tape, ws, nbytes
+        ctx.keep = (x, feat_c, time, cond)          # the tape holds raw pointers into these
+        ctx.params = params
+        ctx.pack_key = module._pack_key
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        module, params = ctx.module, ctx.params
+        if module._pack_key != ctx.pack_key:
+            raise RuntimeError("parameters changed between forward and backward")
+        h = module._native()
+        g = L.require_gpu_f32(grad_out, "grad_out")
+        rows = g.shape[0]
+        grads = [torch.empty_like(p) for p in params]
+        d_feat = torch.empty((rows, module.dim), dtype=torch.float32, device=g.device)
+        pa = L.ptr_array([p.detach() for p in params])
+        ga = L.ptr_array(grads)
+        try:
+            L.check(L.lib().adx_unet_backward(h, module._packed.data_ptr(), ctx.ws.data_ptr(), ctx.nbytes, ctx.tape,
+                                              g.data_ptr(), d_feat.data_ptr(), pa, ga, len(grads),
+                                              L.stream_ptr(g.device)), "adx_unet_backward")
+        finally:
+            L.lib().adx_unet_tape_destroy(ctx.tape)
+            ctx.tape = None
+        return (None, d_feat, None, None, None, *grads)
+
+
 class TemporalMapUnet(nn.Module):
     def __init__(self, horizon, transition_dim=2, attention=False, dim=128, dim_mults=(1, 2, 4, 8),
                  diffuser_building_block="concat", use_cond=GuidanceType.NO_GUIDANCE):
@@ -153,13 +206,28 @@ class TemporalMapUnet(nn.Module):
         self._feat_cache = (weakref.ref(img), img._version, self.perception.weights_key(), feat) if use_cache else None
         return feat
 
+    # -- training path -----------------------------------------------------------------------------
+    def unet_forward_train(self, x, img_feature, time, cond=None):
+        """TemporalMapUnet.forward minus the perception pass, differentiable w.r.t. every temporal-stack
+        parameter and w.r.t. `img_feature` (train.py:242).  NO_GUIDANCE / FREE_GUIDANCE only for now."""
+        if self.use_cond == GuidanceType.CLASSIFIER_GUIDANCE:
+            raise NotImplementedError("CLASSIFIER_GUIDANCE training needs TrajPredict parameter gradients (not built yet)")
+        x = L.require_gpu_f32(x, "x")
+        rows = x.shape[0]
+        time = L.require_gpu_f32(time.reshape(-1), "time", torch.int64)
+        if time.shape[0] != rows or img_feature.shape[0] != rows:
+            raise RuntimeError("training expects time [B] and img_feature [B, dim] for x [B, H, D]")
+        cond_t = None
+        if self.use_cond == GuidanceType.FREE_GUIDANCE and cond is not None:
+            cond_t = L.require_gpu_f32(cond, "cond")
+        return _UnetTrainFn.apply(x, img_feature, time, cond_t, self, *self._unet_params())
+
     # -- forward ---------------------------------------------------------------------------------
     def forward(self, x, img, time, cond=None, return_action_and_time_only=False):
         """x [B, T, D]; img [B or 1, 3, H, W]; time int64 [B or 1]; cond None or [B, 2]."""
-        if self.training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-                             and x.requires_grad):
-            raise NotImplementedError("TemporalMapUnet: the training/backward kernels are not implemented yet; use "
-                                      "model.eval() under torch.no_grad()/inference_mode()")
+        if self.training:
+            feat = self.perception(img)          # train-mode perception (raises until its kernels land)
+            return self.unet_forward_train(x, feat, time, cond)
         x = L.require_gpu_f32(x, "x")
         if x.dim() != 3 or x.shape[1] != self.horizon or x.shape[2] != self.transition_dim:
             raise ValueError(f"x must be [B, {self.horizon}, {self.transition_dim}], got {tuple(x.shape)}")

@@ -48,6 +48,10 @@ typedef struct adx_tconv_desc {
   int32_t lin, lout;
   int32_t groups;            /* 0: no GroupNorm/Mish epilogue; 8: Conv1dBlock (helpers.py:95-112) */
   float eps;
+  /* weight source layout for adx_tconv_pack (0,0 = the module's own weight).  The data-gradient of a
+   * convolution is again a convolution of this family with the SAME weight tensor read differently:
+   *   w_layout 0: w[cout][cin][taps]   1: w[cin][cout][taps];   w_flip 1: taps reversed.          */
+  int32_t w_layout, w_flip;
 } adx_tconv_desc;
 
 /* Size (bytes) of the packed weight image for a conv of this geometry. */
@@ -67,6 +71,9 @@ typedef struct adx_tconv_io {
   const float* res; int64_t res_sb, res_sc, res_sl; /* residual added last (temporal.py:55) or NULL */
   float* y; int64_t y_sb, y_sc, y_sl;
   int32_t batch;
+  /* training only (NULL otherwise): conv+bias before GroupNorm, dense [B][cout][lout], and the
+   * per-(sample, group) statistics [B][groups][2] = (mean, rstd) that the backward pass reuses */
+  float* pre; float* stats;
 } adx_tconv_io;
 
 /* Conv (+bias) [-> GroupNorm -> Mish] [+ time bias] [+ residual], fp32 MFMA.
@@ -124,6 +131,31 @@ typedef struct adx_unet_io {
   float* time_embed;          /* [rows][dim] or NULL (CLASSIFIER: returned to the caller, temporal.py:236-237) */
 } adx_unet_io;
 int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx_unet_io* io, adx_stream s);
+
+/* ------------------------------------------------------------------------------------
+ * Training step T1 (train.py:242-251), temporal stack: forward that keeps a tape, and backward.
+ * The reference gets these from torch autograd; the gradients are written in PyTorch layouts.
+ * -----------------------------------------------------------------------------------*/
+typedef struct adx_unet_tape adx_unet_tape;
+int adx_unet_tape_create(adx_unet_tape** out);
+void adx_unet_tape_destroy(adx_unet_tape* t);
+size_t adx_unet_train_workspace_bytes(const adx_unet* u, int32_t rows);
+int adx_unet_forward_train(adx_unet* u, const void* packed, void* workspace, size_t workspace_bytes,
+                           const adx_unet_io* io, adx_unet_tape* tape, adx_stream s);
+/* d_out [rows][H][D] -> one gradient per parameter of adx_unet_pack's list (written) and
+ * d_img_feature [rows][dim] (gradient entering the perception encoder).  `params` are the same
+ * raw parameter pointers given to adx_unet_pack (the data-gradient convs re-read them). */
+int adx_unet_backward(adx_unet* u, const void* packed, void* workspace, size_t workspace_bytes, adx_unet_tape* tape,
+                      const float* d_out, float* d_img_feature, const float* const* params, float* const* grads,
+                      int32_t n_grads, adx_stream s);
+/* op level: gradient through [+tb] -> Mish -> GroupNorm of a Conv1dBlock (modeling/helpers.py:105-108) */
+int adx_gn_mish_backward(const float* dy, int64_t dy_sb, int64_t dy_sc, int64_t dy_sl, const float* pre,
+                         const float* stats, const float* gamma, const float* beta, float* dc, float* dgamma,
+                         float* dbeta, float* dbias, float* dtb, int64_t dtb_stride, int32_t B, int32_t C, int32_t L,
+                         int32_t groups, adx_stream s);
+/* op level: dW[cout][cin][taps] of a (kind 0) temporal conv from its input (io->x0/x1) and d(conv out) */
+int adx_tconv_wgrad(const adx_tconv_desc* d, const adx_tconv_io* io, const float* dc, float* dw, adx_stream s);
+int adx_bias_grad(const float* dc, float* db, int32_t B, int32_t C, int32_t L, adx_stream s);
 
 /* ------------------------------------------------------------------------------------
  * Perception: ResNet-34 forward (eval mode, BatchNorm folded at pack time),
