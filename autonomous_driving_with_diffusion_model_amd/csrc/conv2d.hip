@@ -15,11 +15,10 @@
 #include <vector>
 
 #include "adx_common.h"
+#include "conv2d_internal.h"
 
 namespace adx {
 
-constexpr int kTileH = 4;    // output rows per workgroup (one per wave)
-constexpr int kTileW = 32;   // output columns per workgroup (= MFMA N)
 constexpr int kCoutT = 64;   // output channels per workgroup (2 MFMA row blocks)
 constexpr size_t kMaxLds = 96 * 1024;
 
@@ -178,6 +177,30 @@ __global__ void conv2d_pack_kernel(const float* __restrict__ w, float* __restric
   p[idx] = ci < Cin ? w[((size_t)co * Cin + ci) * taps + tap] : 0.f;
 }
 
+// data-gradient image of the same weight: K = original cout, N = original cin, taps flipped:
+// p[tap'][co][ci] = w[co][ci][taps-1-tap']
+__global__ void conv2d_pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ p, int Cout, int Cin, int taps,
+                                         size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int ci = idx % Cin;
+  const int co = (idx / Cin) % Cout;
+  const int tap = idx / ((size_t)Cin * Cout);
+  p[idx] = w[((size_t)co * Cin + ci) * taps + (taps - 1 - tap)];
+}
+
+int conv2d_pack_raw(const float* w, float* packed, int cout, int cin, int k, int cin_pad, int dgrad, hipStream_t s) {
+  if (dgrad) {
+    const size_t total = (size_t)k * k * cout * cin;
+    conv2d_pack_dgrad_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(w, packed, cout, cin, k * k, total);
+  } else {
+    const size_t total = (size_t)k * k * cin_pad * cout;
+    conv2d_pack_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(w, packed, cout, cin, k * k, cin_pad, total);
+  }
+  ADX_LAUNCH_CHECK();
+  return ADX_OK;
+}
+
 // eval-mode BatchNorm2d as y = x * scale + shift (eps = 1e-5)
 __global__ void bn_fold_kernel(const float* g, const float* b, const float* mean, const float* var, float* scale,
                                float* shift, int C) {
@@ -237,40 +260,35 @@ __global__ void __launch_bounds__(256) avgpool_fc_kernel(const float* __restrict
   }
 }
 
-struct ConvSpec {
-  int cin, cout, k, stride, pad;
-  int t_w, t_g, t_b, t_m, t_v;           // tensor indices (weight, bn gamma, beta, mean, var)
-  size_t o_w, o_scale, o_shift;          // float offsets in the packed buffer
-  int cin_pad, cc;
-};
+int maxpool_launch(const float* x, float* y, int planes, int H, int W, int OH, int OW, hipStream_t s) {
+  const size_t total = (size_t)planes * OH * OW;
+  maxpool_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(x, y, planes, H, W, OH, OW);
+  ADX_LAUNCH_CHECK();
+  return ADX_OK;
+}
+
+int avgpool_fc_launch(const float* x, const float* fw, const float* fb, float* out, int batch, int C, int HW, int out_dim,
+                      hipStream_t s) {
+  avgpool_fc_kernel<<<dim3(batch), dim3(256), 0, s>>>(x, fw, fb, out, C, HW, out_dim);
+  ADX_LAUNCH_CHECK();
+  return ADX_OK;
+}
 
 }  // namespace adx
-
-struct adx_resnet {
-  int out_dim = 0;
-  std::vector<adx::ConvSpec> convs;      // execution order: stem, then per block conv1, conv2, [downsample]
-  std::vector<int> block_has_ds;         // per BasicBlock
-  int t_fcw = 0, t_fcb = 0, n_tensors = 0;
-  size_t o_fcw = 0, o_fcb = 0, packed_floats = 0;
-  bool packed_once = false;
-};
 
 namespace adx {
 
 static size_t align64f(size_t v) { return (v + 63) / 64 * 64; }
 
-static int conv_out(int h, int k, int s, int p) { return (h + 2 * p - k) / s + 1; }
-
-static int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const float* scale, const float* shift,
-                             const float* res, float* y, int N, int H, int W, int relu, hipStream_t s);
+static int conv_out(int h, int k, int s, int p) { return conv_out_dim(h, k, s, p); }
 
 static int conv2d_launch(const ConvSpec& L, const float* base, const float* x, const float* res, float* y, int N, int H,
                          int W, int relu, hipStream_t s) {
   return conv2d_launch_raw(L, x, base + L.o_w, base + L.o_scale, base + L.o_shift, res, y, N, H, W, relu, s);
 }
 
-static int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const float* scale, const float* shift,
-                             const float* res, float* y, int N, int H, int W, int relu, hipStream_t s) {
+int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const float* scale, const float* shift,
+                      const float* res, float* y, int N, int H, int W, int relu, hipStream_t s) {
   Conv2dArgs a;
   a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.res = res; a.y = y;
   a.N = N; a.Cin = L.cin; a.H = H; a.W = W; a.Cout = L.cout;
@@ -289,8 +307,9 @@ static int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, 
   ADX_REQUIRE(grid < (1u << 31), "conv2d: grid too large");
   static bool attr_set = false;  // dynamic LDS above 64 KB must be opted into once per kernel
   if (!attr_set) {
-    const void* fns[4] = {reinterpret_cast<const void*>(&conv2d_kernel<1, 3>), reinterpret_cast<const void*>(&conv2d_kernel<2, 3>),
-                          reinterpret_cast<const void*>(&conv2d_kernel<2, 1>), reinterpret_cast<const void*>(&conv2d_kernel<2, 7>)};
+    const void* fns[5] = {reinterpret_cast<const void*>(&conv2d_kernel<1, 3>), reinterpret_cast<const void*>(&conv2d_kernel<2, 3>),
+                          reinterpret_cast<const void*>(&conv2d_kernel<2, 1>), reinterpret_cast<const void*>(&conv2d_kernel<2, 7>),
+                          reinterpret_cast<const void*>(&conv2d_kernel<1, 1>)};
     for (const void* f : fns) ADX_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
     attr_set = true;
   }
@@ -299,6 +318,7 @@ static int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, 
   else if (L.stride == 2 && L.k == 3) conv2d_kernel<2, 3><<<g, blk, lds, s>>>(a);
   else if (L.stride == 2 && L.k == 1) conv2d_kernel<2, 1><<<g, blk, lds, s>>>(a);
   else if (L.stride == 2 && L.k == 7) conv2d_kernel<2, 7><<<g, blk, lds, s>>>(a);
+  else if (L.stride == 1 && L.k == 1) conv2d_kernel<1, 1><<<g, blk, lds, s>>>(a);
   else {
     set_error("conv2d: no kernel for k=%d stride=%d (ResNet-34 uses 3x3 s1, 3x3 s2, 1x1 s2, 7x7 s2)", L.k, L.stride);
     return ADX_ERR_INVALID;

@@ -1,0 +1,43 @@
+// Shared between the inference (conv2d.hip) and training (resnet_train.hip) perception executors.
+#pragma once
+#include <vector>
+
+#include "adx_common.h"
+
+namespace adx {
+
+constexpr int kTileH = 4;    // output rows per workgroup (one per wave)
+constexpr int kTileW = 32;   // output columns per workgroup (= MFMA N)
+
+struct ConvSpec {
+  int cin, cout, k, stride, pad;
+  int t_w, t_g, t_b, t_m, t_v;           // tensor indices (weight, bn gamma, beta, mean, var)
+  size_t o_w, o_scale, o_shift;          // float offsets in the packed buffer
+  int cin_pad, cc;
+};
+
+}  // namespace adx
+
+struct adx_resnet {
+  int out_dim = 0;
+  std::vector<adx::ConvSpec> convs;      // execution order: stem, then per block conv1, conv2, [downsample]
+  std::vector<int> block_has_ds;         // per BasicBlock
+  int t_fcw = 0, t_fcb = 0, n_tensors = 0;
+  size_t o_fcw = 0, o_fcb = 0, packed_floats = 0;
+  bool packed_once = false;
+};
+
+namespace adx {
+
+// one conv2d launch: y = [relu](conv(x, w) [* scale + shift] [+ res]); w = packed [tap][cin_pad][cout]
+int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const float* scale, const float* shift,
+                      const float* res, float* y, int N, int H, int W, int relu, hipStream_t s);
+// [Cout][Cin][k][k] -> [tap][cin_pad][Cout]; dgrad = 1 packs the data-gradient view instead:
+// [tap'][cout_pad as K][Cin as N] with the taps flipped (conv of dy with this image gives dx)
+int conv2d_pack_raw(const float* w, float* packed, int cout, int cin, int k, int cin_pad, int dgrad, hipStream_t s);
+inline int conv_out_dim(int h, int k, int s, int p) { return (h + 2 * p - k) / s + 1; }
+int maxpool_launch(const float* x, float* y, int planes, int H, int W, int OH, int OW, hipStream_t s);
+int avgpool_fc_launch(const float* x, const float* fw, const float* fb, float* out, int batch, int C, int HW, int out_dim,
+                      hipStream_t s);
+
+}  // namespace adx

@@ -1,0 +1,642 @@
+// Training-mode perception: ResNet-34 forward with batch-statistics BatchNorm (running buffers updated
+// like nn.BatchNorm2d, momentum 0.1) that keeps what the backward needs, and the backward itself
+// (training step T1, train.py:242-251; modeling/resnet.py:87-102,277-293).
+//
+//   forward, per conv:   raw = conv2d(x)                         (the inference MFMA kernel, no epilogue)
+//                        per-channel sum / sum-of-squares         (fp64 accumulation, one pass)
+//                        out = relu(raw * scale + shift [+ identity])
+//   backward, per conv:  dz = dout * (out > 0); sums of dz and dz*xhat per channel (fp64)
+//                        draw = gamma*rstd * (dz - mean(dz) - xhat*mean(dz*xhat))
+//                        dW   = conv2d_wgrad(x, draw)             (MFMA, pixels as K, atomically reduced)
+//                        dx   = conv2d(draw, W flipped/transposed) -- the same forward kernel;
+//                               stride-2 convs go through a zero-dilated draw (3 of 36 layers)
+#include <algorithm>
+
+#include "conv2d_internal.h"
+
+namespace adx {
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// sums[c][0] += sum a,  sums[c][1] += sum a*a          (MODE 0, BatchNorm forward statistics)
+// sums[c][0] += sum dz, sums[c][1] += sum dz*xhat      (MODE 1, BatchNorm backward), dz = dout * (out > 0 or 1)
+template <int MODE>
+__global__ void __launch_bounds__(256) channel_sums_kernel(const float* __restrict__ a, const float* __restrict__ out,
+                                                            const float* __restrict__ raw, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, double* __restrict__ sums,
+                                                            int C, int HW, int relu_mask) {
+  const int plane = blockIdx.x;            // n * C + c
+  const int c = plane % C, tid = threadIdx.x;
+  const size_t base = (size_t)plane * HW;
+  double s0 = 0.0, s1 = 0.0;
+  const float mu = MODE == 1 ? mean[c] : 0.f, rs = MODE == 1 ? rstd[c] : 0.f;
+  for (int i = tid; i < HW; i += 256) {
+    float v = a[base + i];
+    if (MODE == 0) {
+      s0 += v;
+      s1 += (double)v * v;
+    } else {
+      if (relu_mask && !(out[base + i] > 0.f)) v = 0.f;
+      s0 += v;
+      s1 += (double)v * (double)((raw[base + i] - mu) * rs);
+    }
+  }
+  __shared__ double red[8];
+  s0 = wave_sum_d(s0);
+  s1 = wave_sum_d(s1);
+  if ((tid & 63) == 0) { red[(tid >> 6) * 2] = s0; red[(tid >> 6) * 2 + 1] = s1; }
+  __syncthreads();
+  if (tid == 0) {
+    atomicAdd(sums + 2 * c, (red[0] + red[2]) + (red[4] + red[6]));
+    atomicAdd(sums + 2 * c + 1, (red[1] + red[3]) + (red[5] + red[7]));
+  }
+}
+
+// batch statistics -> scale/shift for the apply pass, saved mean/rstd, running-buffer update
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ mean, float* __restrict__ rstd, float* running_mean,
+                                   float* running_var, int C, double count) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const double m = sums[2 * c] / count;
+  double var = sums[2 * c + 1] / count - m * m;
+  if (var < 0.0) var = 0.0;
+  const float r = (float)(1.0 / sqrt(var + 1e-5));
+  const float sc = gamma[c] * r;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)m * sc;
+  mean[c] = (float)m;
+  rstd[c] = r;
+  if (running_mean != nullptr) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = 0.9f * running_mean[c] + 0.1f * (float)m;
+    running_var[c] = 0.9f * running_var[c] + 0.1f * (float)unbiased;
+  }
+}
+
+__global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__ raw, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, const float* __restrict__ res,
+                                                        float* __restrict__ out, int C, int HW, size_t total, int relu) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (i / HW) % C;
+  float v = raw[i] * scale[c] + shift[c];
+  if (res != nullptr) v += res[i];
+  if (relu) v = v > 0.f ? v : 0.f;
+  out[i] = v;
+}
+
+// draw = gamma*rstd * (dz - m1 - xhat*m2); also d gamma / d beta (one thread per channel does that part)
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                            const float* __restrict__ raw, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                            const double* __restrict__ sums, float* __restrict__ draw,
+                                                            float* __restrict__ dz_out, int C, int HW, size_t total,
+                                                            double count, int relu_mask) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (i / HW) % C;
+  float dz = dout[i];
+  if (relu_mask && !(out[i] > 0.f)) dz = 0.f;
+  if (dz_out != nullptr) dz_out[i] = dz;
+  const float xh = (raw[i] - mean[c]) * rstd[c];
+  const float m1 = (float)(sums[2 * c] / count), m2 = (float)(sums[2 * c + 1] / count);
+  draw[i] = gamma[c] * rstd[c] * (dz - m1 - xh * m2);
+}
+
+__global__ void bn_param_grad_kernel(const double* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                     int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  dbeta[c] = (float)sums[2 * c];
+  dgamma[c] = (float)sums[2 * c + 1];
+}
+
+// dst[n][c][2y][2x] (+)= src[n][c][y][x]; everything else of dst untouched (caller zeroes when accumulate == 0)
+__global__ void __launch_bounds__(256) dilate2_kernel(const float* __restrict__ src, float* __restrict__ dst, int planes,
+                                                       int h, int w, int H, int W, int accumulate) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)planes * h * w) return;
+  const int x = i % w, y = (i / w) % h;
+  const size_t p = i / ((size_t)w * h);
+  float* d = dst + (p * H + 2 * y) * W + 2 * x;
+  *d = accumulate ? *d + src[i] : src[i];
+}
+
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           float* __restrict__ dx, int planes, int H, int W, int OH,
+                                                           int OW) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)planes * OH * OW) return;
+  const int ox = idx % OW, oy = (idx / OW) % OH;
+  const size_t pl = idx / ((size_t)OW * OH);
+  const float* src = x + pl * H * W;
+  float m = -INFINITY;
+  int arg = -1;
+  for (int dyy = 0; dyy < 3; ++dyy) {
+    const int iy = oy * 2 - 1 + dyy;
+    if (iy < 0 || iy >= H) continue;
+    for (int dxx = 0; dxx < 3; ++dxx) {
+      const int ix = ox * 2 - 1 + dxx;
+      if (ix < 0 || ix >= W) continue;
+      const float v = src[(size_t)iy * W + ix];
+      if (v > m || arg < 0) { m = v; arg = iy * W + ix; }   // first maximum, like torch
+    }
+  }
+  atomicAdd(dx + pl * H * W + arg, dy[idx]);
+}
+
+// avgpool + fc backward; one workgroup per image.  pooled is recomputed.
+__global__ void __launch_bounds__(256) avgpool_fc_bwd_kernel(const float* __restrict__ x, const float* __restrict__ fw,
+                                                              const float* __restrict__ dfeat, float* __restrict__ dx,
+                                                              float* __restrict__ dfw, float* __restrict__ dfb, int C,
+                                                              int HW, int out_dim) {
+  __shared__ float pooled[512];
+  __shared__ float dpool[512];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* src = x + (size_t)n * C * HW;
+  const float inv = 1.0f / (float)HW;
+  for (int c = wave; c < C; c += 4) {
+    float s = 0.f;
+    for (int i = lane; i < HW; i += 64) s += src[(size_t)c * HW + i];
+    s = wave_sum(s);
+    if (lane == 0) pooled[c] = s * inv;
+  }
+  for (int c = tid; c < C; c += 256) {
+    float s = 0.f;
+    for (int j = 0; j < out_dim; ++j) s += dfeat[(size_t)n * out_dim + j] * fw[(size_t)j * C + c];
+    dpool[c] = s * inv;
+  }
+  __syncthreads();
+  for (int i = tid; i < C * HW; i += 256) dx[(size_t)n * C * HW + i] = dpool[i / HW];
+  for (int i = tid; i < out_dim * C; i += 256) atomicAdd(dfw + i, dfeat[(size_t)n * out_dim + i / C] * pooled[i % C]);
+  for (int j = tid; j < out_dim; j += 256) atomicAdd(dfb + j, dfeat[(size_t)n * out_dim + j]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv2d weight gradient on v_mfma_f32_32x32x2_f32.
+//   A (32 x 2): draw[co][pixel], B (2 x 32): x[(ci, tap) combination][pixel shifted by the tap],
+//   K = output pixels.  Lane j of column group g stands for one (input channel, tap) pair, so the same
+//   kernel serves 3x3 / 1x1 convs (group = tap, lane = channel) and the 3-channel 7x7 stem
+//   (147 pairs spread over 5 groups).  One workgroup owns a 32-cout x NG*32-pair weight tile, walks a
+//   range of (image, 4x32 pixel tile) units with the register double buffer of the forward conv, sums
+//   its 4 waves through LDS and adds the tile to dW with float atomics.
+struct WgradArgs2 {
+  const float* x;        // [N][Cin][H][W]
+  const float* dy;       // [N][Cout][OH][OW]
+  float* dw;             // [Cout][Cin][K][K], zeroed by the caller
+  int N, Cin, H, W, Cout, OH, OW, pad;
+  int tiles_x, tiles_y, units, units_per_wg, n_ci_tiles, n_co_tiles;
+  int ci_per_tile, pairs;   // channels staged per tile (32, or 3 for the stem), valid (ci, tap) pairs per tile
+};
+
+template <int STRIDE, int K, int NG, int CIT>
+__global__ void __launch_bounds__(256) conv2d_wgrad_kernel(const WgradArgs2 a) {
+  constexpr int PH = (kTileH - 1) * STRIDE + K, PW = (kTileW - 1) * STRIDE + K;
+  constexpr int PLANE = PH * PW + ((PH * PW) % 2 == 0 ? 1 : 0);   // odd plane pitch: lanes = channels hit distinct banks
+  constexpr int NP = CIT * PH * PW;
+  constexpr int PITEMS = (NP + 255) / 256;
+  constexpr int DP = kTileH * kTileW + 1;                          // odd pitch of the draw tile
+  constexpr int ND = 32 * kTileH * kTileW;
+  constexpr int DITEMS = ND / 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* patch = smem;                 // [CIT][PLANE]
+  float* dyt = smem + CIT * PLANE;     // [32][DP]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bid = blockIdx.x;
+  const int ci_t = bid % a.n_ci_tiles; bid /= a.n_ci_tiles;
+  const int co_t = bid % a.n_co_tiles; bid /= a.n_co_tiles;
+  const int u0 = bid * a.units_per_wg, u1 = min(u0 + a.units_per_wg, a.units);
+  const int ci0 = ci_t * a.ci_per_tile, co0 = co_t * 32;
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const size_t hw = (size_t)a.H * a.W, ohw = (size_t)a.OH * a.OW;
+
+  // (ci, tap) pair of this lane in every column group, as an offset into the patch
+  int poff[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int q = g * 32 + l31;
+    int cl, tap;
+    if (K != 7) { cl = l31; tap = g; } else { cl = q / (K * K); tap = q - cl * (K * K); }
+    const bool ok = q < a.pairs && ci0 + cl < a.Cin && cl < CIT;
+    poff[g] = ok ? cl * PLANE + (tap / K) * PW + (tap % K) : -1;
+  }
+  f32x16 acc[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
+
+  float pv[PITEMS], dv[DITEMS];
+  auto load_unit = [&](int u) {
+    const int tx = u % a.tiles_x, ty = (u / a.tiles_x) % a.tiles_y, n = u / (a.tiles_x * a.tiles_y);
+    const int oy0 = ty * kTileH, ox0 = tx * kTileW;
+    const int iy0 = oy0 * STRIDE - a.pad, ix0 = ox0 * STRIDE - a.pad;
+    const float* xin = a.x + ((size_t)n * a.Cin + ci0) * hw;
+#pragma unroll
+    for (int k = 0; k < PITEMS; ++k) {
+      const int e = tid + 256 * k;
+      const int c = e / (PH * PW), rem = e - c * (PH * PW);
+      const int py = rem / PW, px = rem - py * PW;
+      const int iy = iy0 + py, ix = ix0 + px;
+      const bool ok = e < NP && ci0 + c < a.Cin && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      pv[k] = ok ? xin[c * hw + (size_t)iy * a.W + ix] : 0.f;
+    }
+    const float* dyin = a.dy + ((size_t)n * a.Cout + co0) * ohw;
+#pragma unroll
+    for (int k = 0; k < DITEMS; ++k) {
+      const int e = tid + 256 * k;
+      const int c = e / (kTileH * kTileW), rem = e - c * (kTileH * kTileW);
+      const int oy = oy0 + rem / kTileW, ox = ox0 + rem % kTileW;
+      const bool ok = co0 + c < a.Cout && oy < a.OH && ox < a.OW;
+      dv[k] = ok ? dyin[c * ohw + (size_t)oy * a.OW + ox] : 0.f;
+    }
+  };
+  auto store_unit = [&]() {
+#pragma unroll
+    for (int k = 0; k < PITEMS; ++k) {
+      const int e = tid + 256 * k;
+      if (e < NP) {
+        const int c = e / (PH * PW);
+        patch[c * PLANE + (e - c * (PH * PW))] = pv[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < DITEMS; ++k) {
+      const int e = tid + 256 * k;
+      const int c = e / (kTileH * kTileW);
+      dyt[c * DP + (e - c * (kTileH * kTileW))] = dv[k];
+    }
+  };
+
+  if (u0 < u1) load_unit(u0);
+  for (int u = u0; u < u1; ++u) {
+    if (u > u0) __syncthreads();
+    store_unit();
+    __syncthreads();
+    if (u + 1 < u1) load_unit(u + 1);
+    // this wave: output row `wave` of the tile, 16 K-steps of 2 pixels
+    const float* ap = dyt + l31 * DP + wave * kTileW + khalf;
+    const int prow = (wave * STRIDE) * PW + khalf * STRIDE;
+#pragma unroll 4
+    for (int ks = 0; ks < kTileW / 2; ++ks) {
+      const float av = ap[2 * ks];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const float bv = poff[g] >= 0 ? patch[poff[g] + prow + 2 * ks * STRIDE] : 0.f;
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[g], 0, 0, 0);
+      }
+    }
+  }
+  // sum the 4 waves into one LDS tile (one wave at a time), then one atomic per weight
+  __syncthreads();
+  float* red = smem;   // [NG][32 x 32]
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * khalf;   // cout within the tile
+          float* dst = red + (g * 32 + row) * 32 + l31;
+          *dst = w == 0 ? acc[g][r] : *dst + acc[g][r];
+        }
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < NG * 1024; e += 256) {
+    const int g = e >> 10, row = (e >> 5) & 31, j = e & 31;
+    const int q = g * 32 + j;
+    int cl, tap;
+    if (K != 7) { cl = j; tap = g; } else { cl = q / (K * K); tap = q - cl * (K * K); }
+    const int co = co0 + row, ci = ci0 + cl;
+    if (q < a.pairs && co < a.Cout && ci < a.Cin && cl < CIT) atomicAdd(a.dw + ((size_t)co * a.Cin + ci) * (K * K) + tap, red[e]);
+  }
+}
+
+int conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, int k, int stride,
+                 int pad, hipStream_t s) {
+  ADX_REQUIRE(x && dy && dw, "conv2d_wgrad: null tensor");
+  WgradArgs2 a;
+  a.x = x; a.dy = dy; a.dw = dw;
+  a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.pad = pad;
+  a.OH = conv_out_dim(H, k, stride, pad); a.OW = conv_out_dim(W, k, stride, pad);
+  a.tiles_x = ceil_div(a.OW, kTileW); a.tiles_y = ceil_div(a.OH, kTileH);
+  a.units = N * a.tiles_x * a.tiles_y;
+  const bool stem = k == 7;
+  const bool half_tile = stride == 2 && k == 3;   // 9 x 65 patch rows per channel: stage 16 channels to stay in registers
+  a.ci_per_tile = stem ? 3 : (half_tile ? 16 : 32);
+  ADX_REQUIRE(stem ? Cin == 3 : Cin % 32 == 0, "conv2d_wgrad: cin %d unsupported", Cin);
+  ADX_REQUIRE(Cout % 32 == 0, "conv2d_wgrad: cout %d must be a multiple of 32", Cout);
+  a.n_ci_tiles = stem ? 1 : Cin / a.ci_per_tile;
+  a.n_co_tiles = Cout / 32;
+  a.pairs = stem ? 3 * 49 : 32 * k * k;
+  const int tiles = a.n_ci_tiles * a.n_co_tiles;
+  int splits = ceil_div(1024, tiles);
+  if (splits > a.units) splits = a.units;
+  a.units_per_wg = ceil_div(a.units, splits);
+  splits = ceil_div(a.units, a.units_per_wg);
+  ADX_CHECK_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cout * Cin * k * k, s));
+  const dim3 grid((unsigned)(tiles * splits)), blk(256);
+  auto lds_bytes = [&](int cit, int ng) {
+    const int ph = (kTileH - 1) * stride + k, pw = (kTileW - 1) * stride + k;
+    const int plane = ph * pw + ((ph * pw) % 2 == 0 ? 1 : 0);
+    const size_t stage = (size_t)cit * plane + 32 * (kTileH * kTileW + 1);
+    const size_t red = (size_t)ng * 1024;
+    return sizeof(float) * std::max(stage, red);
+  };
+  static bool attr_set = false;
+  if (!attr_set) {
+    const void* fns[4] = {reinterpret_cast<const void*>(&conv2d_wgrad_kernel<1, 3, 9, 32>),
+                          reinterpret_cast<const void*>(&conv2d_wgrad_kernel<2, 3, 9, 16>),
+                          reinterpret_cast<const void*>(&conv2d_wgrad_kernel<2, 1, 1, 32>),
+                          reinterpret_cast<const void*>(&conv2d_wgrad_kernel<2, 7, 5, 3>)};
+    for (const void* f : fns) ADX_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  if (stride == 1 && k == 3) conv2d_wgrad_kernel<1, 3, 9, 32><<<grid, blk, lds_bytes(32, 9), s>>>(a);
+  else if (stride == 2 && k == 3) conv2d_wgrad_kernel<2, 3, 9, 16><<<grid, blk, lds_bytes(16, 9), s>>>(a);
+  else if (stride == 2 && k == 1) conv2d_wgrad_kernel<2, 1, 1, 32><<<grid, blk, lds_bytes(32, 1), s>>>(a);
+  else if (stride == 2 && k == 7) conv2d_wgrad_kernel<2, 7, 5, 3><<<grid, blk, lds_bytes(3, 5), s>>>(a);
+  else {
+    set_error("conv2d_wgrad: no kernel for k=%d stride=%d", k, stride);
+    return ADX_ERR_INVALID;
+  }
+  ADX_LAUNCH_CHECK();
+  return ADX_OK;
+}
+
+static size_t al64(size_t v) { return (v + 63) / 64 * 64; }
+
+struct Bump2 {
+  float* base; size_t off, cap; bool ok = true;
+  float* take(size_t n) {
+    const size_t o = off;
+    off = al64(off + n);
+    if (off > cap) { ok = false; return base; }
+    return base + o;
+  }
+};
+
+}  // namespace adx
+
+// what the forward leaves behind for the backward, per conv launch
+struct adx_resnet_tape {
+  struct Rec {
+    const adx::ConvSpec* L = nullptr;
+    const float* x = nullptr;       // conv input
+    float* raw = nullptr;           // conv output before BN
+    float* out = nullptr;           // after BN [+identity] [ReLU]
+    const float* identity = nullptr;
+    float* mean = nullptr; float* rstd = nullptr;
+    int H = 0, W = 0, OH = 0, OW = 0, relu = 0;
+  };
+  std::vector<Rec> recs;
+  int batch = 0, h = 0, w = 0;
+  float* pool_in = nullptr; float* pool_out = nullptr; int ph = 0, pw = 0, poh = 0, pow_ = 0;
+  float* final_map = nullptr; int fh = 0, fw_ = 0;
+  size_t fwd_floats = 0;
+};
+
+using namespace adx;
+
+extern "C" {
+
+int adx_resnet_tape_create(adx_resnet_tape** out) {
+  ADX_REQUIRE(out != nullptr, "adx_resnet_tape_create: null argument");
+  *out = new adx_resnet_tape();
+  return ADX_OK;
+}
+void adx_resnet_tape_destroy(adx_resnet_tape* t) { delete t; }
+
+size_t adx_resnet_train_workspace_bytes(const adx_resnet* r, int32_t batch, int32_t h, int32_t w) {
+  if (!r || batch < 1 || h < 32 || w < 32) return 0;
+  size_t f = al64(2 * 512 * 2) + 2 * al64(512);            // forward: sums, scale, shift
+  size_t big = 0, wmax = 0;
+  auto conv = [&](const ConvSpec& L, int H, int W) {
+    const int OH = conv_out_dim(H, L.k, L.stride, L.pad), OW = conv_out_dim(W, L.k, L.stride, L.pad);
+    const size_t n = (size_t)batch * L.cout * OH * OW;
+    f += 2 * al64(n) + 2 * al64(L.cout);
+    big = std::max(big, n);
+    big = std::max(big, (size_t)batch * L.cin * H * W);
+    wmax = std::max(wmax, (size_t)L.k * L.k * L.cout * L.cin);
+  };
+  size_t ci = 0;
+  conv(r->convs[ci++], h, w);
+  const int h1 = conv_out_dim(h, 7, 2, 3), w1 = conv_out_dim(w, 7, 2, 3);
+  int H = conv_out_dim(h1, 3, 2, 1), W = conv_out_dim(w1, 3, 2, 1);
+  f += al64((size_t)batch * 64 * H * W);
+  big = std::max(big, (size_t)batch * 64 * h1 * w1);
+  for (size_t b = 0; b < r->block_has_ds.size(); ++b) {
+    const ConvSpec& c1 = r->convs[ci++];
+    const ConvSpec& c2 = r->convs[ci++];
+    conv(c1, H, W);
+    const int OH = conv_out_dim(H, 3, c1.stride, 1), OW = conv_out_dim(W, 3, c1.stride, 1);
+    if (r->block_has_ds[b]) conv(r->convs[ci++], H, W);
+    conv(c2, OH, OW);
+    H = OH; W = OW;
+  }
+  f += al64(2 * 512 * 2) + 5 * al64(big) + al64(wmax);     // backward: sums, 5 gradient buffers, dgrad weight image
+  return (f + 1024) * sizeof(float);
+}
+
+// tensors / running buffers as in adx_resnet_pack (state_dict order without num_batches_tracked); the
+// running_mean / running_var entries are UPDATED in place (momentum 0.1) when update_running != 0.
+int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_tensors, void* packed, void* workspace,
+                             size_t workspace_bytes, const float* img, int32_t batch, int32_t h, int32_t w,
+                             float* feature, adx_resnet_tape* tape, int32_t update_running, adx_stream stream) {
+  ADX_REQUIRE(r && T && packed && workspace && img && feature && tape, "adx_resnet_forward_train: null argument");
+  ADX_REQUIRE(n_tensors == r->n_tensors, "adx_resnet_forward_train: expected %d tensors, got %d", r->n_tensors, n_tensors);
+  ADX_REQUIRE(batch >= 1 && h >= 32 && w >= 32, "adx_resnet_forward_train: image too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* base = (float*)packed;
+  // weights change every step: re-lay them here (conv images only; BN is applied from batch statistics)
+  for (const ConvSpec& L : r->convs) {
+    int rc = conv2d_pack_raw(T[L.t_w], base + L.o_w, L.cout, L.cin, L.k, L.cin_pad, 0, s);
+    if (rc != ADX_OK) return rc;
+  }
+  Bump2 ws{(float*)workspace, 0, workspace_bytes / sizeof(float)};
+  tape->recs.clear();
+  tape->batch = batch; tape->h = h; tape->w = w;
+  double* sums = reinterpret_cast<double*>(ws.take(2 * 512 * 2));
+  float* scale = ws.take(512);
+  float* shift = ws.take(512);
+  int rc = ADX_OK;
+  auto conv_bn = [&](const ConvSpec& L, const float* x, int H, int W, const float* identity, int relu) -> float* {
+    adx_resnet_tape::Rec rec;
+    rec.L = &L; rec.x = x; rec.H = H; rec.W = W; rec.relu = relu; rec.identity = identity;
+    rec.OH = conv_out_dim(H, L.k, L.stride, L.pad); rec.OW = conv_out_dim(W, L.k, L.stride, L.pad);
+    const size_t n = (size_t)batch * L.cout * rec.OH * rec.OW;
+    rec.raw = ws.take(n); rec.out = ws.take(n); rec.mean = ws.take(L.cout); rec.rstd = ws.take(L.cout);
+    if (!ws.ok || rc != ADX_OK) { tape->recs.push_back(rec); return rec.out; }
+    rc = conv2d_launch_raw(L, x, base + L.o_w, nullptr, nullptr, nullptr, rec.raw, batch, H, W, 0, s);
+    if (rc != ADX_OK) { tape->recs.push_back(rec); return rec.out; }
+    const int HW = rec.OH * rec.OW;
+    hipMemsetAsync(sums, 0, sizeof(double) * 2 * L.cout, s);
+    channel_sums_kernel<0><<<dim3(batch * L.cout), dim3(256), 0, s>>>(rec.raw, nullptr, nullptr, nullptr, nullptr, sums,
+                                                                      L.cout, HW, 0);
+    bn_finalize_kernel<<<dim3(ceil_div(L.cout, 256)), dim3(256), 0, s>>>(
+        sums, T[L.t_g], T[L.t_b], scale, shift, rec.mean, rec.rstd, update_running ? const_cast<float*>(T[L.t_m]) : nullptr,
+        update_running ? const_cast<float*>(T[L.t_v]) : nullptr, L.cout, (double)batch * HW);
+    bn_apply_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(rec.raw, scale, shift, identity, rec.out,
+                                                                          L.cout, HW, n, relu);
+    tape->recs.push_back(rec);
+    return rec.out;
+  };
+  size_t ci = 0;
+  float* stem = conv_bn(r->convs[ci++], img, h, w, nullptr, 1);
+  const int h1 = conv_out_dim(h, 7, 2, 3), w1 = conv_out_dim(w, 7, 2, 3);
+  const int h2 = conv_out_dim(h1, 3, 2, 1), w2 = conv_out_dim(w1, 3, 2, 1);
+  float* pooled = ws.take((size_t)batch * 64 * h2 * w2);
+  if (ws.ok && rc == ADX_OK) rc = maxpool_launch(stem, pooled, batch * 64, h1, w1, h2, w2, s);
+  tape->pool_in = stem; tape->pool_out = pooled; tape->ph = h1; tape->pw = w1; tape->poh = h2; tape->pow_ = w2;
+  float* cur = pooled;
+  int H = h2, W = w2;
+  for (size_t b = 0; b < r->block_has_ds.size(); ++b) {
+    const ConvSpec& c1 = r->convs[ci++];
+    const ConvSpec& c2 = r->convs[ci++];
+    float* o1 = conv_bn(c1, cur, H, W, nullptr, 1);
+    const int OH = conv_out_dim(H, 3, c1.stride, 1), OW = conv_out_dim(W, 3, c1.stride, 1);
+    const float* identity = cur;
+    if (r->block_has_ds[b]) identity = conv_bn(r->convs[ci++], cur, H, W, nullptr, 0);
+    cur = conv_bn(c2, o1, OH, OW, identity, 1);
+    H = OH; W = OW;
+  }
+  if (rc != ADX_OK) return rc;
+  ADX_REQUIRE(ws.ok, "adx_resnet_forward_train: workspace of %zu bytes too small", workspace_bytes);
+  tape->final_map = cur; tape->fh = H; tape->fw_ = W;
+  tape->fwd_floats = ws.off;
+  ADX_LAUNCH_CHECK();
+  return avgpool_fc_launch(cur, T[r->t_fcw], T[r->t_fcb], feature, batch, 512, H * W, r->out_dim, s);
+}
+
+// d_feature [batch][out_dim] -> one gradient per tensor slot of adx_resnet_pack's list (conv weight, bn gamma,
+// bn beta written; running-stat slots untouched/NULL allowed), fc weight/bias included.
+int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, int32_t n_tensors, void* workspace,
+                        size_t workspace_bytes, adx_resnet_tape* tape, const float* d_feature, adx_stream stream) {
+  ADX_REQUIRE(r && T && G && workspace && tape && d_feature, "adx_resnet_backward: null argument");
+  ADX_REQUIRE(n_tensors == r->n_tensors && !tape->recs.empty(), "adx_resnet_backward: bad tape / tensor count");
+  hipStream_t s = (hipStream_t)stream;
+  const int batch = tape->batch;
+  Bump2 ws{(float*)workspace, tape->fwd_floats, workspace_bytes / sizeof(float)};
+  double* sums = reinterpret_cast<double*>(ws.take(2 * 512 * 2));
+  size_t big = 0, wmax = 0;
+  for (auto& rec : tape->recs) {
+    big = std::max(big, (size_t)batch * rec.L->cout * rec.OH * rec.OW);
+    big = std::max(big, (size_t)batch * rec.L->cin * rec.H * rec.W);
+    wmax = std::max(wmax, (size_t)rec.L->k * rec.L->k * rec.L->cout * rec.L->cin);
+  }
+  big = std::max(big, (size_t)batch * 64 * tape->ph * tape->pw);
+  // rotating gradient buffers: g_out (incoming), dz, draw, dx candidates
+  float* gb[5];
+  for (auto& p : gb) p = ws.take(big);
+  float* wimg = ws.take(wmax);
+  ADX_REQUIRE(ws.ok, "adx_resnet_backward: workspace of %zu bytes too small", workspace_bytes);
+  int rc = ADX_OK;
+
+  // fc + avgpool
+  float* g_cur = gb[0];
+  {
+    const int HW = tape->fh * tape->fw_;
+    ADX_CHECK_HIP(hipMemsetAsync(G[r->t_fcw], 0, sizeof(float) * (size_t)r->out_dim * 512, s));
+    ADX_CHECK_HIP(hipMemsetAsync(G[r->t_fcb], 0, sizeof(float) * r->out_dim, s));
+    avgpool_fc_bwd_kernel<<<dim3(batch), dim3(256), 0, s>>>(tape->final_map, T[r->t_fcw], d_feature, g_cur, G[r->t_fcw],
+                                                            G[r->t_fcb], 512, HW, r->out_dim);
+    ADX_LAUNCH_CHECK();
+  }
+  // one conv+BN(+identity)(+ReLU) backward.  dout -> (dz for the identity path), d(conv input) accumulated
+  // into dx (dx_has tells whether dx already holds a contribution).
+  auto conv_bn_bwd = [&](const adx_resnet_tape::Rec& rec, const float* dout, float* dz_keep, float* draw, float* dx,
+                         bool dx_has, bool need_dx) -> int {
+    const ConvSpec& L = *rec.L;
+    const int HW = rec.OH * rec.OW;
+    const size_t n = (size_t)batch * L.cout * HW;
+    const double count = (double)batch * HW;
+    ADX_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * L.cout, s));
+    channel_sums_kernel<1><<<dim3(batch * L.cout), dim3(256), 0, s>>>(dout, rec.out, rec.raw, rec.mean, rec.rstd, sums,
+                                                                      L.cout, HW, rec.relu);
+    bn_bwd_apply_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(
+        dout, rec.out, rec.raw, rec.mean, rec.rstd, T[L.t_g], sums, draw, dz_keep, L.cout, HW, n, count, rec.relu);
+    bn_param_grad_kernel<<<dim3(ceil_div(L.cout, 256)), dim3(256), 0, s>>>(sums, G[L.t_g], G[L.t_b], L.cout);
+    ADX_LAUNCH_CHECK();
+    int rc2 = conv2d_wgrad(rec.x, draw, G[L.t_w], batch, L.cin, rec.H, rec.W, L.cout, L.k, L.stride, L.pad, s);
+    if (rc2 != ADX_OK || !need_dx) return rc2;
+    // data gradient
+    rc2 = conv2d_pack_raw(T[L.t_w], wimg, L.cout, L.cin, L.k, L.cin_pad, 1, s);
+    if (rc2 != ADX_OK) return rc2;
+    ConvSpec g{};
+    g.cin = L.cout; g.cout = L.cin; g.k = L.k; g.stride = 1; g.pad = L.k - 1 - L.pad; g.cc = 16; g.cin_pad = L.cout;
+    if (L.stride == 1) {
+      return conv2d_launch_raw(g, draw, wimg, nullptr, nullptr, dx_has ? dx : nullptr, dx, batch, rec.OH, rec.OW, 0, s);
+    }
+    if (L.k == 3) {
+      // zero-dilate draw to the input resolution, then an ordinary 3x3 stride-1 conv with the flipped weights
+      float* dil = gb[4];
+      ADX_CHECK_HIP(hipMemsetAsync(dil, 0, sizeof(float) * (size_t)batch * L.cout * rec.H * rec.W, s));
+      dilate2_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(draw, dil, batch * L.cout, rec.OH, rec.OW, rec.H,
+                                                                          rec.W, 0);
+      ADX_LAUNCH_CHECK();
+      return conv2d_launch_raw(g, dil, wimg, nullptr, nullptr, dx_has ? dx : nullptr, dx, batch, rec.H, rec.W, 0, s);
+    }
+    // 1x1 stride 2: a 1x1 stride-1 conv at the output resolution, scattered to the even input positions
+    float* t = gb[4];
+    rc2 = conv2d_launch_raw(g, draw, wimg, nullptr, nullptr, nullptr, t, batch, rec.OH, rec.OW, 0, s);
+    if (rc2 != ADX_OK) return rc2;
+    if (!dx_has) ADX_CHECK_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)batch * L.cin * rec.H * rec.W, s));
+    const size_t nt = (size_t)batch * L.cin * HW;
+    dilate2_kernel<<<dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s>>>(t, dx, batch * L.cin, rec.OH, rec.OW, rec.H, rec.W, 1);
+    ADX_LAUNCH_CHECK();
+    return ADX_OK;
+  };
+
+  // BasicBlocks in reverse.  recs: [stem, (c1, [ds], c2) per block] in forward launch order
+  size_t ri = tape->recs.size();
+  for (size_t b = r->block_has_ds.size(); b-- > 0 && rc == ADX_OK;) {
+    const bool ds = r->block_has_ds[b] != 0;
+    const adx_resnet_tape::Rec& c2 = tape->recs[--ri];
+    const adx_resnet_tape::Rec* dsr = ds ? &tape->recs[--ri] : nullptr;
+    const adx_resnet_tape::Rec& c1 = tape->recs[--ri];
+    // buffers: g_cur = d(block out).  dz2 (identity gradient), draw scratch, do1, dx
+    float* others[4];
+    int k = 0;
+    for (auto p : gb) if (p != g_cur && p != gb[4] && k < 4) others[k++] = p;
+    float* dz2 = others[0]; float* draw = others[1]; float* do1 = others[2];
+    rc = conv_bn_bwd(c2, g_cur, dz2, draw, do1, false, true);            // -> do1 = d(o1), dz2 = masked dout
+    if (rc != ADX_OK) break;
+    float* dx = g_cur;                                                   // d(block out) is dead now: reuse for d(block in)
+    if (ds) {
+      rc = conv_bn_bwd(*dsr, dz2, nullptr, draw, dx, false, true);       // identity path through the downsample conv
+      if (rc != ADX_OK) break;
+      rc = conv_bn_bwd(c1, do1, nullptr, draw, dx, true, true);          // main path accumulates
+    } else {
+      // identity gradient is dz2 itself: main path = conv(...) + res(dz2)
+      rc = conv_bn_bwd(c1, do1, nullptr, draw, dz2, true, true);
+      dx = dz2;
+    }
+    g_cur = dx;
+  }
+  if (rc != ADX_OK) return rc;
+  // maxpool, then the stem (no data gradient: the image needs none)
+  {
+    float* dstem = nullptr;
+    for (auto p : gb) if (p != g_cur && p != gb[4]) { dstem = p; break; }
+    const size_t nin = (size_t)batch * 64 * tape->ph * tape->pw;
+    ADX_CHECK_HIP(hipMemsetAsync(dstem, 0, sizeof(float) * nin, s));
+    const size_t nout = (size_t)batch * 64 * tape->poh * tape->pow_;
+    maxpool_bwd_kernel<<<dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, s>>>(tape->pool_in, g_cur, dstem, batch * 64,
+                                                                                tape->ph, tape->pw, tape->poh, tape->pow_);
+    ADX_LAUNCH_CHECK();
+    float* draw = nullptr;
+    for (auto p : gb) if (p != g_cur && p != gb[4] && p != dstem) { draw = p; break; }
+    rc = conv_bn_bwd(tape->recs[0], dstem, nullptr, draw, nullptr, false, false);
+  }
+  return rc;
+}
+
+}  // extern "C"

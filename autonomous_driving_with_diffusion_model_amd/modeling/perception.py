@@ -1,8 +1,9 @@
 """ResNet-34 camera encoder (reference: modeling/resnet.py:163-296,325-333 with the fc replaced
 by Linear(512, dim) at modeling/temporal.py:83-84), executed by libadx.so.
 
-Eval mode only for now: BatchNorm uses running statistics and is folded into the conv epilogue at
-pack time.  Training (batch statistics + backward) is not implemented yet and raises.
+Eval mode: BatchNorm uses running statistics, applied as scale/shift in the conv epilogue.
+Train mode: batch statistics, running buffers updated in place (momentum 0.1, num_batches_tracked
+incremented), differentiable w.r.t. every parameter through `_PerceptionTrainFn`.
 """
 from __future__ import annotations
 
@@ -14,6 +15,61 @@ import torch.nn as nn
 from .. import _lib as L
 from .holders import populate
 from .spec import resnet34_entries
+
+
+class _PerceptionTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, module, *params):
+        h = module._native()
+        B, _, H, W = img.shape
+        ts = [L.require_gpu_f32(t.detach(), "perception tensor") for t in module._tensors()]
+        nbytes = L.lib().adx_resnet_train_workspace_bytes(h, B, H, W)
+        if nbytes == 0:
+            raise ValueError(f"image {H}x{W} too small for ResNet-34")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=img.device)
+        pk = L.lib().adx_resnet_packed_bytes(h)
+        packed = torch.empty(pk, dtype=torch.uint8, device=img.device)
+        tape = L.vp()
+        L.check(L.lib().adx_resnet_tape_create(C.byref(tape)), "adx_resnet_tape_create")
+        out = torch.empty((B, module.out_dim), dtype=torch.float32, device=img.device)
+        try:
+            L.check(L.lib().adx_resnet_forward_train(h, L.ptr_array(ts), len(ts), packed.data_ptr(), ws.data_ptr(), nbytes,
+                                                     img.data_ptr(), B, H, W, out.data_ptr(), tape, 1,
+                                                     L.stream_ptr(img.device)), "adx_resnet_forward_train")
+        except Exception:
+            L.lib().adx_resnet_tape_destroy(tape)
+            raise
+        for b in module.buffers():
+            if b.dtype == torch.int64:
+                b += 1                      # num_batches_tracked
+        module.invalidate()                 # running statistics moved: eval-mode image is stale
+        ctx.module, ctx.tape, ctx.ws, ctx.nbytes, ctx.ts, ctx.img = module, tape, ws, nbytes, ts, img
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        module = ctx.module
+        g = L.require_gpu_f32(grad_out, "grad_out")
+        named = dict(module.named_parameters())
+        entries = [e for e in module._entries if e.dtype == "f32"]
+        grads, slots = {}, []
+        for e in entries:
+            if e.is_buffer:
+                slots.append(None)
+            else:
+                grads[e.key] = torch.empty_like(named[e.key])
+                slots.append(grads[e.key])
+        garr = (L.vp * len(slots))()
+        for i, t in enumerate(slots):
+            garr[i] = None if t is None else t.data_ptr()
+        try:
+            L.check(L.lib().adx_resnet_backward(module._native(), L.ptr_array(ctx.ts), garr, len(slots), ctx.ws.data_ptr(),
+                                                ctx.nbytes, ctx.tape, g.data_ptr(), L.stream_ptr(g.device)),
+                    "adx_resnet_backward")
+        finally:
+            L.lib().adx_resnet_tape_destroy(ctx.tape)
+            ctx.tape = None
+        return (None, None, *[grads[k] for k, _ in module.named_parameters()])
 
 
 class PerceptionResNet34(nn.Module):
@@ -71,12 +127,11 @@ class PerceptionResNet34(nn.Module):
         self._pack_key = key
 
     def forward(self, img: torch.Tensor) -> torch.Tensor:
-        if self.training:
-            raise NotImplementedError("perception: train-mode BatchNorm/backward kernels are not implemented yet; "
-                                      "call .eval()")
         img = L.require_gpu_f32(img, "img")
         if img.dim() != 4 or img.shape[1] != 3:
             raise ValueError(f"img must be [B, 3, H, W], got {tuple(img.shape)}")
+        if self.training:
+            return _PerceptionTrainFn.apply(img, self, *[p for _, p in self.named_parameters()])
         self._ensure_packed()
         h = self._native()
         B, _, H, W = img.shape

@@ -183,6 +183,21 @@ int adx_conv2d_forward(const adx_conv2d_desc* d, const float* x, const float* pa
                        const float* shift, const float* res, float* y, int32_t n, int32_t h, int32_t w,
                        int32_t relu, adx_stream s);
 
+/* Training-mode perception (train.py:242 with model.train()): batch-statistics BatchNorm, running buffers
+ * updated in place (momentum 0.1), everything the backward needs kept in the workspace. */
+typedef struct adx_resnet_tape adx_resnet_tape;
+int adx_resnet_tape_create(adx_resnet_tape** out);
+void adx_resnet_tape_destroy(adx_resnet_tape* t);
+size_t adx_resnet_train_workspace_bytes(const adx_resnet* r, int32_t batch, int32_t h, int32_t w);
+int adx_resnet_forward_train(adx_resnet* r, const float* const* tensors, int32_t n_tensors, void* packed,
+                             void* workspace, size_t workspace_bytes, const float* img, int32_t batch, int32_t h,
+                             int32_t w, float* feature, adx_resnet_tape* tape, int32_t update_running, adx_stream s);
+/* grads: one slot per tensor of adx_resnet_pack's list; conv weight / bn weight / bn bias / fc slots are written,
+ * running-statistics slots are ignored (may be NULL). */
+int adx_resnet_backward(adx_resnet* r, const float* const* tensors, float* const* grads, int32_t n_tensors,
+                        void* workspace, size_t workspace_bytes, adx_resnet_tape* tape, const float* d_feature,
+                        adx_stream s);
+
 /* ------------------------------------------------------------------------------------
  * Classifier guidance: TrajPredict state head (modeling/helpers.py:22-59; hidden 64, 4 heads,
  * ff 256, 2 layers, eval mode) forward, input gradient, and the fused guidance update.

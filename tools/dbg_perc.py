@@ -1,0 +1,31 @@
+import sys, os
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import torch
+from oracle import resnet as Rn
+from autonomous_driving_with_diffusion_model_amd.modeling.spec import unet_entries
+from autonomous_driving_with_diffusion_model_amd.utils import procedural as P
+from helpers import oracle_sd
+from test_gpu_model import make_model
+DEV = "cuda:0"
+for hw, B in (((64, 96), 3), ((128, 192), 4), ((160, 224), 6)):
+    m, _ = make_model("NO_GUIDANCE", 16); m.train()
+    sd = oracle_sd("NO_GUIDANCE")
+    pkeys = [e.key for e in unet_entries("NO_GUIDANCE") if e.key.startswith("perception.") and not e.is_buffer]
+    for k in pkeys: sd[k].requires_grad_()
+    img = P.synthetic_batch(B, 16, image_hw=hw, seed=61)["imgs"]
+    fr = Rn.resnet34_forward(sd, "perception.", img, training=True)
+    w = P._uniform("perc.w", 61, (B, 64), -1.0, 1.0)
+    (fr * w).sum().backward()
+    f = m.perception(img.to(DEV))
+    (f * w.to(DEV)).sum().backward()
+    named = dict(m.named_parameters())
+    errs = sorted((((named[k].grad.cpu() - sd[k].grad).norm() / (sd[k].grad.norm() + 1e-12)).item(), k) for k in pkeys)[::-1]
+    print(hw, B, "fwd err", (f.detach().cpu() - fr.detach()).abs().max().item(), "worst", errs[:3], "median", errs[len(errs)//2])
+    # double precision reference to judge conditioning
+    sd64 = {k: v.detach().double().requires_grad_(k in pkeys) if v.is_floating_point() else v for k, v in sd.items()}
+    fr64 = Rn.resnet34_forward(sd64, "perception.", img.double(), training=True)
+    (fr64 * w.double()).sum().backward()
+    e_cpu32 = sorted((((sd[k].grad.double() - sd64[k].grad).norm() / (sd64[k].grad.norm() + 1e-30)).item(), k) for k in pkeys)[::-1]
+    e_gpu = sorted((((named[k].grad.cpu().double() - sd64[k].grad).norm() / (sd64[k].grad.norm() + 1e-30)).item(), k) for k in pkeys)[::-1]
+    print("   vs fp64: torch-cpu-fp32 worst", e_cpu32[:2], " hip worst", e_gpu[:2])
