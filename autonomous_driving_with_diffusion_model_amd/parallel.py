@@ -1,0 +1,97 @@
+"""Data-parallel pieces of the training loop (reference: accelerate -> DistributedDataParallel, train.py:
+115-117,176-178,251).
+
+One process per GPU; `torch.distributed` backend "nccl" is RCCL on ROCm.  The model's gradients arrive
+through ordinary autograd, so `torch.nn.parallel.DistributedDataParallel(model)` works as in the
+reference.  `GradientAverager` is the explicit equivalent used by this package's own trainer: gradients
+are flattened into a few large buckets (fewer, larger collectives suit xGMI's per-link bandwidth) in
+REVERSE registration order, i.e. temporal-stack buckets first — their all-reduce is launched on a side
+stream as soon as the temporal backward has produced them and overlaps the perception backward, which
+is >95 % of the step.  Sampling needs no collective: scenes are sharded with `shard_range`.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Contiguous, balanced shard [lo, hi) of n_items scenes for `rank` (first n % world ranks get one more)."""
+    if world_size < 1 or not 0 <= rank < world_size:
+        raise ValueError(f"bad rank {rank} / world_size {world_size}")
+    q, r = divmod(n_items, world_size)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def make_buckets(sizes: Sequence[int], bucket_elems: int) -> List[List[int]]:
+    """Greedy buckets over indices in REVERSE order (last-registered parameters first = gradients that
+    become ready first)."""
+    buckets, cur, cur_n = [], [], 0
+    for i in reversed(range(len(sizes))):
+        if cur and cur_n + sizes[i] > bucket_elems:
+            buckets.append(cur)
+            cur, cur_n = [], 0
+        cur.append(i)
+        cur_n += sizes[i]
+    if cur:
+        buckets.append(cur)
+    return buckets
+
+
+class GradientAverager:
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 64.0, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.buckets = make_buckets([p.numel() for p in self.params], int(bucket_mb * 1024 * 1024 / 4))
+        self._flat: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
+
+    @torch.no_grad()
+    def average(self, async_op: bool = False):
+        """All-reduce (mean) every gradient.  Returns the list of work handles when async_op."""
+        if self.world == 1:
+            return []
+        works = []
+        for bi, idxs in enumerate(self.buckets):
+            grads = [self.params[i].grad for i in idxs]
+            if any(g is None for g in grads):
+                raise RuntimeError("a parameter has no gradient (every rank must produce every gradient)")
+            n = sum(g.numel() for g in grads)
+            flat = self._flat[bi]
+            if flat is None or flat.numel() != n or flat.device != grads[0].device:
+                flat = self._flat[bi] = torch.empty(n, dtype=grads[0].dtype, device=grads[0].device)
+            off = 0
+            for g in grads:
+                flat[off:off + g.numel()].copy_(g.reshape(-1))
+                off += g.numel()
+            works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), bi))
+        if async_op:
+            return works
+        self.finish(works)
+        return []
+
+    @torch.no_grad()
+    def finish(self, works) -> None:
+        for work, bi in works:
+            work.wait()
+            flat = self._flat[bi]
+            flat.div_(self.world)
+            off = 0
+            for i in self.buckets[bi]:
+                g = self.params[i].grad
+                g.copy_(flat[off:off + g.numel()].view_as(g))
+                off += g.numel()
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:
+    """What DDP's constructor does (train.py:176-178): rank `src`'s parameters and buffers win."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t, src=src, group=group)
+    if hasattr(module, "refresh_weights"):
+        module.refresh_weights()

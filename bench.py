@@ -177,6 +177,61 @@ def cpu_baseline(steps=2):
             "s_per_step": round(per, 3), "unet_only_steps_per_sec": round(1.0 / unet_s, 3)}
 
 
+def train_leg(dev, world, steps=3, warm=1):
+    """BASELINE configs[1]: NO_GUIDANCE training step at B=64, H=32: add_noise -> train-mode forward (batch-stat
+    BatchNorm) -> MSE -> backward -> fused nan_to_num + AdamW + EMA.  One optimizer step = one denoising step."""
+    import contextlib
+    from autonomous_driving_with_diffusion_model_amd import scheduler as S
+    from autonomous_driving_with_diffusion_model_amd.config import create_cfg
+    from autonomous_driving_with_diffusion_model_amd.modeling import build_model
+    from autonomous_driving_with_diffusion_model_amd.optim import FusedAdamWEMA
+    from autonomous_driving_with_diffusion_model_amd.parallel import GradientAverager
+    from autonomous_driving_with_diffusion_model_amd.utils import procedural as P
+    cfg = create_cfg()
+    cfg.MODEL.HORIZON = H
+    with contextlib.redirect_stdout(sys.stderr):
+        model = build_model(cfg)
+    P.load_procedural(model, 0)
+    model = model.to(dev).train()
+    opt = FusedAdamWEMA(model.parameters(), lr=1e-4, warmup_steps=1000, lr_ticks_per_step=world)
+    avg = GradientAverager(model.parameters()) if world > 1 else None
+    sch = S.DDPMScheduler(**SCHED_KW)
+    d = {k: v.to(dev) for k, v in P.synthetic_batch(B, H, image_hw=IMG, seed=7).items()}
+
+    def step():
+        noisy = sch.add_noise(d["trajs"], d["noise"], d["t"], zero_first=True)
+        pred = model(noisy, d["imgs"], d["t"])
+        loss = torch.nn.functional.mse_loss(pred, d["trajs"])
+        loss.backward()
+        if avg is not None:
+            avg.average()
+        opt.step()
+        opt.zero_grad()
+        return loss
+
+    for _ in range(warm):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = tt.item()
+    flops = 3 * (64 * 34.02e9) + 3 * 10.03e9      # ~3x forward (SURVEY §8d)
+    return {"workload": "configs/default.yaml train step, NO_GUIDANCE, batch 64 per GPU, horizon 32, image 3x256x900, "
+                        "fwd + bwd + fused AdamW/EMA" + (" + RCCL gradient all-reduce" if world > 1 else ""),
+            "value": round(world * steps / dt, 3), "unit": "train-steps/sec", "ms_per_step": round(1e3 * dt / steps, 2),
+            "steps": steps, "approx_tflops_per_gpu": round(flops * steps / dt / 1e12, 1), "final_loss": round(float(loss), 5)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,6 +239,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-train", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -252,6 +308,10 @@ def main():
     dt_h = timed(max(args.steps, N_INFER), args.warmup)
     steps_h = max(args.steps, N_INFER)
 
+    del model
+    torch.cuda.empty_cache()
+    train = None if args.no_train else train_leg(dev, world)
+
     if rank == 0:
         res = {
             "metric": "denoising-steps/sec", "value": round(world * args.steps / dt, 3), "unit": "denoising-steps/sec",
@@ -266,9 +326,11 @@ def main():
                         "scene inside the timed region, then UNet + scheduler per step",
                         "trajectories_per_sec": round(world * B / (dt_h * N_INFER / steps_h), 2)},
         }
+        if train is not None:
+            res["train"] = train
         if not args.no_roofline:
             res["roofline"] = conv2d_roofline(dev)
-            res["roofline_tconv"] = tconv_roofline(model, dev)
+            res["roofline_tconv"] = tconv_roofline(None, dev)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
             res["speedup_vs_cpu_baseline"] = round(res["value"] / res["cpu_baseline"]["value"], 1)

@@ -226,6 +226,16 @@ int adx_guided_output(adx_trajpred* t, const void* packed, const float* action /
                       int32_t T, adx_stream s);
 
 /* ------------------------------------------------------------------------------------
+ * Optimizer step of train.py:252-261 in one launch: grad nan_to_num, AdamW, EMA shadow update.
+ * table = device array of {float* p; const float* g; float* m; float* v; float* ema; int64_t n} per tensor;
+ * block_tensor / block_chunk map each workgroup to (tensor, chunk of adx_optim_chunk() elements).
+ * -----------------------------------------------------------------------------------*/
+int adx_optim_chunk(void);
+int adx_adamw_ema_step(const void* table, const int32_t* block_tensor, const int32_t* block_chunk, int32_t n_blocks,
+                       float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                       float ema_decay, int32_t use_ema, int32_t sanitize, adx_stream s);
+
+/* ------------------------------------------------------------------------------------
  * Scheduler step math.  The integer schedule and the fp32 scalar coefficients are computed
  * by the host (the scheduler/ modules keep them as 0-dim CPU tensors) and passed by value.
  * -----------------------------------------------------------------------------------*/

@@ -1,0 +1,76 @@
+"""CPU, world_size 2 over gloo: the data-parallel host logic (scene sharding for sampling, bucketed
+gradient averaging and parameter broadcast for training).  No kernels involved."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from autonomous_driving_with_diffusion_model_amd.parallel import (GradientAverager, broadcast_parameters, make_buckets,
+                                                                  shard_range)
+
+
+def test_shard_range_partitions_every_scene_once():
+    for n, w in ((64, 8), (65, 8), (7, 8), (512, 3), (1, 1)):
+        covered = []
+        for r in range(w):
+            lo, hi = shard_range(n, r, w)
+            assert 0 <= lo <= hi <= n and hi - lo in (n // w, n // w + 1)
+            covered += list(range(lo, hi))
+        assert covered == list(range(n))
+
+
+def test_buckets_cover_all_in_reverse_order():
+    sizes = [10, 200, 30, 4000, 5, 60]
+    b = make_buckets(sizes, 250)
+    flat = [i for bucket in b for i in bucket]
+    assert flat == list(reversed(range(len(sizes))))
+    assert all(sum(sizes[i] for i in bucket) <= 250 or len(bucket) == 1 for bucket in b)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(rank)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Linear(16, 4))
+    broadcast_parameters(model, src=0)
+    w_after_bcast = [p.detach().clone() for p in model.parameters()]
+    x = torch.full((3, 8), float(rank + 1))
+    model(x).sum().backward()
+    local = [p.grad.clone() for p in model.parameters()]
+    avg = GradientAverager(model.parameters(), bucket_mb=1e-4)     # tiny buckets -> several collectives
+    works = avg.average(async_op=True)
+    avg.finish(works)
+    gathered = [torch.zeros_like(local[0]) for _ in range(world)]
+    dist.all_gather(gathered, local[0])
+    ok_avg = torch.allclose(list(model.parameters())[0].grad, sum(gathered) / world, atol=1e-6)
+    ws = [torch.zeros_like(w_after_bcast[0]) for _ in range(world)]
+    dist.all_gather(ws, w_after_bcast[0])
+    ok_bcast = all(torch.equal(ws[0], w) for w in ws)
+    out.put((rank, bool(ok_avg), bool(ok_bcast), len(avg.buckets)))
+    dist.destroy_process_group()
+
+
+def test_gradient_averaging_and_broadcast_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[0] for r in res] == [0, 1]
+    assert all(r[1] and r[2] for r in res), res
+    assert res[0][3] > 1
