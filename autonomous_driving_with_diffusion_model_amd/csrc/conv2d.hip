@@ -12,6 +12,8 @@
 //     in LDS (both read conflict-free: consecutive lanes = consecutive columns / channels);
 //   * epilogue fuses eval-mode BatchNorm as y = acc * scale[c] + shift[c] (the same
 //     alpha/beta form torch uses), the residual add and ReLU.
+#include <stdlib.h>
+
 #include <vector>
 
 #include "adx_common.h"
@@ -21,6 +23,7 @@ namespace adx {
 
 constexpr int kCoutT = 64;   // output channels per workgroup (2 MFMA row blocks)
 constexpr size_t kMaxLds = 96 * 1024;
+static int g_conv_rows = 2;   // rows per wave of the 3x3 stride-1 kernel (ADX_CONV_ROWS=1 selects the 4-row tile)
 
 struct Conv2dArgs {
   const float* x;       // [N][Cin][H][W]
@@ -38,10 +41,13 @@ struct Conv2dArgs {
 // Software pipeline (register double buffer): the global loads of chunk i+1 (input patch + weight
 // slab) are issued before the MFMAs of chunk i and written to LDS after them, so HBM/L2 latency
 // hides behind ~9k cycles of matrix work per 16-channel chunk.
-template <int STRIDE, int K>
+// ROWS = output rows per wave (tile = 4*ROWS rows x 32 columns x 64 channels): ROWS = 2 reuses every
+// weight fragment for two pixel rows (1.0 instead of 1.5 LDS reads per MFMA).
+template <int STRIDE, int K, int ROWS>
 __global__ void __launch_bounds__(256) conv2d_kernel(const Conv2dArgs a) {
+  constexpr int TH = 4 * ROWS;
   constexpr int CC = (K == 7) ? 4 : 16;                   // channels per chunk
-  constexpr int PH = (kTileH - 1) * STRIDE + K;           // staged patch rows / columns
+  constexpr int PH = (TH - 1) * STRIDE + K;           // staged patch rows / columns
   constexpr int PW = (kTileW - 1) * STRIDE + K;
   constexpr int PLANE = PH * PW;
   constexpr int NP = CC * PLANE;                          // patch floats per chunk
@@ -60,7 +66,7 @@ __global__ void __launch_bounds__(256) conv2d_kernel(const Conv2dArgs a) {
   const int tx = bid % a.tiles_x; bid /= a.tiles_x;
   const int ty = bid % a.tiles_y; bid /= a.tiles_y;
   const int n = bid;
-  const int oy0 = ty * kTileH, ox0 = tx * kTileW;
+  const int oy0 = ty * TH, ox0 = tx * kTileW;
   const int iy0 = oy0 * STRIDE - a.pad, ix0 = ox0 * STRIDE - a.pad;
   const int cout0 = ct * kCoutT;
   const int l31 = lane & 31, khalf = lane >> 5;
@@ -83,9 +89,11 @@ __global__ void __launch_bounds__(256) conv2d_kernel(const Conv2dArgs a) {
     ss[tid] = a.scale == nullptr ? (tid < kCoutT ? 1.f : 0.f) : (tid < kCoutT ? a.scale[c] : a.shift[c]);
   }
 
-  f32x16 acc0, acc1;
+  f32x16 acc[ROWS][2];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc[r][0][i] = 0.f; acc[r][1][i] = 0.f; }
   float pv[PITEMS];
   f32x4 wv[WITEMS];
   auto load_chunk = [&](int c0) {
@@ -125,26 +133,32 @@ __global__ void __launch_bounds__(256) conv2d_kernel(const Conv2dArgs a) {
     for (int kh = 0; kh < K; ++kh) {
 #pragma unroll 1
       for (int kw = 0; kw < K; ++kw) {
-        const float* pb = patch + (wave * STRIDE + kh) * PW + l31 * STRIDE + kw + khalf * PLANE;
+        const float* pb = patch + (wave * ROWS * STRIDE + kh) * PW + l31 * STRIDE + kw + khalf * PLANE;
         const float* wa = wl + ((kh * K + kw) * CC + khalf) * kCoutT + l31;
 #pragma unroll
         for (int ks = 0; ks < CC / 2; ++ks) {
-          const float b = pb[2 * ks * PLANE];
           const float a0 = wa[2 * ks * kCoutT];
           const float a1 = wa[2 * ks * kCoutT + 32];
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r) {
+            const float b = pb[2 * ks * PLANE + r * STRIDE * PW];
+            acc[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[r][0], 0, 0, 0);
+            acc[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[r][1], 0, 0, 0);
+          }
         }
       }
     }
   }
 
   // ---- epilogue: BN scale/shift, residual, ReLU; lane = pixel column, register = channel --------
-  const int oy = oy0 + wave, ox = ox0 + l31;
-  if (oy < a.OH && ox < a.OW) {
+  const int ox = ox0 + l31;
+  const size_t img = (size_t)n * a.Cout * a.OH * a.OW;
+  const size_t plane_o = (size_t)a.OH * a.OW;
+#pragma unroll
+  for (int rr = 0; rr < ROWS; ++rr) {
+    const int oy = oy0 + wave * ROWS + rr;
+    if (oy >= a.OH || ox >= a.OW) continue;
     const size_t pix = (size_t)oy * a.OW + ox;
-    const size_t img = (size_t)n * a.Cout * a.OH * a.OW;
-    const size_t plane_o = (size_t)a.OH * a.OW;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       float rv[16];
@@ -156,7 +170,7 @@ __global__ void __launch_bounds__(256) conv2d_kernel(const Conv2dArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int cl = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        float v = half == 0 ? acc0[r] : acc1[r];
+        float v = acc[rr][half][r];
         v = v * ss[cl] + ss[kCoutT + cl];
         v += rv[r];
         if (a.relu) v = v > 0.f ? v : 0.f;
@@ -289,14 +303,22 @@ static int conv2d_launch(const ConvSpec& L, const float* base, const float* x, c
 
 int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const float* scale, const float* shift,
                       const float* res, float* y, int N, int H, int W, int relu, hipStream_t s) {
+  static bool env_read = false;
+  if (!env_read) {
+    const char* e = getenv("ADX_CONV_ROWS");
+    if (e != nullptr && e[0] == '1') g_conv_rows = 1;
+    env_read = true;
+  }
   Conv2dArgs a;
   a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.res = res; a.y = y;
   a.N = N; a.Cin = L.cin; a.H = H; a.W = W; a.Cout = L.cout;
   a.OH = conv_out(H, L.k, L.stride, L.pad); a.OW = conv_out(W, L.k, L.stride, L.pad);
   a.KH = L.k; a.KW = L.k; a.stride = L.stride; a.pad = L.pad; a.relu = relu;
   a.cin_pad = L.cin_pad; a.cc = L.cc;
-  a.tiles_x = ceil_div(a.OW, kTileW); a.tiles_y = ceil_div(a.OH, kTileH); a.cout_tiles = L.cout / kCoutT;
-  a.PH = (kTileH - 1) * L.stride + L.k; a.PW = (kTileW - 1) * L.stride + L.k;
+  const int rows = (L.stride == 1 && L.k == 3 && g_conv_rows == 2) ? 2 : 1;   // 8-row tiles for the 3x3 stride-1 convs
+  const int th = 4 * rows;
+  a.tiles_x = ceil_div(a.OW, kTileW); a.tiles_y = ceil_div(a.OH, th); a.cout_tiles = L.cout / kCoutT;
+  a.PH = (th - 1) * L.stride + L.k; a.PW = (kTileW - 1) * L.stride + L.k;
   a.PWp = a.PW;
   ADX_REQUIRE(L.cin % L.cc == 0 || L.cin < L.cc, "conv2d: cin %d must be < %d or a multiple of it", L.cin, L.cc);
   ADX_REQUIRE((size_t)L.cin * H * W < (1u << 31), "conv2d: image plane too large for 32-bit gather offsets");
@@ -307,18 +329,19 @@ int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const f
   ADX_REQUIRE(grid < (1u << 31), "conv2d: grid too large");
   static bool attr_set = false;  // dynamic LDS above 64 KB must be opted into once per kernel
   if (!attr_set) {
-    const void* fns[5] = {reinterpret_cast<const void*>(&conv2d_kernel<1, 3>), reinterpret_cast<const void*>(&conv2d_kernel<2, 3>),
-                          reinterpret_cast<const void*>(&conv2d_kernel<2, 1>), reinterpret_cast<const void*>(&conv2d_kernel<2, 7>),
-                          reinterpret_cast<const void*>(&conv2d_kernel<1, 1>)};
+    const void* fns[6] = {reinterpret_cast<const void*>(&conv2d_kernel<1, 3, 1>), reinterpret_cast<const void*>(&conv2d_kernel<2, 3, 1>),
+                          reinterpret_cast<const void*>(&conv2d_kernel<2, 1, 1>), reinterpret_cast<const void*>(&conv2d_kernel<2, 7, 1>),
+                          reinterpret_cast<const void*>(&conv2d_kernel<1, 1, 1>), reinterpret_cast<const void*>(&conv2d_kernel<1, 3, 2>)};
     for (const void* f : fns) ADX_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
     attr_set = true;
   }
   const dim3 g((unsigned)grid), blk(256);
-  if (L.stride == 1 && L.k == 3) conv2d_kernel<1, 3><<<g, blk, lds, s>>>(a);
-  else if (L.stride == 2 && L.k == 3) conv2d_kernel<2, 3><<<g, blk, lds, s>>>(a);
-  else if (L.stride == 2 && L.k == 1) conv2d_kernel<2, 1><<<g, blk, lds, s>>>(a);
-  else if (L.stride == 2 && L.k == 7) conv2d_kernel<2, 7><<<g, blk, lds, s>>>(a);
-  else if (L.stride == 1 && L.k == 1) conv2d_kernel<1, 1><<<g, blk, lds, s>>>(a);
+  if (L.stride == 1 && L.k == 3 && rows == 2) conv2d_kernel<1, 3, 2><<<g, blk, lds, s>>>(a);
+  else if (L.stride == 1 && L.k == 3) conv2d_kernel<1, 3, 1><<<g, blk, lds, s>>>(a);
+  else if (L.stride == 2 && L.k == 3) conv2d_kernel<2, 3, 1><<<g, blk, lds, s>>>(a);
+  else if (L.stride == 2 && L.k == 1) conv2d_kernel<2, 1, 1><<<g, blk, lds, s>>>(a);
+  else if (L.stride == 2 && L.k == 7) conv2d_kernel<2, 7, 1><<<g, blk, lds, s>>>(a);
+  else if (L.stride == 1 && L.k == 1) conv2d_kernel<1, 1, 1><<<g, blk, lds, s>>>(a);
   else {
     set_error("conv2d: no kernel for k=%d stride=%d (ResNet-34 uses 3x3 s1, 3x3 s2, 1x1 s2, 7x7 s2)", L.k, L.stride);
     return ADX_ERR_INVALID;

@@ -192,10 +192,27 @@ __global__ void __launch_bounds__(256) tconv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int f = 0; f < NFO; ++f) acc[t][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  constexpr int KSW = 8;   // K-steps per wave per staged super-tile (host keeps sbt * lout <= 128 rows)
   for (int bb = bs; bb < be; bb += a.sbt) {
     const int nsamp = min(a.sbt, be - bb);
+    const int mrows = nsamp << a.log2_lout;
+    const int ksteps = (mrows + 3) >> 2;              // 4 flattened (sample, position) rows per MFMA
+    // all dc operands of this wave for the super-tile: issued first, they land while x is staged
+    float bv[KSW][NFO];
+#pragma unroll
+    for (int j = 0; j < KSW; ++j) {
+      const int m = 4 * (wave + 4 * j) + kq;
+      const bool mok = m < mrows;
+      const int sl_ = mok ? m >> a.log2_lout : 0, l = m & (a.lout - 1);
+#pragma unroll
+      for (int f = 0; f < NFO; ++f) {
+        const int co = co0 + 16 * f + i16;
+        bv[j][f] = (mok && co < a.cout) ? a.dc[((int64_t)(bb + sl_) * a.cout + co) * a.lout + l] : 0.f;
+      }
+    }
     if (bb > bs) __syncthreads();
     // stage x[bb .. bb+nsamp)[ci0 .. ci0+16) zero padded: [16][rs], sample s at column s*lp + pl
+#pragma unroll 4
     for (int it = tid; it < 16 * a.rs; it += 256) {
       const int cl = it / a.rs, col = it - cl * a.rs;
       const int sl_ = col / a.lp, ip = col - sl_ * a.lp - a.pl;
@@ -208,24 +225,19 @@ __global__ void __launch_bounds__(256) tconv_wgrad_kernel(const WgradArgs a) {
       smem[it] = v;
     }
     __syncthreads();
-    const int mrows = nsamp << a.log2_lout;
-    const int ksteps = (mrows + 3) >> 2;              // 4 flattened (sample, position) rows per MFMA
-    for (int ks = wave; ks < ksteps; ks += 4) {
+#pragma unroll
+    for (int j = 0; j < KSW; ++j) {
+      const int ks = wave + 4 * j;
+      if (ks >= ksteps) break;                          // wave-uniform
       const int m = 4 * ks + kq;                        // this lane's K row
       const bool mok = m < mrows;                       // ragged tail contributes zeros
       const int sl_ = mok ? m >> a.log2_lout : 0, l = m & (a.lout - 1);
-      float bv[NFO];
-#pragma unroll
-      for (int f = 0; f < NFO; ++f) {
-        const int co = co0 + 16 * f + i16;
-        bv[f] = (mok && co < a.cout) ? a.dc[((int64_t)(bb + sl_) * a.cout + co) * a.lout + l] : 0.f;
-      }
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
         const int ip = l * a.stride + t - a.pad;        // halo columns are zero in LDS
         const float av = mok ? smem[i16 * a.rs + sl_ * a.lp + a.pl + ip] : 0.f;
 #pragma unroll
-        for (int f = 0; f < NFO; ++f) acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[f], acc[t][f], 0, 0, 0);
+        for (int f = 0; f < NFO; ++f) acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j][f], acc[t][f], 0, 0, 0);
       }
     }
   }
@@ -272,7 +284,7 @@ int tconv_wgrad(const adx_tconv_desc* d, const adx_tconv_io* io, const float* dc
   const int pr = (d->lout - 1) * d->stride + d->taps - 1 - d->pad - (d->lin - 1);
   a.pl = d->pad;
   a.lp = a.pl + d->lin + (pr > 0 ? pr : 0);
-  int sbt = 8192 / (16 * a.lp);            // <= 32 KB of staged input
+  int sbt = 128 / d->lout;                 // 128 (sample, position) rows = 8 K-steps per wave per super-tile
   if (sbt < per4) sbt = per4;
   sbt = sbt / per4 * per4;
   if (sbt > nb) sbt = nb;
