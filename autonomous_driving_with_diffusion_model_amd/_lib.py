@@ -106,6 +106,7 @@ _SIGS = {
     "adx_guided_output": (i32, [vp, vp, vp, vp, vp, f32, f32, vp, vp, i32, i32, vp]),
     "adx_optim_chunk": (i32, []),
     "adx_adamw_ema_step": (i32, [vp, vp, vp, i32, f32, f32, f32, f32, f32, i32, f32, i32, i32, vp]),
+    "adx_image_normalize": (i32, [vp, vp, i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), vp]),
     "adx_ddim_step": (i32, [C.POINTER(StepCoef), vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "adx_ddpm_step": (i32, [C.POINTER(StepCoef), vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "adx_add_noise": (i32, [vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp]),

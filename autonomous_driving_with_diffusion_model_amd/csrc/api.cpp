@@ -24,6 +24,9 @@ int ddpm_step(const adx_step_coef* c, const float* mo, const float* x, const flo
 int add_noise(const float* x, const float* n, const int64_t* t, const float* sa, const float* sb, int n_train,
               float* out, int batch, int horizon, int dim, int zero_first, hipStream_t s);
 
+int image_normalize(const uint8_t* src, float* dst, int n, int h, int w, const float* mean, const float* stdv,
+                    hipStream_t s);
+
 }  // namespace adx
 
 extern "C" {
@@ -61,6 +64,11 @@ int adx_add_noise(const float* x, const float* noise, const int64_t* t, const fl
                   int32_t n_train, float* out, int32_t batch, int32_t horizon, int32_t dim, int32_t zero_first,
                   adx_stream s) {
   return adx::add_noise(x, noise, t, sqrt_ab, sqrt_1mab, n_train, out, batch, horizon, dim, zero_first, (hipStream_t)s);
+}
+
+int adx_image_normalize(const uint8_t* frame_hwc, float* out_nchw, int32_t n, int32_t h, int32_t w, const float* mean,
+                        const float* stdv, adx_stream s) {
+  return adx::image_normalize(frame_hwc, out_nchw, n, h, w, mean, stdv, (hipStream_t)s);
 }
 
 }  // extern "C"

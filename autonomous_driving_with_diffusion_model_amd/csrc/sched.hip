@@ -172,4 +172,33 @@ int add_noise(const float* x, const float* n, const int64_t* t, const float* sa,
   return ADX_OK;
 }
 
+// Camera front-end of the agents (interact.py:73-78, e2e_driving/diffusion_agent.py:96-101,294):
+// torchvision ToTensor + Normalize(mean, std) on a uint8 HWC frame -> fp32 NCHW, one pass.
+__global__ void __launch_bounds__(256) image_normalize_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst,
+                                                               int n, int h, int w, float m0, float m1, float m2,
+                                                               float s0, float s1, float s2) {
+#pragma clang fp contract(off)
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // one output pixel (all 3 channels)
+  const size_t hw = (size_t)h * w;
+  if (i >= (size_t)n * hw) return;
+  const size_t img = i / hw, pix = i - img * hw;
+  const uint8_t* p = src + i * 3;
+  const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float v = (float)p[c] / 255.0f;              // ToTensor
+    dst[(img * 3 + c) * hw + pix] = (v - mean[c]) / stdv[c];
+  }
+}
+
+int image_normalize(const uint8_t* src, float* dst, int n, int h, int w, const float* mean, const float* stdv,
+                    hipStream_t s) {
+  ADX_REQUIRE(src && dst && mean && stdv && n >= 1 && h >= 1 && w >= 1, "image_normalize: bad argument");
+  const size_t total = (size_t)n * h * w;
+  image_normalize_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(src, dst, n, h, w, mean[0], mean[1],
+                                                                                  mean[2], stdv[0], stdv[1], stdv[2]);
+  ADX_LAUNCH_CHECK();
+  return ADX_OK;
+}
+
 }  // namespace adx

@@ -111,3 +111,22 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, *, stride: int = 1, pad: int =
     L.check(L.lib().adx_conv2d_forward(C.byref(d), x.data_ptr(), packed.data_ptr(), L.ptr(scale), L.ptr(shift),
                                        L.ptr(res), y.data_ptr(), n, h, w, int(relu), s), "adx_conv2d_forward")
     return y, packed
+
+
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+def image_transform(frames_u8: torch.Tensor, mean=IMAGENET_MEAN, std=IMAGENET_STD) -> torch.Tensor:
+    """The agents' `T.Compose([T.ToTensor(), T.Normalize(mean, std)])` (interact.py:73-78) for uint8 camera frames
+    [H, W, 3] or [N, H, W, 3] already on the GPU -> fp32 [N, 3, H, W]."""
+    if frames_u8.dim() == 3:
+        frames_u8 = frames_u8[None]
+    if not frames_u8.is_cuda or frames_u8.dtype != torch.uint8 or frames_u8.shape[-1] != 3:
+        raise L.AdxError("image_transform expects a uint8 [N, H, W, 3] tensor on the GPU")
+    f = frames_u8.contiguous()
+    n, h, w, _ = f.shape
+    out = torch.empty((n, 3, h, w), dtype=torch.float32, device=f.device)
+    m, s = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    L.check(L.lib().adx_image_normalize(f.data_ptr(), out.data_ptr(), n, h, w, m, s, L.stream_ptr(f.device)),
+            "adx_image_normalize")
+    return out

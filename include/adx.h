@@ -282,6 +282,11 @@ int adx_add_noise(const float* x, const float* noise, const int64_t* t, const fl
                   int32_t n_train, float* out, int32_t batch, int32_t horizon, int32_t dim, int32_t zero_first,
                   adx_stream s);
 
+/* Camera front-end (interact.py:73-78, e2e_driving/diffusion_agent.py:96-101): ToTensor + Normalize of uint8
+ * [n][h][w][3] frames into fp32 [n][3][h][w]; mean/std are HOST pointers to 3 floats. */
+int adx_image_normalize(const uint8_t* frame_hwc, float* out_nchw, int32_t n, int32_t h, int32_t w, const float* mean,
+                        const float* stdv, adx_stream s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -237,3 +237,15 @@ def test_scheduler_step_equals_stepwise_torch_on_gpu():
             r = s.step(mo, torch.tensor(t), x)
             assert torch.equal(r.prev_sample, prev), (pt, t)
             assert torch.equal(r.pred_original_sample, x0.clamp(-1, 1)), (pt, t)
+
+
+def test_image_front_end():
+    """uint8 HWC camera frame -> ToTensor + ImageNet Normalize (interact.py:73-78), fused."""
+    g = torch.Generator().manual_seed(0)
+    frames = torch.randint(0, 256, (2, 37, 53, 3), generator=g, dtype=torch.uint8)
+    ref = frames.permute(0, 3, 1, 2).float().div(255.0)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    ref = (ref - mean) / std
+    out = _ops().image_transform(frames.to(DEV))
+    close(out.cpu(), ref, 5e-7, rtol=1e-6)
