@@ -207,6 +207,8 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(const WgradArgs2 a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* patch = smem;                 // [CIT][PLANE]
   float* dyt = smem + CIT * PLANE;     // [32][DP]
+  constexpr int kZero = CIT * PLANE + 32 * DP;   // one always-zero word behind the staged tiles
+  const float* pz = smem + kZero;      // B operands are addressed relative to it
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bid = blockIdx.x;
@@ -225,7 +227,7 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(const WgradArgs2 a) {
     int cl, tap;
     if (K != 7) { cl = l31; tap = g; } else { cl = q / (K * K); tap = q - cl * (K * K); }
     const bool ok = q < a.pairs && ci0 + cl < a.Cin && cl < CIT;
-    poff[g] = ok ? cl * PLANE + (tap / K) * PW + (tap % K) : -1;
+    poff[g] = ok ? cl * PLANE + (tap / K) * PW + (tap % K) - kZero : 0;   // invalid pairs read the zero word
   }
   f32x16 acc[NG];
 #pragma unroll
@@ -275,6 +277,7 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(const WgradArgs2 a) {
     }
   };
 
+  if (tid == 0) smem[kZero] = 0.f;
   if (u0 < u1) load_unit(u0);
   for (int u = u0; u < u1; ++u) {
     if (u > u0) __syncthreads();
@@ -289,7 +292,7 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(const WgradArgs2 a) {
       const float av = ap[2 * ks];
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
-        const float bv = poff[g] >= 0 ? patch[poff[g] + prow + 2 * ks * STRIDE] : 0.f;
+        const float bv = pz[poff[g] == 0 ? 0 : poff[g] + prow + 2 * ks * STRIDE];
         acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[g], 0, 0, 0);
       }
     }
@@ -310,13 +313,16 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(const WgradArgs2 a) {
     }
     __syncthreads();
   }
-  for (int e = tid; e < NG * 1024; e += 256) {
-    const int g = e >> 10, row = (e >> 5) & 31, j = e & 31;
-    const int q = g * 32 + j;
-    int cl, tap;
-    if (K != 7) { cl = j; tap = g; } else { cl = q / (K * K); tap = q - cl * (K * K); }
+  // walk the tile in the order of dW ([co][ci][tap]) so that consecutive lanes add to consecutive addresses
+  constexpr int KK = K * K;
+  const int rowf = a.ci_per_tile * KK;   // contiguous floats per output channel in this tile
+  for (int e = tid; e < 32 * rowf; e += 256) {
+    const int row = e / rowf, r = e - row * rowf;
+    const int cl = r / KK, tap = r - cl * KK;
+    int g, j;
+    if (K != 7) { g = tap; j = cl; } else { const int q = cl * KK + tap; g = q >> 5; j = q & 31; }
     const int co = co0 + row, ci = ci0 + cl;
-    if (q < a.pairs && co < a.Cout && ci < a.Cin && cl < CIT) atomicAdd(a.dw + ((size_t)co * a.Cin + ci) * (K * K) + tap, red[e]);
+    if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + ((size_t)co * a.Cin + ci) * KK + tap, red[(g * 32 + row) * 32 + j]);
   }
 }
 
@@ -347,7 +353,7 @@ int conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int
   auto lds_bytes = [&](int cit, int ng) {
     const int ph = (kTileH - 1) * stride + k, pw = (kTileW - 1) * stride + k;
     const int plane = ph * pw + ((ph * pw) % 2 == 0 ? 1 : 0);
-    const size_t stage = (size_t)cit * plane + 32 * (kTileH * kTileW + 1);
+    const size_t stage = (size_t)cit * plane + 32 * (kTileH * kTileW + 1) + 4;
     const size_t red = (size_t)ng * 1024;
     return sizeof(float) * std::max(stage, red);
   };

@@ -241,16 +241,36 @@ __global__ void __launch_bounds__(256) tconv_wgrad_kernel(const WgradArgs a) {
       }
     }
   }
-  // C layout: col = lane & 15 = output channel, row = 4*(lane>>4) + q = input channel
+  // C layout: col = lane & 15 = output channel, row = 4*(lane>>4) + q = input channel.
+  // The 4 waves are summed through LDS into the layout of dW ([co][ci][tap]: 16*TAPS contiguous floats per
+  // output channel), so that every atomic wave-instruction adds to consecutive addresses.
+  __syncthreads();
+  constexpr int ROWF = 16 * TAPS;                  // floats per output channel in this tile
+  float* red = smem;                               // [16 * NFO][ROWF]
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t)
+      for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-    for (int f = 0; f < NFO; ++f)
+        for (int f = 0; f < NFO; ++f)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int ci = ci0 + 4 * kq + q, co = co0 + 16 * f + i16;
-        if (ci < a.cin && co < a.cout) atomicAdd(a.dw + (int64_t)co * a.dw_so + (int64_t)ci * a.dw_si + t, acc[t][f][q]);
-      }
+          for (int q = 0; q < 4; ++q) {
+            float* dst = red + (16 * f + i16) * ROWF + (4 * kq + q) * TAPS + t;
+            *dst = w == 0 ? acc[t][f][q] : *dst + acc[t][f][q];
+          }
+    }
+    __syncthreads();
+  }
+  const int ci_n = min(16, a.cin - ci0);           // valid input channels of this tile
+  for (int e = tid; e < 16 * NFO * ROWF; e += 256) {
+    const int col = e / ROWF, r = e - col * ROWF;
+    const int co = co0 + col;
+    if (co < a.cout && r < ci_n * TAPS) {
+      float* dst = a.dw + (int64_t)co * a.dw_so + (int64_t)ci0 * a.dw_si + r;
+      if (a.nsplit == 1) *dst = red[e];
+      else atomicAdd(dst, red[e]);
+    }
+  }
 }
 
 int tconv_wgrad(const adx_tconv_desc* d, const adx_tconv_io* io, const float* dc, float* dw, hipStream_t s) {
@@ -275,8 +295,8 @@ int tconv_wgrad(const adx_tconv_desc* d, const adx_tconv_io* io, const float* dc
   a.n_ci_tiles = ceil_div(a.cin, 16);
   a.n_co_tiles = ceil_div(d->cout, 16 * nfo);
   const int tiles = a.n_ci_tiles * a.n_co_tiles;
-  // split the batch so that ~512 workgroups exist, each with at least `per4` samples
-  int nsplit = ceil_div(512, tiles);
+  // split the batch so that ~256 workgroups exist, each with at least `per4` samples
+  int nsplit = ceil_div(256, tiles);
   int nb = ceil_div(io->batch, nsplit);
   nb = round_up(nb < per4 ? per4 : nb, per4);
   nsplit = ceil_div(io->batch, nb);
@@ -293,7 +313,8 @@ int tconv_wgrad(const adx_tconv_desc* d, const adx_tconv_io* io, const float* dc
   ADX_REQUIRE((sbt * d->lout) % 4 == 0, "tconv_wgrad: staged tile not a multiple of 4 rows");
   a.dw_so = (int64_t)a.cin * d->taps; a.dw_si = d->taps;
   ADX_CHECK_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->cout * a.cin * d->taps, s));
-  const size_t lds = sizeof(float) * 16 * a.rs;
+  const size_t lds_stage = (size_t)16 * a.rs, lds_red = (size_t)16 * nfo * 16 * d->taps;
+  const size_t lds = sizeof(float) * (lds_stage > lds_red ? lds_stage : lds_red);
   const dim3 grid((unsigned)(tiles * nsplit)), blk(256);
 #define ADX_WG(NFO, TAPS) tconv_wgrad_kernel<NFO, TAPS><<<grid, blk, lds, s>>>(a)
 #define ADX_WG_T(NFO)                                  \
