@@ -67,7 +67,20 @@ def time_events(fn, reps, warm=2):
     return e0.elapsed_time(e1) / reps  # ms per call
 
 
-def conv2d_roofline(dev, reps=5):
+def pmc_traffic(key):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json); rocprof cannot
+    run inside this process, so the number is read back with its provenance."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            for k, v in json.load(f)["kernels"].items():
+                if k.startswith(key):
+                    return round(v["traffic"])
+    except Exception:
+        pass
+    return None
+
+
+def conv2d_roofline(dev, reps=10):
     """Dominant kernel of the timed region: conv2d_kernel<1> (the 29 stride-1 3x3 convs of one
     perception pass).  Every distinct shape is launched alone through the C ABI and timed with HIP
     events on the launch stream; the launch-mix average is what rocprofv3's per-kernel average shows."""
@@ -96,9 +109,10 @@ def conv2d_roofline(dev, reps=5):
         del x, y, wt, packed
     avg_ms = tot_ms / count
     achieved = tot_fl / count / avg_ms / 1e9  # TFLOP/s
-    return {"kernel": "conv2d_kernel<1> (ResNet-34 3x3 stride-1 convs, B=64, 3x256x900)", "bound": "mfma",
+    return {"kernel": "conv2d_kernel<1,3,2> (ResNet-34 3x3 stride-1 convs, B=64, 3x256x900)", "bound": "mfma",
             "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": pmc_traffic("conv2d_kernel<1,3"),
+            "traffic_note": "bytes/launch, FETCH_SIZE+WRITE_SIZE from profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc passes)",
             "avg_launch_ms": round(avg_ms, 4), "launches_per_step": count,
             "algorithmic_gflop_per_launch": round(tot_fl / count / 1e9, 2),
             "algorithmic_mb_per_launch": round(tot_bytes / count / 1e6, 2), "per_shape": per_shape}
@@ -130,7 +144,8 @@ def tconv_roofline(model, dev, reps=20):
     del fn
     return {"kernel": "tconv_kernel<1,4> (Conv1d 512->512 k5 + GroupNorm + Mish, 128x4 positions)",
             "bound": "mfma", "achieved": round(fl / ms / 1e9, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(fl / ms / 1e9 / PEAK_F32_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(ms, 4),
+            "frac": round(fl / ms / 1e9 / PEAK_F32_TFLOPS, 4), "traffic": pmc_traffic("tconv_kernel<1,4"),
+            "avg_launch_ms": round(ms, 4),
             "algorithmic_gflop_per_launch": round(fl / 1e9, 3), "algorithmic_mb_per_launch": round(byts / 1e6, 2),
             "hbm_gbs_at_algorithmic_bytes": round(byts / ms / 1e6, 1),
             "hbm_frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4)}
