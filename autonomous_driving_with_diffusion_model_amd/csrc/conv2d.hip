@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256) conv2d_kernel(const Conv2dArgs a) {
   constexpr int WITEMS = (NW4 + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* patch = smem;                                    // [CC][PH][PW]
-  float* wl = smem + ((NP + 3) & ~3);                     // [NTAPS][CC][64]
+  float* wl = smem + PITEMS * 256;                        // [NTAPS][CC][64]
   float* ss = wl + NTAPS * CC * kCoutT;                   // scale[64], shift[64]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -99,23 +99,24 @@ __global__ void __launch_bounds__(256) conv2d_kernel(const Conv2dArgs a) {
   auto load_chunk = [&](int c0) {
     const float* xc = xin + (size_t)c0 * hw;
 #pragma unroll
-    for (int k = 0; k < PITEMS; ++k) pv[k] = goff[k] >= 0 ? xc[goff[k]] : 0.f;
+    for (int k = 0; k < PITEMS; ++k) {
+      const float v = xc[goff[k] >= 0 ? goff[k] : 0];   // branch-free: out-of-image taps read element 0 and are zeroed
+      pv[k] = goff[k] >= 0 ? v : 0.f;
+    }
 #pragma unroll
     for (int k = 0; k < WITEMS; ++k) {
       const int e = tid + 256 * k;
       const int q = e & 15, row = e >> 4;             // row = tap * CC + c
       const int tap = row / CC, c = row - tap * CC;
-      wv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (e < NW4)
-        wv[k] = *reinterpret_cast<const f32x4*>(a.w + ((size_t)tap * a.cin_pad + c0 + c) * a.Cout + cout0 + 4 * q);
+      const int ec = e < NW4 ? e : 0;                    // clamp instead of branching; the store below is predicated
+      const int rowc = ec >> 4, tapc = rowc / CC, cc_ = rowc - tapc * CC;
+      (void)tap; (void)c;
+      wv[k] = *reinterpret_cast<const f32x4*>(a.w + ((size_t)tapc * a.cin_pad + c0 + cc_) * a.Cout + cout0 + 4 * q);
     }
   };
   auto store_chunk = [&]() {
 #pragma unroll
-    for (int k = 0; k < PITEMS; ++k) {
-      const int e = tid + 256 * k;
-      if (e < NP) patch[e] = pv[k];
-    }
+    for (int k = 0; k < PITEMS; ++k) patch[tid + 256 * k] = pv[k];   // the patch area is padded to PITEMS * 256 floats
 #pragma unroll
     for (int k = 0; k < WITEMS; ++k) {
       const int e = tid + 256 * k;
@@ -323,7 +324,7 @@ int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const f
   ADX_REQUIRE(L.cin % L.cc == 0 || L.cin < L.cc, "conv2d: cin %d must be < %d or a multiple of it", L.cin, L.cc);
   ADX_REQUIRE((size_t)L.cin * H * W < (1u << 31), "conv2d: image plane too large for 32-bit gather offsets");
   const size_t np = (size_t)a.cc * a.PH * a.PW;
-  const size_t lds = sizeof(float) * (((np + 3) & ~(size_t)3) + (size_t)L.k * L.k * a.cc * kCoutT + 2 * kCoutT);
+  const size_t lds = sizeof(float) * ((np + 255) / 256 * 256 + (size_t)L.k * L.k * a.cc * kCoutT + 2 * kCoutT);
   ADX_REQUIRE(lds <= kMaxLds, "conv2d: LDS %zu bytes too large", lds);
   const size_t grid = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y * N;
   ADX_REQUIRE(grid < (1u << 31), "conv2d: grid too large");
