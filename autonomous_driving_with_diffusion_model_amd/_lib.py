@@ -12,7 +12,7 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libadx.so")
+LIB_PATH = os.environ.get("ADX_LIB") or os.path.join(_HERE, "libadx.so")   # ADX_LIB: A/B builds in one run
 
 c_f32p = C.POINTER(C.c_float)
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p

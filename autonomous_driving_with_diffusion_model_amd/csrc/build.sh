@@ -2,7 +2,7 @@
 # Build libadx.so for gfx950 (cross-compiles without a GPU).  Usage: csrc/build.sh [extra hipcc flags]
 set -euo pipefail
 cd "$(dirname "$0")"
-OUT=../libadx.so
+OUT=${ADX_OUT:-../libadx.so}
 SRCS="api.cpp tconv.hip embed.hip sched.hip unet.hip conv2d.hip trajpred.hip tbwd.hip unet_train.hip resnet_train.hip optim.hip"
 hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -x hip $SRCS -o "$OUT" \
   -Wall -Wno-unused-function "$@"

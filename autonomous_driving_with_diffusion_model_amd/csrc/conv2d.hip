@@ -23,6 +23,7 @@ namespace adx {
 
 constexpr int kCoutT = 64;   // output channels per workgroup (2 MFMA row blocks)
 constexpr size_t kMaxLds = 96 * 1024;
+static int g_conv_cc = 16;    // channels per LDS chunk of the 8-row kernel (ADX_CONV_CC=8: smaller chunk, 3 workgroups/CU)
 static int g_conv_rows = 2;   // rows per wave of the 3x3 stride-1 kernel (ADX_CONV_ROWS=1 selects the 4-row tile)
 
 struct Conv2dArgs {
@@ -43,10 +44,10 @@ struct Conv2dArgs {
 // hides behind ~9k cycles of matrix work per 16-channel chunk.
 // ROWS = output rows per wave (tile = 4*ROWS rows x 32 columns x 64 channels): ROWS = 2 reuses every
 // weight fragment for two pixel rows (1.0 instead of 1.5 LDS reads per MFMA).
-template <int STRIDE, int K, int ROWS>
+template <int STRIDE, int K, int ROWS, int CCH = 16>
 __global__ void __launch_bounds__(256) conv2d_kernel(const Conv2dArgs a) {
   constexpr int TH = 4 * ROWS;
-  constexpr int CC = (K == 7) ? 4 : 16;                   // channels per chunk
+  constexpr int CC = (K == 7) ? 4 : CCH;                  // channels per chunk
   constexpr int PH = (TH - 1) * STRIDE + K;           // staged patch rows / columns
   constexpr int PW = (kTileW - 1) * STRIDE + K;
   constexpr int PLANE = PH * PW;
@@ -308,6 +309,8 @@ int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const f
   if (!env_read) {
     const char* e = getenv("ADX_CONV_ROWS");
     if (e != nullptr && e[0] == '1') g_conv_rows = 1;
+    const char* c = getenv("ADX_CONV_CC");
+    if (c != nullptr && c[0] == '8') g_conv_cc = 8;
     env_read = true;
   }
   Conv2dArgs a;
@@ -323,8 +326,9 @@ int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const f
   a.PWp = a.PW;
   ADX_REQUIRE(L.cin % L.cc == 0 || L.cin < L.cc, "conv2d: cin %d must be < %d or a multiple of it", L.cin, L.cc);
   ADX_REQUIRE((size_t)L.cin * H * W < (1u << 31), "conv2d: image plane too large for 32-bit gather offsets");
-  const size_t np = (size_t)a.cc * a.PH * a.PW;
-  const size_t lds = sizeof(float) * ((np + 255) / 256 * 256 + (size_t)L.k * L.k * a.cc * kCoutT + 2 * kCoutT);
+  const int cch = (rows == 2 && g_conv_cc == 8) ? 8 : a.cc;   // channels staged per chunk
+  const size_t np = (size_t)cch * a.PH * a.PW;
+  const size_t lds = sizeof(float) * ((np + 255) / 256 * 256 + (size_t)L.k * L.k * cch * kCoutT + 2 * kCoutT);
   ADX_REQUIRE(lds <= kMaxLds, "conv2d: LDS %zu bytes too large", lds);
   const size_t grid = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y * N;
   ADX_REQUIRE(grid < (1u << 31), "conv2d: grid too large");
@@ -333,11 +337,14 @@ int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const f
     const void* fns[6] = {reinterpret_cast<const void*>(&conv2d_kernel<1, 3, 1>), reinterpret_cast<const void*>(&conv2d_kernel<2, 3, 1>),
                           reinterpret_cast<const void*>(&conv2d_kernel<2, 1, 1>), reinterpret_cast<const void*>(&conv2d_kernel<2, 7, 1>),
                           reinterpret_cast<const void*>(&conv2d_kernel<1, 1, 1>), reinterpret_cast<const void*>(&conv2d_kernel<1, 3, 2>)};
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_kernel<1, 3, 2, 8>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
     for (const void* f : fns) ADX_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
     attr_set = true;
   }
   const dim3 g((unsigned)grid), blk(256);
-  if (L.stride == 1 && L.k == 3 && rows == 2) conv2d_kernel<1, 3, 2><<<g, blk, lds, s>>>(a);
+  if (L.stride == 1 && L.k == 3 && rows == 2 && cch == 8) conv2d_kernel<1, 3, 2, 8><<<g, blk, lds, s>>>(a);
+  else if (L.stride == 1 && L.k == 3 && rows == 2) conv2d_kernel<1, 3, 2><<<g, blk, lds, s>>>(a);
   else if (L.stride == 1 && L.k == 3) conv2d_kernel<1, 3, 1><<<g, blk, lds, s>>>(a);
   else if (L.stride == 2 && L.k == 3) conv2d_kernel<2, 3, 1><<<g, blk, lds, s>>>(a);
   else if (L.stride == 2 && L.k == 1) conv2d_kernel<2, 1, 1><<<g, blk, lds, s>>>(a);
