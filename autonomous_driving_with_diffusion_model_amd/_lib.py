@@ -77,7 +77,7 @@ _SIGS = {
     "adx_unet_tape_destroy": (None, [vp]),
     "adx_unet_train_workspace_bytes": (C.c_size_t, [vp, i32]),
     "adx_unet_forward_train": (i32, [vp, vp, vp, C.c_size_t, C.POINTER(UnetIO), vp, vp]),
-    "adx_unet_backward": (i32, [vp, vp, vp, C.c_size_t, vp, vp, vp, C.POINTER(vp), C.POINTER(vp), i32, vp]),
+    "adx_unet_backward": (i32, [vp, vp, vp, C.c_size_t, vp, vp, vp, vp, C.POINTER(vp), C.POINTER(vp), i32, vp]),
     "adx_gn_mish_backward": (i32, [vp, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
     "adx_tconv_wgrad": (i32, [C.POINTER(TConvDesc), C.POINTER(TConvIO), vp, vp, vp]),
     "adx_bias_grad": (i32, [vp, vp, i32, i32, i32, vp]),
@@ -103,6 +103,8 @@ _SIGS = {
     "adx_trajpred_pack": (i32, [vp, C.POINTER(vp), i32, vp, vp, vp]),
     "adx_trajpred_forward": (i32, [vp, vp, vp, i64, i64, vp, vp, i32, i32, vp]),
     "adx_trajpred_backward": (i32, [vp, vp, vp, i64, i64, vp, vp, vp, i32, i32, vp]),
+    "adx_trajpred_backward_params": (i32, [vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "adx_trajpred_param_offsets": (i32, [vp, C.POINTER(i64), i32]),
     "adx_guided_output": (i32, [vp, vp, vp, vp, vp, f32, f32, vp, vp, i32, i32, vp]),
     "adx_optim_chunk": (i32, []),
     "adx_adamw_ema_step": (i32, [vp, vp, vp, i32, f32, f32, f32, f32, f32, i32, f32, i32, i32, vp]),

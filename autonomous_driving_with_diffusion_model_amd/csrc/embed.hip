@@ -81,7 +81,8 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(const adx_embed_weights 
                                                          const int64_t* __restrict__ t, const int t_rows,
                                                          const float* __restrict__ cond, const float* __restrict__ feat,
                                                          const int feat_rows, const float* __restrict__ time_embed,
-                                                         const float* __restrict__ dmc, float* __restrict__ dfeat) {
+                                                         const float* __restrict__ dmc, const float* __restrict__ dte_extra,
+                                                         float* __restrict__ dfeat) {
   __shared__ float e[kMaxDim];
   __shared__ float a1[4 * kMaxDim];   // pre-activation of time_mlp.1, later d(a1)
   __shared__ float h[4 * kMaxDim];
@@ -116,7 +117,8 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(const adx_embed_weights 
   // d cat = d mc * mish'(cat)
   for (int j = tid; j < dim; j += 256) {
     const float te = time_embed[(size_t)row * dim + j];
-    dte[j] = dmc[(size_t)row * 2 * dim + j] * mish_grad_e(te);
+    dte[j] = dmc[(size_t)row * 2 * dim + j] * mish_grad_e(te) +
+             (dte_extra != nullptr ? dte_extra[(size_t)row * dim + j] : 0.f);   // + gradient from TrajPredict
     const float f = feat[(size_t)(row % feat_rows) * dim + j];
     const float df = dmc[(size_t)row * 2 * dim + dim + j] * mish_grad_e(f);
     if (feat_rows == gridDim.x) dfeat[(size_t)row * dim + j] = df;
@@ -162,7 +164,7 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(const adx_embed_weights 
 
 int embed_backward(const adx_embed_weights* w, int dim, const int64_t* t, int t_rows, const float* cond,
                    const float* feat, int feat_rows, int rows, const float* time_embed, const float* d_mish_cond,
-                   float* d_feat, float* const* grads, hipStream_t s) {
+                   const float* d_time_embed_extra, float* d_feat, float* const* grads, hipStream_t s) {
   ADX_REQUIRE(w && t && feat && time_embed && d_mish_cond && d_feat && grads, "embed_backward: null argument");
   ADX_REQUIRE(dim >= 4 && dim <= kMaxDim && dim % 2 == 0, "embed_backward: dim %d unsupported", dim);
   EmbedGrads g{grads[0], grads[1], grads[2], grads[3], grads[4], grads[5], grads[6], grads[7]};
@@ -181,7 +183,7 @@ int embed_backward(const adx_embed_weights* w, int dim, const int64_t* t, int t_
   }
   if (feat_rows != rows) ADX_CHECK_HIP(hipMemsetAsync(d_feat, 0, sizeof(float) * (size_t)feat_rows * dim, s));
   embed_bwd_kernel<<<dim3(rows), dim3(256), 0, s>>>(*w, g, dim, t, t_rows, cond, feat, feat_rows, time_embed,
-                                                    d_mish_cond, d_feat);
+                                                    d_mish_cond, d_time_embed_extra, d_feat);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
 }

@@ -141,6 +141,26 @@ __device__ __forceinline__ float silu_grad(float x) {
   return s * (1.0f + x * (1.0f - s));
 }
 
+// parameter-gradient accumulation (training): gW[n][k] += sum_t A[t][n] * B[t][k], gb[n] += sum_t A[t][n].
+// One workgroup per sample adds into the shared gradient image with float atomics.
+template <typename FA>
+__device__ __forceinline__ void outer_acc(float* gW, int N, int K, FA fa, const float* Bm, int ldb, int T, int tid) {
+  for (int idx = tid; idx < N * K; idx += 256) {
+    const int n = idx / K, k = idx - n * K;
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) acc += fa(t, n) * Bm[t * ldb + k];
+    atomicAdd(gW + idx, acc);
+  }
+}
+template <typename FA>
+__device__ __forceinline__ void colsum_acc(float* gb, int N, FA fa, int T, int tid) {
+  for (int n = tid; n < N; n += 256) {
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) acc += fa(t, n);
+    atomicAdd(gb + n, acc);
+  }
+}
+
 // LDS plan (floats).  X: layer input; QKV; P: attention probs [NH][TP][TP]; O: attention output,
 // later reused; Y: pre-norm sums / scratch; H1: norm1 output; F: feed-forward pre-activation;
 // XH1/XH2: normalised values for the LayerNorm backward; small per-row vectors at the end.
@@ -269,11 +289,30 @@ __device__ __forceinline__ void layer_forward(const Lds& l, const float* __restr
 
 // back-propagate through one layer: D (in/out, [TP][E]) holds d(layer output) on entry and
 // d(layer input) on exit.  Requires layer_forward() to have just run on this layer's input.
+// G != nullptr (training): parameter gradients are accumulated into the gradient image G, which has the packed
+// buffer's layout (PyTorch-layout slots); Xin = this layer's input tile.
 __device__ __forceinline__ void layer_backward(const Lds& l, float* D, const float* __restrict__ P, const TPLayer& y,
-                                               int T, int tid) {
+                                               int T, int tid, float* G, const float* Xin) {
+  if (G != nullptr) {  // norm2 affine
+    for (int i = tid; i < E; i += 256) {
+      float sg = 0.f, sb = 0.f;
+      for (int t = 0; t < T; ++t) { sg += D[t * E + i] * l.XH2[t * E + i]; sb += D[t * E + i]; }
+      atomicAdd(G + y.g2 + i, sg);
+      atomicAdd(G + y.be2 + i, sb);
+    }
+  }
   // norm2
   layer_norm_bwd_rows(l.Y, D, l.XH2, l.R2, E, P + y.g2, T, tid);   // Y = d(y2) = d(h1 path) = d(ff)
   __syncthreads();
+  if (G != nullptr) {  // linear2: ff = W2 silu(F) + b2, before F is overwritten
+    for (int idx = tid; idx < E * FF; idx += 256) {
+      const int j = idx / FF, n = idx - j * FF;
+      float acc = 0.f;
+      for (int t = 0; t < T; ++t) acc += l.Y[t * E + j] * silu_f(l.F[t * FF + n]);
+      atomicAdd(G + y.w2 + idx, acc);
+    }
+    colsum_acc(G + y.b2, E, [&](int t, int n) { return l.Y[t * E + n]; }, T, tid);
+  }
   // ds = dff @ W2  ([T][256]); dF = ds * silu'(F), stored over F
   for (int item = tid; item < FF * (TP / RT); item += 256) {
     const int n = item % FF, tg = item / FF;
@@ -293,12 +332,28 @@ __device__ __forceinline__ void layer_backward(const Lds& l, float* D, const flo
     }
   }
   __syncthreads();
+  if (G != nullptr) {  // linear1: F = W1 H1 + b1 (F now holds dF)
+    outer_acc(G + y.w1, FF, E, [&](int t, int n) { return l.F[t * FF + n]; }, l.H1, E, T, tid);
+    colsum_acc(G + y.b1, FF, [&](int t, int n) { return l.F[t * FF + n]; }, T, tid);
+  }
   // dH1 = dy2 + dF @ W1   (W1 is [256][64]: K = 256 rows, N = 64 contiguous)
   mm_fwd<true>(l.Y, E, l.F, FF, P + y.w1, nullptr, FF, E, tid);
   __syncthreads();
+  if (G != nullptr) {  // norm1 affine
+    for (int i = tid; i < E; i += 256) {
+      float sg = 0.f, sb = 0.f;
+      for (int t = 0; t < T; ++t) { sg += l.Y[t * E + i] * l.XH1[t * E + i]; sb += l.Y[t * E + i]; }
+      atomicAdd(G + y.g1 + i, sg);
+      atomicAdd(G + y.be1 + i, sb);
+    }
+  }
   // norm1: D = d(y1)
   layer_norm_bwd_rows(D, l.Y, l.XH1, l.R1, E, P + y.g1, T, tid);
   __syncthreads();
+  if (G != nullptr) {  // out_proj: sa = Wout O + bout
+    outer_acc(G + y.w_out, E, E, [&](int t, int n) { return D[t * E + n]; }, l.O, E, T, tid);
+    colsum_acc(G + y.b_out, E, [&](int t, int n) { return D[t * E + n]; }, T, tid);
+  }
   // dO = dsa @ Wout  (Wout [64][64], row j = output feature)
   mm_fwd<false>(l.Y, E, D, E, P + y.w_out, nullptr, E, E, tid);    // Y = dO
   __syncthreads();
@@ -340,6 +395,14 @@ __device__ __forceinline__ void layer_backward(const Lds& l, float* D, const flo
     l.XH1[idx] = dv;
   }
   __syncthreads();
+  if (G != nullptr) {  // in_proj: [q k v] = Win Xin + bin
+    outer_acc(G + y.w_in, E, E, [&](int t, int n) { return l.O[t * E + n]; }, Xin, E, T, tid);
+    outer_acc(G + y.w_in + E * E, E, E, [&](int t, int n) { return l.H1[t * E + n]; }, Xin, E, T, tid);
+    outer_acc(G + y.w_in + 2 * E * E, E, E, [&](int t, int n) { return l.XH1[t * E + n]; }, Xin, E, T, tid);
+    colsum_acc(G + y.b_in, E, [&](int t, int n) { return l.O[t * E + n]; }, T, tid);
+    colsum_acc(G + y.b_in + E, E, [&](int t, int n) { return l.H1[t * E + n]; }, T, tid);
+    colsum_acc(G + y.b_in + 2 * E, E, [&](int t, int n) { return l.XH1[t * E + n]; }, T, tid);
+  }
   // dX = d(y1) + [dq dk dv] @ Win   (Win [192][64]); D already holds d(y1)
   mm_fwd<true>(D, E, l.O, E, P + y.w_in, nullptr, E, E, tid);
   mm_fwd<true>(D, E, l.H1, E, P + y.w_in + E * E, nullptr, E, E, tid);
@@ -364,6 +427,8 @@ struct TrajArgs {
   float* xg;                 // [B][T+1][out_dim+3] guided output (state | action)
   float grad_scale, scale;   // model_std, GUIDANCE.CLASSIFIER_SCALE
   float* loss;               // [B] or null
+  // training: gradient image with the packed buffer's layout (atomically accumulated) and d(time_embed) [B][64]
+  float* G; float* dte;
 };
 
 // head: LayerNorm -> Linear(64, out_dim)
@@ -405,6 +470,20 @@ __device__ __forceinline__ void backward_core(const Lds& l, const TrajArgs& a, i
     layer_forward(l, P, L.layer[li], T, tid);
   }
   head_forward(l, P, L, T, tid);   // XH2 / R2 now belong to the final norm
+  float* G = a.G;
+  if (G != nullptr) {  // output_proj: out = Wop Ynorm + bop
+    for (int idx = tid; idx < od * E; idx += 256) {
+      const int j = idx / E, i = idx - j * E;
+      float acc = 0.f;
+      for (int t = 0; t < T; ++t) acc += dout(t, j) * l.Y[t * E + i];
+      atomicAdd(G + L.w_op + idx, acc);
+    }
+    for (int j = tid; j < od; j += 256) {
+      float acc = 0.f;
+      for (int t = 0; t < T; ++t) acc += dout(t, j);
+      atomicAdd(G + L.b_op + j, acc);
+    }
+  }
   // d(normed) = dout @ Wop  -> H1
   for (int idx = tid; idx < TP * E; idx += 256) {
     const int t = idx >> 6, i = idx & 63;
@@ -415,6 +494,14 @@ __device__ __forceinline__ void backward_core(const Lds& l, const TrajArgs& a, i
   }
   __syncthreads();
   float* D = l.IN(NL);
+  if (G != nullptr) {  // final LayerNorm affine
+    for (int i = tid; i < E; i += 256) {
+      float sg = 0.f, sb = 0.f;
+      for (int t = 0; t < T; ++t) { sg += l.H1[t * E + i] * l.XH2[t * E + i]; sb += l.H1[t * E + i]; }
+      atomicAdd(G + L.gf + i, sg);
+      atomicAdd(G + L.bef + i, sb);
+    }
+  }
   layer_norm_bwd_rows(D, l.H1, l.XH2, l.R2, E, P + L.gf, T, tid);
   for (int idx = tid + 0; idx < TP * E; idx += 256)
     if ((idx >> 6) >= T) D[idx] = 0.f;
@@ -423,10 +510,25 @@ __device__ __forceinline__ void backward_core(const Lds& l, const TrajArgs& a, i
     for (int idx = tid; idx < TP * E; idx += 256) l.X[idx] = l.IN(li)[idx];
     __syncthreads();
     layer_forward(l, P, L.layer[li], T, tid);     // recompute this layer's internals
-    layer_backward(l, D, P, L.layer[li], T, tid);
+    layer_backward(l, D, P, L.layer[li], T, tid, G, l.IN(li));
     for (int idx = tid; idx < TP * E; idx += 256)
       if ((idx >> 6) >= T) D[idx] = 0.f;
     __syncthreads();
+  }
+  if (G != nullptr) {  // input_proj: x0 = Wip a + bip (+ pos + time_embed)
+    const float* act = a.action + (int64_t)b * a.act_sb;
+    for (int idx = tid; idx < E * IN_DIM; idx += 256) {
+      const int j = idx / IN_DIM, i = idx - j * IN_DIM;
+      float acc = 0.f;
+      for (int t = 0; t < T; ++t) acc += D[t * E + j] * act[(int64_t)t * a.act_st + i];
+      atomicAdd(G + L.w_ip + idx, acc);
+    }
+    for (int j = tid; j < E; j += 256) {
+      float acc = 0.f;
+      for (int t = 0; t < T; ++t) acc += D[t * E + j];
+      atomicAdd(G + L.b_ip + j, acc);
+      if (a.dte != nullptr) a.dte[(int64_t)b * E + j] = acc;   // time_embed is added to every row
+    }
   }
   // d(action)[t][i] = sum_j D[t][j] Wip[j][i]
   for (int idx = tid; idx < TP * IN_DIM; idx += 256) {
@@ -446,10 +548,11 @@ __global__ void __launch_bounds__(256) trajpred_backward_kernel(const TrajArgs a
   const float* g = a.gout + (int64_t)b * a.gout_sb;
   const int64_t gst = a.gout_st;
   backward_core(l, a, b, tid, [&](int t, int j) { return g[(int64_t)t * gst + j]; });
-  for (int idx = tid; idx < a.T * IN_DIM; idx += 256) {
-    const int t = idx / IN_DIM, i = idx - t * IN_DIM;
-    a.gact[(int64_t)b * a.gact_sb + (int64_t)t * a.gact_st + i] = l.O[idx];
-  }
+  if (a.gact != nullptr)
+    for (int idx = tid; idx < a.T * IN_DIM; idx += 256) {
+      const int t = idx / IN_DIM, i = idx - t * IN_DIM;
+      a.gact[(int64_t)b * a.gact_sb + (int64_t)t * a.gact_st + i] = l.O[idx];
+    }
 }
 
 // Fused classifier guidance for one sample (GUIDANCE.STEP = 1):
@@ -647,6 +750,41 @@ int adx_trajpred_backward(adx_trajpred* t, const void* packed, const float* acti
   a.gact = grad_action; a.gact_sb = (int64_t)T * IN_DIM; a.gact_st = IN_DIM;
   trajpred_backward_kernel<<<dim3(batch), dim3(256), kLdsFloats * sizeof(float), (hipStream_t)stream>>>(a);
   ADX_LAUNCH_CHECK();
+  return ADX_OK;
+}
+
+// Training: parameter gradients (gradient image in the packed layout, zeroed here, see
+// adx_trajpred_param_offsets) and d(time_embed) [B][64]; grad_action may be NULL.
+int adx_trajpred_backward_params(adx_trajpred* t, const void* packed, const float* action, int64_t act_sb, int64_t act_st,
+                                 const float* time_embed, const float* grad_out, float* grad_action, void* grad_image,
+                                 float* d_time_embed, int32_t batch, int32_t T, adx_stream stream) {
+  TrajArgs a;
+  int rc = tp_common(t, packed, batch, T, &a);
+  if (rc != ADX_OK) return rc;
+  ADX_REQUIRE(action && time_embed && grad_out && grad_image && d_time_embed, "adx_trajpred_backward_params: null tensor");
+  ADX_CHECK_HIP(hipMemsetAsync(grad_image, 0, (size_t)t->L.total * sizeof(float), (hipStream_t)stream));
+  a.action = action; a.act_sb = act_sb; a.act_st = act_st; a.te = time_embed;
+  a.gout = grad_out; a.gout_sb = (int64_t)T * t->L.out_dim; a.gout_st = t->L.out_dim;
+  a.gact = grad_action; a.gact_sb = (int64_t)T * IN_DIM; a.gact_st = IN_DIM;
+  a.G = (float*)grad_image; a.dte = d_time_embed;
+  trajpred_backward_kernel<<<dim3(batch), dim3(256), kLdsFloats * sizeof(float), (hipStream_t)stream>>>(a);
+  ADX_LAUNCH_CHECK();
+  return ADX_OK;
+}
+
+// float offset of every parameter (adx_trajpred_pack order) inside the packed / gradient image
+int adx_trajpred_param_offsets(const adx_trajpred* t, int64_t* offsets, int32_t n) {
+  ADX_REQUIRE(t && offsets && n == adx_trajpred_num_params(t), "adx_trajpred_param_offsets: bad argument");
+  const TPLayout& L = t->L;
+  int i = 0;
+  offsets[i++] = L.w_ip; offsets[i++] = L.b_ip;
+  for (int l = 0; l < NL; ++l) {
+    const TPLayer& y = L.layer[l];
+    offsets[i++] = y.w_in; offsets[i++] = y.b_in; offsets[i++] = y.w_out; offsets[i++] = y.b_out;
+    offsets[i++] = y.w1; offsets[i++] = y.b1; offsets[i++] = y.w2; offsets[i++] = y.b2;
+    offsets[i++] = y.g1; offsets[i++] = y.be1; offsets[i++] = y.g2; offsets[i++] = y.be2;
+  }
+  offsets[i++] = L.gf; offsets[i++] = L.bef; offsets[i++] = L.w_op; offsets[i++] = L.b_op;
   return ADX_OK;
 }
 

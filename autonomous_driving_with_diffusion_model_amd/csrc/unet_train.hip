@@ -24,7 +24,8 @@ int bias_grad(const float* dc, int64_t sb, int64_t sc, int64_t sl, float* db, in
 int add_strided(float* dst, const float* src, int64_t sb, int64_t sc, int64_t sl, int B, int C, int L, hipStream_t s);
 int embed_backward(const adx_embed_weights* w, int dim, const int64_t* t, int t_rows, const float* cond,
                    const float* feat, int feat_rows, int rows, const float* time_embed, const float* d_mish_cond,
-                   float* d_feat, float* const* grads /* w1,b1,w3,b3,cw0,cb0,cw2,cb2 */, hipStream_t s);
+                   const float* d_time_embed_extra, float* d_feat, float* const* grads /* w1,b1,w3,b3,cw0,cb0,cw2,cb2 */,
+                   hipStream_t s);
 
 struct TAct {  // activation view [rows][c][len]
   const float* p = nullptr;
@@ -123,8 +124,6 @@ int adx_unet_forward_train(adx_unet* u, const void* packed, void* workspace, siz
     set_error("adx_unet_forward_train: weights were never packed (call adx_unet_pack first)");
     return ADX_ERR_STATE;
   }
-  ADX_REQUIRE(u->cfg.guidance != 2, "adx_unet_forward_train: CLASSIFIER_GUIDANCE training (TrajPredict parameter "
-                                    "gradients) is not implemented yet");
   ADX_REQUIRE(io->x && io->img_feature && io->t && io->out, "adx_unet_forward_train: null tensor");
   const int rows = io->rows, dim = u->cfg.dim, H = u->cfg.horizon, D = u->cfg.transition_dim;
   ADX_REQUIRE(rows >= 1 && io->t_rows == rows && io->feat_rows == rows,
@@ -232,10 +231,11 @@ int adx_unet_forward_train(adx_unet* u, const void* packed, void* workspace, siz
 }
 
 // grads: one pointer per parameter of adx_unet_pack's list (PyTorch layouts), written (not accumulated).
-// d_out: gradient of the forward's `out` ([rows][H][out_ch]); d_img_feature: [rows][dim] written.
+// d_out: gradient of the forward's `out` ([rows][H][out_ch]); d_time_embed: optional extra gradient w.r.t. the
+// returned time_embed (CLASSIFIER_GUIDANCE: from TrajPredict); d_img_feature: [rows][dim] written.
 int adx_unet_backward(adx_unet* u, const void* packed, void* workspace, size_t workspace_bytes, adx_unet_tape* tape,
-                      const float* d_out, float* d_img_feature, const float* const* params, float* const* grads,
-                      int32_t n_grads, adx_stream stream) {
+                      const float* d_out, const float* d_time_embed, float* d_img_feature, const float* const* params,
+                      float* const* grads, int32_t n_grads, adx_stream stream) {
   ADX_REQUIRE(u && packed && workspace && tape && d_out && d_img_feature && params && grads,
               "adx_unet_backward: null argument");
   ADX_REQUIRE(n_grads >= u->n_params, "adx_unet_backward: expected %d gradient tensors, got %d", u->n_params, n_grads);
@@ -427,7 +427,7 @@ int adx_unet_backward(adx_unet* u, const void* packed, void* workspace, size_t w
     eg[4] = grads[u->p_c0w]; eg[5] = grads[u->p_c0b]; eg[6] = grads[u->p_c2w]; eg[7] = grads[u->p_c2b];
   }
   return embed_backward(&ew, dim, tape->t, tape->t_rows, tape->cond, tape->img_feature, tape->feat_rows, rows, tape->te,
-                        dmc, d_img_feature, eg, s);
+                        dmc, d_time_embed, d_img_feature, eg, s);
 }
 
 }  // extern "C"

@@ -46,12 +46,15 @@ class _UnetTrainFn(torch.autograd.Function):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         tape = L.vp()
         L.check(L.lib().adx_unet_tape_create(C.byref(tape)), "adx_unet_tape_create")
-        out = torch.empty((rows, module.horizon, module.transition_dim), dtype=torch.float32, device=x.device)
+        classifier = module.use_cond == GuidanceType.CLASSIFIER_GUIDANCE
+        out = torch.empty((rows, module.horizon, 3 if classifier else module.transition_dim), dtype=torch.float32,
+                          device=x.device)
+        te = torch.empty((rows, module.dim), dtype=torch.float32, device=x.device)
         feat_c = L.require_gpu_f32(feat.detach(), "img_feature")
         io = L.UnetIO()
         io.x, io.img_feature, io.feat_rows = x.data_ptr(), feat_c.data_ptr(), feat_c.shape[0]
         io.t, io.t_rows, io.cond, io.rows = time.data_ptr(), time.shape[0], L.ptr(cond), rows
-        io.out, io.time_embed = out.data_ptr(), None
+        io.out, io.time_embed = out.data_ptr(), te.data_ptr()
         try:
             L.check(L.lib().adx_unet_forward_train(h, module._packed.data_ptr(), ws.data_ptr(), nbytes, C.byref(io), tape,
                                                    L.stream_ptr(x.device)), "adx_unet_forward_train")
@@ -62,23 +65,24 @@ class _UnetTrainFn(torch.autograd.Function):
         ctx.keep = (x, feat_c, time, cond)          # the tape holds raw pointers into these
         ctx.params = params
         ctx.pack_key = module._pack_key
-        return out
+        return out, te
 
     @staticmethod
-    def backward(ctx, grad_out):
+    def backward(ctx, grad_out, grad_te):
         module, params = ctx.module, ctx.params
         if module._pack_key != ctx.pack_key:
             raise RuntimeError("parameters changed between forward and backward")
         h = module._native()
         g = L.require_gpu_f32(grad_out, "grad_out")
         rows = g.shape[0]
+        gte = None if grad_te is None else L.require_gpu_f32(grad_te, "grad_time_embed")
         grads = [torch.empty_like(p) for p in params]
         d_feat = torch.empty((rows, module.dim), dtype=torch.float32, device=g.device)
         pa = L.ptr_array([p.detach() for p in params])
         ga = L.ptr_array(grads)
         try:
             L.check(L.lib().adx_unet_backward(h, module._packed.data_ptr(), ctx.ws.data_ptr(), ctx.nbytes, ctx.tape,
-                                              g.data_ptr(), d_feat.data_ptr(), pa, ga, len(grads),
+                                              g.data_ptr(), L.ptr(gte), d_feat.data_ptr(), pa, ga, len(grads),
                                               L.stream_ptr(g.device)), "adx_unet_backward")
         finally:
             L.lib().adx_unet_tape_destroy(ctx.tape)
@@ -209,9 +213,7 @@ class TemporalMapUnet(nn.Module):
     # -- training path -----------------------------------------------------------------------------
     def unet_forward_train(self, x, img_feature, time, cond=None):
         """TemporalMapUnet.forward minus the perception pass, differentiable w.r.t. every temporal-stack
-        parameter and w.r.t. `img_feature` (train.py:242).  NO_GUIDANCE / FREE_GUIDANCE only for now."""
-        if self.use_cond == GuidanceType.CLASSIFIER_GUIDANCE:
-            raise NotImplementedError("CLASSIFIER_GUIDANCE training needs TrajPredict parameter gradients (not built yet)")
+        parameter and w.r.t. `img_feature` (train.py:242)."""
         x = L.require_gpu_f32(x, "x")
         rows = x.shape[0]
         time = L.require_gpu_f32(time.reshape(-1), "time", torch.int64)
@@ -220,7 +222,14 @@ class TemporalMapUnet(nn.Module):
         cond_t = None
         if self.use_cond == GuidanceType.FREE_GUIDANCE and cond is not None:
             cond_t = L.require_gpu_f32(cond, "cond")
-        return _UnetTrainFn.apply(x, img_feature, time, cond_t, self, *self._unet_params())
+        out, te = _UnetTrainFn.apply(x, img_feature, time, cond_t, self, *self._unet_params())
+        if self.use_cond != GuidanceType.CLASSIFIER_GUIDANCE:
+            return out
+        # temporal.py:233-242: the state head sees the DETACHED action but the live time_embed
+        action = out
+        state = self.state_pred(action.detach()[:, :-1], te)
+        state = torch.cat([torch.zeros_like(state[:, :1]), state], dim=1)
+        return torch.cat([state, action], dim=-1)
 
     # -- forward ---------------------------------------------------------------------------------
     def forward(self, x, img, time, cond=None, return_action_and_time_only=False):

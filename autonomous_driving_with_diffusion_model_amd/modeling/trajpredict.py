@@ -19,6 +19,43 @@ from .holders import populate
 from .spec import traj_predict_entries
 
 
+class _TrajPredictTrainFn(torch.autograd.Function):
+    """Training node: gradients w.r.t. every state_pred parameter, the action and time_embed."""
+
+    @staticmethod
+    def forward(ctx, action, time_embed, module, *params):
+        action_c = L.require_gpu_f32(action.detach(), "action")
+        te = L.require_gpu_f32(time_embed.detach(), "time_embed")
+        B, T, _ = action_c.shape
+        out = torch.empty((B, T, module.out_dim), dtype=torch.float32, device=action_c.device)
+        h, packed = module._ensure_packed(action_c.device)
+        L.check(L.lib().adx_trajpred_forward(h, packed.data_ptr(), action_c.data_ptr(), action_c.stride(0),
+                                             action_c.stride(1), te.data_ptr(), out.data_ptr(), B, T,
+                                             L.stream_ptr(action_c.device)), "adx_trajpred_forward")
+        ctx.module, ctx.params = module, params
+        ctx.needs_action = action.requires_grad
+        ctx.save_for_backward(action_c, te)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        action_c, te = ctx.saved_tensors
+        module, params = ctx.module, ctx.params
+        B, T, _ = action_c.shape
+        g = L.require_gpu_f32(grad_out, "grad_out")
+        h, packed = module._ensure_packed(g.device)
+        image = torch.empty(packed.numel() // 4, dtype=torch.float32, device=g.device)
+        ga = torch.empty((B, T, 3), dtype=torch.float32, device=g.device) if ctx.needs_action else None
+        dte = torch.empty((B, module.hidden_dim), dtype=torch.float32, device=g.device)
+        L.check(L.lib().adx_trajpred_backward_params(h, packed.data_ptr(), action_c.data_ptr(), action_c.stride(0),
+                                                     action_c.stride(1), te.data_ptr(), g.data_ptr(), L.ptr(ga),
+                                                     image.data_ptr(), dte.data_ptr(), B, T, L.stream_ptr(g.device)),
+                "adx_trajpred_backward_params")
+        offs = module._param_offsets()
+        grads = [image[o:o + p.numel()].view_as(p).clone() for o, p in zip(offs, params)]
+        return (ga, dte, None, *grads)
+
+
 class _TrajPredictFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, action, time_embed, module):
@@ -99,11 +136,23 @@ class TrajPredict(nn.Module):
             self._pack_key = key
         return h, self._packed
 
+    def _param_offsets(self):
+        if getattr(self, "_offs", None) is None:
+            h = self._native()
+            n = L.lib().adx_trajpred_num_params(h)
+            arr = (L.i64 * n)()
+            L.check(L.lib().adx_trajpred_param_offsets(h, arr, n), "adx_trajpred_param_offsets")
+            self._offs = list(arr)
+        return self._offs
+
     def forward(self, x: torch.Tensor, time_embed: torch.Tensor) -> torch.Tensor:
-        if self.training:
-            raise NotImplementedError("TrajPredict: train-mode (dropout, parameter gradients) is not implemented yet")
         if x.dim() != 3 or x.shape[2] != self.in_dim or x.shape[1] > 31:
             raise ValueError(f"x must be [B, T <= 31, {self.in_dim}], got {tuple(x.shape)}")
+        if self.training:
+            # Deviation, documented: nn.TransformerEncoderLayer's dropout(0.1) is NOT applied (the reference draws
+            # its masks from torch's RNG stream, which cannot be reproduced); everything else is exact.
+            named = dict(self.named_parameters())
+            return _TrajPredictTrainFn.apply(x, time_embed, self, *[named[e.key] for e in self._entries])
         return _TrajPredictFn.apply(x, time_embed, self)
 
     def guided_output(self, action: torch.Tensor, time_embed: torch.Tensor, target: torch.Tensor, model_std: float,

@@ -146,8 +146,9 @@ int adx_unet_forward_train(adx_unet* u, const void* packed, void* workspace, siz
  * d_img_feature [rows][dim] (gradient entering the perception encoder).  `params` are the same
  * raw parameter pointers given to adx_unet_pack (the data-gradient convs re-read them). */
 int adx_unet_backward(adx_unet* u, const void* packed, void* workspace, size_t workspace_bytes, adx_unet_tape* tape,
-                      const float* d_out, float* d_img_feature, const float* const* params, float* const* grads,
-                      int32_t n_grads, adx_stream s);
+                      const float* d_out, const float* d_time_embed /* extra gradient into time_embed or NULL */,
+                      float* d_img_feature, const float* const* params, float* const* grads, int32_t n_grads,
+                      adx_stream s);
 /* op level: gradient through [+tb] -> Mish -> GroupNorm of a Conv1dBlock (modeling/helpers.py:105-108) */
 int adx_gn_mish_backward(const float* dy, int64_t dy_sb, int64_t dy_sc, int64_t dy_sl, const float* pre,
                          const float* stats, const float* gamma, const float* beta, float* dc, float* dgamma,
@@ -217,6 +218,13 @@ int adx_trajpred_forward(adx_trajpred* t, const void* packed, const float* actio
 int adx_trajpred_backward(adx_trajpred* t, const void* packed, const float* action, int64_t act_sb, int64_t act_st,
                           const float* time_embed, const float* grad_out, float* grad_action, int32_t batch,
                           int32_t T, adx_stream s);
+/* Training (train.py:242-251 with CLASSIFIER_GUIDANCE): parameter gradients of the state head.  grad_image has
+ * the layout of the packed buffer (adx_trajpred_packed_bytes); parameter i lives at float offset
+ * offsets[i] (adx_trajpred_param_offsets, adx_trajpred_pack order) in its PyTorch layout. */
+int adx_trajpred_backward_params(adx_trajpred* t, const void* packed, const float* action, int64_t act_sb,
+                                 int64_t act_st, const float* time_embed, const float* grad_out, float* grad_action,
+                                 void* grad_image, float* d_time_embed, int32_t batch, int32_t T, adx_stream s);
+int adx_trajpred_param_offsets(const adx_trajpred* t, int64_t* offsets, int32_t n);
 /* One launch for interact.py:153-160 + GuidanceLoss.forward with STEP = 1 (control/guidance.py:35-59) +
  * TargetGuidance (control/guidance_loss.py:10-22), per sample:
  * x = cat([0; state_pred(action[:-1])], action); pick h*; x -= scaled gradient; clip(-1, 1). */

@@ -84,7 +84,39 @@ def test_gn_mish_backward_and_wgrad_ops():
         assert rel_err(dx, xin.grad) < 2e-4, (name, rel_err(dx, xin.grad))
 
 
-@pytest.mark.parametrize("use_cond,H,B", [("NO_GUIDANCE", 16, 2), ("FREE_GUIDANCE", 32, 5)])
+def test_traj_predict_parameter_gradients_vs_oracle_autograd():
+    """adx_trajpred_backward_params: every state_pred parameter, d(action) and d(time_embed) against torch
+    autograd through the oracle's TrajPredict (dropout off on both sides)."""
+    from test_gpu_model import make_model
+    m, _ = make_model("CLASSIFIER_GUIDANCE", 16)
+    m.train()
+    sd = oracle_sd("CLASSIFIER_GUIDANCE")
+    keys = [k for k in sd if k.startswith("state_pred.")]
+    for k in keys:
+        sd[k].requires_grad_()
+    for B, T in ((3, 15), (1, 31), (5, 7)):
+        for k in keys:
+            sd[k].grad = None
+        m.zero_grad()
+        a = P._uniform("tp.a", 71 + T, (B, T, 3), -1.5, 1.5)
+        te = P._uniform("tp.te", 72 + T, (B, 64), -1.0, 1.0)
+        w = P._uniform("tp.w", 73 + T, (B, T, 4), -1.0, 1.0)
+        a_ref, te_ref = a.clone().requires_grad_(), te.clone().requires_grad_()
+        out_ref = U.traj_predict(sd, "state_pred.", a_ref, te_ref)
+        (out_ref * w).sum().backward()
+        a_d, te_d = a.to(DEV).requires_grad_(), te.to(DEV).requires_grad_()
+        out = m.state_pred(a_d, te_d)
+        close(out.detach().cpu(), out_ref.detach(), 2e-5)
+        (out * w.to(DEV)).sum().backward()
+        assert rel_err(a_d.grad, a_ref.grad) < 2e-4, rel_err(a_d.grad, a_ref.grad)
+        assert rel_err(te_d.grad, te_ref.grad) < 2e-4, rel_err(te_d.grad, te_ref.grad)
+        named = dict(m.named_parameters())
+        worst = max(((rel_err(named[k].grad, sd[k].grad), k) for k in keys))
+        assert worst[0] < 5e-4, (B, T, worst)
+
+
+@pytest.mark.parametrize("use_cond,H,B", [("NO_GUIDANCE", 16, 2), ("FREE_GUIDANCE", 32, 5),
+                                          ("CLASSIFIER_GUIDANCE", 16, 3)])
 def test_unet_gradients_vs_oracle_autograd(use_cond, H, B):
     from test_gpu_model import make_model
     m, _ = make_model(use_cond, H)
@@ -151,7 +183,7 @@ def test_perception_train_mode_vs_oracle_autograd():
     assert int(m.perception.bn1.num_batches_tracked) == 1
 
 
-@pytest.mark.parametrize("use_cond", ["NO_GUIDANCE", "FREE_GUIDANCE"])
+@pytest.mark.parametrize("use_cond", ["NO_GUIDANCE", "FREE_GUIDANCE", "CLASSIFIER_GUIDANCE"])
 def test_training_step_vs_golden(golden, use_cond):
     """T1 end to end at the fixture's shape (B = 2, H = 16, 64x96 image): loss and gradient norms of the
     REAL reference (tests/golden/train.npz)."""
