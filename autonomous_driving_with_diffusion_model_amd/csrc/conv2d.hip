@@ -26,19 +26,6 @@ constexpr size_t kMaxLds = 96 * 1024;
 static int g_conv_cc = 16;    // channels per LDS chunk of the 8-row kernel (ADX_CONV_CC=8: smaller chunk, 3 workgroups/CU)
 static int g_conv_rows = 2;   // rows per wave of the 3x3 stride-1 kernel (ADX_CONV_ROWS=1 selects the 4-row tile)
 
-struct Conv2dArgs {
-  const float* x;       // [N][Cin][H][W]
-  const float* w;       // packed [KH*KW][cin_pad][Cout]
-  const float* scale;   // [Cout] or null
-  const float* shift;   // [Cout] or null
-  const float* res;     // [N][Cout][OH][OW] or null
-  float* y;             // [N][Cout][OH][OW]
-  int N, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, relu;
-  int cin_pad, cc;      // channels padded to the chunk size, chunk size (16, or 4 for the stem)
-  int tiles_x, tiles_y, cout_tiles;
-  int PH, PW, PWp;      // staged patch rows, columns, padded row pitch
-};
-
 // Software pipeline (register double buffer): the global loads of chunk i+1 (input patch + weight
 // slab) are issued before the MFMAs of chunk i and written to LDS after them, so HBM/L2 latency
 // hides behind ~9k cycles of matrix work per 16-channel chunk.
@@ -205,6 +192,13 @@ __global__ void conv2d_pack_dgrad_kernel(const float* __restrict__ w, float* __r
   p[idx] = w[((size_t)co * Cin + ci) * taps + (taps - 1 - tap)];
 }
 
+int conv2d_pack_spec(const ConvSpec& c, const float* w, float* packed, int dgrad, hipStream_t s) {
+  if (conv2d_hs_eligible(c)) return conv2d_hs_pack(c, w, packed, dgrad, s);
+  // dgrad: the forward weight is [c.cin][c.cout][k][k]
+  return dgrad ? conv2d_pack_raw(w, packed, c.cin, c.cout, c.k, c.cin, 1, s)
+               : conv2d_pack_raw(w, packed, c.cout, c.cin, c.k, c.cin_pad, 0, s);
+}
+
 int conv2d_pack_raw(const float* w, float* packed, int cout, int cin, int k, int cin_pad, int dgrad, hipStream_t s) {
   if (dgrad) {
     const size_t total = (size_t)k * k * cout * cin;
@@ -319,6 +313,7 @@ int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const f
   a.OH = conv_out(H, L.k, L.stride, L.pad); a.OW = conv_out(W, L.k, L.stride, L.pad);
   a.KH = L.k; a.KW = L.k; a.stride = L.stride; a.pad = L.pad; a.relu = relu;
   a.cin_pad = L.cin_pad; a.cc = L.cc;
+  if (conv2d_hs_eligible(L)) return conv2d_hs_launch(L, a, s);
   const int rows = (L.stride == 1 && L.k == 3 && g_conv_rows == 2) ? 2 : 1;   // 8-row tiles for the 3x3 stride-1 convs
   const int th = 4 * rows;
   a.tiles_x = ceil_div(a.OW, kTileW); a.tiles_y = ceil_div(a.OH, th); a.cout_tiles = L.cout / kCoutT;
@@ -388,11 +383,7 @@ int adx_conv2d_pack(const adx_conv2d_desc* d, const float* w, float* packed, adx
   int rc = spec_from_desc(d, &L);
   if (rc != ADX_OK) return rc;
   ADX_REQUIRE(w && packed, "adx_conv2d_pack: null pointer");
-  const size_t total = (size_t)L.k * L.k * L.cin_pad * L.cout;
-  conv2d_pack_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
-      w, packed, L.cout, L.cin, L.k * L.k, L.cin_pad, total);
-  ADX_LAUNCH_CHECK();
-  return ADX_OK;
+  return conv2d_pack_spec(L, w, packed, 0, (hipStream_t)stream);
 }
 
 int adx_conv2d_forward(const adx_conv2d_desc* d, const float* x, const float* packed_w, const float* scale,
@@ -457,10 +448,8 @@ int adx_resnet_pack(adx_resnet* r, const float* const* T, int32_t n, void* packe
   hipStream_t s = (hipStream_t)stream;
   float* base = (float*)packed;
   for (const ConvSpec& L : r->convs) {
-    const size_t total = (size_t)L.k * L.k * L.cin_pad * L.cout;
-    conv2d_pack_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(T[L.t_w], base + L.o_w, L.cout, L.cin,
-                                                                                L.k * L.k, L.cin_pad, total);
-    ADX_LAUNCH_CHECK();
+    int rc = conv2d_pack_spec(L, T[L.t_w], base + L.o_w, 0, s);
+    if (rc != ADX_OK) return rc;
     bn_fold_kernel<<<dim3(ceil_div(L.cout, 256)), dim3(256), 0, s>>>(T[L.t_g], T[L.t_b], T[L.t_m], T[L.t_v],
                                                                      base + L.o_scale, base + L.o_shift, L.cout);
     ADX_LAUNCH_CHECK();

@@ -16,6 +16,20 @@ struct ConvSpec {
   int cin_pad, cc;
 };
 
+struct Conv2dArgs {
+  const float* x;       // [N][Cin][H][W]
+  const float* w;       // packed [KH*KW][cin_pad][Cout]
+  const float* scale;   // [Cout] or null
+  const float* shift;   // [Cout] or null
+  const float* res;     // [N][Cout][OH][OW] or null
+  float* y;             // [N][Cout][OH][OW]
+  int N, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, relu;
+  int cin_pad, cc;      // channels padded to the chunk size, chunk size (16, or 4 for the stem)
+  int tiles_x, tiles_y, cout_tiles;
+  int PH, PW, PWp;      // staged patch rows, columns, padded row pitch
+};
+
+
 }  // namespace adx
 
 struct adx_resnet {
@@ -35,6 +49,14 @@ int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const f
 // [Cout][Cin][k][k] -> [tap][cin_pad][Cout]; dgrad = 1 packs the data-gradient view instead:
 // [tap'][cout_pad as K][Cin as N] with the taps flipped (conv of dy with this image gives dx)
 int conv2d_pack_raw(const float* w, float* packed, int cout, int cin, int k, int cin_pad, int dgrad, hipStream_t s);
+// fp32 weights -> the layout the kernel chosen for `consumer` reads (fp32 [tap][cin_pad][cout], or the fp16 hi/lo
+// split image of conv2d_hs.hip).  dgrad = 1: `w` is the forward weight [consumer.cin][consumer.cout][k][k] and the
+// image is its data-gradient view (roles swapped, taps flipped).
+int conv2d_pack_spec(const ConvSpec& consumer, const float* w, float* packed, int dgrad, hipStream_t s);
+// conv2d_hs.hip: fp32-equivalent convolution on the fp16 matrix cores (hi/lo split operands, 3 MFMAs per product)
+bool conv2d_hs_eligible(const ConvSpec& L);
+int conv2d_hs_pack(const ConvSpec& consumer, const float* w, void* packed, int dgrad, hipStream_t s);
+int conv2d_hs_launch(const ConvSpec& L, Conv2dArgs a, hipStream_t s);
 inline int conv_out_dim(int h, int k, int s, int p) { return (h + 2 * p - k) / s + 1; }
 int maxpool_launch(const float* x, float* y, int planes, int H, int W, int OH, int OW, hipStream_t s);
 int avgpool_fc_launch(const float* x, const float* fw, const float* fb, float* out, int batch, int C, int HW, int out_dim,

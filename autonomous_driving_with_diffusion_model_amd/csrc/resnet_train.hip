@@ -464,7 +464,7 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
   float* base = (float*)packed;
   // weights change every step: re-lay them here (conv images only; BN is applied from batch statistics)
   for (const ConvSpec& L : r->convs) {
-    int rc = conv2d_pack_raw(T[L.t_w], base + L.o_w, L.cout, L.cin, L.k, L.cin_pad, 0, s);
+    int rc = conv2d_pack_spec(L, T[L.t_w], base + L.o_w, 0, s);
     if (rc != ADX_OK) return rc;
   }
   Bump2 ws{(float*)workspace, 0, workspace_bytes / sizeof(float)};
@@ -574,10 +574,10 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
     int rc2 = conv2d_wgrad(rec.x, draw, G[L.t_w], batch, L.cin, rec.H, rec.W, L.cout, L.k, L.stride, L.pad, s);
     if (rc2 != ADX_OK || !need_dx) return rc2;
     // data gradient
-    rc2 = conv2d_pack_raw(T[L.t_w], wimg, L.cout, L.cin, L.k, L.cin_pad, 1, s);
-    if (rc2 != ADX_OK) return rc2;
     ConvSpec g{};
     g.cin = L.cout; g.cout = L.cin; g.k = L.k; g.stride = 1; g.pad = L.k - 1 - L.pad; g.cc = 16; g.cin_pad = L.cout;
+    rc2 = conv2d_pack_spec(g, T[L.t_w], wimg, 1, s);
+    if (rc2 != ADX_OK) return rc2;
     if (L.stride == 1) {
       return conv2d_launch_raw(g, draw, wimg, nullptr, nullptr, dx_has ? dx : nullptr, dx, batch, rec.OH, rec.OW, 0, s);
     }

@@ -1,0 +1,103 @@
+"""conv2d kernels of the perception encoder, one launch at a time, against an fp64 evaluation of the same op.
+
+The 3x3 stride-1 convs run on the fp16 matrix cores with hi/lo split operands (csrc/conv2d_hs.hip); the bar for
+them is the bar of fp32 arithmetic: the max error against fp64 may not exceed 1.5x what torch's own fp32 convs
+(CPU oneDNN and ROCm MIOpen, whichever is worse; they differ only in summation order) show on the same inputs,
++ 1e-7 relative slack.  Measured (tools/conv_err.py, K = 4608): split-fp16 rms 4.2e-7, exact-fp32 MFMA chain
+1.2e-6, MIOpen fp32 5.8e-7, oneDNN 2.3e-7."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ops():
+    from autonomous_driving_with_diffusion_model_amd import ops
+    return ops
+
+
+def _case(cin, cout, k, h, w, n, seed, xscale=1.0, wscale=None):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, cin, h, w, generator=g) * xscale
+    ws = (2.0 / (k * k * cin)) ** 0.5 if wscale is None else wscale
+    wt = torch.randn(cout, cin, k, k, generator=g) * ws
+    return x, wt
+
+
+def _errs(y_hip, x, wt, stride, pad, post=None):
+    ref = F.conv2d(x.double(), wt.double(), stride=stride, padding=pad)
+    f32 = F.conv2d(x, wt, stride=stride, padding=pad)
+    g32 = F.conv2d(x.to(DEV), wt.to(DEV), stride=stride, padding=pad).cpu()
+    if post is not None:
+        ref, f32, g32 = post(ref), post(f32), post(g32)
+    den = ref.abs().max().item() + 1e-300
+    err = lambda t: (t.double().cpu() - ref).abs().max().item() / den  # noqa: E731
+    return err(y_hip), max(err(f32), err(g32))
+
+
+@pytest.mark.parametrize("cin,cout,h,w,n", [(64, 64, 64, 225, 2), (128, 128, 32, 113, 2), (256, 256, 16, 57, 3),
+                                            (512, 512, 8, 29, 2), (64, 128, 13, 37, 1), (16, 64, 5, 3, 2),
+                                            (32, 192, 9, 70, 1)])
+def test_conv3x3_s1_split_fp16_is_fp32_grade(cin, cout, h, w, n):
+    x, wt = _case(cin, cout, 3, h, w, n, seed=cin + h)
+    y, _ = _ops().conv2d(x.to(DEV), wt.to(DEV), stride=1, pad=1)
+    e_hip, e_f32 = _errs(y, x, wt, 1, 1)
+    assert e_hip <= 1.5 * e_f32 + 1e-7, (e_hip, e_f32)
+
+
+@pytest.mark.parametrize("xscale,wscale", [(2e-3, 1e-2), (300.0, 0.05), (1.0, 30.0), (0.05, 0.002)])
+def test_conv3x3_split_keeps_relative_accuracy_across_magnitudes(xscale, wscale):
+    """hi + 2^-11 lo keeps 22 significant bits for every operand with 2^-14 <= |x| < 65504 (fp16's normal range);
+    smaller elements keep an ABSOLUTE accuracy of 2^-36, which is far below fp32's own rounding of anything they
+    are added to as long as the tensor has elements above ~1e-4."""
+    x, wt = _case(64, 64, 3, 16, 40, 1, seed=5, xscale=xscale, wscale=wscale)
+    y, _ = _ops().conv2d(x.to(DEV), wt.to(DEV), stride=1, pad=1)
+    e_hip, e_f32 = _errs(y, x, wt, 1, 1)
+    assert torch.isfinite(y).all()
+    assert e_hip <= 1.5 * e_f32 + 1e-7, (e_hip, e_f32)
+
+
+def test_conv3x3_split_degrades_gracefully_below_fp16_normal_range():
+    """A tensor whose EVERY element is below fp16's normal range (|x| ~ 3e-6) loses bits gradually (hi is an fp16
+    subnormal), it does not flush: the result is still well inside the 1e-4 parity bar."""
+    x, wt = _case(64, 64, 3, 16, 40, 1, seed=5, xscale=3e-6, wscale=1.0)
+    y, _ = _ops().conv2d(x.to(DEV), wt.to(DEV), stride=1, pad=1)
+    e_hip, _ = _errs(y, x, wt, 1, 1)
+    assert e_hip < 2e-5, e_hip
+
+
+def test_conv3x3_fused_bn_residual_relu_epilogue():
+    x, wt = _case(128, 128, 3, 20, 45, 2, seed=9)
+    g = torch.Generator().manual_seed(10)
+    scale, shift = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g)
+    res = torch.randn(2, 128, 20, 45, generator=g)
+    y, _ = _ops().conv2d(x.to(DEV), wt.to(DEV), stride=1, pad=1, scale=scale.to(DEV), shift=shift.to(DEV),
+                         res=res.to(DEV), relu=True)
+    post = lambda c: torch.relu(c * scale.to(c.dtype)[None, :, None, None] + shift.to(c.dtype)[None, :, None, None]  # noqa: E731
+                                + res.to(c.dtype))
+    e_hip, e_f32 = _errs(y, x, wt, 1, 1, post)
+    assert e_hip <= 1.5 * e_f32 + 2e-7, (e_hip, e_f32)
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,h,w", [(64, 128, 3, 2, 1, 64, 225), (64, 128, 1, 2, 0, 64, 225),
+                                                       (3, 64, 7, 2, 3, 64, 96), (256, 512, 3, 2, 1, 16, 57),
+                                                       (128, 64, 1, 1, 0, 9, 33)])
+def test_other_conv_shapes(cin, cout, k, stride, pad, h, w):
+    x, wt = _case(cin, cout, k, h, w, 2, seed=k + stride + cin)
+    y, _ = _ops().conv2d(x.to(DEV), wt.to(DEV), stride=stride, pad=pad)
+    e_hip, e_f32 = _errs(y, x, wt, stride, pad)
+    # exact-fp32 MFMA kernels: one sequential fp32 chain over K, so up to ~sqrt(K) * eps (4x the blocked sums)
+    assert e_hip <= 4 * e_f32 + 1e-7, (e_hip, e_f32)
+
+
+def test_conv_non_finite_inputs_stay_loud():
+    x, wt = _case(64, 64, 3, 8, 32, 1, seed=2)
+    x[0, 3, 4, 5] = float("nan")
+    y, _ = _ops().conv2d(x.to(DEV), wt.to(DEV), stride=1, pad=1)
+    ref = F.conv2d(x, wt, padding=1)
+    assert torch.equal(torch.isnan(y.cpu()), torch.isnan(ref))
+    x[0, 3, 4, 5] = 1e6          # beyond fp16: must not turn into a silently wrong finite number
+    y, _ = _ops().conv2d(x.to(DEV), wt.to(DEV), stride=1, pad=1)
+    assert not torch.isfinite(y[0, :, 3:6, 4:7]).all()
