@@ -221,48 +221,58 @@ __global__ void bn_fold_kernel(const float* g, const float* b, const float* mean
   shift[c] = b[c] - mean[c] * s;
 }
 
-// MaxPool2d(kernel 3, stride 2, padding 1), modeling/resnet.py:197
+// MaxPool2d(kernel 3, stride 2, padding 1), modeling/resnet.py:197.  One wave per output row (blockIdx.x = plane),
+// lanes along the row: every load instruction of a wave covers one contiguous 512-byte span of an input row.
 __global__ void __launch_bounds__(256) maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, int planes,
                                                        int H, int W, int OH, int OW) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const size_t total = (size_t)planes * OH * OW;
-  if (idx >= total) return;
-  const int ox = idx % OW;
-  const int oy = (idx / OW) % OH;
-  const size_t pl = idx / ((size_t)OW * OH);
-  const float* src = x + pl * H * W;
-  float m = -INFINITY;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int oy = blockIdx.y * 4 + wave;
+  const int pl = blockIdx.x;
+  if (oy >= OH) return;
+  const float* src = x + (size_t)pl * H * W;
+  float* dst = y + ((size_t)pl * OH + oy) * OW;
+  for (int ox = lane; ox < OW; ox += 64) {
+    float m = -INFINITY;
 #pragma unroll
-  for (int dy = 0; dy < 3; ++dy) {
-    const int iy = oy * 2 - 1 + dy;
-    if (iy < 0 || iy >= H) continue;
+    for (int dy = 0; dy < 3; ++dy) {
+      const int iy = oy * 2 - 1 + dy;
+      if (iy < 0 || iy >= H) continue;
+      const float* row = src + (size_t)iy * W;
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      const int ix = ox * 2 - 1 + dx;
-      if (ix < 0 || ix >= W) continue;
-      const float v = src[(size_t)iy * W + ix];
-      m = (v > m || v != v) ? v : m;  // NaN propagates like torch
+      for (int dx = 0; dx < 3; ++dx) {
+        const int ix = ox * 2 - 1 + dx;
+        if (ix < 0 || ix >= W) continue;
+        const float v = row[ix];
+        m = (v > m || v != v) ? v : m;  // NaN propagates like torch
+      }
     }
+    dst[ox] = m;
   }
-  y[idx] = m;
 }
 
-// AdaptiveAvgPool2d(1) + flatten + fc, modeling/resnet.py:288-290; one workgroup per image
-__global__ void __launch_bounds__(256) avgpool_fc_kernel(const float* __restrict__ x, const float* __restrict__ fw,
-                                                          const float* __restrict__ fb, float* __restrict__ out,
-                                                          int C, int HW, int out_dim) {
+// AdaptiveAvgPool2d(1) + flatten + fc, modeling/resnet.py:288-290; one 16-wave workgroup per image, four channel
+// planes in flight per wave (the means are plain sequential-lane sums: deterministic)
+__global__ void __launch_bounds__(1024) avgpool_fc_kernel(const float* __restrict__ x, const float* __restrict__ fw,
+                                                           const float* __restrict__ fb, float* __restrict__ out,
+                                                           int C, int HW, int out_dim) {
   __shared__ float pooled[512];
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* src = x + (size_t)n * C * HW;
   const float inv = 1.0f / (float)HW;
-  for (int c = wave; c < C; c += 4) {
-    float s = 0.f;
-    for (int i = lane; i < HW; i += 64) s += src[(size_t)c * HW + i];
-    s = wave_sum(s);
-    if (lane == 0) pooled[c] = s * inv;
+  for (int c0 = wave * 4; c0 < C; c0 += 64) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = lane; i < HW; i += 64) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s[q] += (c0 + q < C) ? src[(size_t)(c0 + q) * HW + i] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float t = wave_sum(s[q]);
+      if (lane == 0 && c0 + q < C) pooled[c0 + q] = t * inv;
+    }
   }
   __syncthreads();
-  for (int j = wave; j < out_dim; j += 4) {
+  for (int j = wave; j < out_dim; j += 16) {
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s += fw[(size_t)j * C + c] * pooled[c];
     s = wave_sum(s);
@@ -271,15 +281,15 @@ __global__ void __launch_bounds__(256) avgpool_fc_kernel(const float* __restrict
 }
 
 int maxpool_launch(const float* x, float* y, int planes, int H, int W, int OH, int OW, hipStream_t s) {
-  const size_t total = (size_t)planes * OH * OW;
-  maxpool_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(x, y, planes, H, W, OH, OW);
+  maxpool_kernel<<<dim3(planes, ceil_div(OH, 4)), dim3(256), 0, s>>>(x, y, planes, H, W, OH, OW);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
 }
 
 int avgpool_fc_launch(const float* x, const float* fw, const float* fb, float* out, int batch, int C, int HW, int out_dim,
                       hipStream_t s) {
-  avgpool_fc_kernel<<<dim3(batch), dim3(256), 0, s>>>(x, fw, fb, out, C, HW, out_dim);
+  ADX_REQUIRE(C <= 512, "avgpool_fc: at most 512 channels");
+  avgpool_fc_kernel<<<dim3(batch), dim3(1024), 0, s>>>(x, fw, fb, out, C, HW, out_dim);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
 }
@@ -298,7 +308,8 @@ static int conv2d_launch(const ConvSpec& L, const float* base, const float* x, c
 }
 
 int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const float* scale, const float* shift,
-                      const float* res, float* y, int N, int H, int W, int relu, hipStream_t s) {
+                      const float* res, float* y, int N, int H, int W, int relu, hipStream_t s, const uint32_t* x_amax,
+                      int x_amax_n) {
   static bool env_read = false;
   if (!env_read) {
     const char* e = getenv("ADX_CONV_ROWS");
@@ -308,7 +319,8 @@ int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const f
     env_read = true;
   }
   Conv2dArgs a;
-  a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.res = res; a.y = y;
+  a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.res = res; a.y = y; a.x_amax = x_amax; a.x_amax_n = x_amax_n;
+  a.w_ds = nullptr; a.scale_ds = nullptr; a.shift_ds = nullptr; a.y_ds = nullptr;
   a.N = N; a.Cin = L.cin; a.H = H; a.W = W; a.Cout = L.cout;
   a.OH = conv_out(H, L.k, L.stride, L.pad); a.OW = conv_out(W, L.k, L.stride, L.pad);
   a.KH = L.k; a.KW = L.k; a.stride = L.stride; a.pad = L.pad; a.relu = relu;
@@ -398,6 +410,12 @@ int adx_conv2d_forward(const adx_conv2d_desc* d, const float* x, const float* pa
   return conv2d_launch_raw(L, x, packed_w, scale, shift, res, y, n, h, w, relu, (hipStream_t)stream);
 }
 
+// conv1 3x3 stride 2 on the split-fp16 kernel + a 1x1 stride-2 downsample of the same shape: one fused launch
+static bool resnet_fuses_ds(const ConvSpec& c1, const ConvSpec& ds) {
+  return conv2d_hs_eligible(c1) && c1.k == 3 && c1.stride == 2 && c1.pad == 1 && ds.k == 1 && ds.stride == 2 && ds.pad == 0 &&
+         ds.cin == c1.cin && ds.cout == c1.cout;
+}
+
 int adx_resnet_create(int32_t out_dim, adx_resnet** out) {
   ADX_REQUIRE(out != nullptr && out_dim >= 1 && out_dim <= 4096, "adx_resnet_create: bad argument");
   adx_resnet* r = new adx_resnet();
@@ -405,11 +423,12 @@ int adx_resnet_create(int32_t out_dim, adx_resnet** out) {
   int t = 0;
   size_t off = 0;
   auto add = [&](int cin, int cout, int k, int stride, int pad) {
-    ConvSpec L;
+    ConvSpec L{};
     L.cin = cin; L.cout = cout; L.k = k; L.stride = stride; L.pad = pad;
     L.t_w = t++; L.t_g = t++; L.t_b = t++; L.t_m = t++; L.t_v = t++;
     L.cc = cin >= 16 ? 16 : 4;
     L.cin_pad = round_up(cin, L.cc);
+    L.fuse_with = -1;
     L.o_w = off; off = align64f(off + (size_t)k * k * L.cin_pad * cout);
     L.o_scale = off; off = align64f(off + cout);
     L.o_shift = off; off = align64f(off + cout);
@@ -424,7 +443,10 @@ int adx_resnet_create(int32_t out_dim, adx_resnet** out) {
       add(inpl, planes[li], 3, stride, 1);
       add(planes[li], planes[li], 3, 1, 1);
       const int ds = (stride != 1 || inpl != planes[li]) ? 1 : 0;
-      if (ds) add(inpl, planes[li], 1, stride, 0);
+      if (ds) {
+        add(inpl, planes[li], 1, stride, 0);
+        r->convs.back().fuse_with = (int)r->convs.size() - 3;   // its block's conv1
+      }
       r->block_has_ds.push_back(ds);
       inpl = planes[li];
     }
@@ -448,7 +470,9 @@ int adx_resnet_pack(adx_resnet* r, const float* const* T, int32_t n, void* packe
   hipStream_t s = (hipStream_t)stream;
   float* base = (float*)packed;
   for (const ConvSpec& L : r->convs) {
-    int rc = conv2d_pack_spec(L, T[L.t_w], base + L.o_w, 0, s);
+    // a downsample conv that rides on its block's split-fp16 conv1 is packed in that kernel's layout
+    const bool fused = L.fuse_with >= 0 && resnet_fuses_ds(r->convs[L.fuse_with], L);
+    int rc = fused ? conv2d_hs_pack(L, T[L.t_w], base + L.o_w, 0, s) : conv2d_pack_spec(L, T[L.t_w], base + L.o_w, 0, s);
     if (rc != ADX_OK) return rc;
     bn_fold_kernel<<<dim3(ceil_div(L.cout, 256)), dim3(256), 0, s>>>(T[L.t_g], T[L.t_b], T[L.t_m], T[L.t_v],
                                                                      base + L.o_scale, base + L.o_shift, L.cout);
@@ -500,25 +524,30 @@ int adx_resnet_forward(adx_resnet* r, const void* packed, void* workspace, const
   size_t ci = 0;
   int rc = conv2d_launch(r->convs[ci++], base, img, nullptr, stem, batch, h, w, 1, s);
   if (rc != ADX_OK) return rc;
-  {
-    const size_t total = (size_t)batch * 64 * h2 * w2;
-    maxpool_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(stem, buf[0], batch * 64, h1, w1, h2, w2);
-    ADX_LAUNCH_CHECK();
-  }
+  rc = maxpool_launch(stem, buf[0], batch * 64, h1, w1, h2, w2, s);
+  if (rc != ADX_OK) return rc;
   int cur = 0, H = h2, W = w2;
   for (size_t b = 0; b < r->block_has_ds.size(); ++b) {
     const ConvSpec& c1 = r->convs[ci++];
     const ConvSpec& c2 = r->convs[ci++];
     const int mid = (cur + 1) % 3, outb = (cur + 2) % 3;
     const int OH = conv_out(H, 3, c1.stride, 1), OW = conv_out(W, 3, c1.stride, 1);
-    rc = conv2d_launch(c1, base, buf[cur], nullptr, buf[mid], batch, H, W, 1, s);  // conv1 + bn1 + relu
-    if (rc != ADX_OK) return rc;
     const float* identity = buf[cur];
-    if (r->block_has_ds[b]) {
+    if (r->block_has_ds[b] && resnet_fuses_ds(c1, r->convs[ci + 0])) {
       const ConvSpec& ds = r->convs[ci++];
-      rc = conv2d_launch(ds, base, buf[cur], nullptr, buf[outb], batch, H, W, 0, s);  // downsample conv + bn
+      rc = conv2d_hs_launch_block_s2(c1, ds, buf[cur], base + c1.o_w, base + c1.o_scale, base + c1.o_shift, buf[mid],
+                                     base + ds.o_w, base + ds.o_scale, base + ds.o_shift, buf[outb], batch, H, W, s);
       if (rc != ADX_OK) return rc;
       identity = buf[outb];
+    } else {
+      rc = conv2d_launch(c1, base, buf[cur], nullptr, buf[mid], batch, H, W, 1, s);  // conv1 + bn1 + relu
+      if (rc != ADX_OK) return rc;
+      if (r->block_has_ds[b]) {
+        const ConvSpec& ds = r->convs[ci++];
+        rc = conv2d_launch(ds, base, buf[cur], nullptr, buf[outb], batch, H, W, 0, s);  // downsample conv + bn
+        if (rc != ADX_OK) return rc;
+        identity = buf[outb];
+      }
     }
     // conv2 + bn2 + identity + relu.  With a downsample the identity lives in buf[outb] and the result
     // overwrites buf[cur] (the block input is dead by then); otherwise the result goes to buf[outb].
@@ -528,10 +557,7 @@ int adx_resnet_forward(adx_resnet* r, const void* packed, void* workspace, const
     if (!r->block_has_ds[b]) cur = outb;
     H = OH; W = OW;
   }
-  avgpool_fc_kernel<<<dim3(batch), dim3(256), 0, s>>>(buf[cur], base + r->o_fcw, base + r->o_fcb, feature, 512, H * W,
-                                                      r->out_dim);
-  ADX_LAUNCH_CHECK();
-  return ADX_OK;
+  return avgpool_fc_launch(buf[cur], base + r->o_fcw, base + r->o_fcb, feature, batch, 512, H * W, r->out_dim, s);
 }
 
 }  // extern "C"

@@ -13,8 +13,10 @@
 // of the same length has on its own (measured: tests/test_gpu_ops.py::test_conv2d_hs_*).  It costs
 // 3 x v_mfma_f32_32x32x16_f16 (16 k-values each, 32 cycles) where the exact-fp32 path needs
 // 8 x v_mfma_f32_32x32x2_f32 (64 cycles each): 5.3x less matrix time, the same 4 bytes per operand in LDS.
-// Range: |x| must stay below 65504 (fp16 max); larger values become inf/NaN loudly.  The ResNet's
-// normalised image and batch-normalised activations are O(1..100).
+// Range: |x| must stay below 65504 (fp16 max); larger values become inf/NaN loudly, and elements below 2^-14 keep
+// an absolute (not relative) accuracy of 2^-36.  The ResNet's normalised image and batch-normalised activations
+// are O(1..100).  Data gradients are not: the training executor hands their max|x| (Conv2dArgs::x_amax, computed
+// by the kernel that produced them) and the kernel moves them into range by an exact power of two.
 //
 // Tile: one workgroup = 4 waves = 8 output rows x 32 output columns x 64 output channels; wave w owns rows
 // 2w, 2w+1.  Per 16-channel chunk the input patch is split while it is staged (once per staged element) into
@@ -36,23 +38,30 @@ constexpr int kHsCout = 64;          // output channels per workgroup
 constexpr int kHsCC = 16;            // channels per chunk = K of one MFMA
 constexpr float kLoScale = 2048.f;   // 2^11
 
-__device__ __forceinline__ void split8(const float* v, u32x4& hi, u32x4& lo) {
+__device__ __forceinline__ void split8(const float* v, float xs, u32x4& hi, u32x4& lo) {
   f16x8 h, l;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const _Float16 hj = (_Float16)v[j];
+    const float x = v[j] * xs;     // xs is a power of two: exact
+    const _Float16 hj = (_Float16)x;
     h[j] = hj;
-    l[j] = (_Float16)((v[j] - (float)hj) * kLoScale);
+    l[j] = (_Float16)((x - (float)hj) * kLoScale);
   }
   hi = __builtin_bit_cast(u32x4, h);
   lo = __builtin_bit_cast(u32x4, l);
 }
 
-template <int STRIDE, int K>
+// STRIDE/K: the convolution; ROWS: output rows per wave (tile = 4*ROWS rows x 32 columns x 64 channels);
+// PBUF: LDS copies of the patch (2: one barrier per stage; 1: an extra barrier per chunk, for the large stride-2
+// patches); DS: also evaluate the BasicBlock's 1x1 stride-2 downsample conv (modeling/resnet.py:223-232) on the
+// centre tap's operand fragments -- same input pixels, its own weights / BN / output tensor.
+template <int STRIDE, int K, int ROWS, int PBUF, bool DS>
 __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
-  constexpr int TH = 8;
+  static_assert(!DS || (K == 3 && STRIDE == 2 && PBUF == 1), "the fused downsample rides on the 3x3 stride-2 conv");
+  constexpr int TH = 4 * ROWS;
   constexpr int PH = (TH - 1) * STRIDE + K;
   constexpr int PW = (kTileW - 1) * STRIDE + K;
+  constexpr int EVW = (PW + 1) / 2;               // stride 2: a patch row is stored as [even columns][odd columns]
   constexpr int PLANE = PH * PW;                  // pixels of the staged patch
   constexpr int NITEM = 2 * PLANE;                // (k-half, pixel) cells per chunk
   constexpr int PIT = (NITEM + 255) / 256;
@@ -60,9 +69,10 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
   constexpr int NW = NTAPS * 256;                 // 16-byte weight cells per chunk: [tap][plane][k-half][64]
   constexpr int WST = K * 256;                    // weight cells of one stage (= one kernel row kh)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  u32x4* patch = reinterpret_cast<u32x4*>(smem_raw);   // 2 x [k-half][plane][PLANE]
-  u32x4* wl = patch + 8 * PLANE;                       // 2 x [kw][plane][k-half][64]
-  float* ss = reinterpret_cast<float*>(wl + 2 * WST);  // scale[64], shift[64]
+  u32x4* patch = reinterpret_cast<u32x4*>(smem_raw);   // PBUF x [k-half][plane][PLANE]
+  u32x4* wl = patch + PBUF * 4 * PLANE;                // 2 x [kw][plane][k-half][64]
+  u32x4* wds = wl + 2 * WST;                           // DS: [plane][k-half][64]
+  float* ss = reinterpret_cast<float*>(wds + (DS ? 256 : 0));   // scale[64], shift[64] (+ the downsample's)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // workgroup -> tile: consecutive ids go to different XCDs (round robin), so give each XCD one contiguous
@@ -84,8 +94,18 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
   const float* xin = a.x + (size_t)n * a.Cin * hw;
   const int nchunks = a.cin_pad / kHsCC;
   const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.w) + (size_t)ct * nchunks * NW;
+  const u32x4* wdsrc = DS ? reinterpret_cast<const u32x4*>(a.w_ds) + (size_t)ct * nchunks * 256 : nullptr;
 
-  int goff[PIT];     // gather offset of cell k's first channel (-1: outside the image -> zeros)
+  // gather offset (bytes, from the chunk's first channel plane) of cell k's first channel.  The patch is read with
+  // buffer loads: SGPR descriptor + 32-bit VGPR offset + SGPR channel offset (no 64-bit address math, PIT offset
+  // registers in all), and cells outside the image use an offset beyond the descriptor's extent, which the
+  // hardware range check turns into zeros -- the convolution's zero padding.
+  constexpr uint32_t kOutside = 0xC0000000u;
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(xin), 0, (int)((size_t)a.Cin * hw * sizeof(float)), 0x00020000);
+  const uint32_t plane_bytes = (uint32_t)(hw * sizeof(float));
+  uint32_t goff[PIT];
+  int pcell[PIT];        // LDS cell of item k inside its [k-half][plane] image
 #pragma unroll
   for (int k = 0; k < PIT; ++k) {
     const int e = tid + 256 * k;
@@ -94,36 +114,66 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
     const int py = p / PW, px = p - py * PW;
     const int iy = iy0 + py, ix = ix0 + px;
     const bool ok = e < NITEM && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-    goff[k] = ok ? (int)(hg * 8 * hw + (size_t)iy * a.W + ix) : -1;
+    goff[k] = ok ? (uint32_t)((hg * 8 * hw + (size_t)iy * a.W + ix) * sizeof(float)) : kOutside;
+    pcell[k] = hg * 2 * PLANE + (STRIDE == 2 ? py * PW + (px & 1) * EVW + (px >> 1) : p);
   }
   if (tid < 2 * kHsCout) {
     const int c = cout0 + (tid & (kHsCout - 1));
     ss[tid] = a.scale == nullptr ? (tid < kHsCout ? 1.f : 0.f) : (tid < kHsCout ? a.scale[c] : a.shift[c]);
+    if (DS) ss[2 * kHsCout + tid] = tid < kHsCout ? a.scale_ds[c] : a.shift_ds[c];
   }
 
-  f32x16 accm[2][2], accl[2][2];   // [row][cout half]: hi*hi sums, cross-term sums (scaled by 2^11)
+  // optional dynamic range: scale x so that max|x| lands in [2^14, 2^15), undone exactly in the epilogue
+  float xs = 1.f, xs_inv = 1.f;
+  if (a.x_amax != nullptr) {
+    uint32_t* red = reinterpret_cast<uint32_t*>(ss + (DS ? 4 : 2) * kHsCout);
+    uint32_t b = 0;
+    for (int i = tid; i < a.x_amax_n; i += 256) b = a.x_amax[i] > b ? a.x_amax[i] : b;
 #pragma unroll
-  for (int r = 0; r < 2; ++r)
+    for (int off = 32; off > 0; off >>= 1) {
+      const uint32_t o = (uint32_t)__shfl_xor((int)b, off, 64);
+      b = o > b ? o : b;
+    }
+    if (lane == 0) red[wave] = b;
+    __syncthreads();
+    b = red[0] > red[1] ? red[0] : red[1];
+    b = red[2] > b ? red[2] : b;
+    b = red[3] > b ? red[3] : b;
+    const int e = (int)((b >> 23) & 0xFF);
+    if (e != 0 && e != 255) {
+      int sh = 127 + 14 - e;
+      sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+      xs = __builtin_bit_cast(float, (uint32_t)(127 + sh) << 23);
+      xs_inv = __builtin_bit_cast(float, (uint32_t)(127 - sh) << 23);
+    }
+  }
+
+  constexpr int NDS = DS ? ROWS : 0;
+  f32x16 accm[ROWS][2], accl[ROWS][2];   // [row][cout half]: hi*hi sums, cross-term sums (scaled by 2^11)
+  f32x16 adm[NDS + 1][2], adl[NDS + 1][2];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { accm[r][m][i] = 0.f; accl[r][m][i] = 0.f; }
+      for (int i = 0; i < 16; ++i) {
+        accm[r][m][i] = 0.f; accl[r][m][i] = 0.f;
+        if (DS) { adm[r][m][i] = 0.f; adl[r][m][i] = 0.f; }
+      }
 
   // Pipeline stage = (chunk, kernel row kh): weights are double-buffered per stage, the patch per chunk, so one
   // barrier per stage is enough and only K weight cells + PIT patch cells per thread are ever in registers.
   float pv[PIT][8];
   u32x4 wv[K];
+  u32x4 wdv;
   auto load_p = [&](int chunk) {
-    const float* xc = xin + (size_t)chunk * kHsCC * hw;
+    const uint32_t cbase = (uint32_t)chunk * kHsCC * plane_bytes;
 #pragma unroll
-    for (int k = 0; k < PIT; ++k) {
-      const int g = goff[k] >= 0 ? goff[k] : 0;
+    for (int k = 0; k < PIT; ++k)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float v = xc[(size_t)j * hw + g];
-        pv[k][j] = goff[k] >= 0 ? v : 0.f;
-      }
-    }
+      for (int j = 0; j < 8; ++j)
+        pv[k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, goff[k], cbase + j * plane_bytes, 0));
+    if (DS) wdv = wdsrc[(size_t)chunk * 256 + tid];
   };
   auto store_p = [&](int buf) {
     u32x4* pd = patch + buf * 4 * PLANE;
@@ -131,14 +181,13 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
     for (int k = 0; k < PIT; ++k) {
       const int e = tid + 256 * k;
       if (PIT * 256 == NITEM || e < NITEM) {
-        const int hg = e >= PLANE ? 1 : 0;
-        const int p = e - hg * PLANE;
         u32x4 hi, lo;
-        split8(pv[k], hi, lo);
-        pd[(hg * 2 + 0) * PLANE + p] = hi;
-        pd[(hg * 2 + 1) * PLANE + p] = lo;
+        split8(pv[k], xs, hi, lo);
+        pd[pcell[k]] = hi;
+        pd[pcell[k] + PLANE] = lo;
       }
     }
+    if (DS) wds[tid] = wdv;
   };
   auto load_w = [&](int stage) {
     const u32x4* ws = wsrc + (size_t)stage * WST;
@@ -150,7 +199,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
     for (int k = 0; k < K; ++k) wl[buf * WST + tid + 256 * k] = wv[k];
   };
 
-  const int pb_lane = khalf * 2 * PLANE + (wave * 2 * STRIDE) * PW + l31 * STRIDE;
+  const int pb_lane = khalf * 2 * PLANE + (wave * ROWS * STRIDE) * PW + (STRIDE == 2 ? l31 : l31 * STRIDE);
   const int wa_lane = khalf * 64 + l31;
   const int nstages = nchunks * K;
 
@@ -161,33 +210,56 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
   __syncthreads();
   int stage = 0;
   for (int chunk = 0; chunk < nchunks; ++chunk) {
-    const u32x4* pb0 = patch + (chunk & 1) * 4 * PLANE + pb_lane;
+    const u32x4* pb0 = patch + (PBUF == 2 ? (chunk & 1) * 4 * PLANE : 0) + pb_lane;
 #pragma unroll
     for (int kh = 0; kh < K; ++kh, ++stage) {
       const u32x4* wa0 = wl + (stage & 1) * WST + wa_lane;
+#ifndef HS_NO_GLOBAL
       if (stage + 1 < nstages) load_w(stage + 1);
       if (kh == 0 && chunk + 1 < nchunks) load_p(chunk + 1);
+#endif
+#ifndef HS_NO_MFMA
 #pragma unroll
       for (int kw = 0; kw < K; ++kw) {
-        f16x8 A[2][2], B[2][2];   // [plane][cout half], [plane][row]
+        f16x8 A[2][2], B[2][ROWS];   // [plane][cout half], [plane][row]
+        const int col = STRIDE == 2 ? (kw & 1) * EVW + (kw >> 1) : kw;
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
           for (int m = 0; m < 2; ++m) A[pl][m] = __builtin_bit_cast(f16x8, wa0[(kw * 2 + pl) * 128 + m * 32]);
 #pragma unroll
-          for (int r = 0; r < 2; ++r) B[pl][r] = __builtin_bit_cast(f16x8, pb0[pl * PLANE + (r * STRIDE + kh) * PW + kw]);
+          for (int r = 0; r < ROWS; ++r) B[pl][r] = __builtin_bit_cast(f16x8, pb0[pl * PLANE + (r * STRIDE + kh) * PW + col]);
         }
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+        for (int r = 0; r < ROWS; ++r)
 #pragma unroll
           for (int m = 0; m < 2; ++m) {
             accm[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][m], B[0][r], accm[r][m], 0, 0, 0);
             accl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][m], B[1][r], accl[r][m], 0, 0, 0);
             accl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][m], B[0][r], accl[r][m], 0, 0, 0);
           }
+        if (DS && kh == 1 && kw == 1) {   // x[2 oy][2 ox]: the 1x1 stride-2 conv's only tap
+          f16x8 D[2][2];
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) D[pl][m] = __builtin_bit_cast(f16x8, wds[pl * 128 + wa_lane + m * 32]);
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+              adm[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(D[0][m], B[0][r], adm[r][m], 0, 0, 0);
+              adl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(D[0][m], B[1][r], adl[r][m], 0, 0, 0);
+              adl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(D[1][m], B[0][r], adl[r][m], 0, 0, 0);
+            }
+        }
       }
+#endif
       if (stage + 1 < nstages) store_w((stage + 1) & 1);
-      if (kh == K - 1 && chunk + 1 < nchunks) store_p((chunk + 1) & 1);
+      if (kh == K - 1 && chunk + 1 < nchunks) {
+        if (PBUF == 1) __syncthreads();      // every wave is done with the only patch copy
+        store_p(PBUF == 2 ? (chunk + 1) & 1 : 0);
+      }
       __syncthreads();
     }
   }
@@ -197,8 +269,8 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
   const size_t img = (size_t)n * a.Cout * a.OH * a.OW;
   const size_t plane_o = (size_t)a.OH * a.OW;
 #pragma unroll
-  for (int rr = 0; rr < 2; ++rr) {
-    const int oy = oy0 + wave * 2 + rr;
+  for (int rr = 0; rr < ROWS; ++rr) {
+    const int oy = oy0 + wave * ROWS + rr;
     if (oy >= a.OH || ox >= a.OW) continue;
     const size_t pix = (size_t)oy * a.OW + ox;
 #pragma unroll
@@ -212,11 +284,15 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int cl = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        float v = accm[rr][half][r] + accl[rr][half][r] * (1.f / kLoScale);
+        float v = (accm[rr][half][r] + accl[rr][half][r] * (1.f / kLoScale)) * xs_inv;
         v = v * ss[cl] + ss[kHsCout + cl];
         v += rv[r];
         if (a.relu) v = v > 0.f ? v : 0.f;
         a.y[img + (size_t)(cout0 + cl) * plane_o + pix] = v;
+        if (DS) {    // downsample branch: BN only (resnet.py:230-231), no ReLU, no residual
+          float d = (adm[rr][half][r] + adl[rr][half][r] * (1.f / kLoScale)) * xs_inv;
+          a.y_ds[img + (size_t)(cout0 + cl) * plane_o + pix] = d * ss[2 * kHsCout + cl] + ss[3 * kHsCout + cl];
+        }
       }
     }
   }
@@ -253,7 +329,14 @@ bool conv2d_hs_eligible(const ConvSpec& L) {
     exact = (e != nullptr && e[0] == '1') ? 1 : 0;
   }
   if (exact) return false;
-  return L.k == 3 && L.stride == 1 && L.cin % kHsCC == 0 && L.cin_pad == L.cin && L.cout % kHsCout == 0;
+  static int mode = -1;                          // debugging aid: ADX_HS_ONLY=fwd|dgrad restricts the split kernels
+  if (mode < 0) {
+    const char* e = getenv("ADX_HS_ONLY");
+    mode = e == nullptr ? 0 : (e[0] == 'f' ? 1 : 2);
+  }
+  if ((mode == 1 && L.dgrad) || (mode == 2 && !L.dgrad)) return false;
+  if (L.cin % kHsCC != 0 || L.cin_pad != L.cin || L.cout % kHsCout != 0) return false;
+  return L.k == 3 && (L.stride == 1 || L.stride == 2);
 }
 
 int conv2d_hs_pack(const ConvSpec& c, const float* w, void* packed, int dgrad, hipStream_t s) {
@@ -264,29 +347,48 @@ int conv2d_hs_pack(const ConvSpec& c, const float* w, void* packed, int dgrad, h
   return ADX_OK;
 }
 
-template <int STRIDE, int K>
+template <int STRIDE, int K, int ROWS, int PBUF, bool DS>
 static int hs_launch_t(Conv2dArgs a, hipStream_t s) {
-  constexpr int PH = 7 * STRIDE + K, PW = (kTileW - 1) * STRIDE + K;
-  constexpr size_t lds = (size_t)2 * 64 * PH * PW + (size_t)2 * K * 256 * 16 + 2 * kHsCout * sizeof(float);
+  constexpr int TH = 4 * ROWS;
+  constexpr int PH = (TH - 1) * STRIDE + K, PW = (kTileW - 1) * STRIDE + K;
+  constexpr size_t lds = (size_t)PBUF * 64 * PH * PW + (size_t)2 * K * 256 * 16 + (DS ? 256 * 16 : 0) +
+                         (DS ? 4 : 2) * kHsCout * sizeof(float) + 16;
   static_assert(lds <= 80 * 1024, "two workgroups per CU need <= 80 KB each");
   static bool attr = false;
   if (!attr) {
-    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs_kernel<STRIDE, K>),
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs_kernel<STRIDE, K, ROWS, PBUF, DS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = true;
   }
-  a.tiles_x = ceil_div(a.OW, kTileW); a.tiles_y = ceil_div(a.OH, 8); a.cout_tiles = a.Cout / kHsCout;
+  a.tiles_x = ceil_div(a.OW, kTileW); a.tiles_y = ceil_div(a.OH, TH); a.cout_tiles = a.Cout / kHsCout;
   const size_t grid = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y * a.N;
   ADX_REQUIRE(grid < (1u << 31), "conv2d_hs: grid too large");
-  conv2d_hs_kernel<STRIDE, K><<<dim3((unsigned)grid), dim3(256), lds, s>>>(a);
+  conv2d_hs_kernel<STRIDE, K, ROWS, PBUF, DS><<<dim3((unsigned)grid), dim3(256), lds, s>>>(a);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
 }
 
+int conv2d_hs_launch_block_s2(const ConvSpec& c1, const ConvSpec& ds, const float* x, const float* w1, const float* scale1,
+                              const float* shift1, float* y1, const float* wd, const float* scaled, const float* shiftd,
+                              float* yd, int N, int H, int W, hipStream_t s) {
+  ADX_REQUIRE(x && w1 && scale1 && shift1 && y1 && wd && scaled && shiftd && yd, "conv2d_hs block launch: null pointer");
+  Conv2dArgs a{};
+  a.x = x; a.w = w1; a.scale = scale1; a.shift = shift1; a.res = nullptr; a.y = y1; a.x_amax = nullptr; a.x_amax_n = 0;
+  a.w_ds = wd; a.scale_ds = scaled; a.shift_ds = shiftd; a.y_ds = yd;
+  a.N = N; a.Cin = c1.cin; a.H = H; a.W = W; a.Cout = c1.cout;
+  a.OH = conv_out_dim(H, 3, 2, 1); a.OW = conv_out_dim(W, 3, 2, 1);
+  a.KH = 3; a.KW = 3; a.stride = 2; a.pad = 1; a.relu = 1;
+  a.cin_pad = c1.cin_pad; a.cc = c1.cc;
+  (void)ds;
+  return conv2d_hs_launch(c1, a, s);
+}
+
 int conv2d_hs_launch(const ConvSpec& L, Conv2dArgs a, hipStream_t s) {
-  ADX_REQUIRE((size_t)L.cin * a.H * a.W < (1u << 31), "conv2d_hs: image plane too large for 32-bit gather offsets");
-  if (L.k == 3 && L.stride == 1) return hs_launch_t<1, 3>(a, s);
-  set_error("conv2d_hs: no kernel for k=%d stride=%d", L.k, L.stride);
+  ADX_REQUIRE((size_t)L.cin * a.H * a.W * sizeof(float) < 0xC0000000u, "conv2d_hs: one image of the input exceeds the 32-bit byte offsets");
+  const bool ds = a.w_ds != nullptr;
+  if (L.k == 3 && L.stride == 1 && !ds) return hs_launch_t<1, 3, 2, 2, false>(a, s);
+  if (L.k == 3 && L.stride == 2 && L.pad == 1) return ds ? hs_launch_t<2, 3, 1, 1, true>(a, s) : hs_launch_t<2, 3, 1, 1, false>(a, s);
+  set_error("conv2d_hs: no kernel for k=%d stride=%d pad=%d%s", L.k, L.stride, L.pad, ds ? " with a fused downsample" : "");
   return ADX_ERR_INVALID;
 }
 

@@ -14,6 +14,8 @@ struct ConvSpec {
   int t_w, t_g, t_b, t_m, t_v;           // tensor indices (weight, bn gamma, beta, mean, var)
   size_t o_w, o_scale, o_shift;          // float offsets in the packed buffer
   int cin_pad, cc;
+  int fuse_with;                         // ResNet executor: index of the conv1 this downsample conv can ride on, or -1
+  int dgrad;                             // 1: this launch is the data-gradient view of a forward conv
 };
 
 struct Conv2dArgs {
@@ -23,6 +25,12 @@ struct Conv2dArgs {
   const float* shift;   // [Cout] or null
   const float* res;     // [N][Cout][OH][OW] or null
   float* y;             // [N][Cout][OH][OW]
+  const float* w_ds;    // conv2d_hs only: fused 1x1 stride-2 downsample (packed weights, BN scale/shift, output) or null
+  const float* scale_ds;
+  const float* shift_ds;
+  float* y_ds;
+  const uint32_t* x_amax;  // optional: x_amax_n partial maxima of |x| as bit patterns (conv2d_hs rescales x by a power of two)
+  int x_amax_n;
   int N, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, relu;
   int cin_pad, cc;      // channels padded to the chunk size, chunk size (16, or 4 for the stem)
   int tiles_x, tiles_y, cout_tiles;
@@ -44,8 +52,11 @@ struct adx_resnet {
 namespace adx {
 
 // one conv2d launch: y = [relu](conv(x, w) [* scale + shift] [+ res]); w = packed [tap][cin_pad][cout]
+// x_amax (optional, device): x_amax_n bit patterns whose maximum is max|x| over the whole input; the split-fp16 kernels use it to move x
+// into fp16's normal range by an exact power of two (data gradients are far below 2^-14)
 int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const float* scale, const float* shift,
-                      const float* res, float* y, int N, int H, int W, int relu, hipStream_t s);
+                      const float* res, float* y, int N, int H, int W, int relu, hipStream_t s,
+                      const uint32_t* x_amax = nullptr, int x_amax_n = 0);
 // [Cout][Cin][k][k] -> [tap][cin_pad][Cout]; dgrad = 1 packs the data-gradient view instead:
 // [tap'][cout_pad as K][Cin as N] with the taps flipped (conv of dy with this image gives dx)
 int conv2d_pack_raw(const float* w, float* packed, int cout, int cin, int k, int cin_pad, int dgrad, hipStream_t s);
@@ -57,6 +68,11 @@ int conv2d_pack_spec(const ConvSpec& consumer, const float* w, float* packed, in
 bool conv2d_hs_eligible(const ConvSpec& L);
 int conv2d_hs_pack(const ConvSpec& consumer, const float* w, void* packed, int dgrad, hipStream_t s);
 int conv2d_hs_launch(const ConvSpec& L, Conv2dArgs a, hipStream_t s);
+// conv1 (3x3 stride 2, +BN+ReLU) and the block's downsample (1x1 stride 2, +BN) in one pass over x; both must be
+// conv2d_hs_eligible (the downsample's weights packed with conv2d_hs_pack_ds)
+int conv2d_hs_launch_block_s2(const ConvSpec& c1, const ConvSpec& ds, const float* x, const float* w1, const float* scale1,
+                              const float* shift1, float* y1, const float* wd, const float* scaled, const float* shiftd,
+                              float* yd, int N, int H, int W, hipStream_t s);
 inline int conv_out_dim(int h, int k, int s, int p) { return (h + 2 * p - k) / s + 1; }
 int maxpool_launch(const float* x, float* y, int planes, int H, int W, int OH, int OW, hipStream_t s);
 int avgpool_fc_launch(const float* x, const float* fw, const float* fb, float* out, int batch, int C, int HW, int out_dim,

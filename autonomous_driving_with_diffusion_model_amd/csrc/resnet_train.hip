@@ -91,22 +91,42 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__
   out[i] = v;
 }
 
+constexpr size_t kAmaxPartials = 4096;   // workgroups of bn_bwd_apply_kernel = partial maxima handed to the dgrad conv
+
 // draw = gamma*rstd * (dz - m1 - xhat*m2); also d gamma / d beta (one thread per channel does that part)
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                             const float* __restrict__ raw, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                             const double* __restrict__ sums, float* __restrict__ draw,
                                                             float* __restrict__ dz_out, int C, int HW, size_t total,
-                                                            double count, int relu_mask) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const int c = (i / HW) % C;
-  float dz = dout[i];
-  if (relu_mask && !(out[i] > 0.f)) dz = 0.f;
-  if (dz_out != nullptr) dz_out[i] = dz;
-  const float xh = (raw[i] - mean[c]) * rstd[c];
-  const float m1 = (float)(sums[2 * c] / count), m2 = (float)(sums[2 * c + 1] / count);
-  draw[i] = gamma[c] * rstd[c] * (dz - m1 - xh * m2);
+                                                            double count, int relu_mask, uint32_t* __restrict__ amax) {
+  // grid-stride: a fixed number of workgroups, each leaving max |draw| of its share in amax[blockIdx.x] (bits:
+  // monotonic for non-negative floats); the data-gradient conv reduces those partials for its dynamic range
+  __shared__ uint32_t red[4];
+  uint32_t b = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (i / HW) % C;
+    float dz = dout[i];
+    if (relu_mask && !(out[i] > 0.f)) dz = 0.f;
+    if (dz_out != nullptr) dz_out[i] = dz;
+    const float xh = (raw[i] - mean[c]) * rstd[c];
+    const float m1 = (float)(sums[2 * c] / count), m2 = (float)(sums[2 * c + 1] / count);
+    const float v = gamma[c] * rstd[c] * (dz - m1 - xh * m2);
+    draw[i] = v;
+    const uint32_t vb = __builtin_bit_cast(uint32_t, v) & 0x7FFFFFFFu;
+    b = vb > b ? vb : b;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)b, off, 64);
+    b = o > b ? o : b;
+  }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = b;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t m01 = red[0] > red[1] ? red[0] : red[1], m23 = red[2] > red[3] ? red[2] : red[3];
+    amax[blockIdx.x] = m01 > m23 ? m01 : m23;
+  }
 }
 
 __global__ void bn_param_grad_kernel(const double* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta,
@@ -448,7 +468,7 @@ size_t adx_resnet_train_workspace_bytes(const adx_resnet* r, int32_t batch, int3
     conv(c2, OH, OW);
     H = OH; W = OW;
   }
-  f += al64(2 * 512 * 2) + 5 * al64(big) + al64(wmax);     // backward: sums, 5 gradient buffers, dgrad weight image
+  f += al64(2 * 512 * 2) + al64(kAmaxPartials) + 5 * al64(big) + al64(wmax);   // backward: sums, amax, 5 gradient buffers, dgrad weights
   return (f + 1024) * sizeof(float);
 }
 
@@ -532,6 +552,7 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
   const int batch = tape->batch;
   Bump2 ws{(float*)workspace, tape->fwd_floats, workspace_bytes / sizeof(float)};
   double* sums = reinterpret_cast<double*>(ws.take(2 * 512 * 2));
+  uint32_t* amax = reinterpret_cast<uint32_t*>(ws.take(kAmaxPartials));   // per-workgroup max |draw| of the conv being differentiated
   size_t big = 0, wmax = 0;
   for (auto& rec : tape->recs) {
     big = std::max(big, (size_t)batch * rec.L->cout * rec.OH * rec.OW);
@@ -567,19 +588,20 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
     ADX_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * L.cout, s));
     channel_sums_kernel<1><<<dim3(batch * L.cout), dim3(256), 0, s>>>(dout, rec.out, rec.raw, rec.mean, rec.rstd, sums,
                                                                       L.cout, HW, rec.relu);
-    bn_bwd_apply_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(
-        dout, rec.out, rec.raw, rec.mean, rec.rstd, T[L.t_g], sums, draw, dz_keep, L.cout, HW, n, count, rec.relu);
+    const int n_amax = (int)std::min<size_t>(kAmaxPartials, (n + 255) / 256);
+    bn_bwd_apply_kernel<<<dim3(n_amax), dim3(256), 0, s>>>(
+        dout, rec.out, rec.raw, rec.mean, rec.rstd, T[L.t_g], sums, draw, dz_keep, L.cout, HW, n, count, rec.relu, amax);
     bn_param_grad_kernel<<<dim3(ceil_div(L.cout, 256)), dim3(256), 0, s>>>(sums, G[L.t_g], G[L.t_b], L.cout);
     ADX_LAUNCH_CHECK();
     int rc2 = conv2d_wgrad(rec.x, draw, G[L.t_w], batch, L.cin, rec.H, rec.W, L.cout, L.k, L.stride, L.pad, s);
     if (rc2 != ADX_OK || !need_dx) return rc2;
     // data gradient
     ConvSpec g{};
-    g.cin = L.cout; g.cout = L.cin; g.k = L.k; g.stride = 1; g.pad = L.k - 1 - L.pad; g.cc = 16; g.cin_pad = L.cout;
+    g.cin = L.cout; g.cout = L.cin; g.k = L.k; g.stride = 1; g.pad = L.k - 1 - L.pad; g.cc = 16; g.cin_pad = L.cout; g.dgrad = 1;
     rc2 = conv2d_pack_spec(g, T[L.t_w], wimg, 1, s);
     if (rc2 != ADX_OK) return rc2;
     if (L.stride == 1) {
-      return conv2d_launch_raw(g, draw, wimg, nullptr, nullptr, dx_has ? dx : nullptr, dx, batch, rec.OH, rec.OW, 0, s);
+      return conv2d_launch_raw(g, draw, wimg, nullptr, nullptr, dx_has ? dx : nullptr, dx, batch, rec.OH, rec.OW, 0, s, amax, n_amax);
     }
     if (L.k == 3) {
       // zero-dilate draw to the input resolution, then an ordinary 3x3 stride-1 conv with the flipped weights
@@ -588,11 +610,11 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
       dilate2_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(draw, dil, batch * L.cout, rec.OH, rec.OW, rec.H,
                                                                           rec.W, 0);
       ADX_LAUNCH_CHECK();
-      return conv2d_launch_raw(g, dil, wimg, nullptr, nullptr, dx_has ? dx : nullptr, dx, batch, rec.H, rec.W, 0, s);
+      return conv2d_launch_raw(g, dil, wimg, nullptr, nullptr, dx_has ? dx : nullptr, dx, batch, rec.H, rec.W, 0, s, amax, n_amax);
     }
     // 1x1 stride 2: a 1x1 stride-1 conv at the output resolution, scattered to the even input positions
     float* t = gb[4];
-    rc2 = conv2d_launch_raw(g, draw, wimg, nullptr, nullptr, nullptr, t, batch, rec.OH, rec.OW, 0, s);
+    rc2 = conv2d_launch_raw(g, draw, wimg, nullptr, nullptr, nullptr, t, batch, rec.OH, rec.OW, 0, s, amax, n_amax);
     if (rc2 != ADX_OK) return rc2;
     if (!dx_has) ADX_CHECK_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)batch * L.cin * rec.H * rec.W, s));
     const size_t nt = (size_t)batch * L.cin * HW;

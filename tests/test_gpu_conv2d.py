@@ -81,10 +81,17 @@ def test_conv3x3_fused_bn_residual_relu_epilogue():
     assert e_hip <= 1.5 * e_f32 + 2e-7, (e_hip, e_f32)
 
 
-@pytest.mark.parametrize("cin,cout,k,stride,pad,h,w", [(64, 128, 3, 2, 1, 64, 225), (64, 128, 1, 2, 0, 64, 225),
-                                                       (3, 64, 7, 2, 3, 64, 96), (256, 512, 3, 2, 1, 16, 57),
+@pytest.mark.parametrize("cin,cout,h,w", [(64, 128, 64, 225), (256, 512, 16, 57), (128, 256, 9, 31), (64, 64, 7, 8)])
+def test_conv3x3_s2_split_fp16_is_fp32_grade(cin, cout, h, w):
+    x, wt = _case(cin, cout, 3, h, w, 2, seed=cin + w)
+    y, _ = _ops().conv2d(x.to(DEV), wt.to(DEV), stride=2, pad=1)
+    e_hip, e_f32 = _errs(y, x, wt, 2, 1)
+    assert e_hip <= 1.5 * e_f32 + 1e-7, (e_hip, e_f32)
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,h,w", [(64, 128, 1, 2, 0, 64, 225), (3, 64, 7, 2, 3, 64, 96),
                                                        (128, 64, 1, 1, 0, 9, 33)])
-def test_other_conv_shapes(cin, cout, k, stride, pad, h, w):
+def test_exact_fp32_mfma_conv_shapes(cin, cout, k, stride, pad, h, w):
     x, wt = _case(cin, cout, k, h, w, 2, seed=k + stride + cin)
     y, _ = _ops().conv2d(x.to(DEV), wt.to(DEV), stride=stride, pad=pad)
     e_hip, e_f32 = _errs(y, x, wt, stride, pad)

@@ -1,0 +1,34 @@
+"""Perception gradient error per parameter vs fp64 oracle (debug aid)."""
+import sys
+import torch
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from helpers import *  # noqa
+from oracle import resnet as R
+from test_gpu_model import make_model
+from test_gpu_train import oracle_sd
+import autonomous_driving_with_diffusion_model_amd.utils.procedural as P
+from autonomous_driving_with_diffusion_model_amd.modeling.spec import unet_entries
+DEV = "cuda:0"
+m, _ = make_model("NO_GUIDANCE", 16)
+m.train()
+sd = oracle_sd("NO_GUIDANCE")
+pkeys = [e.key for e in unet_entries("NO_GUIDANCE") if e.key.startswith("perception.") and not e.is_buffer]
+import os
+BB, HH, WW = [int(v) for v in os.environ.get("DBG_SHAPE", "3,64,96").split(",")]
+img = P.synthetic_batch(BB, 16, image_hw=(HH, WW), seed=61)["imgs"]
+w = P._uniform("perc.w", 61, (BB, 64), -1.0, 1.0)
+def oracle_grads(dtype):
+    s_ = {k: (v.detach().to(dtype).requires_grad_(k in pkeys) if v.is_floating_point() else v) for k, v in sd.items()}
+    f = R.resnet34_forward(s_, "perception.", img.to(dtype), training=True)
+    (f * w.to(dtype)).sum().backward()
+    return f.detach(), {k: s_[k].grad for k in pkeys}
+f64, g64 = oracle_grads(torch.float64)
+f32, g32 = oracle_grads(torch.float32)
+feat = m.perception(img.to(DEV))
+print("feat err", (feat.detach().cpu().double() - f64).abs().max().item(), "f32:", (f32.double() - f64).abs().max().item())
+(feat * w.to(DEV)).sum().backward()
+named = dict(m.named_parameters())
+rel = lambda a, b: ((a.double() - b).norm() / (b.norm() + 1e-30)).item()
+for k in pkeys:
+    if k.endswith("conv1.weight") or k.endswith("conv2.weight"):
+        print(f"{k:45s} hip {rel(named[k].grad.cpu(), g64[k]):.2e}  f32 {rel(g32[k], g64[k]):.2e}  |g| {g64[k].abs().max().item():.2e}")
