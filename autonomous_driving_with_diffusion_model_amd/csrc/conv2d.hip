@@ -231,22 +231,27 @@ __global__ void __launch_bounds__(256) maxpool_kernel(const float* __restrict__ 
   if (oy >= OH) return;
   const float* src = x + (size_t)pl * H * W;
   float* dst = y + ((size_t)pl * OH + oy) * OW;
-  for (int ox = lane; ox < OW; ox += 64) {
-    float m = -INFINITY;
+  // four 64-column chunks per pass: 36 independent loads in flight per lane
+  for (int ox0 = lane; ox0 < OW; ox0 += 256) {
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
       const int iy = oy * 2 - 1 + dy;
-      if (iy < 0 || iy >= H) continue;
-      const float* row = src + (size_t)iy * W;
+      const bool rok = iy >= 0 && iy < H;
+      const float* row = src + (size_t)(rok ? iy : 0) * W;
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int ix = ox * 2 - 1 + dx;
-        if (ix < 0 || ix >= W) continue;
-        const float v = row[ix];
-        m = (v > m || v != v) ? v : m;  // NaN propagates like torch
-      }
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int ix = (ox0 + 64 * q) * 2 - 1 + dx;
+          const bool ok = rok && ix >= 0 && ix < W;
+          const float v = ok ? row[ix] : -INFINITY;
+          m[q] = (v > m[q] || v != v) ? v : m[q];  // NaN propagates like torch
+        }
     }
-    dst[ox] = m;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (ox0 + 64 * q < OW) dst[ox0 + 64 * q] = m[q];
   }
 }
 

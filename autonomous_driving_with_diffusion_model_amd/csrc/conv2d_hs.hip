@@ -298,6 +298,183 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
   }
 }
 
+// ---- the stem: Conv2d(3, 64, 7, stride 2, padding 3), modeling/resnet.py:191 --------------------------------
+// K = 3 channels x 7 x 7 = 147 has no 16-channel chunks, so the GEMM's k axis is laid out as 21 (channel, kernel
+// row) "combos" x 8 kernel columns (7 real + one zero weight): a lane's B fragment -- 8 consecutive k for one
+// output pixel -- is then 8 CONSECUTIVE input columns of one patch row, i.e. 16 contiguous bytes of the fp16 patch
+// image [plane][channel][row][column] (read as 4 dwords: the start column 2*ox is only 4-byte aligned), and one
+// MFMA (K = 16) covers two combos.  11 k-steps x 3 products per 32x32 tile; 84 % of the k slots are real work.
+// One workgroup owns a band of 8 output rows of one image and walks its 32-column tiles: the 45 KB split weight
+// image is loaded into LDS once per band, the patch of tile i+1 is fetched while tile i is multiplied.
+constexpr int kStemSteps = 11;
+constexpr int kStemPH = 21, kStemPP = 72;                 // patch rows, row pitch in halves (70 columns are staged)
+constexpr int kStemCP = kStemPH * kStemPP;                // halves per channel plane
+constexpr int kStemPlane = 3 * kStemCP;                   // halves per split plane
+constexpr int kStemItems = 3 * kStemPH * 35;              // (channel, row, column pair) cells per tile
+constexpr int kStemPIT = (kStemItems + 255) / 256;
+
+__global__ void __launch_bounds__(256, 2) conv2d_hs_stem_kernel(const Conv2dArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32x4* wl = reinterpret_cast<u32x4*>(smem_raw);                         // [step][plane][k-half][64]
+  uint32_t* patch = reinterpret_cast<uint32_t*>(wl + kStemSteps * 256);   // 2 x [plane][channel][row][pitch/2] dwords
+  float* ss = reinterpret_cast<float*>(patch + 2 * kStemPlane);           // 2 bufs x 2 planes x kStemPlane/2 dwords
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const int n = blockIdx.x / a.tiles_y, ty = blockIdx.x - n * a.tiles_y;
+  const int oy0 = ty * 8, iy0 = oy0 * 2 - 3;
+  const size_t hw = (size_t)a.H * a.W;
+  const float* xin = a.x + (size_t)n * 3 * hw;
+  constexpr uint32_t kOutside = 0xC0000000u;
+  const __amdgpu_buffer_rsrc_t xrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0, (int)(3 * hw * sizeof(float)), 0x00020000);
+
+  {
+    const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.w);
+#pragma unroll
+    for (int k = 0; k < kStemSteps; ++k) wl[tid + 256 * k] = wsrc[tid + 256 * k];
+  }
+  if (tid < 2 * kHsCout) {
+    const int c = tid & (kHsCout - 1);
+    ss[tid] = a.scale == nullptr ? (tid < kHsCout ? 1.f : 0.f) : (tid < kHsCout ? a.scale[c] : a.shift[c]);
+  }
+
+  // per-thread cells: (channel, patch row, column pair); the row part of the gather offset is tile independent
+  // cell k of this thread: (channel, patch row, column pair); its geometry is recomputed where it is used (a few
+  // integer ops per tile) instead of living in registers beside the 128 accumulators
+  auto decode = [&](int k, int& c, int& py, int& pp) {
+    int e = tid + 256 * k;
+    asm volatile("" : "+v"(e));    // opaque: otherwise the geometry is hoisted out of the tile loop and spilled
+    c = e / (kStemPH * 35);
+    const int rem = e - c * (kStemPH * 35);
+    py = rem / 35;
+    pp = rem - py * 35;
+  };
+  float pv[kStemPIT][2];
+  auto load_p = [&](int tx) {
+    const int ix0 = tx * 64 - 3;
+#pragma unroll
+    for (int k = 0; k < kStemPIT; ++k) {
+      int c, py, pp;
+      decode(k, c, py, pp);
+      const int ix = ix0 + 2 * pp, iy = iy0 + py;
+      const bool rok = tid + 256 * k < kStemItems && iy >= 0 && iy < a.H;
+      const uint32_t grow = (uint32_t)(c * (int)hw + iy * a.W) * 4u;
+      const uint32_t o0 = (rok && ix >= 0 && ix < a.W) ? grow + (uint32_t)ix * 4u : kOutside;
+      const uint32_t o1 = (rok && ix + 1 >= 0 && ix + 1 < a.W) ? grow + (uint32_t)(ix + 1) * 4u : kOutside;
+      pv[k][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, o0, 0, 0));
+      pv[k][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, o1, 0, 0));
+    }
+  };
+  auto store_p = [&](int buf) {
+    uint32_t* pd = patch + buf * kStemPlane;     // a buffer = 2 planes of kStemPlane/2 dwords
+#pragma unroll
+    for (int k = 0; k < kStemPIT; ++k) {
+      if (kStemPIT * 256 == kStemItems || tid + 256 * k < kStemItems) {
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        f16x2 h, l;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const _Float16 hj = (_Float16)pv[k][j];
+          h[j] = hj;
+          l[j] = (_Float16)((pv[k][j] - (float)hj) * kLoScale);
+        }
+        int c, py, pp;
+        decode(k, c, py, pp);
+        const int dw = (c * kStemCP + py * kStemPP) / 2 + pp;
+        pd[dw] = __builtin_bit_cast(uint32_t, h);
+        pd[kStemPlane / 2 + dw] = __builtin_bit_cast(uint32_t, l);
+      }
+    }
+  };
+
+  const u32x4* wa0 = wl + khalf * 64 + l31;
+  const size_t img = (size_t)n * a.Cout * a.OH * a.OW;
+  const size_t plane_o = (size_t)a.OH * a.OW;
+
+  load_p(0);
+  store_p(0);
+  __syncthreads();
+  for (int tx = 0; tx < a.tiles_x; ++tx) {
+    if (tx + 1 < a.tiles_x) load_p(tx + 1);
+    const uint32_t* pb0 = patch + (tx & 1) * kStemPlane + (wave * 2 * 2) * (kStemPP / 2) + l31;
+    f32x16 accm[2][2], accl[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { accm[r][m][i] = 0.f; accl[r][m][i] = 0.f; }
+#pragma unroll 1
+    for (int step = 0; step < kStemSteps; ++step) {
+      // this lane's (channel, kernel row): combo 2*step + khalf; the 22nd combo has zero weights and re-reads the 21st
+      const int c0 = 2 * step, c1 = 2 * step + 1 > 20 ? 20 : 2 * step + 1;
+      const int off0 = ((c0 / 7) * kStemCP + (c0 % 7) * kStemPP) / 2, off1 = ((c1 / 7) * kStemCP + (c1 % 7) * kStemPP) / 2;
+      const uint32_t* pb = pb0 + (khalf ? off1 : off0);
+      f16x8 A[2][2], B[2][2];
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) A[pl][m] = __builtin_bit_cast(f16x8, wa0[(step * 2 + pl) * 128 + m * 32]);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const uint32_t* q = pb + pl * (kStemPlane / 2) + r * 2 * (kStemPP / 2);
+          u32x4 v;
+          v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+          B[pl][r] = __builtin_bit_cast(f16x8, v);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          accm[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][m], B[0][r], accm[r][m], 0, 0, 0);
+          accl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][m], B[1][r], accl[r][m], 0, 0, 0);
+          accl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][m], B[0][r], accl[r][m], 0, 0, 0);
+        }
+    }
+    if (tx + 1 < a.tiles_x) store_p((tx + 1) & 1);
+    // epilogue of this tile (registers only), then the barrier that publishes the next patch
+    const int ox = tx * kTileW + l31;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int oy = oy0 + wave * 2 + rr;
+      if (oy < a.OH && ox < a.OW) {
+        const size_t pix = (size_t)oy * a.OW + ox;
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int cl = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            float v = accm[rr][half][r] + accl[rr][half][r] * (1.f / kLoScale);
+            v = v * ss[cl] + ss[kHsCout + cl];
+            if (a.relu) v = v > 0.f ? v : 0.f;
+            a.y[img + (size_t)cl * plane_o + pix] = v;
+          }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// [64][3][7][7] fp32 -> [step][plane][k-half][64][8] fp16 with k = (combo = 2*step + k-half -> channel combo/7,
+// kernel row combo%7; element j = kernel column, the 8th and the 22nd combo are zero)
+__global__ void conv2d_hs_stem_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ p) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;      // over [step][k-half][64][8]
+  if (idx >= kStemSteps * 2 * 64 * 8) return;
+  const int j = idx & 7, ml = (idx >> 3) & 63, h = (idx >> 9) & 1, step = idx >> 10;
+  const int combo = 2 * step + h;
+  float v = 0.f;
+  if (combo < 21 && j < 7) v = w[((size_t)ml * 3 + combo / 7) * 49 + (combo % 7) * 7 + j];
+  const _Float16 hi = (_Float16)v;
+  const _Float16 lo = (_Float16)((v - (float)hi) * kLoScale);
+  const size_t cell = ((size_t)(step * 2 + 0) * 2 + h) * 64 + ml;
+  p[cell * 8 + j] = hi;
+  p[(cell + 128) * 8 + j] = lo;
+}
+
+static bool hs_is_stem(const ConvSpec& L) { return L.k == 7 && L.stride == 2 && L.pad == 3 && L.cin == 3 && L.cout == 64; }
+
 // fp32 [M][Kc][taps] (forward: M = cout, Kc = cin) or its data-gradient view (dgrad: M = original cin,
 // Kc = original cout, taps flipped) -> [M/64][Kc/16][tap][plane][k-half][64][8] fp16
 __global__ void conv2d_hs_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ p, int M, int Kc, int Kreal,
@@ -335,11 +512,17 @@ bool conv2d_hs_eligible(const ConvSpec& L) {
     mode = e == nullptr ? 0 : (e[0] == 'f' ? 1 : 2);
   }
   if ((mode == 1 && L.dgrad) || (mode == 2 && !L.dgrad)) return false;
+  if (hs_is_stem(L) && !L.dgrad) return true;
   if (L.cin % kHsCC != 0 || L.cin_pad != L.cin || L.cout % kHsCout != 0) return false;
   return L.k == 3 && (L.stride == 1 || L.stride == 2);
 }
 
 int conv2d_hs_pack(const ConvSpec& c, const float* w, void* packed, int dgrad, hipStream_t s) {
+  if (hs_is_stem(c) && !dgrad) {
+    conv2d_hs_stem_pack_kernel<<<dim3(ceil_div(kStemSteps * 2 * 64 * 8, 256)), dim3(256), 0, s>>>(w, (_Float16*)packed);
+    ADX_LAUNCH_CHECK();
+    return ADX_OK;
+  }
   const size_t total = (size_t)c.cout * c.cin_pad * c.k * c.k;
   conv2d_hs_pack_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
       w, (_Float16*)packed, c.cout, c.cin_pad, c.cin, c.k * c.k, dgrad, total);
@@ -386,6 +569,21 @@ int conv2d_hs_launch_block_s2(const ConvSpec& c1, const ConvSpec& ds, const floa
 int conv2d_hs_launch(const ConvSpec& L, Conv2dArgs a, hipStream_t s) {
   ADX_REQUIRE((size_t)L.cin * a.H * a.W * sizeof(float) < 0xC0000000u, "conv2d_hs: one image of the input exceeds the 32-bit byte offsets");
   const bool ds = a.w_ds != nullptr;
+  if (hs_is_stem(L) && !ds) {
+    constexpr size_t lds = (size_t)kStemSteps * 4096 + (size_t)2 * 2 * kStemPlane * 2 + 2 * kHsCout * sizeof(float);
+    static_assert(lds <= 80 * 1024, "two workgroups per CU need <= 80 KB each");
+    static bool attr = false;
+    if (!attr) {
+      ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs_stem_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr = true;
+    }
+    ADX_REQUIRE(a.x_amax == nullptr && a.res == nullptr, "conv2d_hs stem: no residual / dynamic range");
+    a.tiles_x = ceil_div(a.OW, kTileW); a.tiles_y = ceil_div(a.OH, 8); a.cout_tiles = 1;
+    conv2d_hs_stem_kernel<<<dim3((unsigned)(a.tiles_y * a.N)), dim3(256), lds, s>>>(a);
+    ADX_LAUNCH_CHECK();
+    return ADX_OK;
+  }
   if (L.k == 3 && L.stride == 1 && !ds) return hs_launch_t<1, 3, 2, 2, false>(a, s);
   if (L.k == 3 && L.stride == 2 && L.pad == 1) return ds ? hs_launch_t<2, 3, 1, 1, true>(a, s) : hs_launch_t<2, 3, 1, 1, false>(a, s);
   set_error("conv2d_hs: no kernel for k=%d stride=%d pad=%d%s", L.k, L.stride, L.pad, ds ? " with a fused downsample" : "");

@@ -192,7 +192,7 @@ def cpu_baseline(steps=2):
             "s_per_step": round(per, 3), "unet_only_steps_per_sec": round(1.0 / unet_s, 3)}
 
 
-def train_leg(dev, world, steps=3, warm=1):
+def train_leg(dev, world, steps=3, warm=2):
     """BASELINE configs[1]: NO_GUIDANCE training step at B=64, H=32: add_noise -> train-mode forward (batch-stat
     BatchNorm) -> MSE -> backward -> fused nan_to_num + AdamW + EMA.  One optimizer step = one denoising step."""
     import contextlib

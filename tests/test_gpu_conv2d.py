@@ -89,8 +89,18 @@ def test_conv3x3_s2_split_fp16_is_fp32_grade(cin, cout, h, w):
     assert e_hip <= 1.5 * e_f32 + 1e-7, (e_hip, e_f32)
 
 
-@pytest.mark.parametrize("cin,cout,k,stride,pad,h,w", [(64, 128, 1, 2, 0, 64, 225), (3, 64, 7, 2, 3, 64, 96),
-                                                       (128, 64, 1, 1, 0, 9, 33)])
+@pytest.mark.parametrize("h,w,n", [(64, 96, 2), (256, 900, 1), (37, 45, 3), (32, 32, 1)])
+def test_stem_7x7_s2_split_fp16_is_fp32_grade(h, w, n):
+    x, wt = _case(3, 64, 7, h, w, n, seed=h)
+    g = torch.Generator().manual_seed(h + 1)
+    scale, shift = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    y, _ = _ops().conv2d(x.to(DEV), wt.to(DEV), stride=2, pad=3, scale=scale.to(DEV), shift=shift.to(DEV), relu=True)
+    post = lambda c: torch.relu(c * scale.to(c.dtype)[None, :, None, None] + shift.to(c.dtype)[None, :, None, None])  # noqa: E731
+    e_hip, e_f32 = _errs(y, x, wt, 2, 3, post)
+    assert e_hip <= 1.5 * e_f32 + 2e-7, (e_hip, e_f32)
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,h,w", [(64, 128, 1, 2, 0, 64, 225), (128, 64, 1, 1, 0, 9, 33)])
 def test_exact_fp32_mfma_conv_shapes(cin, cout, k, stride, pad, h, w):
     x, wt = _case(cin, cout, k, h, w, 2, seed=k + stride + cin)
     y, _ = _ops().conv2d(x.to(DEV), wt.to(DEV), stride=stride, pad=pad)
