@@ -163,31 +163,35 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
 
   // Pipeline stage = (chunk, kernel row kh): weights are double-buffered per stage, the patch per chunk, so one
   // barrier per stage is enough and only K weight cells + PIT patch cells per thread are ever in registers.
-  float pv[PIT][8];
+  float pv[(PIT == K && PBUF == 2) ? 1 : PIT][8];
   u32x4 wv[K];
   u32x4 wdv;
-  auto load_p = [&](int chunk) {
+  // the patch of the next chunk travels in K slices, one per stage (round k of the cell list <-> stage kh), so only
+  // one slice (8 registers) is in flight at a time; with PIT != K everything goes with the first stage
+  constexpr bool kSliced = (PIT == K) && PBUF == 2;
+  auto load_p = [&](int chunk, int k0, int k1) {
     const uint32_t cbase = (uint32_t)chunk * kHsCC * plane_bytes;
 #pragma unroll
-    for (int k = 0; k < PIT; ++k)
+    for (int k = k0; k < k1; ++k)
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        pv[k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, goff[k], cbase + j * plane_bytes, 0));
-    if (DS) wdv = wdsrc[(size_t)chunk * 256 + tid];
+        pv[kSliced ? 0 : k][j] =
+            __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, goff[k], cbase + j * plane_bytes, 0));
+    if (DS && k0 == 0) wdv = wdsrc[(size_t)chunk * 256 + tid];
   };
-  auto store_p = [&](int buf) {
+  auto store_p = [&](int buf, int k0, int k1) {
     u32x4* pd = patch + buf * 4 * PLANE;
 #pragma unroll
-    for (int k = 0; k < PIT; ++k) {
+    for (int k = k0; k < k1; ++k) {
       const int e = tid + 256 * k;
       if (PIT * 256 == NITEM || e < NITEM) {
         u32x4 hi, lo;
-        split8(pv[k], xs, hi, lo);
+        split8(pv[kSliced ? 0 : k], xs, hi, lo);
         pd[pcell[k]] = hi;
         pd[pcell[k] + PLANE] = lo;
       }
     }
-    if (DS) wds[tid] = wdv;
+    if (DS && k0 == 0) wds[tid] = wdv;
   };
   auto load_w = [&](int stage) {
     const u32x4* ws = wsrc + (size_t)stage * WST;
@@ -204,10 +208,16 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
   const int nstages = nchunks * K;
 
   load_w(0);
-  load_p(0);
   store_w(0);
-  store_p(0);
+  if (kSliced) {
+#pragma unroll
+    for (int k = 0; k < PIT; ++k) { load_p(0, k, k + 1); store_p(0, k, k + 1); }
+  } else {
+    load_p(0, 0, PIT);
+    store_p(0, 0, PIT);
+  }
   __syncthreads();
+  struct Frags { f16x8 A[2][2], B[2][ROWS]; };   // [plane][cout half], [plane][row]
   int stage = 0;
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const u32x4* pb0 = patch + (PBUF == 2 ? (chunk & 1) * 4 * PLANE : 0) + pb_lane;
@@ -216,27 +226,36 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
       const u32x4* wa0 = wl + (stage & 1) * WST + wa_lane;
 #ifndef HS_NO_GLOBAL
       if (stage + 1 < nstages) load_w(stage + 1);
-      if (kh == 0 && chunk + 1 < nchunks) load_p(chunk + 1);
+      if (chunk + 1 < nchunks) {
+        if (kSliced) load_p(chunk + 1, kh, kh + 1);
+        else if (kh == 0) load_p(chunk + 1, 0, PIT);
+      }
 #endif
 #ifndef HS_NO_MFMA
-#pragma unroll
-      for (int kw = 0; kw < K; ++kw) {
-        f16x8 A[2][2], B[2][ROWS];   // [plane][cout half], [plane][row]
+      auto fetch = [&](Frags& f, int kw) {
         const int col = STRIDE == 2 ? (kw & 1) * EVW + (kw >> 1) : kw;
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
-          for (int m = 0; m < 2; ++m) A[pl][m] = __builtin_bit_cast(f16x8, wa0[(kw * 2 + pl) * 128 + m * 32]);
+          for (int m = 0; m < 2; ++m) f.A[pl][m] = __builtin_bit_cast(f16x8, wa0[(kw * 2 + pl) * 128 + m * 32]);
 #pragma unroll
-          for (int r = 0; r < ROWS; ++r) B[pl][r] = __builtin_bit_cast(f16x8, pb0[pl * PLANE + (r * STRIDE + kh) * PW + col]);
+          for (int r = 0; r < ROWS; ++r) f.B[pl][r] = __builtin_bit_cast(f16x8, pb0[pl * PLANE + (r * STRIDE + kh) * PW + col]);
         }
+      };
+      Frags fr[2];               // fragments of tap kw+1 are fetched under the MFMAs of tap kw
+      fetch(fr[0], 0);
+#pragma unroll
+      for (int kw = 0; kw < K; ++kw) {
+        const Frags& f = fr[kw & 1];
+        if (kw + 1 < K) fetch(fr[(kw + 1) & 1], kw + 1);
+        __builtin_amdgcn_sched_barrier(0);     // the next tap's reads are issued before this tap's MFMAs, in this order
 #pragma unroll
         for (int r = 0; r < ROWS; ++r)
 #pragma unroll
           for (int m = 0; m < 2; ++m) {
-            accm[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][m], B[0][r], accm[r][m], 0, 0, 0);
-            accl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][m], B[1][r], accl[r][m], 0, 0, 0);
-            accl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][m], B[0][r], accl[r][m], 0, 0, 0);
+            accm[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.A[0][m], f.B[0][r], accm[r][m], 0, 0, 0);
+            accl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.A[0][m], f.B[1][r], accl[r][m], 0, 0, 0);
+            accl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.A[1][m], f.B[0][r], accl[r][m], 0, 0, 0);
           }
         if (DS && kh == 1 && kw == 1) {   // x[2 oy][2 ox]: the 1x1 stride-2 conv's only tap
           f16x8 D[2][2];
@@ -248,26 +267,51 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
           for (int r = 0; r < ROWS; ++r)
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-              adm[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(D[0][m], B[0][r], adm[r][m], 0, 0, 0);
-              adl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(D[0][m], B[1][r], adl[r][m], 0, 0, 0);
-              adl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(D[1][m], B[0][r], adl[r][m], 0, 0, 0);
+              adm[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(D[0][m], f.B[0][r], adm[r][m], 0, 0, 0);
+              adl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(D[0][m], f.B[1][r], adl[r][m], 0, 0, 0);
+              adl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(D[1][m], f.B[0][r], adl[r][m], 0, 0, 0);
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
+#ifndef HS_NO_STORE
+      if (stage + 1 < nstages) store_w((stage + 1) & 1);
+      if (chunk + 1 < nchunks) {
+        if (kSliced) {
+          store_p((chunk + 1) & 1, kh, kh + 1);
+        } else if (kh == K - 1) {
+          if (PBUF == 1) __syncthreads();      // every wave is done with the only patch copy
+          store_p(PBUF == 2 ? (chunk + 1) & 1 : 0, 0, PIT);
         }
       }
 #endif
-      if (stage + 1 < nstages) store_w((stage + 1) & 1);
-      if (kh == K - 1 && chunk + 1 < nchunks) {
-        if (PBUF == 1) __syncthreads();      // every wave is done with the only patch copy
-        store_p(PBUF == 2 ? (chunk + 1) & 1 : 0);
-      }
+#ifndef HS_NO_BARRIER
       __syncthreads();
+#endif
     }
   }
 
   // ---- epilogue: combine, BN scale/shift, residual, ReLU; lane = pixel column, register = channel ----
+  // All residual loads of the tile are issued up front (the staging registers are dead by now): one exposed
+  // latency per tile instead of one per 16 values.
   const int ox = ox0 + l31;
   const size_t img = (size_t)n * a.Cout * a.OH * a.OW;
   const size_t plane_o = (size_t)a.OH * a.OW;
+  float rv[ROWS][2][16];
+#pragma unroll
+  for (int rr = 0; rr < ROWS; ++rr) {
+    const int oy = oy0 + wave * ROWS + rr;
+    const bool ok = a.res != nullptr && oy < a.OH && ox < a.OW;
+    const size_t pix = (size_t)oy * a.OW + ox;
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cl = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        rv[rr][half][r] = ok ? a.res[img + (size_t)(cout0 + cl) * plane_o + pix] : 0.f;
+      }
+  }
 #pragma unroll
   for (int rr = 0; rr < ROWS; ++rr) {
     const int oy = oy0 + wave * ROWS + rr;
@@ -275,18 +319,12 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
     const size_t pix = (size_t)oy * a.OW + ox;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      float rv[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int cl = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        rv[r] = a.res != nullptr ? a.res[img + (size_t)(cout0 + cl) * plane_o + pix] : 0.f;
-      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int cl = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
         float v = (accm[rr][half][r] + accl[rr][half][r] * (1.f / kLoScale)) * xs_inv;
         v = v * ss[cl] + ss[kHsCout + cl];
-        v += rv[r];
+        v += rv[rr][half][r];
         if (a.relu) v = v > 0.f ? v : 0.f;
         a.y[img + (size_t)(cout0 + cl) * plane_o + pix] = v;
         if (DS) {    // downsample branch: BN only (resnet.py:230-231), no ReLU, no residual

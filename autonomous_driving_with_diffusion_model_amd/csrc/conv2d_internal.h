@@ -73,6 +73,10 @@ int conv2d_hs_launch(const ConvSpec& L, Conv2dArgs a, hipStream_t s);
 int conv2d_hs_launch_block_s2(const ConvSpec& c1, const ConvSpec& ds, const float* x, const float* w1, const float* scale1,
                               const float* shift1, float* y1, const float* wd, const float* scaled, const float* shiftd,
                               float* yd, int N, int H, int W, hipStream_t s);
+// conv2d_wgrad_hs.hip: weight gradient of the 3x3 stride-1 convs on the fp16 matrix cores (dw is zeroed inside)
+bool conv2d_wgrad_hs_eligible(int Cin, int Cout, int k, int stride, int pad);
+int conv2d_wgrad_hs(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout,
+                    const uint32_t* dy_amax, int dy_amax_n, hipStream_t s);
 inline int conv_out_dim(int h, int k, int s, int p) { return (h + 2 * p - k) / s + 1; }
 int maxpool_launch(const float* x, float* y, int planes, int H, int W, int OH, int OW, hipStream_t s);
 int avgpool_fc_launch(const float* x, const float* fw, const float* fb, float* out, int batch, int C, int HW, int out_dim,

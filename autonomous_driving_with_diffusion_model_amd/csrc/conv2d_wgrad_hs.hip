@@ -1,0 +1,275 @@
+// Weight gradient of the 3x3 stride-1 convolutions on the fp16 matrix cores (hi/lo split operands, see
+// conv2d_hs.hip for the arithmetic):
+//     dW[co][ci][kh][kw] = sum over (n, oy, ox) of dy[n][co][oy][ox] * x[n][ci][oy + kh - 1][ox + kw - 1]
+// (torch.nn.grad.conv2d_weight of modeling/resnet.py's conv3x3).  Per tap this is a GEMM with M = co, N = ci and
+// the PIXELS as the reduction axis, so both operands are needed k-major while NCHW (and the forward kernel's LDS
+// image) is channel-major per pixel.  gfx950's transposing LDS read does the turn for free: activations and
+// gradients are staged exactly like the forward patch -- 16-byte cells of 8 channels per pixel, split into an fp16
+// hi and a scaled lo plane -- in [32-channel panel][pixel][32] images, and ds_read_b64_tr_b16 hands every lane the
+// 4 consecutive PIXELS of its channel.  A tap's kw shift is then a whole-cell (64-byte) offset, never a misaligned
+// read.
+//
+// One workgroup = 12 waves owns a 64 (co) x 64 (ci) x 9 (taps) block of dW: wave (cb, nb, kh) accumulates the three
+// kw taps of kernel row kh for output-channel panel cb and input-channel panel nb (3 x 2 accumulators of 16
+// registers).  It walks its share of (image, 64- or 32-pixel column segment) units row by row with a rolling
+// window: per output row one new dy row and one new x row are fetched (buffer loads, range check = zero padding),
+// split and stored while the previous row is multiplied; x rows live in a ring of four, dy rows in two buffers,
+// one barrier per row.  The block is reduced across workgroups with coalesced float atomics through an LDS
+// transpose ([co][ci][9] order = dW's memory order).  dy is far below fp16's normal range: its max|.| comes from
+// the kernel that produced it and moves it into range by an exact power of two.
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "adx_common.h"
+#include "conv2d_internal.h"
+
+namespace adx {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) h4 lds_h4;
+
+struct WgradHsArgs {
+  const float* x;        // [N][Cin][H][W]
+  const float* dy;       // [N][Cout][H][W]
+  float* dw;             // [Cout][Cin][3][3], zeroed by the caller
+  const uint32_t* dy_amax;
+  int dy_amax_n;
+  int N, Cin, Cout, H, W;
+  int segs, units, units_per_wg, n_ci_tiles, n_co_tiles;
+};
+
+constexpr float kWLo = 2048.f;
+constexpr int kWThreads = 768;
+
+__device__ __forceinline__ f16x8 tr_pair(const unsigned char* p) {
+  // 8 consecutive pixels of this lane's channel: two transposing reads of 4 pixel rows each (64 B per pixel row)
+  const u32x2 a = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4*)(p)));
+  const u32x2 b = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4*)(p + 256)));
+  u32x4 v;
+  v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+  return __builtin_bit_cast(f16x8, v);
+}
+
+template <int NPX>
+__global__ void __launch_bounds__(kWThreads) conv2d_wgrad_hs_kernel(const WgradHsArgs a) {
+  constexpr int NPXB = NPX + 2;                   // x row segment with its two halo columns
+  constexpr int KS = NPX / 16;                    // MFMA k-steps per row segment
+  constexpr int A_PLANE = 2 * NPX * 64;           // bytes: [co panel][pixel][32 halves]
+  constexpr int A_BUF = 2 * A_PLANE;              // hi + lo
+  constexpr int B_PLANE = 2 * NPXB * 64;          // bytes: [ci panel][pixel + halo][32 halves]
+  constexpr int B_SLOT = 2 * B_PLANE;
+  constexpr int NA = NPX * 8, NB = NPXB * 8;      // 16-byte cells per staged dy / x row
+  constexpr int PIT = (NA + NB + kWThreads - 1) / kWThreads;
+  static_assert(NA % 64 == 0, "a wave stages either dy cells or x cells");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* lA = smem;                       // 2 x A_BUF  (dy row r -> buffer r & 1)
+  unsigned char* lB = smem + 2 * A_BUF;           // 4 x B_SLOT (x row r -> slot r & 3)
+  uint32_t* red = reinterpret_cast<uint32_t*>(lB + 4 * B_SLOT);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cb = wave / 6, nb = (wave / 3) % 2, kh = wave % 3;
+  const int tiles = a.n_co_tiles * a.n_ci_tiles;
+  const int tile = blockIdx.x % tiles, split = blockIdx.x / tiles;
+  const int co0 = (tile / a.n_ci_tiles) * 64, ci0 = (tile % a.n_ci_tiles) * 64;
+  const size_t hw = (size_t)a.H * a.W;
+  const uint32_t plane_bytes = (uint32_t)(hw * sizeof(float));
+  constexpr uint32_t kOutside = 0xC0000000u;
+
+  // dy's dynamic range: scale so that max|dy| lands in [2^14, 2^15), undone exactly in the epilogue
+  float xs = 1.f, xs_inv = 1.f;
+  if (a.dy_amax != nullptr) {
+    uint32_t b = 0;
+    for (int i = tid; i < a.dy_amax_n; i += kWThreads) b = a.dy_amax[i] > b ? a.dy_amax[i] : b;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const uint32_t o = (uint32_t)__shfl_xor((int)b, off, 64);
+      b = o > b ? o : b;
+    }
+    if (lane == 0) red[wave] = b;
+    __syncthreads();
+    b = 0;
+#pragma unroll
+    for (int w = 0; w < kWThreads / 64; ++w) b = red[w] > b ? red[w] : b;
+    const int e = (int)((b >> 23) & 0xFF);
+    if (e != 0 && e != 255) {
+      int sh = 127 + 14 - e;
+      sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+      xs = __builtin_bit_cast(float, (uint32_t)(127 + sh) << 23);
+      xs_inv = __builtin_bit_cast(float, (uint32_t)(127 - sh) << 23);
+    }
+  }
+
+  f32x16 am[3], al[3];   // per kw tap: hi*hi sums, cross-term sums (scaled by 2^11)
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { am[k][i] = 0.f; al[k][i] = 0.f; }
+
+  // transposing reads: lane (16-lane group g, member 4q + p) supplies pixel row q, channels 4p..4p+3 of channel
+  // group g & 1; the group's k half is g >> 1 (MFMA lanes 32..63 hold k = 8..15)
+  const int gi = lane >> 4, li = lane & 15;
+  const int tr_lane = ((8 * (gi >> 1) + (li >> 2)) * 32 + (gi & 1) * 16 + 4 * (li & 3)) * 2;
+  const int aoff = cb * NPX * 64 + tr_lane;
+  const int boff = nb * NPXB * 64 + tr_lane;
+
+  // staging cells of this thread (the same for every row): kind, LDS byte offset inside a buffer / slot, column
+  int sto[PIT], colv[PIT];
+  uint32_t chan[PIT];
+  bool isA[PIT];
+#pragma unroll
+  for (int k = 0; k < PIT; ++k) {
+    const int e = tid + kWThreads * k;
+    isA[k] = e < NA;
+    if (isA[k]) {
+      const int px = e % NPX, cg = e / NPX;
+      sto[k] = ((cg >> 2) * NPX + px) * 64 + (cg & 3) * 16;
+      colv[k] = px;
+      chan[k] = (uint32_t)cg * 8u * plane_bytes;
+    } else {
+      const int e2 = e - NA;
+      const int pp = e2 % NPXB, cg = e2 / NPXB;
+      sto[k] = e2 < NB ? ((cg >> 2) * NPXB + pp) * 64 + (cg & 3) * 16 : -1;
+      colv[k] = pp - 1;
+      chan[k] = (uint32_t)cg * 8u * plane_bytes;
+    }
+  }
+
+  const int u0 = split * a.units_per_wg;
+  const int u1 = u0 + a.units_per_wg < a.units ? u0 + a.units_per_wg : a.units;
+  float pv[PIT][8];
+  for (int u = u0; u < u1; ++u) {
+    const int n = u / a.segs, ox0 = (u - n * a.segs) * NPX;
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.dy + ((size_t)n * a.Cout + co0) * hw), 0, (int)(64 * plane_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x + ((size_t)n * a.Cin + ci0) * hw), 0, (int)(64 * plane_bytes), 0x00020000);
+    // iteration t: fetch dy row t+1 and x row t+2, multiply row t, publish the fetched rows
+    for (int t = -2; t < a.H; ++t) {
+#pragma unroll
+      for (int k = 0; k < PIT; ++k) {
+        const bool ka = __builtin_amdgcn_readfirstlane((int)isA[k]) != 0;     // wave-uniform by construction
+        const int row = ka ? t + 1 : t + 2;
+        const int col = ox0 + colv[k];
+        const bool ok = sto[k] >= 0 && row >= 0 && row < a.H && col >= 0 && col < a.W;
+        const uint32_t vo = ok ? chan[k] + (uint32_t)(row * a.W + col) * 4u : kOutside;
+        if (ka) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            pv[k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdy, vo, j * plane_bytes, 0));
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            pv[k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo, j * plane_bytes, 0));
+        }
+      }
+      // kernel row 0 of output row 0 would read x row -1 (zero padding): nothing to add
+      if (t >= 0 && !(kh == 0 && t == 0)) {
+        const unsigned char* Ab = lA + (t & 1) * A_BUF + aoff;
+        const unsigned char* Bb = lB + ((t + kh - 1) & 3) * B_SLOT + boff;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const f16x8 Ahi = tr_pair(Ab + ks * 1024), Alo = tr_pair(Ab + A_PLANE + ks * 1024);
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const f16x8 Bhi = tr_pair(Bb + ks * 1024 + kw * 64), Blo = tr_pair(Bb + B_PLANE + ks * 1024 + kw * 64);
+            am[kw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi, Bhi, am[kw], 0, 0, 0);
+            al[kw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi, Blo, al[kw], 0, 0, 0);
+            al[kw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo, Bhi, al[kw], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < PIT; ++k) {
+        if (sto[k] < 0) continue;
+        const bool ka = isA[k];
+        f16x8 h, l;
+        const float sc = ka ? xs : 1.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = pv[k][j] * sc;
+          const _Float16 hj = (_Float16)v;
+          h[j] = hj;
+          l[j] = (_Float16)((v - (float)hj) * kWLo);
+        }
+        unsigned char* d = ka ? lA + ((t + 1) & 1) * A_BUF + sto[k] : lB + ((t + 2) & 3) * B_SLOT + sto[k];
+        *reinterpret_cast<u32x4*>(d) = __builtin_bit_cast(u32x4, h);
+        *reinterpret_cast<u32x4*>(d + (ka ? A_PLANE : B_PLANE)) = __builtin_bit_cast(u32x4, l);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- reduce across workgroups: [32 co][64 ci][9] floats per co panel through LDS, then coalesced atomics ----
+  float* tbuf = reinterpret_cast<float*>(smem);
+  const int l31 = lane & 31, khalf = lane >> 5;
+#pragma unroll 1
+  for (int pb = 0; pb < 2; ++pb) {
+    if (cb == pb) {
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co_l = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+          tbuf[(co_l * 64 + nb * 32 + l31) * 9 + kh * 3 + kw] = (am[kw][r] + al[kw][r] * (1.f / kWLo)) * xs_inv;
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 32 * 576; idx += kWThreads) {
+      const int co_l = idx / 576, rem = idx - co_l * 576;
+      atomicAdd(a.dw + ((size_t)(co0 + pb * 32 + co_l) * a.Cin + ci0) * 9 + rem, tbuf[idx]);
+    }
+    __syncthreads();
+  }
+}
+
+bool conv2d_wgrad_hs_eligible(int Cin, int Cout, int k, int stride, int pad) {
+  static int exact = -1;
+  if (exact < 0) {
+    const char* e = getenv("ADX_CONV_EXACT");
+    const char* w = getenv("ADX_WGRAD_EXACT");
+    exact = ((e != nullptr && e[0] == '1') || (w != nullptr && w[0] == '1')) ? 1 : 0;
+  }
+  return !exact && k == 3 && stride == 1 && pad == 1 && Cin % 64 == 0 && Cout % 64 == 0;
+}
+
+template <int NPX>
+static int wgrad_hs_launch(WgradHsArgs a, hipStream_t s) {
+  constexpr size_t lds = (size_t)2 * (2 * 2 * NPX * 64) + (size_t)4 * (2 * 2 * (NPX + 2) * 64) + 64;
+  constexpr size_t need = std::max(lds, (size_t)32 * 576 * sizeof(float));
+  static bool attr = false;
+  if (!attr) {
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad_hs_kernel<NPX>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+    attr = true;
+  }
+  a.segs = ceil_div(a.W, NPX);
+  a.units = a.N * a.segs;
+  const int tiles = a.n_co_tiles * a.n_ci_tiles;
+  int splits = std::max(1, 256 / tiles);          // one 12-wave workgroup per CU
+  if (splits > a.units) splits = a.units;
+  a.units_per_wg = ceil_div(a.units, splits);
+  splits = ceil_div(a.units, a.units_per_wg);
+  conv2d_wgrad_hs_kernel<NPX><<<dim3((unsigned)(tiles * splits)), dim3(kWThreads), need, s>>>(a);
+  ADX_LAUNCH_CHECK();
+  return ADX_OK;
+}
+
+int conv2d_wgrad_hs(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout,
+                    const uint32_t* dy_amax, int dy_amax_n, hipStream_t s) {
+  ADX_REQUIRE(x && dy && dw, "conv2d_wgrad_hs: null tensor");
+  ADX_REQUIRE((size_t)64 * H * W * sizeof(float) < 0xC0000000u, "conv2d_wgrad_hs: image too large for 32-bit offsets");
+  WgradHsArgs a{};
+  a.x = x; a.dy = dy; a.dw = dw; a.dy_amax = dy_amax; a.dy_amax_n = dy_amax_n;
+  a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+  a.n_ci_tiles = Cin / 64; a.n_co_tiles = Cout / 64;
+  ADX_CHECK_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cout * Cin * 9, s));
+  // rows of <= 32 (or 33..48 -> two 32-pixel segments waste less than one 64) pixels use the narrow variant
+  const int waste64 = ceil_div(W, 64) * 64 - W, waste32 = ceil_div(W, 32) * 32 - W;
+  return waste32 < waste64 ? wgrad_hs_launch<32>(a, s) : wgrad_hs_launch<64>(a, s);
+}
+
+}  // namespace adx

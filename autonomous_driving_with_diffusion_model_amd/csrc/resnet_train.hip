@@ -347,8 +347,10 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(const WgradArgs2 a) {
 }
 
 int conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, int k, int stride,
-                 int pad, hipStream_t s) {
+                 int pad, hipStream_t s, const uint32_t* dy_amax = nullptr, int dy_amax_n = 0) {
   ADX_REQUIRE(x && dy && dw, "conv2d_wgrad: null tensor");
+  if (conv2d_wgrad_hs_eligible(Cin, Cout, k, stride, pad))
+    return conv2d_wgrad_hs(x, dy, dw, N, Cin, H, W, Cout, dy_amax, dy_amax_n, s);
   WgradArgs2 a;
   a.x = x; a.dy = dy; a.dw = dw;
   a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.pad = pad;
@@ -593,7 +595,7 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
         dout, rec.out, rec.raw, rec.mean, rec.rstd, T[L.t_g], sums, draw, dz_keep, L.cout, HW, n, count, rec.relu, amax);
     bn_param_grad_kernel<<<dim3(ceil_div(L.cout, 256)), dim3(256), 0, s>>>(sums, G[L.t_g], G[L.t_b], L.cout);
     ADX_LAUNCH_CHECK();
-    int rc2 = conv2d_wgrad(rec.x, draw, G[L.t_w], batch, L.cin, rec.H, rec.W, L.cout, L.k, L.stride, L.pad, s);
+    int rc2 = conv2d_wgrad(rec.x, draw, G[L.t_w], batch, L.cin, rec.H, rec.W, L.cout, L.k, L.stride, L.pad, s, amax, n_amax);
     if (rc2 != ADX_OK || !need_dx) return rc2;
     // data gradient
     ConvSpec g{};
