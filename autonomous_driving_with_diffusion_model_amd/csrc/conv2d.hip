@@ -222,7 +222,11 @@ __global__ void bn_fold_kernel(const float* g, const float* b, const float* mean
 }
 
 // MaxPool2d(kernel 3, stride 2, padding 1), modeling/resnet.py:197.  One wave per output row (blockIdx.x = plane),
-// lanes along the row: every load instruction of a wave covers one contiguous 512-byte span of an input row.
+// lanes along the row.  Even widths: a lane loads columns (2 ox, 2 ox + 1) as one 8-byte word -- every load
+// instruction of a wave covers one contiguous 512-byte span, each input row is fetched exactly once -- and takes
+// column 2 ox - 1 from its left neighbour's word (only the first lane of a 64-column chunk loads it itself).
+__device__ __forceinline__ float pool_max(float m, float v) { return (v > m || v != v) ? v : m; }   // NaN propagates like torch
+
 __global__ void __launch_bounds__(256) maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, int planes,
                                                        int H, int W, int OH, int OW) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -231,7 +235,38 @@ __global__ void __launch_bounds__(256) maxpool_kernel(const float* __restrict__ 
   if (oy >= OH) return;
   const float* src = x + (size_t)pl * H * W;
   float* dst = y + ((size_t)pl * OH + oy) * OW;
-  // four 64-column chunks per pass: 36 independent loads in flight per lane
+  if ((W & 1) == 0 && ((size_t)x & 7) == 0) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    for (int ox0 = lane; ox0 - lane < OW; ox0 += 256) {   // wave-uniform trip count: the shuffles need every lane
+      float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int iy = oy * 2 - 1 + dy;
+        if (iy < 0 || iy >= H) continue;               // wave-uniform
+        const float* row = src + (size_t)iy * W;
+        f32x2 v[4];
+        float left[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int ox = ox0 + 64 * q;
+          const bool in = 2 * ox + 1 < W;              // W even: both columns exist or neither
+          v[q] = in ? *reinterpret_cast<const f32x2*>(row + 2 * ox) : f32x2{-INFINITY, -INFINITY};
+          left[q] = (lane == 0 && ox > 0 && 2 * ox - 1 < W) ? row[2 * ox - 1] : -INFINITY;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float nb = __shfl_up(v[q][1], 1, 64);
+          const float l = lane == 0 ? left[q] : nb;
+          m[q] = pool_max(pool_max(pool_max(m[q], l), v[q][0]), v[q][1]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (ox0 + 64 * q < OW) dst[ox0 + 64 * q] = m[q];
+    }
+    return;
+  }
+  // generic widths: four 64-column chunks per pass, 36 independent loads in flight per lane
   for (int ox0 = lane; ox0 < OW; ox0 += 256) {
     float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
@@ -246,7 +281,7 @@ __global__ void __launch_bounds__(256) maxpool_kernel(const float* __restrict__ 
           const int ix = (ox0 + 64 * q) * 2 - 1 + dx;
           const bool ok = rok && ix >= 0 && ix < W;
           const float v = ok ? row[ix] : -INFINITY;
-          m[q] = (v > m[q] || v != v) ? v : m[q];  // NaN propagates like torch
+          m[q] = pool_max(m[q], v);
         }
     }
 #pragma unroll

@@ -400,6 +400,54 @@ int conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int
   return ADX_OK;
 }
 
+// max |v| over a tensor as gridDim.x partial maxima (bit patterns), for the split-fp16 kernels' dynamic range
+__global__ void __launch_bounds__(256) amax_partials_kernel(const float* __restrict__ v, size_t total, uint32_t* __restrict__ out) {
+  __shared__ uint32_t red[4];
+  uint32_t b = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const uint32_t vb = __builtin_bit_cast(uint32_t, v[i]) & 0x7FFFFFFFu;
+    b = vb > b ? vb : b;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)b, off, 64);
+    b = o > b ? o : b;
+  }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = b;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t m01 = red[0] > red[1] ? red[0] : red[1], m23 = red[2] > red[3] ? red[2] : red[3];
+    out[blockIdx.x] = m01 > m23 ? m01 : m23;
+  }
+}
+
+}  // namespace adx
+
+extern "C" {
+
+size_t adx_conv2d_wgrad_scratch_bytes(void) { return adx::kAmaxPartials * sizeof(uint32_t); }
+
+int adx_conv2d_wgrad(const adx_conv2d_desc* d, const float* x, const float* dy, float* dw, int32_t n, int32_t h,
+                     int32_t w, void* scratch, adx_stream stream) {
+  using namespace adx;
+  ADX_REQUIRE(d && x && dy && dw, "adx_conv2d_wgrad: null argument");
+  ADX_REQUIRE(n >= 1 && h + 2 * d->pad >= d->k && w + 2 * d->pad >= d->k, "adx_conv2d_wgrad: input too small");
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t* amax = (uint32_t*)scratch;
+  int n_amax = 0;
+  if (amax != nullptr) {
+    const size_t total = (size_t)n * d->cout * conv_out_dim(h, d->k, d->stride, d->pad) * conv_out_dim(w, d->k, d->stride, d->pad);
+    n_amax = (int)std::min<size_t>(kAmaxPartials, (total + 255) / 256);
+    amax_partials_kernel<<<dim3(n_amax), dim3(256), 0, s>>>(dy, total, amax);
+    ADX_LAUNCH_CHECK();
+  }
+  return conv2d_wgrad(x, dy, dw, n, d->cin, h, w, d->cout, d->k, d->stride, d->pad, s, amax, n_amax);
+}
+
+}  // extern "C"
+
+namespace adx {
+
 static size_t al64(size_t v) { return (v + 63) / 64 * 64; }
 
 struct Bump2 {

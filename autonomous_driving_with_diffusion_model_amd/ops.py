@@ -113,6 +113,22 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, *, stride: int = 1, pad: int =
     return y, packed
 
 
+def conv2d_weight_grad(x: torch.Tensor, dy: torch.Tensor, k: int, *, stride: int = 1, pad: int = 0,
+                       estimate_range: bool = True) -> torch.Tensor:
+    """d(loss)/d(weight) of conv2d(x, weight, stride, pad) given dy = d(loss)/d(output): [cout, cin, k, k]."""
+    assert x.is_cuda and dy.is_cuda and x.dtype == dy.dtype == torch.float32 and x.is_contiguous() and dy.is_contiguous()
+    n, cin, h, w = x.shape
+    cout = dy.shape[1]
+    d = L.Conv2dDesc(cin, cout, k, stride, pad)
+    dw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=x.device)
+    scratch = None
+    if estimate_range:
+        scratch = torch.empty(L.lib().adx_conv2d_wgrad_scratch_bytes(), dtype=torch.uint8, device=x.device)
+    L.check(L.lib().adx_conv2d_wgrad(C.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, h, w, L.ptr(scratch),
+                                     L.stream_ptr(x.device)), "adx_conv2d_wgrad")
+    return dw
+
+
 IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 
 

@@ -183,6 +183,14 @@ int adx_conv2d_pack(const adx_conv2d_desc* d, const float* w /* [cout][cin][k][k
 int adx_conv2d_forward(const adx_conv2d_desc* d, const float* x, const float* packed_w, const float* scale,
                        const float* shift, const float* res, float* y, int32_t n, int32_t h, int32_t w,
                        int32_t relu, adx_stream s);
+/* Weight gradient of the same convolution (torch.nn.grad.conv2d_weight; train.py:242 reaches it through
+ * loss.backward()): dw [cout][cin][k][k] = sum over batch and pixels of dy (x) x.  dy is [n][cout][oh][ow].
+ * scratch: NULL, or >= adx_conv2d_wgrad_scratch_bytes() of device memory in which the range of dy is estimated
+ * first -- the 3x3 stride-1 path multiplies on the fp16 matrix cores with hi/lo split operands and rescales dy by an
+ * exact power of two; without scratch dy is taken as is (full accuracy only for |dy| >= 6e-5). */
+size_t adx_conv2d_wgrad_scratch_bytes(void);
+int adx_conv2d_wgrad(const adx_conv2d_desc* d, const float* x, const float* dy, float* dw, int32_t n, int32_t h,
+                     int32_t w, void* scratch, adx_stream s);
 
 /* Training-mode perception (train.py:242 with model.train()): batch-statistics BatchNorm, running buffers
  * updated in place (momentum 0.1), everything the backward needs kept in the workspace. */
