@@ -1,0 +1,64 @@
+"""Fold the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; tools/pmc_kernels.py under each) into
+profiles/r01_pmc_traffic.json: bytes per launch of the two roofline kernels.
+
+usage: python tools/pmc_to_json.py <FETCH_counter_collection.csv> <WRITE_counter_collection.csv> <out.json>"""
+import csv
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def per_kernel(path, counter):
+    """{kernel name: {grid size: [values...]}} of one counter; rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB."""
+    out = {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            out.setdefault(r["Kernel_Name"], {}).setdefault(int(r["Grid_Size"]), []).append(float(r["Counter_Value"]) * 1024.0)
+    return out
+
+
+def main():
+    import bench
+    fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, --kernel-trace only) -- "
+                     "python3 tools/pmc_kernels.py, 1x MI355X",
+           "unit": "bytes per launch (counter in KiB; raw TCC_EA0 request counts, no gfx950 x2 read correction applied: "
+                   "the patch loads are 4 B/lane, an access width MI355X_MICROARCH.md lists as uncalibrated)",
+           "kernels": {}}
+    # 3x3 stride-1 convs: one grid size per shape, launch mix of one perception pass
+    shapes = {}
+    for c in bench.resnet_conv_table(*bench.IMG):
+        if c[3] == 1:
+            shapes[c] = shapes.get(c, 0) + 1
+    name = next(k for k in fetch if "conv2d_hs_kernel<1, 3" in k)
+    grids = {}
+    for (cin, cout, k, s, p, h, w), cnt in shapes.items():
+        wgs = bench.B * ((h + 7) // 8) * ((w + 31) // 32) * (cout // 64)
+        grids[wgs * 256] = (f"{cin}->{cout} @{h}x{w}", cnt)
+    per_shape, tf, tw, n = {}, 0.0, 0.0, 0
+    for g, (label, cnt) in grids.items():
+        fv, wv = fetch[name][g], write[name][g]
+        f_, w_ = sum(fv) / len(fv), sum(wv) / len(wv)
+        per_shape[label] = {"count": cnt, "fetch": f_, "write": w_}
+        tf += f_ * cnt
+        tw += w_ * cnt
+        n += cnt
+    res["kernels"]["conv2d_hs_kernel<1,3,2,2,false>"] = {"per_shape": per_shape, "fetch": tf / n, "write": tw / n,
+                                                         "traffic": (tf + tw) / n}
+    tname = next(k for k in fetch if "tconv_kernel<1, 4" in k)
+    fv = [v for g in fetch[tname].values() for v in g]
+    wv = [v for g in write[tname].values() for v in g]
+    res["kernels"]["tconv_kernel<1,4,4,16> 512->512 k5, 128x4 positions"] = {
+        "fetch": sum(fv) / len(fv), "write": sum(wv) / len(wv), "traffic": sum(fv) / len(fv) + sum(wv) / len(wv)}
+    with open(sys.argv[3], "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps(res["kernels"], indent=1))
+
+
+if __name__ == "__main__":
+    main()
