@@ -224,8 +224,10 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
 #pragma unroll
     for (int kh = 0; kh < K; ++kh, ++stage) {
       const u32x4* wa0 = wl + (stage & 1) * WST + wa_lane;
-#ifndef HS_NO_GLOBAL
+#if !defined(HS_NO_GLOBAL) && !defined(HS_NO_GLOBAL_W)
       if (stage + 1 < nstages) load_w(stage + 1);
+#endif
+#if !defined(HS_NO_GLOBAL) && !defined(HS_NO_GLOBAL_P)
       if (chunk + 1 < nchunks) {
         if (kSliced) load_p(chunk + 1, kh, kh + 1);
         else if (kh == 0) load_p(chunk + 1, 0, PIT);
@@ -333,6 +335,216 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
         }
       }
     }
+  }
+}
+
+// ---- 3x3 stride-1, deferred-store pipeline ---------------------------------------------------------------------
+// Same tile, LDS images and arithmetic as conv2d_hs_kernel<1,3,2,2,false>; what changes is WHEN staged data moves.
+// There the loads of stage s+1 are issued at the start of stage s and converted + written to LDS after its MFMAs,
+// so every stage ends with a serial tail (wait for HBM, ~60 VALU, 5 LDS writes, LDS drain, barrier) during which
+// this wave issues no MFMA -- and with two waves per SIMD the tails of the two workgroups meet often enough to
+// leave the matrix pipe idle for a third of the time (SQ_VALU_MFMA_BUSY 53 %).  Here data is fetched TWO stages
+// ahead into a second register set, and the set that arrived during the previous stage is split and written
+// between the MFMAs of this stage, where its VALU / LDS-write slots are free; a stage then ends with just the LDS
+// drain and the barrier.  Two chunks (6 stages) are unrolled so that every register-set index is a constant.
+__global__ void __launch_bounds__(256, 2) conv2d_hs3x3_kernel(const Conv2dArgs a) {
+  constexpr int K = 3, PH = 10, PW = 34, PLANE = PH * PW, NITEM = 2 * PLANE, PIT = 3;
+  constexpr int NW = 9 * 256, WST = 3 * 256;
+  static_assert(PIT * 256 >= NITEM, "three rounds cover the patch");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32x4* patch = reinterpret_cast<u32x4*>(smem_raw);   // 2 x [k-half][plane][PLANE]
+  u32x4* wl = patch + 2 * 4 * PLANE;                   // 2 x [kw][plane][k-half][64]
+  float* ss = reinterpret_cast<float*>(wl + 2 * WST);  // scale[64], shift[64], 4 words for the range reduction
+  u32x4* dummy = reinterpret_cast<u32x4*>(ss + 2 * kHsCout + 4);   // where the idle threads of the last round write
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bid = blockIdx.x;
+  {
+    const int per = gridDim.x >> 3;
+    if (bid < per * 8) bid = (bid & 7) * per + (bid >> 3);
+  }
+  const int ct = bid % a.cout_tiles; bid /= a.cout_tiles;
+  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y; bid /= a.tiles_y;
+  const int n = bid;
+  const int oy0 = ty * 8, ox0 = tx * kTileW;
+  const int iy0 = oy0 - a.pad, ix0 = ox0 - a.pad;
+  const int cout0 = ct * kHsCout;
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const size_t hw = (size_t)a.H * a.W;
+  const float* xin = a.x + (size_t)n * a.Cin * hw;
+  const int nchunks = a.cin_pad / kHsCC;
+  const int nstages = nchunks * K;
+  const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.w) + (size_t)ct * nchunks * NW;
+  constexpr uint32_t kOutside = 0xC0000000u;
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(xin), 0, (int)((size_t)a.Cin * hw * sizeof(float)), 0x00020000);
+  const uint32_t plane_bytes = (uint32_t)(hw * sizeof(float));
+  uint32_t goff[PIT];
+  int pcell[PIT];
+#pragma unroll
+  for (int k = 0; k < PIT; ++k) {
+    const int e = tid + 256 * k;
+    const int hg = e >= PLANE ? 1 : 0;
+    const int p = e - hg * PLANE;
+    const int py = p / PW, px = p - py * PW;
+    const int iy = iy0 + py, ix = ix0 + px;
+    const bool ok = e < NITEM && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    goff[k] = ok ? (uint32_t)((hg * 8 * hw + (size_t)iy * a.W + ix) * sizeof(float)) : kOutside;
+    pcell[k] = e < NITEM ? hg * 2 * PLANE + p : -1;
+  }
+  if (tid < 2 * kHsCout) {
+    const int c = cout0 + (tid & (kHsCout - 1));
+    ss[tid] = a.scale == nullptr ? (tid < kHsCout ? 1.f : 0.f) : (tid < kHsCout ? a.scale[c] : a.shift[c]);
+  }
+  float xs = 1.f, xs_inv = 1.f;
+  if (a.x_amax != nullptr) {
+    uint32_t* red = reinterpret_cast<uint32_t*>(ss + 2 * kHsCout);
+    uint32_t b = 0;
+    for (int i = tid; i < a.x_amax_n; i += 256) b = a.x_amax[i] > b ? a.x_amax[i] : b;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const uint32_t o = (uint32_t)__shfl_xor((int)b, off, 64);
+      b = o > b ? o : b;
+    }
+    if (lane == 0) red[wave] = b;
+    __syncthreads();
+    b = red[0] > red[1] ? red[0] : red[1];
+    b = red[2] > b ? red[2] : b;
+    b = red[3] > b ? red[3] : b;
+    const int e = (int)((b >> 23) & 0xFF);
+    if (e != 0 && e != 255) {
+      int sh = 127 + 14 - e;
+      sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+      xs = __builtin_bit_cast(float, (uint32_t)(127 + sh) << 23);
+      xs_inv = __builtin_bit_cast(float, (uint32_t)(127 - sh) << 23);
+    }
+  }
+
+  f32x16 accm[2][2], accl[2][2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { accm[r][m][i] = 0.f; accl[r][m][i] = 0.f; }
+
+  // register sets: weights of stage s live in wv[s & 1]; patch slice g (= 3 * chunk + round) in pv[g & 1]
+  u32x4 wv[2][K];
+  float pv[2][8];
+  auto load_w = [&](int stage, int set) {
+    const u32x4* ws = wsrc + (size_t)stage * WST;
+#pragma unroll
+    for (int k = 0; k < K; ++k) wv[set][k] = ws[tid + 256 * k];
+  };
+  auto store_w = [&](int set, int buf) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) wl[buf * WST + tid + 256 * k] = wv[set][k];
+  };
+  auto load_p = [&](int chunk, int k, int set) {
+    const uint32_t cbase = (uint32_t)chunk * kHsCC * plane_bytes;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      pv[set][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, goff[k], cbase + j * plane_bytes, 0));
+  };
+  // no branches anywhere in the stage body: with control flow the compiler's s_waitcnt bookkeeping merges states
+  // conservatively and every wait becomes vmcnt(0), i.e. a wait for the loads issued a moment ago
+  auto store_p = [&](int set, int k, int buf) {
+    u32x4 hi, lo;
+    split8(pv[set], xs, hi, lo);
+    u32x4* pd = patch + buf * 4 * PLANE + pcell[k];
+    u32x4* d0 = pcell[k] >= 0 ? pd : dummy;
+    u32x4* d1 = pcell[k] >= 0 ? pd + PLANE : dummy + 1;
+    *d0 = hi;
+    *d1 = lo;
+  };
+
+  const int pb_lane = khalf * 2 * PLANE + (wave * 2) * PW + l31;
+  const int wa_lane = khalf * 64 + l31;
+
+  // prologue: stage 0 complete in LDS; weights of stage 1 and the first slice of chunk 1 in flight
+  load_w(0, 0);
+  store_w(0, 0);
+#pragma unroll
+  for (int k = 0; k < PIT; ++k) { load_p(0, k, 0); store_p(0, k, 0); }
+  load_w(1, 1);                 // nchunks is even (>= 2): stage 1 and chunk 1 exist
+  load_p(1, 0, 1);
+  __syncthreads();
+
+  for (int cp = 0; cp < nchunks; cp += 2) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int s = 3 * cp + i;                 // global stage; s & 1 == i & 1 because cp is even
+      const int kh = i % 3, cpar = (i / 3) & 1; // kernel row, parity of this stage's chunk
+      const u32x4* pb0 = patch + cpar * 4 * PLANE + pb_lane;
+      const u32x4* wa0 = wl + (i & 1) * WST + wa_lane;
+      // fetch two stages ahead (weights of s+2, patch slice s+4) into the sets that were consumed last stage
+      // (past the end the last stage / chunk is fetched again and its copy in the idle buffers is never read)
+      load_w(s + 2 < nstages ? s + 2 : nstages - 1, i & 1);
+      load_p(s + 4 < nstages ? (s + 4) / 3 : nchunks - 1, (i + 1) % 3, i & 1);
+      __builtin_amdgcn_sched_barrier(0);      // the fetches stay at the top of the stage: two stages of latency cover
+#pragma unroll
+      for (int kw = 0; kw < K; ++kw) {
+        f16x8 A[2][2], B[2][2];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+          for (int m = 0; m < 2; ++m) A[pl][m] = __builtin_bit_cast(f16x8, wa0[(kw * 2 + pl) * 128 + m * 32]);
+#pragma unroll
+          for (int r = 0; r < 2; ++r) B[pl][r] = __builtin_bit_cast(f16x8, pb0[pl * PLANE + (r + kh) * PW + kw]);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            accm[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][m], B[0][r], accm[r][m], 0, 0, 0);
+            accl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][m], B[1][r], accl[r][m], 0, 0, 0);
+            accl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][m], B[0][r], accl[r][m], 0, 0, 0);
+          }
+        if (kw == 0) {
+          // what arrived during the previous stage goes to LDS under this stage's remaining MFMAs:
+          // weights of stage s+1 -> the other weight buffer, patch slice s+3 -> the next chunk's patch copy
+          store_w((i + 1) & 1, (i + 1) & 1);
+          store_p((i + 1) & 1, i % 3, ((i + 3) / 3) & 1);
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  const int ox = ox0 + l31;
+  const size_t img = (size_t)n * a.Cout * a.OH * a.OW;
+  const size_t plane_o = (size_t)a.OH * a.OW;
+  float rv[2][2][16];
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const int oy = oy0 + wave * 2 + rr;
+    const bool ok = a.res != nullptr && oy < a.OH && ox < a.OW;
+    const size_t pix = (size_t)oy * a.OW + ox;
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cl = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        rv[rr][half][r] = ok ? a.res[img + (size_t)(cout0 + cl) * plane_o + pix] : 0.f;
+      }
+  }
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const int oy = oy0 + wave * 2 + rr;
+    if (oy >= a.OH || ox >= a.OW) continue;
+    const size_t pix = (size_t)oy * a.OW + ox;
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cl = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        float v = (accm[rr][half][r] + accl[rr][half][r] * (1.f / kLoScale)) * xs_inv;
+        v = v * ss[cl] + ss[kHsCout + cl];
+        v += rv[rr][half][r];
+        if (a.relu) v = v > 0.f ? v : 0.f;
+        a.y[img + (size_t)(cout0 + cl) * plane_o + pix] = v;
+      }
   }
 }
 
@@ -622,7 +834,29 @@ int conv2d_hs_launch(const ConvSpec& L, Conv2dArgs a, hipStream_t s) {
     ADX_LAUNCH_CHECK();
     return ADX_OK;
   }
-  if (L.k == 3 && L.stride == 1 && !ds) return hs_launch_t<1, 3, 2, 2, false>(a, s);
+  if (L.k == 3 && L.stride == 1 && !ds) {
+    static int pipe = -1;
+    if (pipe < 0) {
+      const char* e = getenv("ADX_HS_PIPE");      // ADX_HS_PIPE=0: the one-stage-ahead kernel for every 3x3 conv
+      pipe = (e != nullptr && e[0] == '0') ? 0 : 1;
+    }
+    if (pipe && (L.cin_pad / kHsCC) % 2 == 0 && L.pad == 1) {
+      constexpr size_t lds = (size_t)2 * 64 * 340 + (size_t)2 * 3 * 256 * 16 + 2 * kHsCout * sizeof(float) + 16 + 32;
+      static bool attr = false;
+      if (!attr) {
+        ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+      }
+      a.tiles_x = ceil_div(a.OW, kTileW); a.tiles_y = ceil_div(a.OH, 8); a.cout_tiles = a.Cout / kHsCout;
+      const size_t grid = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y * a.N;
+      ADX_REQUIRE(grid < (1u << 31), "conv2d_hs: grid too large");
+      conv2d_hs3x3_kernel<<<dim3((unsigned)grid), dim3(256), lds, s>>>(a);
+      ADX_LAUNCH_CHECK();
+      return ADX_OK;
+    }
+    return hs_launch_t<1, 3, 2, 2, false>(a, s);
+  }
   if (L.k == 3 && L.stride == 2 && L.pad == 1) return ds ? hs_launch_t<2, 3, 1, 1, true>(a, s) : hs_launch_t<2, 3, 1, 1, false>(a, s);
   set_error("conv2d_hs: no kernel for k=%d stride=%d pad=%d%s", L.k, L.stride, L.pad, ds ? " with a fused downsample" : "");
   return ADX_ERR_INVALID;

@@ -206,7 +206,7 @@ def cpu_baseline(steps=2):
             "s_per_step": round(per, 3), "unet_only_steps_per_sec": round(1.0 / unet_s, 3)}
 
 
-def train_leg(dev, world, steps=3, warm=2):
+def train_leg(dev, world, steps=5, warm=3):
     """BASELINE configs[1]: NO_GUIDANCE training step at B=64, H=32: add_noise -> train-mode forward (batch-stat
     BatchNorm) -> MSE -> backward -> fused nan_to_num + AdamW + EMA.  One optimizer step = one denoising step."""
     import contextlib
@@ -216,6 +216,7 @@ def train_leg(dev, world, steps=3, warm=2):
     from autonomous_driving_with_diffusion_model_amd.optim import FusedAdamWEMA
     from autonomous_driving_with_diffusion_model_amd.parallel import GradientAverager
     from autonomous_driving_with_diffusion_model_amd.utils import procedural as P
+    torch.cuda.empty_cache()      # the sampling legs' workspaces go back to the driver before the 27 GB of tapes arrive
     cfg = create_cfg()
     cfg.MODEL.HORIZON = H
     with contextlib.redirect_stdout(sys.stderr):
