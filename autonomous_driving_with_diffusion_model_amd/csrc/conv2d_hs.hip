@@ -339,25 +339,40 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
 }
 
 // ---- 3x3 stride-1, deferred-store pipeline ---------------------------------------------------------------------
-// Same tile, LDS images and arithmetic as conv2d_hs_kernel<1,3,2,2,false>; what changes is WHEN staged data moves.
-// There the loads of stage s+1 are issued at the start of stage s and converted + written to LDS after its MFMAs,
-// so every stage ends with a serial tail (wait for HBM, ~60 VALU, 5 LDS writes, LDS drain, barrier) during which
-// this wave issues no MFMA -- and with two waves per SIMD the tails of the two workgroups meet often enough to
-// leave the matrix pipe idle for a third of the time (SQ_VALU_MFMA_BUSY 53 %).  Here data is fetched TWO stages
-// ahead into a second register set, and the set that arrived during the previous stage is split and written
-// between the MFMAs of this stage, where its VALU / LDS-write slots are free; a stage then ends with just the LDS
-// drain and the barrier.  Two chunks (6 stages) are unrolled so that every register-set index is a constant.
-__global__ void __launch_bounds__(256, 2) conv2d_hs3x3_kernel(const Conv2dArgs a) {
-  constexpr int K = 3, PH = 10, PW = 34, PLANE = PH * PW, NITEM = 2 * PLANE, PIT = 3;
-  constexpr int NW = 9 * 256, WST = 3 * 256;
-  static_assert(PIT * 256 >= NITEM, "three rounds cover the patch");
+// Same LDS images and arithmetic as conv2d_hs_kernel<1,3,2,2,false>; what changes is WHEN staged data moves and how
+// much of it a CU needs per MFMA.
+//  * There the loads of stage s+1 are issued at the start of stage s and converted + written to LDS after its MFMAs,
+//    so every stage ends with a serial tail (wait for HBM, ~60 VALU, 5 LDS writes, LDS drain, barrier).  Here data is
+//    fetched TWO stages ahead into a second register set, and the set that arrived during the previous stage is split
+//    and written between the MFMAs of this stage; a stage ends with just the LDS drain and the barrier.  Two chunks
+//    (6 stages) are unrolled so that every register-set index is a constant, and the stage body has no branches:
+//    with control flow the compiler's s_waitcnt bookkeeping merges states and every wait degrades to vmcnt(0).
+//  * Measured on the 4-wave tile (SQ counters, tools/pmc_sq.sh; 512->512 layer): SQ_VALU_MFMA_BUSY 53 % at an
+//    effective 1.98 GHz, i.e. ~1040 TFLOP/s of fp16 MFMA; ONE workgroup per CU is as fast as two, removing the LDS
+//    fragment reads changes 7 %, and tiles that move 18-35 % fewer operand bytes per MFMA (MODE 1 / 2) change
+//    nothing: the loop runs at the MFMA rate the chip sustains on random data (MI355X_MICROARCH.md quotes 1247
+//    TFLOP/s for a tuned bf16 GEMM at 1.9-1.95 GHz), not at a rate set by operand delivery.  Tile modes:
+//      MODE 0: 4 waves,  8 rows x 32 columns x  64 channels (two per CU)  19.5 KB per 36 MFMAs/wave
+//      MODE 1: 8 waves, 16 rows x 32 columns x  64 channels               25.4 KB per 2 x 36   (-35 %)
+//      MODE 2: 8 waves,  8 rows x 32 columns x 128 channels               31.9 KB per 2 x 36   (-18 %; 8-row maps)
+template <int MODE>
+__global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(const Conv2dArgs a) {
+  constexpr int NT = MODE == 0 ? 256 : 512;            // threads
+  constexpr int TH = MODE == 1 ? 16 : 8;               // output rows per workgroup
+  constexpr int CT = MODE == 2 ? 2 : 1;                // 64-channel slabs per workgroup
+  constexpr int K = 3, PH = TH + 2, PW = 34, PLANE = PH * PW, NITEM = 2 * PLANE;
+  constexpr int PIT = (NITEM + NT - 1) / NT;           // patch rounds = slices, one per stage while they last
+  constexpr int NW = 9 * 256, WST = 3 * 256 * CT;      // weight cells per chunk and 64-channel slab / per stage
+  constexpr int WIT = (WST + NT - 1) / NT;
+  static_assert(PIT <= K, "a patch slice travels with each stage of a chunk");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32x4* patch = reinterpret_cast<u32x4*>(smem_raw);   // 2 x [k-half][plane][PLANE]
-  u32x4* wl = patch + 2 * 4 * PLANE;                   // 2 x [kw][plane][k-half][64]
-  float* ss = reinterpret_cast<float*>(wl + 2 * WST);  // scale[64], shift[64], 4 words for the range reduction
-  u32x4* dummy = reinterpret_cast<u32x4*>(ss + 2 * kHsCout + 4);   // where the idle threads of the last round write
+  u32x4* wl = patch + 2 * 4 * PLANE;                   // 2 x [slab][kw][plane][k-half][64]
+  float* ss = reinterpret_cast<float*>(wl + 2 * WST);  // scale[64 CT], shift[64 CT], 8 words for the range reduction
+  u32x4* dummy = reinterpret_cast<u32x4*>(ss + 2 * 64 * CT + 8);   // where idle threads of a partial round write
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rowpair = MODE == 2 ? (wave & 3) : wave, slab = MODE == 2 ? (wave >> 2) : 0;
   int bid = blockIdx.x;
   {
     const int per = gridDim.x >> 3;
@@ -367,15 +382,15 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs3x3_kernel(const Conv2dArgs a
   const int tx = bid % a.tiles_x; bid /= a.tiles_x;
   const int ty = bid % a.tiles_y; bid /= a.tiles_y;
   const int n = bid;
-  const int oy0 = ty * 8, ox0 = tx * kTileW;
+  const int oy0 = ty * TH, ox0 = tx * kTileW;
   const int iy0 = oy0 - a.pad, ix0 = ox0 - a.pad;
-  const int cout0 = ct * kHsCout;
+  const int cout0 = (ct * CT + slab) * kHsCout;
   const int l31 = lane & 31, khalf = lane >> 5;
   const size_t hw = (size_t)a.H * a.W;
   const float* xin = a.x + (size_t)n * a.Cin * hw;
   const int nchunks = a.cin_pad / kHsCC;
   const int nstages = nchunks * K;
-  const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.w) + (size_t)ct * nchunks * NW;
+  const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.w) + (size_t)ct * CT * nchunks * NW;
   constexpr uint32_t kOutside = 0xC0000000u;
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(xin), 0, (int)((size_t)a.Cin * hw * sizeof(float)), 0x00020000);
@@ -384,7 +399,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs3x3_kernel(const Conv2dArgs a
   int pcell[PIT];
 #pragma unroll
   for (int k = 0; k < PIT; ++k) {
-    const int e = tid + 256 * k;
+    const int e = tid + NT * k;
     const int hg = e >= PLANE ? 1 : 0;
     const int p = e - hg * PLANE;
     const int py = p / PW, px = p - py * PW;
@@ -393,15 +408,26 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs3x3_kernel(const Conv2dArgs a
     goff[k] = ok ? (uint32_t)((hg * 8 * hw + (size_t)iy * a.W + ix) * sizeof(float)) : kOutside;
     pcell[k] = e < NITEM ? hg * 2 * PLANE + p : -1;
   }
-  if (tid < 2 * kHsCout) {
-    const int c = cout0 + (tid & (kHsCout - 1));
-    ss[tid] = a.scale == nullptr ? (tid < kHsCout ? 1.f : 0.f) : (tid < kHsCout ? a.scale[c] : a.shift[c]);
+  // weight cells of this thread: global offset inside a stage (slab-major) and LDS cell, or the dummy
+  int wsrc_off[WIT], wdst[WIT];
+#pragma unroll
+  for (int k = 0; k < WIT; ++k) {
+    const int e = tid + NT * k;
+    const int sl = e / 768, within = e - sl * 768;
+    const bool ok = e < WST;
+    wsrc_off[k] = ok ? sl * nchunks * NW + within : 0;
+    wdst[k] = ok ? e : -1;
+  }
+  if (tid < 2 * 64 * CT) {
+    const int half = tid / (64 * CT), cc = tid - half * 64 * CT;
+    const int c = ct * CT * kHsCout + cc;
+    ss[tid] = a.scale == nullptr ? (half == 0 ? 1.f : 0.f) : (half == 0 ? a.scale[c] : a.shift[c]);
   }
   float xs = 1.f, xs_inv = 1.f;
   if (a.x_amax != nullptr) {
-    uint32_t* red = reinterpret_cast<uint32_t*>(ss + 2 * kHsCout);
+    uint32_t* red = reinterpret_cast<uint32_t*>(ss + 2 * 64 * CT);
     uint32_t b = 0;
-    for (int i = tid; i < a.x_amax_n; i += 256) b = a.x_amax[i] > b ? a.x_amax[i] : b;
+    for (int i = tid; i < a.x_amax_n; i += NT) b = a.x_amax[i] > b ? a.x_amax[i] : b;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       const uint32_t o = (uint32_t)__shfl_xor((int)b, off, 64);
@@ -409,9 +435,9 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs3x3_kernel(const Conv2dArgs a
     }
     if (lane == 0) red[wave] = b;
     __syncthreads();
-    b = red[0] > red[1] ? red[0] : red[1];
-    b = red[2] > b ? red[2] : b;
-    b = red[3] > b ? red[3] : b;
+    b = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) b = red[w] > b ? red[w] : b;
     const int e = (int)((b >> 23) & 0xFF);
     if (e != 0 && e != 255) {
       int sh = 127 + 14 - e;
@@ -430,16 +456,19 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs3x3_kernel(const Conv2dArgs a
       for (int i = 0; i < 16; ++i) { accm[r][m][i] = 0.f; accl[r][m][i] = 0.f; }
 
   // register sets: weights of stage s live in wv[s & 1]; patch slice g (= 3 * chunk + round) in pv[g & 1]
-  u32x4 wv[2][K];
+  u32x4 wv[2][WIT];
   float pv[2][8];
   auto load_w = [&](int stage, int set) {
-    const u32x4* ws = wsrc + (size_t)stage * WST;
+    const u32x4* ws = wsrc + (size_t)stage * 768;
 #pragma unroll
-    for (int k = 0; k < K; ++k) wv[set][k] = ws[tid + 256 * k];
+    for (int k = 0; k < WIT; ++k) wv[set][k] = ws[wsrc_off[k]];
   };
   auto store_w = [&](int set, int buf) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) wl[buf * WST + tid + 256 * k] = wv[set][k];
+    for (int k = 0; k < WIT; ++k) {
+      u32x4* d = (WST % NT == 0 || wdst[k] >= 0) ? wl + buf * WST + wdst[k] : dummy + 2;
+      *d = wv[set][k];
+    }
   };
   auto load_p = [&](int chunk, int k, int set) {
     const uint32_t cbase = (uint32_t)chunk * kHsCC * plane_bytes;
@@ -447,8 +476,6 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs3x3_kernel(const Conv2dArgs a
     for (int j = 0; j < 8; ++j)
       pv[set][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, goff[k], cbase + j * plane_bytes, 0));
   };
-  // no branches anywhere in the stage body: with control flow the compiler's s_waitcnt bookkeeping merges states
-  // conservatively and every wait becomes vmcnt(0), i.e. a wait for the loads issued a moment ago
   auto store_p = [&](int set, int k, int buf) {
     u32x4 hi, lo;
     split8(pv[set], xs, hi, lo);
@@ -459,8 +486,8 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs3x3_kernel(const Conv2dArgs a
     *d1 = lo;
   };
 
-  const int pb_lane = khalf * 2 * PLANE + (wave * 2) * PW + l31;
-  const int wa_lane = khalf * 64 + l31;
+  const int pb_lane = khalf * 2 * PLANE + (rowpair * 2) * PW + l31;
+  const int wa_lane = slab * 768 + khalf * 64 + l31;
 
   // prologue: stage 0 complete in LDS; weights of stage 1 and the first slice of chunk 1 in flight
   load_w(0, 0);
@@ -481,7 +508,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs3x3_kernel(const Conv2dArgs a
       // fetch two stages ahead (weights of s+2, patch slice s+4) into the sets that were consumed last stage
       // (past the end the last stage / chunk is fetched again and its copy in the idle buffers is never read)
       load_w(s + 2 < nstages ? s + 2 : nstages - 1, i & 1);
-      load_p(s + 4 < nstages ? (s + 4) / 3 : nchunks - 1, (i + 1) % 3, i & 1);
+      if ((i + 1) % 3 < PIT) load_p(s + 4 < nstages ? (s + 4) / 3 : nchunks - 1, (i + 1) % 3, i & 1);
       __builtin_amdgcn_sched_barrier(0);      // the fetches stay at the top of the stage: two stages of latency cover
 #pragma unroll
       for (int kw = 0; kw < K; ++kw) {
@@ -505,7 +532,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs3x3_kernel(const Conv2dArgs a
           // what arrived during the previous stage goes to LDS under this stage's remaining MFMAs:
           // weights of stage s+1 -> the other weight buffer, patch slice s+3 -> the next chunk's patch copy
           store_w((i + 1) & 1, (i + 1) & 1);
-          store_p((i + 1) & 1, i % 3, ((i + 3) / 3) & 1);
+          if (i % 3 < PIT) store_p((i + 1) & 1, i % 3, ((i + 3) / 3) & 1);
         }
       }
       __syncthreads();
@@ -515,10 +542,11 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs3x3_kernel(const Conv2dArgs a
   const int ox = ox0 + l31;
   const size_t img = (size_t)n * a.Cout * a.OH * a.OW;
   const size_t plane_o = (size_t)a.OH * a.OW;
+  const float* sst = ss + slab * 64;
   float rv[2][2][16];
 #pragma unroll
   for (int rr = 0; rr < 2; ++rr) {
-    const int oy = oy0 + wave * 2 + rr;
+    const int oy = oy0 + rowpair * 2 + rr;
     const bool ok = a.res != nullptr && oy < a.OH && ox < a.OW;
     const size_t pix = (size_t)oy * a.OW + ox;
 #pragma unroll
@@ -531,7 +559,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs3x3_kernel(const Conv2dArgs a
   }
 #pragma unroll
   for (int rr = 0; rr < 2; ++rr) {
-    const int oy = oy0 + wave * 2 + rr;
+    const int oy = oy0 + rowpair * 2 + rr;
     if (oy >= a.OH || ox >= a.OW) continue;
     const size_t pix = (size_t)oy * a.OW + ox;
 #pragma unroll
@@ -540,7 +568,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs3x3_kernel(const Conv2dArgs a
       for (int r = 0; r < 16; ++r) {
         const int cl = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
         float v = (accm[rr][half][r] + accl[rr][half][r] * (1.f / kLoScale)) * xs_inv;
-        v = v * ss[cl] + ss[kHsCout + cl];
+        v = v * sst[cl] + sst[64 * CT + cl];
         v += rv[rr][half][r];
         if (a.relu) v = v > 0.f ? v : 0.f;
         a.y[img + (size_t)(cout0 + cl) * plane_o + pix] = v;
@@ -816,6 +844,25 @@ int conv2d_hs_launch_block_s2(const ConvSpec& c1, const ConvSpec& ds, const floa
   return conv2d_hs_launch(c1, a, s);
 }
 
+template <int MODE>
+static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
+  constexpr int NT = MODE == 0 ? 256 : 512, TH = MODE == 1 ? 16 : 8, CT = MODE == 2 ? 2 : 1;
+  constexpr size_t lds = (size_t)2 * 64 * (TH + 2) * 34 + (size_t)2 * 3 * 256 * CT * 16 + (2 * 64 * CT + 8) * sizeof(float) + 48;
+  static_assert(lds <= (MODE == 0 ? 80 : 160) * 1024, "LDS budget");
+  static bool attr = false;
+  if (!attr) {
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  a.tiles_x = ceil_div(a.OW, kTileW); a.tiles_y = ceil_div(a.OH, TH); a.cout_tiles = a.Cout / (kHsCout * CT);
+  const size_t grid = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y * a.N;
+  ADX_REQUIRE(grid < (1u << 31), "conv2d_hs: grid too large");
+  conv2d_hs3x3_kernel<MODE><<<dim3((unsigned)grid), dim3(NT), lds, s>>>(a);
+  ADX_LAUNCH_CHECK();
+  return ADX_OK;
+}
+
 int conv2d_hs_launch(const ConvSpec& L, Conv2dArgs a, hipStream_t s) {
   ADX_REQUIRE((size_t)L.cin * a.H * a.W * sizeof(float) < 0xC0000000u, "conv2d_hs: one image of the input exceeds the 32-bit byte offsets");
   const bool ds = a.w_ds != nullptr;
@@ -841,19 +888,17 @@ int conv2d_hs_launch(const ConvSpec& L, Conv2dArgs a, hipStream_t s) {
       pipe = (e != nullptr && e[0] == '0') ? 0 : 1;
     }
     if (pipe && (L.cin_pad / kHsCC) % 2 == 0 && L.pad == 1) {
-      constexpr size_t lds = (size_t)2 * 64 * 340 + (size_t)2 * 3 * 256 * 16 + 2 * kHsCout * sizeof(float) + 16 + 32;
-      static bool attr = false;
-      if (!attr) {
-        ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
+      static int mode_env = -2;       // ADX_HS_MODE=0|1|2 pins the tile mode (default: by shape)
+      if (mode_env == -2) {
+        const char* e = getenv("ADX_HS_MODE");
+        mode_env = e != nullptr ? atoi(e) : -1;
       }
-      a.tiles_x = ceil_div(a.OW, kTileW); a.tiles_y = ceil_div(a.OH, 8); a.cout_tiles = a.Cout / kHsCout;
-      const size_t grid = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y * a.N;
-      ADX_REQUIRE(grid < (1u << 31), "conv2d_hs: grid too large");
-      conv2d_hs3x3_kernel<<<dim3((unsigned)grid), dim3(256), lds, s>>>(a);
-      ADX_LAUNCH_CHECK();
-      return ADX_OK;
+      // The three tiles time within 3 % of each other on every ResNet-34 shape (the MFMA rate the chip sustains on
+      // random data paces all of them): short K loops take the small tile (better tail balance), long ones the
+      // 8-wave tiles that move fewer operand bytes per MFMA.
+      int mode = a.Cin < 256 ? 0 : (a.OH > 8 ? 1 : (a.Cout % 128 == 0 ? 2 : 0));
+      if (mode_env >= 0 && !(mode_env == 2 && a.Cout % 128 != 0)) mode = mode_env;
+      return mode == 1 ? hs3x3_launch<1>(a, s) : (mode == 2 ? hs3x3_launch<2>(a, s) : hs3x3_launch<0>(a, s));
     }
     return hs_launch_t<1, 3, 2, 2, false>(a, s);
   }
