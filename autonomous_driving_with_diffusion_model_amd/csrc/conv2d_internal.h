@@ -75,7 +75,7 @@ int conv2d_hs_launch_block_s2(const ConvSpec& c1, const ConvSpec& ds, const floa
                               float* yd, int N, int H, int W, hipStream_t s);
 // conv2d_wgrad_hs.hip: weight gradient of the 3x3 stride-1 convs on the fp16 matrix cores (dw is zeroed inside)
 bool conv2d_wgrad_hs_eligible(int Cin, int Cout, int k, int stride, int pad);
-int conv2d_wgrad_hs(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout,
+int conv2d_wgrad_hs(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, int stride,
                     const uint32_t* dy_amax, int dy_amax_n, hipStream_t s);
 inline int conv_out_dim(int h, int k, int s, int p) { return (h + 2 * p - k) / s + 1; }
 int maxpool_launch(const float* x, float* y, int planes, int H, int W, int OH, int OW, hipStream_t s);

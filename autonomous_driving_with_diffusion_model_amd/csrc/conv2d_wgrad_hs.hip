@@ -1,6 +1,6 @@
-// Weight gradient of the 3x3 stride-1 convolutions on the fp16 matrix cores (hi/lo split operands, see
+// Weight gradient of the 3x3 (stride 1 and 2) convolutions on the fp16 matrix cores (hi/lo split operands, see
 // conv2d_hs.hip for the arithmetic):
-//     dW[co][ci][kh][kw] = sum over (n, oy, ox) of dy[n][co][oy][ox] * x[n][ci][oy + kh - 1][ox + kw - 1]
+//     dW[co][ci][kh][kw] = sum over (n, oy, ox) of dy[n][co][oy][ox] * x[n][ci][S oy + kh - 1][S ox + kw - 1]
 // (torch.nn.grad.conv2d_weight of modeling/resnet.py's conv3x3).  Per tap this is a GEMM with M = co, N = ci and
 // the PIXELS as the reduction axis, so both operands are needed k-major while NCHW (and the forward kernel's LDS
 // image) is channel-major per pixel.  gfx950's transposing LDS read does the turn for free: activations and
@@ -34,41 +34,44 @@ typedef __attribute__((address_space(3))) h4 lds_h4;
 
 struct WgradHsArgs {
   const float* x;        // [N][Cin][H][W]
-  const float* dy;       // [N][Cout][H][W]
+  const float* dy;       // [N][Cout][OH][OW]
   float* dw;             // [Cout][Cin][3][3], zeroed by the caller
   const uint32_t* dy_amax;
   int dy_amax_n;
-  int N, Cin, Cout, H, W;
+  int N, Cin, Cout, H, W, OH, OW;
   int segs, units, units_per_wg, n_ci_tiles, n_co_tiles;
 };
 
 constexpr float kWLo = 2048.f;
 constexpr int kWThreads = 768;
 
+template <int SECOND>
 __device__ __forceinline__ f16x8 tr_pair(const unsigned char* p) {
-  // 8 consecutive pixels of this lane's channel: two transposing reads of 4 pixel rows each (64 B per pixel row)
+  // 8 consecutive k (pixels) of this lane's channel: two transposing reads of 4 pixel rows each (64 B per staged
+  // pixel; SECOND = byte distance of 4 k-steps: 256 for stride 1, 512 when every other staged pixel is a k)
   const u32x2 a = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4*)(p)));
-  const u32x2 b = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4*)(p + 256)));
+  const u32x2 b = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4*)(p + SECOND)));
   u32x4 v;
   v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
   return __builtin_bit_cast(f16x8, v);
 }
 
-template <int NPX>
+template <int NPX, int S>
 __global__ void __launch_bounds__(kWThreads) conv2d_wgrad_hs_kernel(const WgradHsArgs a) {
-  constexpr int NPXB = NPX + 2;                   // x row segment with its two halo columns
+  constexpr int NPXB = S * NPX + 2;               // x row segment with its halo columns
+  constexpr int NSLOT = S == 1 ? 4 : 6;           // x rows kept: 3 in use + S arriving
   constexpr int KS = NPX / 16;                    // MFMA k-steps per row segment
   constexpr int A_PLANE = 2 * NPX * 64;           // bytes: [co panel][pixel][32 halves]
   constexpr int A_BUF = 2 * A_PLANE;              // hi + lo
   constexpr int B_PLANE = 2 * NPXB * 64;          // bytes: [ci panel][pixel + halo][32 halves]
   constexpr int B_SLOT = 2 * B_PLANE;
   constexpr int NA = NPX * 8, NB = NPXB * 8;      // 16-byte cells per staged dy / x row
-  constexpr int PIT = (NA + NB + kWThreads - 1) / kWThreads;
+  constexpr int PIT = (NA + S * NB + kWThreads - 1) / kWThreads;
   static_assert(NA % 64 == 0, "a wave stages either dy cells or x cells");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* lA = smem;                       // 2 x A_BUF  (dy row r -> buffer r & 1)
-  unsigned char* lB = smem + 2 * A_BUF;           // 4 x B_SLOT (x row r -> slot r & 3)
-  uint32_t* red = reinterpret_cast<uint32_t*>(lB + 4 * B_SLOT);
+  unsigned char* lB = smem + 2 * A_BUF;           // NSLOT x B_SLOT (x row r -> slot r % NSLOT)
+  uint32_t* red = reinterpret_cast<uint32_t*>(lB + NSLOT * B_SLOT);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cb = wave / 6, nb = (wave / 3) % 2, kh = wave % 3;
@@ -112,27 +115,31 @@ __global__ void __launch_bounds__(kWThreads) conv2d_wgrad_hs_kernel(const WgradH
   // transposing reads: lane (16-lane group g, member 4q + p) supplies pixel row q, channels 4p..4p+3 of channel
   // group g & 1; the group's k half is g >> 1 (MFMA lanes 32..63 hold k = 8..15)
   const int gi = lane >> 4, li = lane & 15;
-  const int tr_lane = ((8 * (gi >> 1) + (li >> 2)) * 32 + (gi & 1) * 16 + 4 * (li & 3)) * 2;
-  const int aoff = cb * NPX * 64 + tr_lane;
-  const int boff = nb * NPXB * 64 + tr_lane;
+  const int tr_px = 8 * (gi >> 1) + (li >> 2), tr_ch = ((gi & 1) * 16 + 4 * (li & 3)) * 2;
+  const int aoff = cb * NPX * 64 + tr_px * 64 + tr_ch;
+  const int boff = nb * NPXB * 64 + tr_px * S * 64 + tr_ch;
 
   // staging cells of this thread (the same for every row): kind, LDS byte offset inside a buffer / slot, column
-  int sto[PIT], colv[PIT];
+  int sto[PIT], colv[PIT], rsel[PIT];
   uint32_t chan[PIT];
   bool isA[PIT];
+  const uint32_t dplane_bytes = (uint32_t)((size_t)a.OH * a.OW * sizeof(float));
 #pragma unroll
   for (int k = 0; k < PIT; ++k) {
     const int e = tid + kWThreads * k;
     isA[k] = e < NA;
+    rsel[k] = 0;
     if (isA[k]) {
       const int px = e % NPX, cg = e / NPX;
       sto[k] = ((cg >> 2) * NPX + px) * 64 + (cg & 3) * 16;
       colv[k] = px;
-      chan[k] = (uint32_t)cg * 8u * plane_bytes;
+      chan[k] = (uint32_t)cg * 8u * dplane_bytes;
     } else {
       const int e2 = e - NA;
-      const int pp = e2 % NPXB, cg = e2 / NPXB;
-      sto[k] = e2 < NB ? ((cg >> 2) * NPXB + pp) * 64 + (cg & 3) * 16 : -1;
+      const int r = e2 / NB, e3 = e2 - r * NB;
+      const int pp = e3 % NPXB, cg = e3 / NPXB;
+      sto[k] = r < S ? ((cg >> 2) * NPXB + pp) * 64 + (cg & 3) * 16 : -1;
+      rsel[k] = r;
       colv[k] = pp - 1;
       chan[k] = (uint32_t)cg * 8u * plane_bytes;
     }
@@ -144,23 +151,27 @@ __global__ void __launch_bounds__(kWThreads) conv2d_wgrad_hs_kernel(const WgradH
   for (int u = u0; u < u1; ++u) {
     const int n = u / a.segs, ox0 = (u - n * a.segs) * NPX;
     const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.dy + ((size_t)n * a.Cout + co0) * hw), 0, (int)(64 * plane_bytes), 0x00020000);
+        const_cast<float*>(a.dy + ((size_t)n * a.Cout + co0) * a.OH * a.OW), 0, (int)(64 * dplane_bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.x + ((size_t)n * a.Cin + ci0) * hw), 0, (int)(64 * plane_bytes), 0x00020000);
-    // iteration t: fetch dy row t+1 and x row t+2, multiply row t, publish the fetched rows
-    for (int t = -2; t < a.H; ++t) {
+    // iteration t: fetch dy row t+1 and the S x rows that output row t+1 adds to the window, multiply output row t,
+    // publish the fetched rows
+    for (int t = (S == 1 ? -2 : -1); t < a.OH; ++t) {
+      const int xrow0 = S * (t + 1) + (S == 1 ? 1 : 0);
 #pragma unroll
       for (int k = 0; k < PIT; ++k) {
         const bool ka = __builtin_amdgcn_readfirstlane((int)isA[k]) != 0;     // wave-uniform by construction
-        const int row = ka ? t + 1 : t + 2;
-        const int col = ox0 + colv[k];
-        const bool ok = sto[k] >= 0 && row >= 0 && row < a.H && col >= 0 && col < a.W;
-        const uint32_t vo = ok ? chan[k] + (uint32_t)(row * a.W + col) * 4u : kOutside;
         if (ka) {
+          const int row = t + 1, col = ox0 + colv[k];
+          const bool ok = row >= 0 && row < a.OH && col < a.OW;
+          const uint32_t vo = ok ? chan[k] + (uint32_t)(row * a.OW + col) * 4u : kOutside;
 #pragma unroll
           for (int j = 0; j < 8; ++j)
-            pv[k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdy, vo, j * plane_bytes, 0));
+            pv[k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdy, vo, j * dplane_bytes, 0));
         } else {
+          const int row = xrow0 + rsel[k], col = S * ox0 + colv[k];
+          const bool ok = sto[k] >= 0 && row >= 0 && row < a.H && col >= 0 && col < a.W;
+          const uint32_t vo = ok ? chan[k] + (uint32_t)(row * a.W + col) * 4u : kOutside;
 #pragma unroll
           for (int j = 0; j < 8; ++j)
             pv[k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo, j * plane_bytes, 0));
@@ -169,13 +180,14 @@ __global__ void __launch_bounds__(kWThreads) conv2d_wgrad_hs_kernel(const WgradH
       // kernel row 0 of output row 0 would read x row -1 (zero padding): nothing to add
       if (t >= 0 && !(kh == 0 && t == 0)) {
         const unsigned char* Ab = lA + (t & 1) * A_BUF + aoff;
-        const unsigned char* Bb = lB + ((t + kh - 1) & 3) * B_SLOT + boff;
+        const unsigned char* Bb = lB + ((S * t + kh - 1 + NSLOT) % NSLOT) * B_SLOT + boff;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const f16x8 Ahi = tr_pair(Ab + ks * 1024), Alo = tr_pair(Ab + A_PLANE + ks * 1024);
+          const f16x8 Ahi = tr_pair<256>(Ab + ks * 1024), Alo = tr_pair<256>(Ab + A_PLANE + ks * 1024);
 #pragma unroll
           for (int kw = 0; kw < 3; ++kw) {
-            const f16x8 Bhi = tr_pair(Bb + ks * 1024 + kw * 64), Blo = tr_pair(Bb + B_PLANE + ks * 1024 + kw * 64);
+            const f16x8 Bhi = tr_pair<256 * S>(Bb + ks * 1024 * S + kw * 64);
+            const f16x8 Blo = tr_pair<256 * S>(Bb + B_PLANE + ks * 1024 * S + kw * 64);
             am[kw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi, Bhi, am[kw], 0, 0, 0);
             al[kw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi, Blo, al[kw], 0, 0, 0);
             al[kw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo, Bhi, al[kw], 0, 0, 0);
@@ -195,7 +207,7 @@ __global__ void __launch_bounds__(kWThreads) conv2d_wgrad_hs_kernel(const WgradH
           h[j] = hj;
           l[j] = (_Float16)((v - (float)hj) * kWLo);
         }
-        unsigned char* d = ka ? lA + ((t + 1) & 1) * A_BUF + sto[k] : lB + ((t + 2) & 3) * B_SLOT + sto[k];
+        unsigned char* d = ka ? lA + ((t + 1) & 1) * A_BUF + sto[k] : lB + ((xrow0 + rsel[k]) % NSLOT) * B_SLOT + sto[k];
         *reinterpret_cast<u32x4*>(d) = __builtin_bit_cast(u32x4, h);
         *reinterpret_cast<u32x4*>(d + (ka ? A_PLANE : B_PLANE)) = __builtin_bit_cast(u32x4, l);
       }
@@ -233,43 +245,47 @@ bool conv2d_wgrad_hs_eligible(int Cin, int Cout, int k, int stride, int pad) {
     const char* w = getenv("ADX_WGRAD_EXACT");
     exact = ((e != nullptr && e[0] == '1') || (w != nullptr && w[0] == '1')) ? 1 : 0;
   }
-  return !exact && k == 3 && stride == 1 && pad == 1 && Cin % 64 == 0 && Cout % 64 == 0;
+  return !exact && k == 3 && (stride == 1 || stride == 2) && pad == 1 && Cin % 64 == 0 && Cout % 64 == 0;
 }
 
-template <int NPX>
+template <int NPX, int S>
 static int wgrad_hs_launch(WgradHsArgs a, hipStream_t s) {
-  constexpr size_t lds = (size_t)2 * (2 * 2 * NPX * 64) + (size_t)4 * (2 * 2 * (NPX + 2) * 64) + 64;
+  constexpr int NSLOT = S == 1 ? 4 : 6;
+  constexpr size_t lds = (size_t)2 * (2 * 2 * NPX * 64) + (size_t)NSLOT * (2 * 2 * (S * NPX + 2) * 64) + 64;
   constexpr size_t need = std::max(lds, (size_t)32 * 576 * sizeof(float));
+  static_assert(need <= 160 * 1024, "LDS budget");
   static bool attr = false;
   if (!attr) {
-    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad_hs_kernel<NPX>),
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad_hs_kernel<NPX, S>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     attr = true;
   }
-  a.segs = ceil_div(a.W, NPX);
+  a.segs = ceil_div(a.OW, NPX);
   a.units = a.N * a.segs;
   const int tiles = a.n_co_tiles * a.n_ci_tiles;
   int splits = std::max(1, 256 / tiles);          // one 12-wave workgroup per CU
   if (splits > a.units) splits = a.units;
   a.units_per_wg = ceil_div(a.units, splits);
   splits = ceil_div(a.units, a.units_per_wg);
-  conv2d_wgrad_hs_kernel<NPX><<<dim3((unsigned)(tiles * splits)), dim3(kWThreads), need, s>>>(a);
+  conv2d_wgrad_hs_kernel<NPX, S><<<dim3((unsigned)(tiles * splits)), dim3(kWThreads), need, s>>>(a);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
 }
 
-int conv2d_wgrad_hs(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout,
+int conv2d_wgrad_hs(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, int stride,
                     const uint32_t* dy_amax, int dy_amax_n, hipStream_t s) {
   ADX_REQUIRE(x && dy && dw, "conv2d_wgrad_hs: null tensor");
   ADX_REQUIRE((size_t)64 * H * W * sizeof(float) < 0xC0000000u, "conv2d_wgrad_hs: image too large for 32-bit offsets");
   WgradHsArgs a{};
   a.x = x; a.dy = dy; a.dw = dw; a.dy_amax = dy_amax; a.dy_amax_n = dy_amax_n;
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+  a.OH = conv_out_dim(H, 3, stride, 1); a.OW = conv_out_dim(W, 3, stride, 1);
   a.n_ci_tiles = Cin / 64; a.n_co_tiles = Cout / 64;
   ADX_CHECK_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cout * Cin * 9, s));
+  if (stride == 2) return wgrad_hs_launch<32, 2>(a, s);
   // rows of <= 32 (or 33..48 -> two 32-pixel segments waste less than one 64) pixels use the narrow variant
-  const int waste64 = ceil_div(W, 64) * 64 - W, waste32 = ceil_div(W, 32) * 32 - W;
-  return waste32 < waste64 ? wgrad_hs_launch<32>(a, s) : wgrad_hs_launch<64>(a, s);
+  const int waste64 = ceil_div(a.OW, 64) * 64 - a.OW, waste32 = ceil_div(a.OW, 32) * 32 - a.OW;
+  return waste32 < waste64 ? wgrad_hs_launch<32, 1>(a, s) : wgrad_hs_launch<64, 1>(a, s);
 }
 
 }  // namespace adx

@@ -350,7 +350,7 @@ int conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int
                  int pad, hipStream_t s, const uint32_t* dy_amax = nullptr, int dy_amax_n = 0) {
   ADX_REQUIRE(x && dy && dw, "conv2d_wgrad: null tensor");
   if (conv2d_wgrad_hs_eligible(Cin, Cout, k, stride, pad))
-    return conv2d_wgrad_hs(x, dy, dw, N, Cin, H, W, Cout, dy_amax, dy_amax_n, s);
+    return conv2d_wgrad_hs(x, dy, dw, N, Cin, H, W, Cout, stride, dy_amax, dy_amax_n, s);
   WgradArgs2 a;
   a.x = x; a.dy = dy; a.dw = dw;
   a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.pad = pad;

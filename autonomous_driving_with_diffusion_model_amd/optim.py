@@ -70,13 +70,16 @@ class FusedAdamWEMA:
                 raise RuntimeError("a parameter has no gradient (DDP find_unused_parameters=False contract)")
         lr = self.current_lr()
         self.step_count += 1
+        # pointer table through numpy (one vectorised write per column; per-element tensor indexing costs ~2 us each)
+        tn = self._table_host.numpy()
+        grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in self.params]
+        tn[:, 0] = [p.data_ptr() for p in self.params]
+        tn[:, 1] = [g.data_ptr() for g in grads]
+        tn[:, 2] = [t.data_ptr() for t in self.exp_avg]
+        tn[:, 3] = [t.data_ptr() for t in self.exp_avg_sq]
+        tn[:, 4] = [t.data_ptr() for t in self.shadow_params] if self.use_ema else 0
+        tn[:, 5] = [p.numel() for p in self.params]
         th = self._table_host
-        for i, p in enumerate(self.params):
-            g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-            th[i, 0], th[i, 1] = p.data_ptr(), g.data_ptr()
-            th[i, 2], th[i, 3] = self.exp_avg[i].data_ptr(), self.exp_avg_sq[i].data_ptr()
-            th[i, 4] = self.shadow_params[i].data_ptr() if self.use_ema else 0
-            th[i, 5] = p.numel()
         self._table_dev.copy_(th, non_blocking=True)
         decay = ema_decay(self.step_count, **self.ema_kw) if self.use_ema else 0.0
         L.check(L.lib().adx_adamw_ema_step(self._table_dev.data_ptr(), self._block_tensor.data_ptr(),

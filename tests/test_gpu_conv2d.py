@@ -120,25 +120,29 @@ def test_conv_non_finite_inputs_stay_loud():
     assert not torch.isfinite(y[0, :, 3:6, 4:7]).all()
 
 
-@pytest.mark.parametrize("cin,cout,h,w,n,dyscale", [(64, 64, 64, 225, 2, 1e-4), (128, 128, 32, 113, 2, 1.0),
-                                                   (256, 256, 16, 57, 3, 3e-7), (512, 512, 8, 29, 4, 1e-3),
-                                                   (64, 128, 9, 40, 1, 1e-5), (128, 64, 5, 70, 2, 20.0)])
-def test_conv3x3_weight_gradient_split_fp16(cin, cout, h, w, n, dyscale):
-    """adx_conv2d_wgrad (3x3 stride 1: fp16 matrix cores, transposing LDS reads, dy rescaled by its measured range)
-    against an fp64 evaluation; the bar is torch's own fp32 weight gradient on CPU and on the GPU, x1.5."""
+@pytest.mark.parametrize("cin,cout,h,w,n,dyscale,stride", [(64, 64, 64, 225, 2, 1e-4, 1), (128, 128, 32, 113, 2, 1.0, 1),
+                                                          (256, 256, 16, 57, 3, 3e-7, 1), (512, 512, 8, 29, 4, 1e-3, 1),
+                                                          (64, 128, 9, 40, 1, 1e-5, 1), (128, 64, 5, 70, 2, 20.0, 1),
+                                                          (64, 128, 64, 225, 2, 1e-4, 2), (128, 256, 32, 113, 2, 1.0, 2),
+                                                          (256, 512, 16, 57, 3, 1e-6, 2), (64, 64, 7, 9, 2, 1e-2, 2),
+                                                          (64, 128, 33, 70, 1, 1.0, 2)])
+def test_conv3x3_weight_gradient_split_fp16(cin, cout, h, w, n, dyscale, stride):
+    """adx_conv2d_wgrad (3x3, stride 1 and 2: fp16 matrix cores, transposing LDS reads, dy rescaled by its measured
+    range) against an fp64 evaluation; the bar is torch's own fp32 weight gradient on CPU and on the GPU, x1.5."""
     g = torch.Generator().manual_seed(cin + w)
     x = torch.randn(n, cin, h, w, generator=g).relu_()
-    dy = torch.randn(n, cout, h, w, generator=g) * dyscale
-    ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, 3, 3), dy.double(), padding=1)
-    f32 = torch.nn.grad.conv2d_weight(x, (cout, cin, 3, 3), dy, padding=1)
-    g32 = torch.nn.grad.conv2d_weight(x.to(DEV), (cout, cin, 3, 3), dy.to(DEV), padding=1).cpu()
-    dw = _ops().conv2d_weight_grad(x.to(DEV), dy.to(DEV), 3, stride=1, pad=1)
+    oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
+    dy = torch.randn(n, cout, oh, ow, generator=g) * dyscale
+    ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, 3, 3), dy.double(), stride=stride, padding=1)
+    f32 = torch.nn.grad.conv2d_weight(x, (cout, cin, 3, 3), dy, stride=stride, padding=1)
+    g32 = torch.nn.grad.conv2d_weight(x.to(DEV), (cout, cin, 3, 3), dy.to(DEV), stride=stride, padding=1).cpu()
+    dw = _ops().conv2d_weight_grad(x.to(DEV), dy.to(DEV), 3, stride=stride, pad=1)
     den = ref.abs().max().item()
     err = lambda t: (t.double().cpu() - ref).abs().max().item() / den  # noqa: E731
     assert err(dw) <= 1.5 * max(err(f32), err(g32)) + 2e-7, (err(dw), err(f32), err(g32))
 
 
-@pytest.mark.parametrize("cin,cout,k,stride,pad,h,w", [(64, 128, 3, 2, 1, 32, 57), (64, 128, 1, 2, 0, 32, 57),
+@pytest.mark.parametrize("cin,cout,k,stride,pad,h,w", [(32, 64, 3, 2, 1, 32, 57), (64, 128, 1, 2, 0, 32, 57),
                                                        (3, 64, 7, 2, 3, 64, 96)])
 def test_other_weight_gradients(cin, cout, k, stride, pad, h, w):
     g = torch.Generator().manual_seed(k + h)
