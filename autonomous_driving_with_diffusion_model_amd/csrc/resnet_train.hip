@@ -148,27 +148,78 @@ __global__ void __launch_bounds__(256) dilate2_kernel(const float* __restrict__ 
   *d = accumulate ? *d + src[i] : src[i];
 }
 
-__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                           float* __restrict__ dx, int planes, int H, int W, int OH,
-                                                           int OW) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (size_t)planes * OH * OW) return;
-  const int ox = idx % OW, oy = (idx / OW) % OH;
-  const size_t pl = idx / ((size_t)OW * OH);
-  const float* src = x + pl * H * W;
-  float m = -INFINITY;
-  int arg = -1;
-  for (int dyy = 0; dyy < 3; ++dyy) {
-    const int iy = oy * 2 - 1 + dyy;
-    if (iy < 0 || iy >= H) continue;
-    for (int dxx = 0; dxx < 3; ++dxx) {
-      const int ix = ox * 2 - 1 + dxx;
-      if (ix < 0 || ix >= W) continue;
-      const float v = src[(size_t)iy * W + ix];
-      if (v > m || arg < 0) { m = v; arg = iy * W + ix; }   // first maximum, like torch
+// MaxPool2d(3, 2, 1) backward without atomics, two passes.  Pass 1 (one wave per output row): which of its 9 taps
+// is each window's first maximum (torch's tie rule) -> one byte per output.  Pass 2 (one wave per input row): an
+// input pixel lies in at most 2 x 2 windows; it receives dy of those whose code points back at it.
+__global__ void __launch_bounds__(256) maxpool_argcode_kernel(const float* __restrict__ x, uint8_t* __restrict__ code,
+                                                               int H, int W, int OH, int OW) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int oy = blockIdx.y * 4 + wave;
+  const int pl = blockIdx.x;
+  if (oy >= OH) return;
+  const float* src = x + (size_t)pl * H * W;
+  uint8_t* dst = code + ((size_t)pl * OH + oy) * OW;
+  for (int ox0 = lane; ox0 < OW; ox0 += 256) {
+    float v[4][9];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int iy = oy * 2 - 1 + dy;
+      const bool rok = iy >= 0 && iy < H;
+      const float* row = src + (size_t)(rok ? iy : 0) * W;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int ix = (ox0 + 64 * q) * 2 - 1 + dx;
+          v[q][dy * 3 + dx] = (rok && ix >= 0 && ix < W) ? row[ix] : -INFINITY;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float m = -INFINITY;
+      int arg = -1;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int iy = oy * 2 - 1 + t / 3, ix = (ox0 + 64 * q) * 2 - 1 + t % 3;
+        const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        if (in && (v[q][t] > m || arg < 0)) { m = v[q][t]; arg = t; }
+      }
+      if (ox0 + 64 * q < OW) dst[ox0 + 64 * q] = (uint8_t)arg;
     }
   }
-  atomicAdd(dx + pl * H * W + arg, dy[idx]);
+}
+
+__global__ void __launch_bounds__(256) maxpool_bwd_gather_kernel(const uint8_t* __restrict__ code, const float* __restrict__ dy,
+                                                                  float* __restrict__ dx, int H, int W, int OH, int OW) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int iy = blockIdx.y * 4 + wave;
+  const int pl = blockIdx.x;
+  if (iy >= H) return;
+  const uint8_t* cp = code + (size_t)pl * OH * OW;
+  const float* gp = dy + (size_t)pl * OH * OW;
+  float* dst = dx + ((size_t)pl * H + iy) * W;
+  // windows containing row iy: oy with 2 oy - 1 <= iy <= 2 oy + 1
+  const int oya = (iy + 1) >> 1, oyb = iy >> 1;           // tap rows: iy - (2 oy - 1)
+  for (int ix = lane; ix < W; ix += 64) {
+    const int oxa = (ix + 1) >> 1, oxb = ix >> 1;
+    float g = 0.f;
+#pragma unroll
+    for (int a2 = 0; a2 < 2; ++a2) {
+      const int oy = a2 == 0 ? oya : oyb;
+      if (a2 == 1 && oyb == oya) continue;
+      if (oy < 0 || oy >= OH) continue;
+      const int ty = iy - (2 * oy - 1);
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2) {
+        const int ox = b2 == 0 ? oxa : oxb;
+        if (b2 == 1 && oxb == oxa) continue;
+        if (ox < 0 || ox >= OW) continue;
+        const int tx = ix - (2 * ox - 1);
+        if (cp[(size_t)oy * OW + ox] == ty * 3 + tx) g += gp[(size_t)oy * OW + ox];
+      }
+    }
+    dst[ix] = g;
+  }
 }
 
 // avgpool + fc backward; one workgroup per image.  pooled is recomputed.
@@ -705,10 +756,14 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
     float* dstem = nullptr;
     for (auto p : gb) if (p != g_cur && p != gb[4]) { dstem = p; break; }
     const size_t nin = (size_t)batch * 64 * tape->ph * tape->pw;
-    ADX_CHECK_HIP(hipMemsetAsync(dstem, 0, sizeof(float) * nin, s));
-    const size_t nout = (size_t)batch * 64 * tape->poh * tape->pow_;
-    maxpool_bwd_kernel<<<dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, s>>>(tape->pool_in, g_cur, dstem, batch * 64,
-                                                                                tape->ph, tape->pw, tape->poh, tape->pow_);
+    (void)nin;
+    // the byte codes live in the (still unused) dilation buffer
+    uint8_t* code = reinterpret_cast<uint8_t*>(gb[4]);
+    ADX_REQUIRE(dstem != gb[4] && g_cur != gb[4], "adx_resnet_backward: scratch buffer clash");
+    maxpool_argcode_kernel<<<dim3(batch * 64, ceil_div(tape->poh, 4)), dim3(256), 0, s>>>(tape->pool_in, code, tape->ph, tape->pw,
+                                                                                      tape->poh, tape->pow_);
+    maxpool_bwd_gather_kernel<<<dim3(batch * 64, ceil_div(tape->ph, 4)), dim3(256), 0, s>>>(code, g_cur, dstem, tape->ph, tape->pw,
+                                                                                        tape->poh, tape->pow_);
     ADX_LAUNCH_CHECK();
     float* draw = nullptr;
     for (auto p : gb) if (p != g_cur && p != gb[4] && p != dstem) { draw = p; break; }
