@@ -82,7 +82,7 @@ def pmc_traffic(key):
 
 
 def conv2d_roofline(dev, reps=10):
-    """Dominant kernel of the timed region: conv2d_hs_kernel<1,3,2,2,false> (the 29 stride-1 3x3 convs of one
+    """Dominant kernel of the timed region: conv2d_hs3x3_kernel (the 29 stride-1 3x3 convs of one
     perception pass).  Every distinct shape is launched alone through the C ABI and timed with HIP events on the
     launch stream; the launch-mix average is what rocprofv3's per-kernel average shows.
 
@@ -117,13 +117,13 @@ def conv2d_roofline(dev, reps=10):
     avg_ms = tot_ms / count
     equiv = tot_fl / count / avg_ms / 1e9      # algorithmic TFLOP/s
     achieved = 3.0 * equiv                     # fp16 MFMA TFLOP/s issued
-    return {"kernel": "conv2d_hs_kernel<1,3,2,2,false> (ResNet-34 3x3 stride-1 convs, B=64, 3x256x900; fp32-grade result "
+    return {"kernel": "conv2d_hs3x3_kernel<0|1|2> (ResNet-34 3x3 stride-1 convs, B=64, 3x256x900; fp32-grade result "
                       "from fp16 hi/lo split operands, 3 MFMA products per multiply-add)",
             "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_F16_TFLOPS, 4),
             "achieved_note": "fp16 MFMA flops issued = 3 x algorithmic conv flops, / HIP-event launch time",
             "fp32_equivalent_tflops": round(equiv, 1), "fp32_mfma_peak_tflops": PEAK_F32_TFLOPS,
-            "traffic": pmc_traffic("conv2d_hs_kernel<1,3"),
+            "traffic": pmc_traffic("conv2d_hs3x3_kernel"),
             "traffic_note": "bytes/launch, FETCH_SIZE+WRITE_SIZE from profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc passes)",
             "avg_launch_ms": round(avg_ms, 4), "launches_per_step": count,
             "algorithmic_gflop_per_launch": round(tot_fl / count / 1e9, 2),

@@ -35,20 +35,27 @@ def main():
     for c in bench.resnet_conv_table(*bench.IMG):
         if c[3] == 1:
             shapes[c] = shapes.get(c, 0) + 1
-    name = next(k for k in fetch if "conv2d_hs_kernel<1, 3" in k)
+    def lookup(table, grid):
+        for kname, grids_ in table.items():
+            if "conv2d_hs3x3_kernel" in kname and grid in grids_:
+                return grids_[grid]
+        raise KeyError(grid)
+
     grids = {}
     for (cin, cout, k, s, p, h, w), cnt in shapes.items():
-        wgs = bench.B * ((h + 7) // 8) * ((w + 31) // 32) * (cout // 64)
-        grids[wgs * 256] = (f"{cin}->{cout} @{h}x{w}", cnt)
+        mode = 0 if cin < 256 else (1 if h > 8 else 2)       # conv2d_hs_launch's tile-mode rule
+        th, ct, nt = (16 if mode == 1 else 8), (2 if mode == 2 else 1), (256 if mode == 0 else 512)
+        wgs = bench.B * ((h + th - 1) // th) * ((w + 31) // 32) * (cout // (64 * ct))
+        grids[wgs * nt] = (f"{cin}->{cout} @{h}x{w} (tile mode {mode})", cnt)
     per_shape, tf, tw, n = {}, 0.0, 0.0, 0
     for g, (label, cnt) in grids.items():
-        fv, wv = fetch[name][g], write[name][g]
+        fv, wv = lookup(fetch, g), lookup(write, g)
         f_, w_ = sum(fv) / len(fv), sum(wv) / len(wv)
         per_shape[label] = {"count": cnt, "fetch": f_, "write": w_}
         tf += f_ * cnt
         tw += w_ * cnt
         n += cnt
-    res["kernels"]["conv2d_hs_kernel<1,3,2,2,false>"] = {"per_shape": per_shape, "fetch": tf / n, "write": tw / n,
+    res["kernels"]["conv2d_hs3x3_kernel<0|1|2>"] = {"per_shape": per_shape, "fetch": tf / n, "write": tw / n,
                                                          "traffic": (tf + tw) / n}
     tname = next(k for k in fetch if "tconv_kernel<1, 4" in k)
     fv = [v for g in fetch[tname].values() for v in g]
