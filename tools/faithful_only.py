@@ -1,0 +1,41 @@
+"""The reference-faithful sampling leg alone (3 warm-up + 20 timed steps), for kernel-level profiling."""
+import contextlib
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+import bench  # noqa: E402
+from autonomous_driving_with_diffusion_model_amd import scheduler as S  # noqa: E402
+from autonomous_driving_with_diffusion_model_amd.config import create_cfg  # noqa: E402
+from autonomous_driving_with_diffusion_model_amd.modeling import build_model  # noqa: E402
+from autonomous_driving_with_diffusion_model_amd.utils import procedural as P  # noqa: E402
+
+dev = torch.device("cuda:0")
+cfg = create_cfg()
+cfg.MODEL.HORIZON = bench.H
+cfg.TRAIN.USE_COND = cfg.GUIDANCE.USE_COND = "FREE_GUIDANCE"
+cfg.GUIDANCE.FREE_SCALE, cfg.EVAL.SAMPLE_STEPS = bench.FREE_SCALE, bench.N_INFER
+with contextlib.redirect_stdout(sys.stderr):
+    model = build_model(cfg)
+P.load_procedural(model, 0)
+model = model.to(dev).eval()
+model.cache_perception = False
+sch = S.GuidanceDDIMScheduler(cfg=cfg, thresholding=True, **bench.SCHED_KW)
+sch.set_timesteps(bench.N_INFER, device=dev)
+d = {k: v.to(dev) for k, v in P.synthetic_batch(bench.B, bench.H, image_hw=bench.IMG, seed=0).items()}
+cond = torch.cat([d["target"], torch.zeros_like(d["target"])], 0)
+ts = list(sch.timesteps)
+trajs = d["init_trajs"].clone()
+trajs[:, 0, :3] = 0
+with torch.no_grad():
+    for i in range(23):
+        if i == 3:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        t = ts[i % len(ts)]
+        out = model(torch.cat([trajs, trajs], 0), d["imgs"], t.reshape(-1), cond=cond)
+        trajs = sch.step(out, t, trajs, cfg_scale=bench.FREE_SCALE, zero_first=True).prev_sample
+torch.cuda.synchronize()
+print(f"{(time.perf_counter() - t0) / 20 * 1e3:.3f} ms per faithful step")
