@@ -562,10 +562,24 @@ int adx_resnet_forward(adx_resnet* r, const void* packed, void* workspace, const
   buf[2] = buf[1] + act;
 
   size_t ci = 0;
-  int rc = conv2d_launch(r->convs[ci++], base, img, nullptr, stem, batch, h, w, 1, s);
-  if (rc != ADX_OK) return rc;
-  rc = maxpool_launch(stem, buf[0], batch * 64, h1, w1, h2, w2, s);
-  if (rc != ADX_OK) return rc;
+  int rc;
+  {
+    const ConvSpec& c0 = r->convs[ci++];
+    static int fuse = -1;           // ADX_STEM_POOL=0 keeps the stem and the pool as two launches
+    if (fuse < 0) {
+      const char* e = getenv("ADX_STEM_POOL");
+      fuse = (e != nullptr && e[0] == '0') ? 0 : 1;
+    }
+    if (fuse && conv2d_hs_eligible(c0)) {
+      rc = conv2d_hs_stem_pool(c0, img, base + c0.o_w, base + c0.o_scale, base + c0.o_shift, buf[0], batch, h, w, s);
+      if (rc != ADX_OK) return rc;
+    } else {
+      rc = conv2d_launch(c0, base, img, nullptr, stem, batch, h, w, 1, s);
+      if (rc != ADX_OK) return rc;
+      rc = maxpool_launch(stem, buf[0], batch * 64, h1, w1, h2, w2, s);
+      if (rc != ADX_OK) return rc;
+    }
+  }
   int cur = 0, H = h2, W = w2;
   for (size_t b = 0; b < r->block_has_ds.size(); ++b) {
     const ConvSpec& c1 = r->convs[ci++];

@@ -584,23 +584,44 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
 // MFMA (K = 16) covers two combos.  11 k-steps x 3 products per 32x32 tile; 84 % of the k slots are real work.
 // One workgroup owns a band of 8 output rows of one image and walks its 32-column tiles: the 45 KB split weight
 // image is loaded into LDS once per band, the patch of tile i+1 is fetched while tile i is multiplied.
-constexpr int kStemSteps = 11;
-constexpr int kStemPH = 21, kStemPP = 72;                 // patch rows, row pitch in halves (70 columns are staged)
-constexpr int kStemCP = kStemPH * kStemPP;                // halves per channel plane
-constexpr int kStemPlane = 3 * kStemCP;                   // halves per split plane
-constexpr int kStemItems = 3 * kStemPH * 35;              // (channel, row, column pair) cells per tile
-constexpr int kStemPIT = (kStemItems + 255) / 256;
+// max with torch's NaN rule (a NaN in the window wins)
+__device__ __forceinline__ float pool_max3(float a, float b, float c) {
+  float m = a;
+  m = (b > m || b != b) ? b : m;
+  m = (c > m || c != c) ? c : m;
+  return m;
+}
 
+constexpr int kStemSteps = 11;
+constexpr int kStemPP = 72;                               // patch row pitch in halves (70 columns are staged)
+
+// POOL = true additionally applies MaxPool2d(3, 2, 1) (modeling/resnet.py:197) before anything is written: the stem's
+// own output (944 MB at B=64, 3x256x900 -- the largest tensor of the network) is then never stored nor re-read.  A
+// workgroup produces a band of 4 pooled rows, one per wave: the wave multiplies the three stem rows of its pooled
+// row one after the other (64 accumulators each, folded into a running maximum), so the vertical maximum needs no
+// exchange at the price of computing the shared odd rows twice (+50 % MFMAs, still cheaper than the traffic it
+// removes); the horizontal maximum takes the neighbouring lanes (shuffles) and, at a tile's left edge, the last
+// column of the previous tile (parked in LDS while the workgroup walks its band).  One patch copy (the next tile
+// waits in registers), so two workgroups still fit a CU.
+template <bool POOL>
 __global__ void __launch_bounds__(256, 2) conv2d_hs_stem_kernel(const Conv2dArgs a) {
+  constexpr int NT = 256;
+  constexpr int PH = POOL ? 25 : 21;                       // patch rows (9 / 8 stem rows)
+  constexpr int PBUF = POOL ? 1 : 2;
+  constexpr int CP = PH * kStemPP;                         // halves per channel plane
+  constexpr int PLANEH = 3 * CP;                           // halves per split plane
+  constexpr int ITEMS = 3 * PH * 35;                       // (channel, row, column pair) cells per tile
+  constexpr int PIT = (ITEMS + NT - 1) / NT;
+  constexpr int NROW = POOL ? 3 : 1;                       // passes per tile: stem rows folded into one pooled row
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32x4* wl = reinterpret_cast<u32x4*>(smem_raw);                         // [step][plane][k-half][64]
-  uint32_t* patch = reinterpret_cast<uint32_t*>(wl + kStemSteps * 256);   // 2 x [plane][channel][row][pitch/2] dwords
-  float* ss = reinterpret_cast<float*>(patch + 2 * kStemPlane);           // 2 bufs x 2 planes x kStemPlane/2 dwords
+  uint32_t* patch = reinterpret_cast<uint32_t*>(wl + kStemSteps * 256);   // PBUF x [plane][channel][row][pitch/2] dwords
+  float* ss = reinterpret_cast<float*>(patch + PBUF * PLANEH);            // a buffer = 2 planes x PLANEH/2 dwords
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, khalf = lane >> 5;
   const int n = blockIdx.x / a.tiles_y, ty = blockIdx.x - n * a.tiles_y;
-  const int oy0 = ty * 8, iy0 = oy0 * 2 - 3;
+  const int oy0 = POOL ? ty * 8 - 1 : ty * 8, iy0 = oy0 * 2 - 3;          // first stem row of the band
   const size_t hw = (size_t)a.H * a.W;
   const float* xin = a.x + (size_t)n * 3 * hw;
   constexpr uint32_t kOutside = 0xC0000000u;
@@ -616,27 +637,32 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_stem_kernel(const Conv2dArgs
     const int c = tid & (kHsCout - 1);
     ss[tid] = a.scale == nullptr ? (tid < kHsCout ? 1.f : 0.f) : (tid < kHsCout ? a.scale[c] : a.shift[c]);
   }
+  // POOL: vertical maxima of the previous tile's last column (left neighbour of lane 0): [wave][32 registers][k-half]
+  float* cbuf = ss + 2 * kHsCout + wave * 64 + khalf;
+  if (POOL && l31 == 0) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) cbuf[2 * i] = -INFINITY;
+  }
 
-  // per-thread cells: (channel, patch row, column pair); the row part of the gather offset is tile independent
   // cell k of this thread: (channel, patch row, column pair); its geometry is recomputed where it is used (a few
-  // integer ops per tile) instead of living in registers beside the 128 accumulators
+  // integer ops per tile) instead of living in registers beside the accumulators
   auto decode = [&](int k, int& c, int& py, int& pp) {
-    int e = tid + 256 * k;
+    int e = tid + NT * k;
     asm volatile("" : "+v"(e));    // opaque: otherwise the geometry is hoisted out of the tile loop and spilled
-    c = e / (kStemPH * 35);
-    const int rem = e - c * (kStemPH * 35);
+    c = e / (PH * 35);
+    const int rem = e - c * (PH * 35);
     py = rem / 35;
     pp = rem - py * 35;
   };
-  float pv[kStemPIT][2];
+  float pv[PIT][2];
   auto load_p = [&](int tx) {
     const int ix0 = tx * 64 - 3;
 #pragma unroll
-    for (int k = 0; k < kStemPIT; ++k) {
+    for (int k = 0; k < PIT; ++k) {
       int c, py, pp;
       decode(k, c, py, pp);
       const int ix = ix0 + 2 * pp, iy = iy0 + py;
-      const bool rok = tid + 256 * k < kStemItems && iy >= 0 && iy < a.H;
+      const bool rok = tid + NT * k < ITEMS && iy >= 0 && iy < a.H;
       const uint32_t grow = (uint32_t)(c * (int)hw + iy * a.W) * 4u;
       const uint32_t o0 = (rok && ix >= 0 && ix < a.W) ? grow + (uint32_t)ix * 4u : kOutside;
       const uint32_t o1 = (rok && ix + 1 >= 0 && ix + 1 < a.W) ? grow + (uint32_t)(ix + 1) * 4u : kOutside;
@@ -645,10 +671,10 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_stem_kernel(const Conv2dArgs
     }
   };
   auto store_p = [&](int buf) {
-    uint32_t* pd = patch + buf * kStemPlane;     // a buffer = 2 planes of kStemPlane/2 dwords
+    uint32_t* pd = patch + buf * PLANEH;
 #pragma unroll
-    for (int k = 0; k < kStemPIT; ++k) {
-      if (kStemPIT * 256 == kStemItems || tid + 256 * k < kStemItems) {
+    for (int k = 0; k < PIT; ++k) {
+      if (PIT * NT == ITEMS || tid + NT * k < ITEMS) {
         typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
         f16x2 h, l;
 #pragma unroll
@@ -659,77 +685,142 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_stem_kernel(const Conv2dArgs
         }
         int c, py, pp;
         decode(k, c, py, pp);
-        const int dw = (c * kStemCP + py * kStemPP) / 2 + pp;
+        const int dw = (c * CP + py * kStemPP) / 2 + pp;
         pd[dw] = __builtin_bit_cast(uint32_t, h);
-        pd[kStemPlane / 2 + dw] = __builtin_bit_cast(uint32_t, l);
+        pd[PLANEH / 2 + dw] = __builtin_bit_cast(uint32_t, l);
       }
     }
   };
 
   const u32x4* wa0 = wl + khalf * 64 + l31;
-  const size_t img = (size_t)n * a.Cout * a.OH * a.OW;
-  const size_t plane_o = (size_t)a.OH * a.OW;
+  // output geometry: the stem map (a.OH x a.OW) or, pooled, its MaxPool2d(3, 2, 1) image
+  const int PHo = POOL ? (a.OH - 1) / 2 + 1 : a.OH, PWo = POOL ? (a.OW - 1) / 2 + 1 : a.OW;
+  const size_t img = (size_t)n * a.Cout * PHo * PWo;
+  const size_t plane_o = (size_t)PHo * PWo;
 
   load_p(0);
   store_p(0);
   __syncthreads();
   for (int tx = 0; tx < a.tiles_x; ++tx) {
     if (tx + 1 < a.tiles_x) load_p(tx + 1);
-    const uint32_t* pb0 = patch + (tx & 1) * kStemPlane + (wave * 2 * 2) * (kStemPP / 2) + l31;
-    f32x16 accm[2][2], accl[2][2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { accm[r][m][i] = 0.f; accl[r][m][i] = 0.f; }
+    const int ox = tx * kTileW + l31;
+    float vm[2][16];                 // POOL: running vertical maximum of this wave's pooled row
 #pragma unroll 1
-    for (int step = 0; step < kStemSteps; ++step) {
-      // this lane's (channel, kernel row): combo 2*step + khalf; the 22nd combo has zero weights and re-reads the 21st
-      const int c0 = 2 * step, c1 = 2 * step + 1 > 20 ? 20 : 2 * step + 1;
-      const int off0 = ((c0 / 7) * kStemCP + (c0 % 7) * kStemPP) / 2, off1 = ((c1 / 7) * kStemCP + (c1 % 7) * kStemPP) / 2;
-      const uint32_t* pb = pb0 + (khalf ? off1 : off0);
-      f16x8 A[2][2], B[2][2];
+    for (int pass = 0; pass < NROW; ++pass) {
+      // stem rows of this pass: POOL: row 2 (4 ty + w) - 1 + pass (one row); else rows 8 ty + 2 w, + 1
+      const int prow = POOL ? (2 * wave + pass) * 2 : wave * 2 * 2;     // first patch row
+      const uint32_t* pb0 = patch + (PBUF == 2 ? (tx & 1) * PLANEH : 0) + prow * (kStemPP / 2) + l31;
+      constexpr int NR = POOL ? 1 : 2;
+      f32x16 accm[NR][2], accl[NR][2];
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) {
+      for (int r = 0; r < NR; ++r)
 #pragma unroll
-        for (int m = 0; m < 2; ++m) A[pl][m] = __builtin_bit_cast(f16x8, wa0[(step * 2 + pl) * 128 + m * 32]);
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const uint32_t* q = pb + pl * (kStemPlane / 2) + r * 2 * (kStemPP / 2);
-          u32x4 v;
-          v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
-          B[pl][r] = __builtin_bit_cast(f16x8, v);
+          for (int i = 0; i < 16; ++i) { accm[r][m][i] = 0.f; accl[r][m][i] = 0.f; }
+      struct Frags { f16x8 A[2][2], B[2][NR]; };
+      auto fetch = [&](Frags& f, int step) {
+        // this lane's (channel, kernel row): combo 2*step + khalf; the 22nd combo has zero weights, re-reads the 21st
+        const int c0 = 2 * step, c1 = 2 * step + 1 > 20 ? 20 : 2 * step + 1;
+        const int off0 = ((c0 / 7) * CP + (c0 % 7) * kStemPP) / 2, off1 = ((c1 / 7) * CP + (c1 % 7) * kStemPP) / 2;
+        const uint32_t* pb = pb0 + (khalf ? off1 : off0);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+          for (int m = 0; m < 2; ++m) f.A[pl][m] = __builtin_bit_cast(f16x8, wa0[(step * 2 + pl) * 128 + m * 32]);
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            const uint32_t* q = pb + pl * (PLANEH / 2) + r * 2 * (kStemPP / 2);
+            u32x4 v;
+            v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+            f.B[pl][r] = __builtin_bit_cast(f16x8, v);
+          }
+        }
+      };
+      auto mfmas = [&](const Frags& f) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            accm[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.A[0][m], f.B[0][r], accm[r][m], 0, 0, 0);
+            accl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.A[0][m], f.B[1][r], accl[r][m], 0, 0, 0);
+            accl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.A[1][m], f.B[0][r], accl[r][m], 0, 0, 0);
+          }
+      };
+      if (POOL) {
+        // one stem row per pass = 6 MFMAs per k-step: the fragments of step s+1 are read under the MFMAs of step s
+        // (with the 128 accumulators of the two-row variant the second fragment set does not fit: it spills)
+        Frags fr[2];
+        fetch(fr[0], 0);
+#pragma unroll
+        for (int step = 0; step < kStemSteps; ++step) {
+          if (step + 1 < kStemSteps) fetch(fr[(step + 1) & 1], step + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          mfmas(fr[step & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll 1
+        for (int step = 0; step < kStemSteps; ++step) {
+          Frags f;
+          fetch(f, step);
+          mfmas(f);
         }
       }
+      if (!POOL) {
 #pragma unroll
-      for (int r = 0; r < 2; ++r)
+        for (int rr = 0; rr < NR; ++rr) {
+          const int oy = oy0 + wave * 2 + rr;
+          if (oy < a.OH && ox < a.OW) {
+            const size_t pix = (size_t)oy * a.OW + ox;
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          accm[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][m], B[0][r], accm[r][m], 0, 0, 0);
-          accl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][m], B[1][r], accl[r][m], 0, 0, 0);
-          accl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][m], B[0][r], accl[r][m], 0, 0, 0);
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int cl = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                float v = accm[rr][half][r] + accl[rr][half][r] * (1.f / kLoScale);
+                v = v * ss[cl] + ss[kHsCout + cl];
+                if (a.relu) v = v > 0.f ? v : 0.f;
+                a.y[img + (size_t)cl * plane_o + pix] = v;
+              }
+          }
         }
-    }
-    if (tx + 1 < a.tiles_x) store_p((tx + 1) & 1);
-    // epilogue of this tile (registers only), then the barrier that publishes the next patch
-    const int ox = tx * kTileW + l31;
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      const int oy = oy0 + wave * 2 + rr;
-      if (oy < a.OH && ox < a.OW) {
-        const size_t pix = (size_t)oy * a.OW + ox;
+      } else {
+        // BN + ReLU; rows / columns outside the stem map are the pool's padding
+        const int oy = oy0 + 2 * wave + pass;
+        const bool in = oy >= 0 && oy < a.OH && ox < a.OW;
 #pragma unroll
         for (int half = 0; half < 2; ++half)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int cl = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-            float v = accm[rr][half][r] + accl[rr][half][r] * (1.f / kLoScale);
-            v = v * ss[cl] + ss[kHsCout + cl];
-            if (a.relu) v = v > 0.f ? v : 0.f;
-            a.y[img + (size_t)cl * plane_o + pix] = v;
+            float t = (accm[0][half][r] + accl[0][half][r] * (1.f / kLoScale)) * ss[cl] + ss[kHsCout + cl];
+            if (a.relu) t = t > 0.f ? t : 0.f;
+            t = in ? t : -INFINITY;
+            vm[half][r] = pass == 0 ? t : pool_max3(vm[half][r], t, -INFINITY);
           }
       }
+    }
+    if (POOL) {
+      // horizontal: pooled column 16 tx + i sits on lane 2 i; left neighbour of lane 0 = previous tile's lane 31
+      const int pr = ty * 4 + wave, pq = tx * 16 + (l31 >> 1);
+      const bool st = pr < PHo && (l31 & 1) == 0 && pq < PWo;
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float up = __shfl_up(vm[half][r], 1, 32), dn = __shfl_down(vm[half][r], 1, 32);
+          const float left = l31 == 0 ? cbuf[2 * (half * 16 + r)] : up;     // written by lane 31 one tile ago
+          const float right = l31 == 31 ? -INFINITY : dn;
+          const float m = pool_max3(left, vm[half][r], right);
+          if (l31 == 31) cbuf[2 * (half * 16 + r)] = vm[half][r];
+          const int cl = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+          if (st) a.y[img + (size_t)cl * plane_o + (size_t)pr * PWo + pq] = m;
+        }
+    }
+    if (tx + 1 < a.tiles_x) {
+      if (PBUF == 1) __syncthreads();        // every wave is done with the only patch copy
+      store_p(PBUF == 2 ? (tx + 1) & 1 : 0);
     }
     __syncthreads();
   }
@@ -829,6 +920,38 @@ static int hs_launch_t(Conv2dArgs a, hipStream_t s) {
   return ADX_OK;
 }
 
+template <bool POOL>
+static int hs_stem_launch(Conv2dArgs a, hipStream_t s) {
+  constexpr int PH = POOL ? 25 : 21, PBUF = POOL ? 1 : 2;
+  constexpr size_t lds = (size_t)kStemSteps * 4096 + (size_t)PBUF * 4 * 3 * PH * kStemPP + 2 * kHsCout * sizeof(float) +
+                         (POOL ? 4 * 64 * sizeof(float) : 0);
+  static_assert(lds <= 80 * 1024, "two workgroups per CU need <= 80 KB each");
+  static bool attr = false;
+  if (!attr) {
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs_stem_kernel<POOL>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  a.tiles_x = ceil_div(a.OW, kTileW); a.cout_tiles = 1;
+  a.tiles_y = POOL ? ceil_div((a.OH - 1) / 2 + 1, 4) : ceil_div(a.OH, 8);
+  conv2d_hs_stem_kernel<POOL><<<dim3((unsigned)(a.tiles_y * a.N)), dim3(256), lds, s>>>(a);
+  ADX_LAUNCH_CHECK();
+  return ADX_OK;
+}
+
+int conv2d_hs_stem_pool(const ConvSpec& L, const float* x, const float* w, const float* scale, const float* shift,
+                        float* pooled, int N, int H, int W, hipStream_t s) {
+  ADX_REQUIRE(x && w && scale && shift && pooled, "conv2d_hs_stem_pool: null pointer");
+  ADX_REQUIRE((size_t)3 * H * W * sizeof(float) < 0xC0000000u, "conv2d_hs_stem_pool: image too large for 32-bit offsets");
+  Conv2dArgs a{};
+  a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.y = pooled;
+  a.N = N; a.Cin = 3; a.H = H; a.W = W; a.Cout = 64;
+  a.OH = conv_out_dim(H, 7, 2, 3); a.OW = conv_out_dim(W, 7, 2, 3);
+  a.KH = 7; a.KW = 7; a.stride = 2; a.pad = 3; a.relu = 1;
+  a.cin_pad = L.cin_pad; a.cc = L.cc;
+  return hs_stem_launch<true>(a, s);
+}
+
 int conv2d_hs_launch_block_s2(const ConvSpec& c1, const ConvSpec& ds, const float* x, const float* w1, const float* scale1,
                               const float* shift1, float* y1, const float* wd, const float* scaled, const float* shiftd,
                               float* yd, int N, int H, int W, hipStream_t s) {
@@ -867,19 +990,8 @@ int conv2d_hs_launch(const ConvSpec& L, Conv2dArgs a, hipStream_t s) {
   ADX_REQUIRE((size_t)L.cin * a.H * a.W * sizeof(float) < 0xC0000000u, "conv2d_hs: one image of the input exceeds the 32-bit byte offsets");
   const bool ds = a.w_ds != nullptr;
   if (hs_is_stem(L) && !ds) {
-    constexpr size_t lds = (size_t)kStemSteps * 4096 + (size_t)2 * 2 * kStemPlane * 2 + 2 * kHsCout * sizeof(float);
-    static_assert(lds <= 80 * 1024, "two workgroups per CU need <= 80 KB each");
-    static bool attr = false;
-    if (!attr) {
-      ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs_stem_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr = true;
-    }
     ADX_REQUIRE(a.x_amax == nullptr && a.res == nullptr, "conv2d_hs stem: no residual / dynamic range");
-    a.tiles_x = ceil_div(a.OW, kTileW); a.tiles_y = ceil_div(a.OH, 8); a.cout_tiles = 1;
-    conv2d_hs_stem_kernel<<<dim3((unsigned)(a.tiles_y * a.N)), dim3(256), lds, s>>>(a);
-    ADX_LAUNCH_CHECK();
-    return ADX_OK;
+    return hs_stem_launch<false>(a, s);
   }
   if (L.k == 3 && L.stride == 1 && !ds) {
     static int pipe = -1;

@@ -68,6 +68,9 @@ int conv2d_pack_spec(const ConvSpec& consumer, const float* w, float* packed, in
 bool conv2d_hs_eligible(const ConvSpec& L);
 int conv2d_hs_pack(const ConvSpec& consumer, const float* w, void* packed, int dgrad, hipStream_t s);
 int conv2d_hs_launch(const ConvSpec& L, Conv2dArgs a, hipStream_t s);
+// stem conv + BN + ReLU + MaxPool2d(3, 2, 1) in one pass: writes only the pooled map [N][64][PH][PW]
+int conv2d_hs_stem_pool(const ConvSpec& L, const float* x, const float* w, const float* scale, const float* shift,
+                        float* pooled, int N, int H, int W, hipStream_t s);
 // conv1 (3x3 stride 2, +BN+ReLU) and the block's downsample (1x1 stride 2, +BN) in one pass over x; both must be
 // conv2d_hs_eligible (the downsample's weights packed with conv2d_hs_pack_ds)
 int conv2d_hs_launch_block_s2(const ConvSpec& c1, const ConvSpec& ds, const float* x, const float* w1, const float* scale1,
