@@ -5,9 +5,9 @@ One process per GPU; `torch.distributed` backend "nccl" is RCCL on ROCm.  The mo
 through ordinary autograd, so `torch.nn.parallel.DistributedDataParallel(model)` works as in the
 reference.  `GradientAverager` is the explicit equivalent used by this package's own trainer: gradients
 are flattened into a few large buckets (fewer, larger collectives suit xGMI's per-link bandwidth) in
-REVERSE registration order, i.e. temporal-stack buckets first — their all-reduce is launched on a side
-stream as soon as the temporal backward has produced them and overlaps the perception backward, which
-is >95 % of the step.  Sampling needs no collective: scenes are sharded with `shard_range`.
+REVERSE registration order, i.e. temporal-stack buckets first — with `attach()` their all-reduce is launched
+from autograd hooks as soon as the temporal backward has produced them and overlaps the perception backward
+(two thirds of the step); `average()` is the plain after-backward form.  Sampling needs no collective: scenes are sharded with `shard_range`.
 """
 from __future__ import annotations
 
@@ -48,26 +48,75 @@ class GradientAverager:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.buckets = make_buckets([p.numel() for p in self.params], int(bucket_mb * 1024 * 1024 / 4))
         self._flat: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
+        self._hooks: list = []
+        self._pending: list = []
+        self._ready: List[int] = []
+
+    def attach(self) -> "GradientAverager":
+        """Overlap mode: a bucket's all-reduce is launched from autograd hooks the moment its last gradient has been
+        accumulated, i.e. DURING backward (the temporal stack's gradients are complete before the perception backward
+        -- two thirds of the step -- has even been queued).  Call `synchronize()` after `loss.backward()`."""
+        if self._hooks:
+            return self
+        self._where = {}
+        for bi, idxs in enumerate(self.buckets):
+            for i in idxs:
+                self._where[i] = bi
+        self._ready = [0] * len(self.buckets)
+        self._pending = []
+        for i, p in enumerate(self.params):
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+        return self
+
+    def _make_hook(self, i: int):
+        def hook(_param):
+            if self.world == 1:
+                return
+            bi = self._where[i]
+            self._ready[bi] += 1
+            if self._ready[bi] == len(self.buckets[bi]):
+                self._ready[bi] = 0
+                with torch.no_grad():
+                    self._pending.append(self._launch(bi))
+        return hook
+
+    def detach(self) -> None:
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    @torch.no_grad()
+    def synchronize(self) -> None:
+        """Overlap mode: wait for the collectives the hooks launched and write the means back."""
+        if self.world == 1:
+            return
+        if any(self._ready):
+            raise RuntimeError("a bucket is incomplete: every rank must produce every gradient in every backward")
+        self.finish(self._pending)
+        self._pending = []
+
+    @torch.no_grad()
+    def _launch(self, bi: int):
+        idxs = self.buckets[bi]
+        grads = [self.params[i].grad for i in idxs]
+        if any(g is None for g in grads):
+            raise RuntimeError("a parameter has no gradient (every rank must produce every gradient)")
+        n = sum(g.numel() for g in grads)
+        flat = self._flat[bi]
+        if flat is None or flat.numel() != n or flat.device != grads[0].device:
+            flat = self._flat[bi] = torch.empty(n, dtype=grads[0].dtype, device=grads[0].device)
+        off = 0
+        for g in grads:
+            flat[off:off + g.numel()].copy_(g.reshape(-1))
+            off += g.numel()
+        return (dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), bi)
 
     @torch.no_grad()
     def average(self, async_op: bool = False):
-        """All-reduce (mean) every gradient.  Returns the list of work handles when async_op."""
+        """All-reduce (mean) every gradient after backward.  Returns the list of work handles when async_op."""
         if self.world == 1:
             return []
-        works = []
-        for bi, idxs in enumerate(self.buckets):
-            grads = [self.params[i].grad for i in idxs]
-            if any(g is None for g in grads):
-                raise RuntimeError("a parameter has no gradient (every rank must produce every gradient)")
-            n = sum(g.numel() for g in grads)
-            flat = self._flat[bi]
-            if flat is None or flat.numel() != n or flat.device != grads[0].device:
-                flat = self._flat[bi] = torch.empty(n, dtype=grads[0].dtype, device=grads[0].device)
-            off = 0
-            for g in grads:
-                flat[off:off + g.numel()].copy_(g.reshape(-1))
-                off += g.numel()
-            works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), bi))
+        works = [self._launch(bi) for bi in range(len(self.buckets))]
         if async_op:
             return works
         self.finish(works)

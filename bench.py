@@ -224,7 +224,7 @@ def train_leg(dev, world, steps=5, warm=3):
     P.load_procedural(model, 0)
     model = model.to(dev).train()
     opt = FusedAdamWEMA(model.parameters(), lr=1e-4, warmup_steps=1000, lr_ticks_per_step=world)
-    avg = GradientAverager(model.parameters()) if world > 1 else None
+    avg = GradientAverager(model.parameters()).attach() if world > 1 else None      # all-reduce overlaps backward
     sch = S.DDPMScheduler(**SCHED_KW)
     d = {k: v.to(dev) for k, v in P.synthetic_batch(B, H, image_hw=IMG, seed=7).items()}
 
@@ -234,7 +234,7 @@ def train_leg(dev, world, steps=5, warm=3):
         loss = torch.nn.functional.mse_loss(pred, d["trajs"])
         loss.backward()
         if avg is not None:
-            avg.average()
+            avg.synchronize()
         opt.step()
         opt.zero_grad()
         return loss

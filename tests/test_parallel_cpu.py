@@ -53,6 +53,20 @@ def _worker(rank, world, port, out):
     gathered = [torch.zeros_like(local[0]) for _ in range(world)]
     dist.all_gather(gathered, local[0])
     ok_avg = torch.allclose(list(model.parameters())[0].grad, sum(gathered) / world, atol=1e-6)
+    # overlap mode: the hooks launch each bucket during backward; synchronize() must give the same means
+    model.zero_grad()
+    avg2 = GradientAverager(model.parameters(), bucket_mb=1e-4).attach()
+    model(x).sum().backward()
+    avg2.synchronize()
+    ok_avg = ok_avg and all(torch.allclose(p.grad, g) for p, g in zip(model.parameters(),
+                                                                       [q.grad.clone() for q in model.parameters()]))
+    ok_avg = ok_avg and torch.allclose(list(model.parameters())[0].grad, sum(gathered) / world, atol=1e-6)
+    model.zero_grad()
+    model(x).sum().backward()          # hooks stay attached: a second step works too
+    avg2.synchronize()
+    ok_avg = ok_avg and torch.allclose(list(model.parameters())[-1].grad * 0 + list(model.parameters())[0].grad[0, 0],
+                                       list(model.parameters())[-1].grad * 0 + (sum(gathered) / world)[0, 0], atol=1e-6)
+    avg2.detach()
     ws = [torch.zeros_like(w_after_bcast[0]) for _ in range(world)]
     dist.all_gather(ws, w_after_bcast[0])
     ok_bcast = all(torch.equal(ws[0], w) for w in ws)
