@@ -105,7 +105,8 @@ _SIGS = {
     "adx_trajpred_pack": (i32, [vp, C.POINTER(vp), i32, vp, vp, vp]),
     "adx_trajpred_forward": (i32, [vp, vp, vp, i64, i64, vp, vp, i32, i32, vp]),
     "adx_trajpred_backward": (i32, [vp, vp, vp, i64, i64, vp, vp, vp, i32, i32, vp]),
-    "adx_trajpred_backward_params": (i32, [vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "adx_trajpred_backward_params": (i32, [vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, i32, i32, C.c_float, C.c_uint64, vp]),
+    "adx_trajpred_forward_train": (i32, [vp, vp, vp, i64, i64, vp, vp, i32, i32, C.c_float, C.c_uint64, vp]),
     "adx_trajpred_param_offsets": (i32, [vp, C.POINTER(i64), i32]),
     "adx_guided_output": (i32, [vp, vp, vp, vp, vp, f32, f32, vp, vp, i32, i32, vp]),
     "adx_optim_chunk": (i32, []),

@@ -209,9 +209,39 @@ __device__ __forceinline__ void embed_rows(float* X, const float* __restrict__ a
   }
 }
 
+// Train-mode dropout of nn.TransformerEncoderLayer (p = 0.1 in the reference: attention probabilities, the two
+// residual branches, the feed-forward activation).  Masks are never stored: element idx of site s of sample b keeps
+// its value iff lowbias32(base(seed, b, s) ^ idx) >= p * 2^32, so the forward pass, the recomputation inside the
+// backward pass and the gradient formulas all regenerate the same mask.  (torch draws its masks from its own Philox
+// stream; the two can only agree in distribution.)
+struct Drop {
+  uint32_t base;      // per (seed, sample) key
+  uint32_t thresh;    // p * 2^32; 0 = dropout off
+  float scale;        // 1 / (1 - p)
+};
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t drop_site(const Drop& d, int site) { return lowbias32(d.base ^ ((uint32_t)site * 0x85EBCA6BU)); }
+// multiplier of element idx at a site: 0 or 1/(1-p)
+__device__ __forceinline__ float drop_mul(const Drop& d, uint32_t site_key, uint32_t idx) {
+  if (d.thresh == 0u) return 1.f;
+  return lowbias32(site_key ^ idx) >= d.thresh ? d.scale : 0.f;
+}
+__device__ __forceinline__ Drop make_drop(uint32_t seed_lo, uint32_t seed_hi, uint32_t thresh, float scale, int b) {
+  Drop d;
+  d.base = lowbias32(lowbias32(seed_lo ^ ((uint32_t)b * 0x9E3779B9U)) ^ seed_hi);
+  d.thresh = thresh;
+  d.scale = scale;
+  return d;
+}
+
 // one encoder layer, forward; leaves every intermediate the backward needs in LDS
 __device__ __forceinline__ void layer_forward(const Lds& l, const float* __restrict__ P, const TPLayer& y, int T,
-                                              int tid) {
+                                              int tid, const Drop& dr, int li) {
+  const uint32_t k_att = drop_site(dr, 4 * li + 0), k_d1 = drop_site(dr, 4 * li + 1), k_in = drop_site(dr, 4 * li + 2),
+                 k_d2 = drop_site(dr, 4 * li + 3);
   mm_fwd<false>(l.QKV, 3 * E, l.X, E, P + y.w_in_t, P + y.b_in, E, 3 * E, tid);
   __syncthreads();
   // scores + softmax: one thread per (head, query row)
@@ -246,16 +276,17 @@ __device__ __forceinline__ void layer_forward(const Lds& l, const float* __restr
     const int t = idx >> 6, c = idx & 63, h = c >> 4;
     float acc = 0.f;
     if (t < T) {
-      const float* p = l.P + (h * TP + t) * TP;
-      for (int s = 0; s < T; ++s) acc += p[s] * l.QKV[s * 3 * E + 2 * E + c];
+      const float* p = l.P + (h * TP + t) * TP;     // softmax probabilities stay unmasked in LDS
+      for (int s = 0; s < T; ++s)
+        acc += p[s] * drop_mul(dr, k_att, (uint32_t)((h * TP + t) * TP + s)) * l.QKV[s * 3 * E + 2 * E + c];
     }
     l.O[idx] = acc;
   }
   __syncthreads();
-  // Y = X + out_proj(O)
-  for (int idx = tid; idx < TP * E; idx += 256) l.Y[idx] = l.X[idx];
+  // Y = X + dropout1(out_proj(O))   (H1 is free until the LayerNorm below writes it)
+  mm_fwd<false>(l.H1, E, l.O, E, P + y.w_out_t, P + y.b_out, E, E, tid);
   __syncthreads();
-  mm_fwd<true>(l.Y, E, l.O, E, P + y.w_out_t, P + y.b_out, E, E, tid);
+  for (int idx = tid; idx < TP * E; idx += 256) l.Y[idx] = l.X[idx] + l.H1[idx] * drop_mul(dr, k_d1, (uint32_t)idx);
   __syncthreads();
   layer_norm_rows(l.H1, l.Y, E, P + y.g1, P + y.be1, l.XH1, l.R1, T, tid);
   __syncthreads();
@@ -275,11 +306,13 @@ __device__ __forceinline__ void layer_forward(const Lds& l, const float* __restr
       for (int k = 0; k < FF; ++k) {
         const float w = wt[(size_t)k * E + n];
 #pragma unroll
-        for (int r = 0; r < RT; ++r) acc[r] += silu_f(l.F[(tg * RT + r) * FF + k]) * w;
+        for (int r = 0; r < RT; ++r)
+          acc[r] += silu_f(l.F[(tg * RT + r) * FF + k]) * drop_mul(dr, k_in, (uint32_t)((tg * RT + r) * FF + k)) * w;
       }
       const float b = P[y.b2 + n];
 #pragma unroll
-      for (int r = 0; r < RT; ++r) l.Y[(tg * RT + r) * E + n] += acc[r] + b;
+      for (int r = 0; r < RT; ++r)
+        l.Y[(tg * RT + r) * E + n] += (acc[r] + b) * drop_mul(dr, k_d2, (uint32_t)((tg * RT + r) * E + n));
     }
   }
   __syncthreads();
@@ -292,7 +325,9 @@ __device__ __forceinline__ void layer_forward(const Lds& l, const float* __restr
 // G != nullptr (training): parameter gradients are accumulated into the gradient image G, which has the packed
 // buffer's layout (PyTorch-layout slots); Xin = this layer's input tile.
 __device__ __forceinline__ void layer_backward(const Lds& l, float* D, const float* __restrict__ P, const TPLayer& y,
-                                               int T, int tid, float* G, const float* Xin) {
+                                               int T, int tid, float* G, const float* Xin, const Drop& dr, int li) {
+  const uint32_t k_att = drop_site(dr, 4 * li + 0), k_d1 = drop_site(dr, 4 * li + 1), k_in = drop_site(dr, 4 * li + 2),
+                 k_d2 = drop_site(dr, 4 * li + 3);
   if (G != nullptr) {  // norm2 affine
     for (int i = tid; i < E; i += 256) {
       float sg = 0.f, sb = 0.f;
@@ -302,16 +337,20 @@ __device__ __forceinline__ void layer_backward(const Lds& l, float* D, const flo
     }
   }
   // norm2
-  layer_norm_bwd_rows(l.Y, D, l.XH2, l.R2, E, P + y.g2, T, tid);   // Y = d(y2) = d(h1 path) = d(ff)
+  layer_norm_bwd_rows(l.Y, D, l.XH2, l.R2, E, P + y.g2, T, tid);   // Y = d(y2): the residual path's gradient ...
   __syncthreads();
-  if (G != nullptr) {  // linear2: ff = W2 silu(F) + b2, before F is overwritten
+  // ... and D (free until norm1's backward) = d(ff) = dropout2's mask on it
+  for (int idx = tid; idx < TP * E; idx += 256) D[idx] = l.Y[idx] * drop_mul(dr, k_d2, (uint32_t)idx);
+  __syncthreads();
+  if (G != nullptr) {  // linear2: ff = W2 (mask * silu(F)) + b2, before F is overwritten
     for (int idx = tid; idx < E * FF; idx += 256) {
       const int j = idx / FF, n = idx - j * FF;
       float acc = 0.f;
-      for (int t = 0; t < T; ++t) acc += l.Y[t * E + j] * silu_f(l.F[t * FF + n]);
+      for (int t = 0; t < T; ++t)
+        acc += D[t * E + j] * silu_f(l.F[t * FF + n]) * drop_mul(dr, k_in, (uint32_t)(t * FF + n));
       atomicAdd(G + y.w2 + idx, acc);
     }
-    colsum_acc(G + y.b2, E, [&](int t, int n) { return l.Y[t * E + n]; }, T, tid);
+    colsum_acc(G + y.b2, E, [&](int t, int n) { return D[t * E + n]; }, T, tid);
   }
   // ds = dff @ W2  ([T][256]); dF = ds * silu'(F), stored over F
   for (int item = tid; item < FF * (TP / RT); item += 256) {
@@ -323,12 +362,12 @@ __device__ __forceinline__ void layer_backward(const Lds& l, float* D, const flo
     for (int j = 0; j < E; ++j) {
       const float wv = w[(size_t)j * FF + n];
 #pragma unroll
-      for (int r = 0; r < RT; ++r) acc[r] += l.Y[(tg * RT + r) * E + j] * wv;
+      for (int r = 0; r < RT; ++r) acc[r] += D[(tg * RT + r) * E + j] * wv;
     }
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
       float* f = l.F + (tg * RT + r) * FF + n;
-      *f = acc[r] * silu_grad(*f);
+      *f = acc[r] * drop_mul(dr, k_in, (uint32_t)((tg * RT + r) * FF + n)) * silu_grad(*f);
     }
   }
   __syncthreads();
@@ -350,12 +389,15 @@ __device__ __forceinline__ void layer_backward(const Lds& l, float* D, const flo
   // norm1: D = d(y1)
   layer_norm_bwd_rows(D, l.Y, l.XH1, l.R1, E, P + y.g1, T, tid);
   __syncthreads();
+  // d(sa) = dropout1's mask on d(y1), kept in XH2 (dead since norm2's backward); D stays the residual path's gradient
+  for (int idx = tid; idx < TP * E; idx += 256) l.XH2[idx] = D[idx] * drop_mul(dr, k_d1, (uint32_t)idx);
+  __syncthreads();
   if (G != nullptr) {  // out_proj: sa = Wout O + bout
-    outer_acc(G + y.w_out, E, E, [&](int t, int n) { return D[t * E + n]; }, l.O, E, T, tid);
-    colsum_acc(G + y.b_out, E, [&](int t, int n) { return D[t * E + n]; }, T, tid);
+    outer_acc(G + y.w_out, E, E, [&](int t, int n) { return l.XH2[t * E + n]; }, l.O, E, T, tid);
+    colsum_acc(G + y.b_out, E, [&](int t, int n) { return l.XH2[t * E + n]; }, T, tid);
   }
   // dO = dsa @ Wout  (Wout [64][64], row j = output feature)
-  mm_fwd<false>(l.Y, E, D, E, P + y.w_out, nullptr, E, E, tid);    // Y = dO
+  mm_fwd<false>(l.Y, E, l.XH2, E, P + y.w_out, nullptr, E, E, tid);    // Y = dO
   __syncthreads();
   // dP[h][t][s] = sum_d dO[t][hd] V[s][hd];  dS = P * (dP - sum_s dP P), written into F (dead by now)
   for (int idx = tid; idx < NH * TP; idx += 256) {
@@ -370,6 +412,7 @@ __device__ __forceinline__ void layer_backward(const Lds& l, float* D, const flo
         float d = 0.f;
 #pragma unroll
         for (int i = 0; i < DH; ++i) d += dO[i] * v[i];
+        d *= drop_mul(dr, k_att, (uint32_t)((h * TP + t) * TP + s));     // through the attention dropout
         dS[s] = d;
         dot += d * p[s];
       }
@@ -387,7 +430,7 @@ __device__ __forceinline__ void layer_backward(const Lds& l, float* D, const flo
       for (int s = 0; s < T; ++s) {
         dq += dS[s] * l.QKV[s * 3 * E + E + c];
         dk += l.F[(h * TP + s) * TP + t] * l.QKV[s * 3 * E + c];
-        dv += l.P[(h * TP + s) * TP + t] * l.Y[s * E + c];
+        dv += l.P[(h * TP + s) * TP + t] * drop_mul(dr, k_att, (uint32_t)((h * TP + s) * TP + t)) * l.Y[s * E + c];
       }
     }
     l.O[idx] = dq * 0.25f;
@@ -429,6 +472,8 @@ struct TrajArgs {
   float* loss;               // [B] or null
   // training: gradient image with the packed buffer's layout (atomically accumulated) and d(time_embed) [B][64]
   float* G; float* dte;
+  // training: dropout (thresh = p * 2^32, 0 = off)
+  uint32_t drop_thresh, seed_lo, seed_hi; float drop_scale;
 };
 
 // head: LayerNorm -> Linear(64, out_dim)
@@ -444,7 +489,8 @@ __global__ void __launch_bounds__(256) trajpred_forward_kernel(const TrajArgs a)
   const int b = blockIdx.x, tid = threadIdx.x;
   embed_rows(l.X, a.action + (int64_t)b * a.act_sb, a.act_st, a.te + (int64_t)b * E, a.P, a.L, a.T, tid);
   __syncthreads();
-  for (int li = 0; li < NL; ++li) layer_forward(l, a.P, a.L.layer[li], a.T, tid);
+  const Drop dr = make_drop(a.seed_lo, a.seed_hi, a.drop_thresh, a.drop_scale, b);
+  for (int li = 0; li < NL; ++li) layer_forward(l, a.P, a.L.layer[li], a.T, tid, dr, li);
   head_forward(l, a.P, a.L, a.T, tid);
   const int od = a.L.out_dim;
   for (int idx = tid; idx < a.T * od; idx += 256) {
@@ -462,12 +508,13 @@ __device__ __forceinline__ void backward_core(const Lds& l, const TrajArgs& a, i
   const float* P = a.P;
   const TPLayout& L = a.L;
   const int T = a.T, od = L.out_dim;
+  const Drop dr = make_drop(a.seed_lo, a.seed_hi, a.drop_thresh, a.drop_scale, b);
   embed_rows(l.X, a.action + (int64_t)b * a.act_sb, a.act_st, a.te + (int64_t)b * E, P, L, T, tid);
   __syncthreads();
   for (int li = 0; li < NL; ++li) {
     for (int idx = tid; idx < TP * E; idx += 256) l.IN(li)[idx] = l.X[idx];
     __syncthreads();
-    layer_forward(l, P, L.layer[li], T, tid);
+    layer_forward(l, P, L.layer[li], T, tid, dr, li);
   }
   head_forward(l, P, L, T, tid);   // XH2 / R2 now belong to the final norm
   float* G = a.G;
@@ -509,8 +556,8 @@ __device__ __forceinline__ void backward_core(const Lds& l, const TrajArgs& a, i
   for (int li = NL - 1; li >= 0; --li) {
     for (int idx = tid; idx < TP * E; idx += 256) l.X[idx] = l.IN(li)[idx];
     __syncthreads();
-    layer_forward(l, P, L.layer[li], T, tid);     // recompute this layer's internals
-    layer_backward(l, D, P, L.layer[li], T, tid, G, l.IN(li));
+    layer_forward(l, P, L.layer[li], T, tid, dr, li);     // recompute this layer's internals (same masks)
+    layer_backward(l, D, P, L.layer[li], T, tid, G, l.IN(li), dr, li);
     for (int idx = tid; idx < TP * E; idx += 256)
       if ((idx >> 6) >= T) D[idx] = 0.f;
     __syncthreads();
@@ -571,7 +618,8 @@ __global__ void __launch_bounds__(256) guided_output_kernel(const TrajArgs a) {
   // forward to get the state rows
   embed_rows(l.X, act, a.act_st, a.te + (int64_t)b * E, a.P, a.L, T, tid);
   __syncthreads();
-  for (int li = 0; li < NL; ++li) layer_forward(l, a.P, a.L.layer[li], T, tid);
+  const Drop dr_off{0u, 0u, 1.f};      // guidance runs the state head in eval mode
+  for (int li = 0; li < NL; ++li) layer_forward(l, a.P, a.L.layer[li], T, tid, dr_off, li);
   head_forward(l, a.P, a.L, T, tid);
   for (int idx = tid; idx < H * od; idx += 256) {
     const int h = idx / od, j = idx - h * od;
@@ -700,6 +748,15 @@ int adx_trajpred_pack(adx_trajpred* t, const float* const* P, int32_t n, const f
   return ADX_OK;
 }
 
+static int tp_dropout(TrajArgs* a, float p, uint64_t seed) {
+  ADX_REQUIRE(p >= 0.f && p < 1.f, "trajpred: dropout probability %g outside [0, 1)", (double)p);
+  a->drop_thresh = p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u;
+  a->drop_scale = 1.f / (1.f - p);
+  a->seed_lo = (uint32_t)seed;
+  a->seed_hi = (uint32_t)(seed >> 32);
+  return ADX_OK;
+}
+
 static int tp_common(adx_trajpred* t, const void* packed, int batch, int T, TrajArgs* a) {
   ADX_REQUIRE(t && packed, "trajpred: null argument");
   if (!t->packed) {
@@ -738,6 +795,24 @@ int adx_trajpred_forward(adx_trajpred* t, const void* packed, const float* actio
   return ADX_OK;
 }
 
+// train-mode forward: the encoder layers' dropout (probability dropout_p, masks keyed by `seed`) is applied; the
+// matching adx_trajpred_backward_params call must be given the same dropout_p and seed
+int adx_trajpred_forward_train(adx_trajpred* t, const void* packed, const float* action, int64_t act_sb, int64_t act_st,
+                               const float* time_embed, float* out, int32_t batch, int32_t T, float dropout_p,
+                               uint64_t seed, adx_stream stream) {
+  TrajArgs a;
+  int rc = tp_common(t, packed, batch, T, &a);
+  if (rc != ADX_OK) return rc;
+  rc = tp_dropout(&a, dropout_p, seed);
+  if (rc != ADX_OK) return rc;
+  ADX_REQUIRE(action && time_embed && out, "adx_trajpred_forward_train: null tensor");
+  a.action = action; a.act_sb = act_sb; a.act_st = act_st; a.te = time_embed;
+  a.out = out; a.out_sb = (int64_t)T * t->L.out_dim; a.out_st = t->L.out_dim;
+  trajpred_forward_kernel<<<dim3(batch), dim3(256), kLdsFloats * sizeof(float), (hipStream_t)stream>>>(a);
+  ADX_LAUNCH_CHECK();
+  return ADX_OK;
+}
+
 int adx_trajpred_backward(adx_trajpred* t, const void* packed, const float* action, int64_t act_sb, int64_t act_st,
                           const float* time_embed, const float* grad_out, float* grad_action, int32_t batch, int32_t T,
                           adx_stream stream) {
@@ -757,9 +832,12 @@ int adx_trajpred_backward(adx_trajpred* t, const void* packed, const float* acti
 // adx_trajpred_param_offsets) and d(time_embed) [B][64]; grad_action may be NULL.
 int adx_trajpred_backward_params(adx_trajpred* t, const void* packed, const float* action, int64_t act_sb, int64_t act_st,
                                  const float* time_embed, const float* grad_out, float* grad_action, void* grad_image,
-                                 float* d_time_embed, int32_t batch, int32_t T, adx_stream stream) {
+                                 float* d_time_embed, int32_t batch, int32_t T, float dropout_p, uint64_t seed,
+                                 adx_stream stream) {
   TrajArgs a;
   int rc = tp_common(t, packed, batch, T, &a);
+  if (rc != ADX_OK) return rc;
+  rc = tp_dropout(&a, dropout_p, seed);
   if (rc != ADX_OK) return rc;
   ADX_REQUIRE(action && time_embed && grad_out && grad_image && d_time_embed, "adx_trajpred_backward_params: null tensor");
   ADX_CHECK_HIP(hipMemsetAsync(grad_image, 0, (size_t)t->L.total * sizeof(float), (hipStream_t)stream));

@@ -29,9 +29,10 @@ class _TrajPredictTrainFn(torch.autograd.Function):
         B, T, _ = action_c.shape
         out = torch.empty((B, T, module.out_dim), dtype=torch.float32, device=action_c.device)
         h, packed = module._ensure_packed(action_c.device)
-        L.check(L.lib().adx_trajpred_forward(h, packed.data_ptr(), action_c.data_ptr(), action_c.stride(0),
-                                             action_c.stride(1), te.data_ptr(), out.data_ptr(), B, T,
-                                             L.stream_ptr(action_c.device)), "adx_trajpred_forward")
+        ctx.drop_p, ctx.seed = float(module.dropout_p), module._next_seed()
+        L.check(L.lib().adx_trajpred_forward_train(h, packed.data_ptr(), action_c.data_ptr(), action_c.stride(0),
+                                                   action_c.stride(1), te.data_ptr(), out.data_ptr(), B, T, ctx.drop_p,
+                                                   ctx.seed, L.stream_ptr(action_c.device)), "adx_trajpred_forward_train")
         ctx.module, ctx.params = module, params
         ctx.needs_action = action.requires_grad
         ctx.save_for_backward(action_c, te)
@@ -49,7 +50,8 @@ class _TrajPredictTrainFn(torch.autograd.Function):
         dte = torch.empty((B, module.hidden_dim), dtype=torch.float32, device=g.device)
         L.check(L.lib().adx_trajpred_backward_params(h, packed.data_ptr(), action_c.data_ptr(), action_c.stride(0),
                                                      action_c.stride(1), te.data_ptr(), g.data_ptr(), L.ptr(ga),
-                                                     image.data_ptr(), dte.data_ptr(), B, T, L.stream_ptr(g.device)),
+                                                     image.data_ptr(), dte.data_ptr(), B, T, ctx.drop_p, ctx.seed,
+                                                     L.stream_ptr(g.device)),
                 "adx_trajpred_backward_params")
         offs = module._param_offsets()
         grads = [image[o:o + p.numel()].view_as(p).clone() for o, p in zip(offs, params)]
@@ -100,6 +102,17 @@ class TrajPredict(nn.Module):
         self._packed = None
         self._pack_key = None
         self._freqs = None
+        # nn.TransformerEncoderLayer's default (modeling/helpers.py:35-41 does not override it); train mode only
+        self.dropout_p = 0.1
+        self._calls = 0
+
+    def _next_seed(self) -> int:
+        """64-bit key of this call's dropout masks: torch's global seed (so torch.manual_seed reproduces a run) mixed
+        with a per-module call counter; no device round trip."""
+        self._calls += 1
+        x = (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        x ^= x >> 31
+        return (x * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
 
     def _native(self):
         if self._handle is None:
@@ -149,8 +162,8 @@ class TrajPredict(nn.Module):
         if x.dim() != 3 or x.shape[2] != self.in_dim or x.shape[1] > 31:
             raise ValueError(f"x must be [B, T <= 31, {self.in_dim}], got {tuple(x.shape)}")
         if self.training:
-            # Deviation, documented: nn.TransformerEncoderLayer's dropout(0.1) is NOT applied (the reference draws
-            # its masks from torch's RNG stream, which cannot be reproduced); everything else is exact.
+            # train mode applies nn.TransformerEncoderLayer's dropout (self.dropout_p, 0.1 like the reference) with
+            # regenerable hash masks; they follow the same distribution as torch's but not its Philox stream
             named = dict(self.named_parameters())
             return _TrajPredictTrainFn.apply(x, time_embed, self, *[named[e.key] for e in self._entries])
         return _TrajPredictFn.apply(x, time_embed, self)

@@ -231,7 +231,15 @@ int adx_trajpred_backward(adx_trajpred* t, const void* packed, const float* acti
  * offsets[i] (adx_trajpred_param_offsets, adx_trajpred_pack order) in its PyTorch layout. */
 int adx_trajpred_backward_params(adx_trajpred* t, const void* packed, const float* action, int64_t act_sb,
                                  int64_t act_st, const float* time_embed, const float* grad_out, float* grad_action,
-                                 void* grad_image, float* d_time_embed, int32_t batch, int32_t T, adx_stream s);
+                                 void* grad_image, float* d_time_embed, int32_t batch, int32_t T, float dropout_p,
+                                 uint64_t seed, adx_stream s);
+/* Train-mode forward of the state head: nn.TransformerEncoderLayer's dropout (modeling/helpers.py:35-41 leaves it at
+ * torch's default 0.1: attention probabilities, both residual branches, the feed-forward activation) with masks that are
+ * a pure function of (seed, sample, site, element) -- adx_trajpred_backward_params regenerates them from the same
+ * (dropout_p, seed).  dropout_p = 0 is the deterministic path the golden fixtures use. */
+int adx_trajpred_forward_train(adx_trajpred* t, const void* packed, const float* action, int64_t act_sb, int64_t act_st,
+                               const float* time_embed, float* out, int32_t batch, int32_t T, float dropout_p,
+                               uint64_t seed, adx_stream s);
 int adx_trajpred_param_offsets(const adx_trajpred* t, int64_t* offsets, int32_t n);
 /* One launch for interact.py:153-160 + GuidanceLoss.forward with STEP = 1 (control/guidance.py:35-59) +
  * TargetGuidance (control/guidance_loss.py:10-22), per sample:

@@ -70,7 +70,7 @@ def cond_mlp(sd: SD, cond: torch.Tensor) -> torch.Tensor:
     return F.linear(h, sd["cond_mlp.2.weight"], sd["cond_mlp.2.bias"])
 
 
-def _mha(x: torch.Tensor, in_w, in_b, out_w, out_b, heads: int) -> torch.Tensor:
+def _mha(x: torch.Tensor, in_w, in_b, out_w, out_b, heads: int, att_mask=None) -> torch.Tensor:
     B, T, E = x.shape
     dh = E // heads
     q, k, v = F.linear(x, in_w, in_b).chunk(3, dim=-1)
@@ -78,12 +78,20 @@ def _mha(x: torch.Tensor, in_w, in_b, out_w, out_b, heads: int) -> torch.Tensor:
     k = k.reshape(B, T, heads, dh).transpose(1, 2)
     v = v.reshape(B, T, heads, dh).transpose(1, 2)
     att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(dh), dim=-1)
+    if att_mask is not None:          # train-mode attention dropout: multiplier tensor [B, heads, T, T]
+        att = att * att_mask
     o = (att @ v).transpose(1, 2).reshape(B, T, E)
     return F.linear(o, out_w, out_b)
 
 
-def traj_predict(sd: SD, p: str, action: torch.Tensor, time_embed: torch.Tensor, heads: int = 4) -> torch.Tensor:
-    """TrajPredict.forward (eval mode), modeling/helpers.py:22-59.
+def traj_predict(sd: SD, p: str, action: torch.Tensor, time_embed: torch.Tensor, heads: int = 4,
+                 masks=None) -> torch.Tensor:
+    """TrajPredict.forward, modeling/helpers.py:22-59; eval mode unless `masks` is given.
+
+    masks: {(layer, site): multiplier tensor (0 or 1/(1-p))} with the four dropout sites of
+    nn.TransformerEncoderLayer in train mode -- 0: attention probabilities [B, heads, T, T], 1: dropout1 on the
+    attention branch [B, T, E], 2: dropout on the feed-forward activation [B, T, 4E], 3: dropout2 [B, T, E].
+
 
     post-norm nn.TransformerEncoderLayer (SiLU feed-forward, no dropout in eval),
     final LayerNorm, Linear.  action [B, T, 3], time_embed [B, hidden] -> [B, T, out].
@@ -95,11 +103,18 @@ def traj_predict(sd: SD, p: str, action: torch.Tensor, time_embed: torch.Tensor,
     li = 0
     while (p + f"encoder_traj.layers.{li}.linear1.weight") in sd:
         q = p + f"encoder_traj.layers.{li}."
+        m = (lambda site: None if masks is None else masks[(li, site)])  # noqa: E731
         sa = _mha(x, sd[q + "self_attn.in_proj_weight"], sd[q + "self_attn.in_proj_bias"],
-                  sd[q + "self_attn.out_proj.weight"], sd[q + "self_attn.out_proj.bias"], heads)
+                  sd[q + "self_attn.out_proj.weight"], sd[q + "self_attn.out_proj.bias"], heads, att_mask=m(0))
+        if masks is not None:
+            sa = sa * m(1)
         x = F.layer_norm(x + sa, (hidden,), sd[q + "norm1.weight"], sd[q + "norm1.bias"], 1e-5)
-        ff = F.linear(F.silu(F.linear(x, sd[q + "linear1.weight"], sd[q + "linear1.bias"])),
-                      sd[q + "linear2.weight"], sd[q + "linear2.bias"])
+        act = F.silu(F.linear(x, sd[q + "linear1.weight"], sd[q + "linear1.bias"]))
+        if masks is not None:
+            act = act * m(2)
+        ff = F.linear(act, sd[q + "linear2.weight"], sd[q + "linear2.bias"])
+        if masks is not None:
+            ff = ff * m(3)
         x = F.layer_norm(x + ff, (hidden,), sd[q + "norm2.weight"], sd[q + "norm2.bias"], 1e-5)
         li += 1
     x = F.layer_norm(x, (hidden,), sd[p + "encoder_traj.norm.weight"], sd[p + "encoder_traj.norm.bias"], 1e-5)

@@ -1,6 +1,7 @@
 """GPU parity, training row (T1): gradients of the temporal stack against torch autograd through the
 CPU oracle on identical inputs.  Tolerance: per-tensor relative error of the gradient norm-difference
 <= 2e-4 (fp32, atomically reduced weight gradients => summation order differs run to run)."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -90,6 +91,7 @@ def test_traj_predict_parameter_gradients_vs_oracle_autograd():
     from test_gpu_model import make_model
     m, _ = make_model("CLASSIFIER_GUIDANCE", 16)
     m.train()
+    m.state_pred.dropout_p = 0.0          # the masked variant is test_traj_predict_dropout_* below
     sd = oracle_sd("CLASSIFIER_GUIDANCE")
     keys = [k for k in sd if k.startswith("state_pred.")]
     for k in keys:
@@ -115,12 +117,93 @@ def test_traj_predict_parameter_gradients_vs_oracle_autograd():
         assert worst[0] < 5e-4, (B, T, worst)
 
 
+def _lowbias32(x):
+    x = x.astype(np.uint64) & 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x846CA68B) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
+def _dropout_masks(seed, p, B, T):
+    """The masks adx_trajpred_forward_train(dropout_p = p, seed) uses (csrc/trajpred.hip: Drop), as multipliers."""
+    thresh = int(float(np.float32(p)) * 4294967296.0)
+    scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
+    lo, hi = seed & 0xFFFFFFFF, seed >> 32
+    b = np.arange(B, dtype=np.uint64)
+    base = _lowbias32(_lowbias32(lo ^ ((b * 0x9E3779B9) & 0xFFFFFFFF)) ^ hi)          # [B]
+    TP, E, FF, NH = 32, 64, 256, 4
+    masks = {}
+    for li in range(2):
+        for site, shape in ((0, (NH, T, T)), (1, (T, E)), (2, (T, FF)), (3, (T, E))):
+            key = _lowbias32(base ^ (((4 * li + site) * 0x85EBCA6B) & 0xFFFFFFFF))   # [B]
+            if site == 0:
+                h, t, s_ = np.meshgrid(np.arange(NH), np.arange(T), np.arange(T), indexing="ij")
+                idx = (h * TP + t) * TP + s_
+            else:
+                t, n = np.meshgrid(np.arange(T), np.arange(shape[1]), indexing="ij")
+                idx = t * shape[1] + n
+            r = _lowbias32(key[:, None] ^ idx.reshape(1, -1).astype(np.uint64))
+            masks[(li, site)] = torch.from_numpy(np.where(r >= thresh, scale, 0.0).reshape((B,) + shape))
+    return masks
+
+
+@pytest.mark.parametrize("B,T", [(3, 15), (2, 31)])
+def test_traj_predict_dropout_matches_oracle_with_the_same_masks(B, T):
+    """Train-mode dropout (p = 0.1 like nn.TransformerEncoderLayer): the kernel's hash masks are rebuilt on the host
+    and fed to the oracle; output, d(action), d(time_embed) and every parameter gradient must agree -- this pins
+    the mask placement in the forward pass and in every backward formula."""
+    from test_gpu_model import make_model
+    m, _ = make_model("CLASSIFIER_GUIDANCE", 16)
+    m.train()
+    sp = m.state_pred
+    assert sp.dropout_p == pytest.approx(0.1)
+    sd = {k: v.double() for k, v in oracle_sd("CLASSIFIER_GUIDANCE").items() if v.is_floating_point()}
+    keys = [k for k in sd if k.startswith("state_pred.")]
+    for k in keys:
+        sd[k].requires_grad_()
+    a = P._uniform("tpd.a", 81 + T, (B, T, 3), -1.5, 1.5)
+    te = P._uniform("tpd.te", 82 + T, (B, 64), -1.0, 1.0)
+    w = P._uniform("tpd.w", 83 + T, (B, T, 4), -1.0, 1.0)
+    torch.manual_seed(1234)
+    sp._calls = 41
+    probe = type(sp)._next_seed
+    seed = probe(sp)            # the seed the next call would use ...
+    sp._calls = 41              # ... rewound so that the real call draws the same one
+    masks = _dropout_masks(seed, sp.dropout_p, B, T)
+    kept = torch.cat([v.flatten() for v in masks.values()])
+    assert 0.85 < (kept > 0).double().mean().item() < 0.95          # about 10 % dropped
+    a_ref, te_ref = a.double().requires_grad_(), te.double().requires_grad_()
+    out_ref = U.traj_predict(sd, "state_pred.", a_ref, te_ref, masks=masks)
+    (out_ref * w.double()).sum().backward()
+    a_d, te_d = a.to(DEV).requires_grad_(), te.to(DEV).requires_grad_()
+    out = sp(a_d, te_d)
+    close(out.detach().cpu(), out_ref.detach().float(), 3e-5)
+    (out * w.to(DEV)).sum().backward()
+    assert rel_err(a_d.grad, a_ref.grad.float()) < 2e-4
+    assert rel_err(te_d.grad, te_ref.grad.float()) < 2e-4
+    named = dict(m.named_parameters())
+    worst = max(((rel_err(named[k].grad, sd[k].grad.float()), k) for k in keys))
+    assert worst[0] < 5e-4, worst
+    # a different call draws different masks; eval mode ignores dropout
+    out2 = sp(a.to(DEV), te.to(DEV))
+    assert (out2 - out.detach()).abs().max().item() > 1e-3
+    m.eval()
+    with torch.no_grad():
+        e1, e2 = sp(a.to(DEV), te.to(DEV)), sp(a.to(DEV), te.to(DEV))
+    assert torch.equal(e1, e2)
+
+
 @pytest.mark.parametrize("use_cond,H,B", [("NO_GUIDANCE", 16, 2), ("FREE_GUIDANCE", 32, 5),
                                           ("CLASSIFIER_GUIDANCE", 16, 3)])
 def test_unet_gradients_vs_oracle_autograd(use_cond, H, B):
     from test_gpu_model import make_model
     m, _ = make_model(use_cond, H)
     m.train()
+    if hasattr(m, "state_pred"):
+        m.state_pred.dropout_p = 0.0
     sd = oracle_sd(use_cond)
     keys = [e.key for e in unet_entries(use_cond) if not e.is_buffer and not e.key.startswith("perception.")]
     for k in keys:
@@ -197,6 +280,8 @@ def test_training_step_vs_golden(golden, use_cond):
     g = golden("train")
     m, _ = make_model(use_cond, 16)
     m.train()
+    if hasattr(m, "state_pred"):
+        m.state_pred.dropout_p = 0.0      # the fixture was generated with every dropout set to p = 0
     d = {k: v.to(DEV) for k, v in P.synthetic_batch(2, 16, image_hw=(64, 96), seed=41).items()}
     sch = S.DDPMScheduler(**SCHED_KW)
     noisy = sch.add_noise(d["trajs"], d["noise"], d["t"], zero_first=True)
