@@ -198,27 +198,46 @@ __global__ void __launch_bounds__(256) maxpool_bwd_gather_kernel(const uint8_t* 
   const uint8_t* cp = code + (size_t)pl * OH * OW;
   const float* gp = dy + (size_t)pl * OH * OW;
   float* dst = dx + ((size_t)pl * H + iy) * W;
-  // windows containing row iy: oy with 2 oy - 1 <= iy <= 2 oy + 1
-  const int oya = (iy + 1) >> 1, oyb = iy >> 1;           // tap rows: iy - (2 oy - 1)
-  for (int ix = lane; ix < W; ix += 64) {
-    const int oxa = (ix + 1) >> 1, oxb = ix >> 1;
-    float g = 0.f;
+  // windows containing row iy: oy with 2 oy - 1 <= iy <= 2 oy + 1 (one for even rows, two for odd ones)
+  const int oys[2] = {(iy + 1) >> 1, iy >> 1};
+  const int noy = oys[0] == oys[1] ? 1 : 2;
+  // a lane owns 4 consecutive pixels 4j .. 4j+3: their windows lie in output columns 2j, 2j+1, 2j+2, so the lane
+  // fetches 3 codes + 3 gradients per window row once instead of up to 4 + 4 per pixel
+  for (int j = lane; 4 * j < W; j += 64) {
+    int cd[2][3];
+    float g[2][3];
 #pragma unroll
-    for (int a2 = 0; a2 < 2; ++a2) {
-      const int oy = a2 == 0 ? oya : oyb;
-      if (a2 == 1 && oyb == oya) continue;
-      if (oy < 0 || oy >= OH) continue;
-      const int ty = iy - (2 * oy - 1);
+    for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-      for (int b2 = 0; b2 < 2; ++b2) {
-        const int ox = b2 == 0 ? oxa : oxb;
-        if (b2 == 1 && oxb == oxa) continue;
-        if (ox < 0 || ox >= OW) continue;
-        const int tx = ix - (2 * ox - 1);
-        if (cp[(size_t)oy * OW + ox] == ty * 3 + tx) g += gp[(size_t)oy * OW + ox];
+      for (int c = 0; c < 3; ++c) {
+        const int oy = oys[a2], ox = 2 * j + c;
+        const bool ok = a2 < noy && oy < OH && ox < OW;
+        cd[a2][c] = ok ? cp[(size_t)oy * OW + ox] : 255;
+        g[a2][c] = ok ? gp[(size_t)oy * OW + ox] : 0.f;
       }
+    float out[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ix = 4 * j + q;
+      const int oxa = (ix + 1) >> 1, oxb = ix >> 1;
+      float acc = 0.f;
+#pragma unroll
+      for (int a2 = 0; a2 < 2; ++a2) {
+        const int ty = iy - (2 * oys[a2] - 1);
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) {
+          const int ox = b2 == 0 ? oxa : oxb;
+          if (b2 == 1 && oxb == oxa) continue;
+          const int c = ox - 2 * j;                        // 0..2 by construction
+          const int tx = ix - (2 * ox - 1);
+          acc += cd[a2][c] == ty * 3 + tx ? g[a2][c] : 0.f;
+        }
+      }
+      out[q] = acc;
     }
-    dst[ix] = g;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (4 * j + q < W) dst[4 * j + q] = out[q];
   }
 }
 
