@@ -351,7 +351,8 @@ def main():
         res = {
             "metric": "denoising-steps/sec", "value": round(world * args.steps / dt, 3), "unit": "denoising-steps/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (inputs, outputs, accumulation; the 2-D convolutions multiply fp16 hi/lo split operands, 3 MFMAs per product)", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "dtype_note": "fp32 inputs, outputs and accumulation; the 2-D convolutions multiply fp16 hi/lo split operands (3 MFMAs per product, error below fp32 accumulation's own: DESIGN.md section 3)", "data": "synthetic",
             "config": {"workload": "configs/guidance/free_guidance.yaml: 50-step DDIM sampling, classifier-free "
                                    "guidance scale 7.5, 64 scenes per GPU (UNet batch 128), horizon 32, image 3x256x900, "
                                    "reference-faithful (ResNet-34 perception re-run every step)",
