@@ -224,16 +224,11 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
 #pragma unroll
     for (int kh = 0; kh < K; ++kh, ++stage) {
       const u32x4* wa0 = wl + (stage & 1) * WST + wa_lane;
-#if !defined(HS_NO_GLOBAL) && !defined(HS_NO_GLOBAL_W)
       if (stage + 1 < nstages) load_w(stage + 1);
-#endif
-#if !defined(HS_NO_GLOBAL) && !defined(HS_NO_GLOBAL_P)
       if (chunk + 1 < nchunks) {
         if (kSliced) load_p(chunk + 1, kh, kh + 1);
         else if (kh == 0) load_p(chunk + 1, 0, PIT);
       }
-#endif
-#ifndef HS_NO_MFMA
       auto fetch = [&](Frags& f, int kw) {
         const int col = STRIDE == 2 ? (kw & 1) * EVW + (kw >> 1) : kw;
 #pragma unroll
@@ -276,8 +271,6 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-#endif
-#ifndef HS_NO_STORE
       if (stage + 1 < nstages) store_w((stage + 1) & 1);
       if (chunk + 1 < nchunks) {
         if (kSliced) {
@@ -287,10 +280,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
           store_p(PBUF == 2 ? (chunk + 1) & 1 : 0, 0, PIT);
         }
       }
-#endif
-#ifndef HS_NO_BARRIER
       __syncthreads();
-#endif
     }
   }
 
