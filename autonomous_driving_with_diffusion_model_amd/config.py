@@ -46,7 +46,7 @@ def create_cfg() -> CfgNode:
     c = CfgNode()
     c.MODEL = CfgNode(HORIZON=16, TRANSITION_DIM=7, USE_ATTN=False, DIM=64, DIM_MULTS=(1, 2, 4, 8),
                       DIFFUSER_BUILDING_BLOCK="concat")
-    c.TRAIN = CfgNode(RESUME=None, USE_COND="NO_GUIDANCE", USE_FREE_COND_PROB=0.7, BATCH_SIZE=32, MAX_ITER=100000,
+    c.TRAIN = CfgNode(RESUME=None, ROOT=None, USE_IMG_AUGMENTOR=False, NUM_WORKERS=4, USE_COND="NO_GUIDANCE", USE_FREE_COND_PROB=0.7, BATCH_SIZE=32, MAX_ITER=100000,
                       IMAGE_HEIGHT=256, IMAGE_WIDTH=900, GRAD_NORM=1.0, EMA_MAX_DECAY=0.9999, EMA_INV_GAMMA=1.0,
                       EMA_POWER=0.75, LR=1e-4, LR_WARMUP=1000, TIME_STEPS=100, SAMPLE_STEPS=100,
                       GRADIENT_ACCUMULATION_STEPS=1,
@@ -54,6 +54,10 @@ def create_cfg() -> CfgNode:
                                               PRED_TYPE="sample"))
     c.GUIDANCE = CfgNode(USE_COND="NO_GUIDANCE", LOSS_LIST=None, STEP=1, CLASSIFIER_SCALE=0.1, FREE_SCALE=1.0)
     c.EVAL = CfgNode(BATCH_SIZE=4, ETA=0, CHECKPOINT=None, SCHEDULER="ddim", SAMPLE_STEPS=100)
+    # post-sampling control (reference config.py:67-86)
+    c.PID = CfgNode(TURN_KP=1, TURN_KI=0.5, TURN_KD=1.0, TURN_N=40, SPEED_KP=5, SPEED_KI=0.5, SPEED_KD=1.0, SPEED_N=40)
+    c.CONTROL = CfgNode(AIM_DIST=4.0, ANGLE_THRESH=0.3, DIST_THRESH=10, BRAKE_SPEED=0.4, BRAKE_RATIO=1.1, CLIP_DELTA=0.25,
+                        MAX_THROTTLE=9)
     return c
 
 

@@ -86,3 +86,18 @@ def synthetic_batch(batch: int, horizon: int, transition_dim: int = 7, image_hw=
 def step_noise(step: int, shape, seed: int = 0) -> torch.Tensor:
     """Injected per-step Gaussian noise for DDPM parity runs (the reference draws it on-device)."""
     return torch.from_numpy(_rng(f"step_noise.{step}", seed).standard_normal(size=tuple(shape), dtype=np.float32))
+
+
+def control_inputs(tick: int, horizon: int = 16):
+    """Waypoints [horizon, 2] (a gently curving path ahead of the ego vehicle, metres), speed [1] and target [2] for
+    tick `tick` of the controller parity run (tests/golden/control.npz)."""
+    r = _rng("control", tick)
+    step = 0.2 + 1.2 * r.random()                       # mean segment length: both sides of BRAKE_SPEED
+    curve = (r.random() - 0.5) * 0.12
+    s = np.arange(1, horizon + 1, dtype=np.float64) * step
+    x = curve * s * s + (r.random(horizon) - 0.5) * 0.05
+    y = s + (r.random(horizon) - 0.5) * 0.05
+    wp = torch.from_numpy(np.stack([x, y], 1).astype(np.float32))
+    vel = torch.tensor([float(3.0 * r.random())], dtype=torch.float32)
+    tgt = torch.from_numpy(np.array([(r.random() - 0.5) * 8.0, 2.0 + 14.0 * r.random()], dtype=np.float32))
+    return wp, vel, tgt

@@ -366,6 +366,23 @@ def gen_train():
         put(f"train.{name}.n_state", np.array(len(m.state_dict())))
 
 
+def gen_control():
+    """Post-sampling control: the reference Controller driven for 80 ticks (its PID windows are
+    stateful) on procedural waypoints / speeds / targets; inputs are regenerated by the test from the same seeds."""
+    from control.controller import Controller
+    cfg = SimpleNamespace(
+        PID=SimpleNamespace(TURN_KP=1, TURN_KI=0.5, TURN_KD=1.0, TURN_N=40, SPEED_KP=5, SPEED_KI=0.5, SPEED_KD=1.0, SPEED_N=40),
+        CONTROL=SimpleNamespace(AIM_DIST=4.0, ANGLE_THRESH=0.3, DIST_THRESH=10, BRAKE_SPEED=0.4, BRAKE_RATIO=1.1,
+                                CLIP_DELTA=0.25, MAX_THROTTLE=9))
+    ctl = Controller(cfg)
+    res = []
+    for tick in range(80):
+        wp, vel, tgt = P.control_inputs(tick)
+        th, st, br = ctl.control_pid(wp, vel, tgt)
+        res.append([float(th), float(st), float(bool(br))])
+    put("control.pid80", np.array(res, dtype=np.float64))
+
+
 def gen_spec():
     """state_dict keys/shapes and named_parameters order of the reference model (data only)."""
     import json
@@ -383,7 +400,8 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["spec"]:
         gen_spec()
         sys.exit(0)
-    groups = {"ops": gen_ops, "unet": gen_unet, "sched": gen_sched, "loop": gen_loops, "train": gen_train}
+    groups = {"ops": gen_ops, "unet": gen_unet, "sched": gen_sched, "loop": gen_loops, "train": gen_train,
+              "control": gen_control}
     which = sys.argv[1:] or list(groups)
     for gname in which:
         out.clear()
