@@ -251,3 +251,25 @@ def test_classifier_guidance_loop_vs_golden_and_batched_vmap(golden):
     want = OS.generate_traj(oracle_sd("CLASSIFIER_GUIDANCE"), d["imgs"], d["init_trajs"], d["target"],
                             use_cond="CLASSIFIER_GUIDANCE", n_steps=4, classifier_scale=15.0, hoist_perception=True)
     close(got.cpu(), want, 23.315 * TRAJ_TOL)
+
+
+@pytest.mark.parametrize("use_cond,B", [("FREE_GUIDANCE", 1), ("NO_GUIDANCE", 2), ("CLASSIFIER_GUIDANCE", 2)])
+def test_graphed_sampler_replays_the_eager_loop_bit_for_bit(use_cond, B):
+    """sampling.GraphedSampler: the DDIM loop captured as one HIP graph; replays with new inputs (camera frame
+    included: the perception pass is inside the graph) equal the eager loop exactly."""
+    from autonomous_driving_with_diffusion_model_amd import scheduler as S
+    from autonomous_driving_with_diffusion_model_amd.sampling import GraphedSampler, generate_traj
+    from helpers import SCHED_KW
+    m, cfg = make_model(use_cond, 16)
+    cfg.EVAL.SAMPLE_STEPS = 10
+    cfg.GUIDANCE.FREE_SCALE, cfg.GUIDANCE.CLASSIFIER_SCALE = 7.5, 15.0
+    if use_cond == "CLASSIFIER_GUIDANCE":
+        cfg.GUIDANCE.LOSS_LIST = [["TargetGuidance", []]]
+    sch = S.GuidanceDDIMScheduler(cfg=cfg, thresholding=True, **SCHED_KW)
+    gs = GraphedSampler(m, sch, cfg)
+    for seed in (21, 22, 23):            # the first call captures, the others replay with new inputs
+        d = {k: v.to(DEV) for k, v in P.synthetic_batch(B, 16, image_hw=IMG_SMALL, seed=seed).items()}
+        tgt = None if use_cond == "NO_GUIDANCE" else d["target"]
+        got = gs(d["imgs"], tgt, d["init_trajs"])
+        want = generate_traj(m, sch, cfg, d["imgs"], tgt, d["init_trajs"])
+        assert torch.equal(got, want), (seed, (got - want).abs().max().item())
