@@ -235,7 +235,7 @@ class TemporalMapUnet(nn.Module):
     def forward(self, x, img, time, cond=None, return_action_and_time_only=False):
         """x [B, T, D]; img [B or 1, 3, H, W]; time int64 [B or 1]; cond None or [B, 2]."""
         if self.training:
-            feat = self.perception(img)          # train-mode perception (raises until its kernels land)
+            feat = self.perception(img)          # train-mode perception: batch-statistics BatchNorm, autograd node
             return self.unet_forward_train(x, feat, time, cond)
         x = L.require_gpu_f32(x, "x")
         if x.dim() != 3 or x.shape[1] != self.horizon or x.shape[2] != self.transition_dim:

@@ -4,7 +4,8 @@ executed by libadx.so (csrc/trajpred.hip).
 Parameter holder with the reference's keys (input_proj, encoder_traj.layers.N.*, encoder_traj.norm,
 output_proj).  `forward(x, time_embed)` is an autograd node whose backward returns the gradient
 w.r.t. `x` (the action), which is what `GuidanceLoss` differentiates (control/guidance.py:47-50).
-Eval-mode semantics (no dropout); parameter gradients belong to the training row (not built yet).
+In eval mode (guidance) there is no dropout and only d(action) is produced; in train mode the node applies the
+encoder layers' dropout (regenerable hash masks) and also returns every parameter gradient and d(time_embed).
 """
 from __future__ import annotations
 
