@@ -22,27 +22,42 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// BatchNorm's affine form of one channel, evaluated identically in the forward apply pass and wherever the backward
+// pass re-derives the ReLU mask from the conv output (explicit fma: no dependence on the compiler's contraction)
+__device__ __forceinline__ void bn_affine(float gamma, float beta, float mean, float rstd, float& scale, float& shift) {
+  scale = gamma * rstd;
+  shift = __builtin_fmaf(-mean, scale, beta);
+}
+__device__ __forceinline__ float bn_eval(float raw, float scale, float shift) { return __builtin_fmaf(raw, scale, shift); }
+
 // sums[c][0] += sum a,  sums[c][1] += sum a*a          (MODE 0, BatchNorm forward statistics)
-// sums[c][0] += sum dz, sums[c][1] += sum dz*xhat      (MODE 1, BatchNorm backward), dz = dout * (out > 0 or 1)
+// sums[c][0] += sum dz, sums[c][1] += sum dz*xhat      (MODE 1, BatchNorm backward), dz = dout * ReLU mask
+// relu_mask: 0 none, 1 read from `out` (ReLU after the residual add), 2 re-derived from the conv output (ReLU
+// directly after BN: out > 0 <=> bn_eval(raw) > 0, one tensor read less)
 template <int MODE>
 __global__ void __launch_bounds__(256) channel_sums_kernel(const float* __restrict__ a, const float* __restrict__ out,
                                                             const float* __restrict__ raw, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, double* __restrict__ sums,
-                                                            int C, int HW, int relu_mask) {
+                                                            int C, int HW, int relu_mask, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta) {
   const int plane = blockIdx.x;            // n * C + c
   const int c = plane % C, tid = threadIdx.x;
   const size_t base = (size_t)plane * HW;
   double s0 = 0.0, s1 = 0.0;
   const float mu = MODE == 1 ? mean[c] : 0.f, rs = MODE == 1 ? rstd[c] : 0.f;
+  float sc = 0.f, sh = 0.f;
+  if (MODE == 1 && relu_mask == 2) bn_affine(gamma[c], beta[c], mu, rs, sc, sh);
   for (int i = tid; i < HW; i += 256) {
     float v = a[base + i];
     if (MODE == 0) {
       s0 += v;
       s1 += (double)v * v;
     } else {
-      if (relu_mask && !(out[base + i] > 0.f)) v = 0.f;
+      const float rw = raw[base + i];
+      if (relu_mask == 1 && !(out[base + i] > 0.f)) v = 0.f;
+      if (relu_mask == 2 && !(bn_eval(rw, sc, sh) > 0.f)) v = 0.f;
       s0 += v;
-      s1 += (double)v * (double)((raw[base + i] - mu) * rs);
+      s1 += (double)v * (double)((rw - mu) * rs);
     }
   }
   __shared__ double red[8];
@@ -67,9 +82,10 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, const float*
   double var = sums[2 * c + 1] / count - m * m;
   if (var < 0.0) var = 0.0;
   const float r = (float)(1.0 / sqrt(var + 1e-5));
-  const float sc = gamma[c] * r;
+  float sc, sh;
+  bn_affine(gamma[c], beta[c], (float)m, r, sc, sh);
   scale[c] = sc;
-  shift[c] = beta[c] - (float)m * sc;
+  shift[c] = sh;
   mean[c] = (float)m;
   rstd[c] = r;
   if (running_mean != nullptr) {
@@ -85,7 +101,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int c = (i / HW) % C;
-  float v = raw[i] * scale[c] + shift[c];
+  float v = bn_eval(raw[i], scale[c], shift[c]);
   if (res != nullptr) v += res[i];
   if (relu) v = v > 0.f ? v : 0.f;
   out[i] = v;
@@ -99,7 +115,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                             const double* __restrict__ sums, float* __restrict__ draw,
                                                             float* __restrict__ dz_out, int C, int HW, size_t total,
-                                                            double count, int relu_mask, uint32_t* __restrict__ amax) {
+                                                            double count, int relu_mask, uint32_t* __restrict__ amax,
+                                                            const float* __restrict__ beta) {
   // grid-stride: a fixed number of workgroups, each leaving max |draw| of its share in amax[blockIdx.x] (bits:
   // monotonic for non-negative floats); the data-gradient conv reduces those partials for its dynamic range
   __shared__ uint32_t red[4];
@@ -107,9 +124,15 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int c = (i / HW) % C;
     float dz = dout[i];
-    if (relu_mask && !(out[i] > 0.f)) dz = 0.f;
+    const float rw = raw[i];
+    if (relu_mask == 1 && !(out[i] > 0.f)) dz = 0.f;
+    if (relu_mask == 2) {
+      float sc, sh;
+      bn_affine(gamma[c], beta[c], mean[c], rstd[c], sc, sh);
+      if (!(bn_eval(rw, sc, sh) > 0.f)) dz = 0.f;
+    }
     if (dz_out != nullptr) dz_out[i] = dz;
-    const float xh = (raw[i] - mean[c]) * rstd[c];
+    const float xh = (rw - mean[c]) * rstd[c];
     const float m1 = (float)(sums[2 * c] / count), m2 = (float)(sums[2 * c + 1] / count);
     const float v = gamma[c] * rstd[c] * (dz - m1 - xh * m2);
     draw[i] = v;
@@ -626,7 +649,7 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
     const int HW = rec.OH * rec.OW;
     hipMemsetAsync(sums, 0, sizeof(double) * 2 * L.cout, s);
     channel_sums_kernel<0><<<dim3(batch * L.cout), dim3(256), 0, s>>>(rec.raw, nullptr, nullptr, nullptr, nullptr, sums,
-                                                                      L.cout, HW, 0);
+                                                                      L.cout, HW, 0, nullptr, nullptr);
     bn_finalize_kernel<<<dim3(ceil_div(L.cout, 256)), dim3(256), 0, s>>>(
         sums, T[L.t_g], T[L.t_b], scale, shift, rec.mean, rec.rstd, update_running ? const_cast<float*>(T[L.t_m]) : nullptr,
         update_running ? const_cast<float*>(T[L.t_v]) : nullptr, L.cout, (double)batch * HW);
@@ -706,11 +729,13 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
     const size_t n = (size_t)batch * L.cout * HW;
     const double count = (double)batch * HW;
     ADX_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * L.cout, s));
+    // ReLU mask: straight after BN it is re-derived from the conv output (one tensor read less in both passes)
+    const int mask = !rec.relu ? 0 : (rec.identity != nullptr ? 1 : 2);
     channel_sums_kernel<1><<<dim3(batch * L.cout), dim3(256), 0, s>>>(dout, rec.out, rec.raw, rec.mean, rec.rstd, sums,
-                                                                      L.cout, HW, rec.relu);
+                                                                      L.cout, HW, mask, T[L.t_g], T[L.t_b]);
     const int n_amax = (int)std::min<size_t>(kAmaxPartials, (n + 255) / 256);
     bn_bwd_apply_kernel<<<dim3(n_amax), dim3(256), 0, s>>>(
-        dout, rec.out, rec.raw, rec.mean, rec.rstd, T[L.t_g], sums, draw, dz_keep, L.cout, HW, n, count, rec.relu, amax);
+        dout, rec.out, rec.raw, rec.mean, rec.rstd, T[L.t_g], sums, draw, dz_keep, L.cout, HW, n, count, mask, amax, T[L.t_b]);
     bn_param_grad_kernel<<<dim3(ceil_div(L.cout, 256)), dim3(256), 0, s>>>(sums, G[L.t_g], G[L.t_b], L.cout);
     ADX_LAUNCH_CHECK();
     int rc2 = conv2d_wgrad(rec.x, draw, G[L.t_w], batch, L.cin, rec.H, rec.W, L.cout, L.k, L.stride, L.pad, s, amax, n_amax);
