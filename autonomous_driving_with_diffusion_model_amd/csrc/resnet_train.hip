@@ -100,7 +100,8 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__
                                                         float* __restrict__ out, int C, int HW, size_t total, int relu) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  const int c = (i / HW) % C;
+  // 32-bit channel arithmetic whenever the tensor allows it: a 64-bit divide per element costs more than the loads
+  const int c = total <= 0xFFFFFFFFull ? (int)(((uint32_t)i / (uint32_t)HW) % (uint32_t)C) : (int)((i / HW) % C);
   float v = bn_eval(raw[i], scale[c], shift[c]);
   if (res != nullptr) v += res[i];
   if (relu) v = v > 0.f ? v : 0.f;
@@ -121,8 +122,9 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
   // monotonic for non-negative floats); the data-gradient conv reduces those partials for its dynamic range
   __shared__ uint32_t red[4];
   uint32_t b = 0;
+  const bool small = total <= 0xFFFFFFFFull;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int c = (i / HW) % C;
+    const int c = small ? (int)(((uint32_t)i / (uint32_t)HW) % (uint32_t)C) : (int)((i / HW) % C);
     float dz = dout[i];
     const float rw = raw[i];
     if (relu_mask == 1 && !(out[i] > 0.f)) dz = 0.f;
