@@ -76,7 +76,7 @@ int conv2d_hs_stem_pool(const ConvSpec& L, const float* x, const float* w, const
 int conv2d_hs_launch_block_s2(const ConvSpec& c1, const ConvSpec& ds, const float* x, const float* w1, const float* scale1,
                               const float* shift1, float* y1, const float* wd, const float* scaled, const float* shiftd,
                               float* yd, int N, int H, int W, hipStream_t s);
-// conv2d_wgrad_hs.hip: weight gradient of the 3x3 stride-1 convs on the fp16 matrix cores (dw is zeroed inside)
+// conv2d_wgrad_hs.hip: weight gradient of the 3x3 convs on the fp16 matrix cores; dw must be zero on entry
 bool conv2d_wgrad_hs_eligible(int Cin, int Cout, int k, int stride, int pad);
 int conv2d_wgrad_hs(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, int stride,
                     const uint32_t* dy_amax, int dy_amax_n, hipStream_t s);

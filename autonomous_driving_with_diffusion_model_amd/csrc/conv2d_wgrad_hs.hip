@@ -35,7 +35,7 @@ typedef __attribute__((address_space(3))) h4 lds_h4;
 struct WgradHsArgs {
   const float* x;        // [N][Cin][H][W]
   const float* dy;       // [N][Cout][OH][OW]
-  float* dw;             // [Cout][Cin][3][3], zeroed by the caller
+  float* dw;             // [Cout][Cin][3][3], zeroed by the caller (conv2d_wgrad)
   const uint32_t* dy_amax;
   int dy_amax_n;
   int N, Cin, Cout, H, W, OH, OW;
@@ -281,7 +281,6 @@ int conv2d_wgrad_hs(const float* x, const float* dy, float* dw, int N, int Cin, 
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
   a.OH = conv_out_dim(H, 3, stride, 1); a.OW = conv_out_dim(W, 3, stride, 1);
   a.n_ci_tiles = Cin / 64; a.n_co_tiles = Cout / 64;
-  ADX_CHECK_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cout * Cin * 9, s));
   if (stride == 2) return wgrad_hs_launch<32, 2>(a, s);
   // rows of <= 32 (or 33..48 -> two 32-pixel segments waste less than one 64) pixels use the narrow variant
   const int waste64 = ceil_div(a.OW, 64) * 64 - a.OW, waste32 = ceil_div(a.OW, 32) * 32 - a.OW;

@@ -12,6 +12,7 @@
 //                               stride-2 convs go through a zero-dilated draw (3 of 36 layers)
 #include <algorithm>
 
+#include "batch_ops.h"
 #include "conv2d_internal.h"
 
 namespace adx {
@@ -442,8 +443,10 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(const WgradArgs2 a) {
 }
 
 int conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, int k, int stride,
-                 int pad, hipStream_t s, const uint32_t* dy_amax = nullptr, int dy_amax_n = 0) {
+                 int pad, hipStream_t s, const uint32_t* dy_amax = nullptr, int dy_amax_n = 0, bool zero = true) {
   ADX_REQUIRE(x && dy && dw, "conv2d_wgrad: null tensor");
+  // zero = false: the caller has already cleared dw (the training executor clears every weight gradient in one batch)
+  if (zero) ADX_CHECK_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cout * Cin * k * k, s));
   if (conv2d_wgrad_hs_eligible(Cin, Cout, k, stride, pad))
     return conv2d_wgrad_hs(x, dy, dw, N, Cin, H, W, Cout, stride, dy_amax, dy_amax_n, s);
   WgradArgs2 a;
@@ -465,7 +468,6 @@ int conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int
   if (splits > a.units) splits = a.units;
   a.units_per_wg = ceil_div(a.units, splits);
   splits = ceil_div(a.units, a.units_per_wg);
-  ADX_CHECK_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cout * Cin * k * k, s));
   const dim3 grid((unsigned)(tiles * splits)), blk(256);
   auto lds_bytes = [&](int cit, int ng) {
     const int ph = (kTileH - 1) * stride + k, pw = (kTileW - 1) * stride + k;
@@ -588,7 +590,7 @@ void adx_resnet_tape_destroy(adx_resnet_tape* t) { delete t; }
 
 size_t adx_resnet_train_workspace_bytes(const adx_resnet* r, int32_t batch, int32_t h, int32_t w) {
   if (!r || batch < 1 || h < 32 || w < 32) return 0;
-  size_t f = al64(2 * 512 * 2) + 2 * al64(512);            // forward: sums, scale, shift
+  size_t f = al64(r->convs.size() * 2 * 512 * 2) + 2 * al64(512);   // forward: per-conv sums, scale, shift
   size_t big = 0, wmax = 0;
   auto conv = [&](const ConvSpec& L, int H, int W) {
     const int OH = conv_out_dim(H, L.k, L.stride, L.pad), OW = conv_out_dim(W, L.k, L.stride, L.pad);
@@ -613,7 +615,7 @@ size_t adx_resnet_train_workspace_bytes(const adx_resnet* r, int32_t batch, int3
     conv(c2, OH, OW);
     H = OH; W = OW;
   }
-  f += al64(2 * 512 * 2) + al64(kAmaxPartials) + 5 * al64(big) + al64(wmax);   // backward: sums, amax, 5 gradient buffers, dgrad weights
+  f += al64(r->convs.size() * 2 * 512 * 2) + al64(kAmaxPartials) + 5 * al64(big) + al64(wmax);   // backward: sums, amax, 5 gradient buffers, dgrad weights
   return (f + 1024) * sizeof(float);
 }
 
@@ -635,7 +637,10 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
   Bump2 ws{(float*)workspace, 0, workspace_bytes / sizeof(float)};
   tape->recs.clear();
   tape->batch = batch; tape->h = h; tape->w = w;
-  double* sums = reinterpret_cast<double*>(ws.take(2 * 512 * 2));
+  // one statistics slot per conv, all cleared by a single memset (they are accumulated atomically)
+  const size_t n_convs = r->convs.size();
+  double* sums_all = reinterpret_cast<double*>(ws.take(n_convs * 2 * 512 * 2));
+  if (ws.ok) ADX_CHECK_HIP(hipMemsetAsync(sums_all, 0, sizeof(double) * n_convs * 2 * 512, s));
   float* scale = ws.take(512);
   float* shift = ws.take(512);
   int rc = ADX_OK;
@@ -649,7 +654,7 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
     rc = conv2d_launch_raw(L, x, base + L.o_w, nullptr, nullptr, nullptr, rec.raw, batch, H, W, 0, s);
     if (rc != ADX_OK) { tape->recs.push_back(rec); return rec.out; }
     const int HW = rec.OH * rec.OW;
-    hipMemsetAsync(sums, 0, sizeof(double) * 2 * L.cout, s);
+    double* sums = sums_all + (size_t)(&L - r->convs.data()) * 2 * 512;
     channel_sums_kernel<0><<<dim3(batch * L.cout), dim3(256), 0, s>>>(rec.raw, nullptr, nullptr, nullptr, nullptr, sums,
                                                                       L.cout, HW, 0, nullptr, nullptr);
     bn_finalize_kernel<<<dim3(ceil_div(L.cout, 256)), dim3(256), 0, s>>>(
@@ -696,7 +701,14 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
   hipStream_t s = (hipStream_t)stream;
   const int batch = tape->batch;
   Bump2 ws{(float*)workspace, tape->fwd_floats, workspace_bytes / sizeof(float)};
-  double* sums = reinterpret_cast<double*>(ws.take(2 * 512 * 2));
+  const size_t n_convs = r->convs.size();
+  double* sums_all = reinterpret_cast<double*>(ws.take(n_convs * 2 * 512 * 2));
+  ADX_CHECK_HIP(hipMemsetAsync(sums_all, 0, sizeof(double) * n_convs * 2 * 512, s));
+  for (const ConvSpec& L : r->convs) batch_fill_add(G[L.t_w], (size_t)L.cout * L.cin * L.k * L.k);
+  {
+    const int rf = batch_fill_flush(s);
+    if (rf != ADX_OK) return rf;
+  }
   uint32_t* amax = reinterpret_cast<uint32_t*>(ws.take(kAmaxPartials));   // per-workgroup max |draw| of the conv being differentiated
   size_t big = 0, wmax = 0;
   for (auto& rec : tape->recs) {
@@ -730,7 +742,7 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
     const int HW = rec.OH * rec.OW;
     const size_t n = (size_t)batch * L.cout * HW;
     const double count = (double)batch * HW;
-    ADX_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * L.cout, s));
+    double* sums = sums_all + (size_t)(&L - r->convs.data()) * 2 * 512;
     // ReLU mask: straight after BN it is re-derived from the conv output (one tensor read less in both passes)
     const int mask = !rec.relu ? 0 : (rec.identity != nullptr ? 1 : 2);
     channel_sums_kernel<1><<<dim3(batch * L.cout), dim3(256), 0, s>>>(dout, rec.out, rec.raw, rec.mean, rec.rstd, sums,
@@ -740,7 +752,7 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
         dout, rec.out, rec.raw, rec.mean, rec.rstd, T[L.t_g], sums, draw, dz_keep, L.cout, HW, n, count, mask, amax, T[L.t_b]);
     bn_param_grad_kernel<<<dim3(ceil_div(L.cout, 256)), dim3(256), 0, s>>>(sums, G[L.t_g], G[L.t_b], L.cout);
     ADX_LAUNCH_CHECK();
-    int rc2 = conv2d_wgrad(rec.x, draw, G[L.t_w], batch, L.cin, rec.H, rec.W, L.cout, L.k, L.stride, L.pad, s, amax, n_amax);
+    int rc2 = conv2d_wgrad(rec.x, draw, G[L.t_w], batch, L.cin, rec.H, rec.W, L.cout, L.k, L.stride, L.pad, s, amax, n_amax, false);
     if (rc2 != ADX_OK || !need_dx) return rc2;
     // data gradient
     ConvSpec g{};

@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256) tconv_wgrad_kernel(const WgradArgs a) {
   }
 }
 
-int tconv_wgrad(const adx_tconv_desc* d, const adx_tconv_io* io, const float* dc, float* dw, hipStream_t s) {
+int tconv_wgrad(const adx_tconv_desc* d, const adx_tconv_io* io, const float* dc, float* dw, hipStream_t s, bool zero) {
   int rc = tconv_check(d);
   if (rc != ADX_OK) return rc;
   ADX_REQUIRE(d->kind == 0, "tconv_wgrad: express a transposed conv's weight gradient as a strided conv with x and dy swapped");
@@ -312,7 +312,7 @@ int tconv_wgrad(const adx_tconv_desc* d, const adx_tconv_io* io, const float* dc
   a.rs = sbt * a.lp + 1;                   // odd pitch: the 16 channel rows of an A fragment hit distinct banks
   ADX_REQUIRE((sbt * d->lout) % 4 == 0, "tconv_wgrad: staged tile not a multiple of 4 rows");
   a.dw_so = (int64_t)a.cin * d->taps; a.dw_si = d->taps;
-  ADX_CHECK_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->cout * a.cin * d->taps, s));
+  if (zero) ADX_CHECK_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->cout * a.cin * d->taps, s));   // else: pre-zeroed by the caller
   const size_t lds_stage = (size_t)16 * a.rs, lds_red = (size_t)16 * nfo * 16 * d->taps;
   const size_t lds = sizeof(float) * (lds_stage > lds_red ? lds_stage : lds_red);
   const dim3 grid((unsigned)(tiles * nsplit)), blk(256);
@@ -355,7 +355,7 @@ int adx_gn_mish_backward(const float* dy, int64_t dy_sb, int64_t dy_sc, int64_t 
 }
 
 int adx_tconv_wgrad(const adx_tconv_desc* d, const adx_tconv_io* io, const float* dc, float* dw, adx_stream stream) {
-  return tconv_wgrad(d, io, dc, dw, (hipStream_t)stream);
+  return tconv_wgrad(d, io, dc, dw, (hipStream_t)stream, true);
 }
 
 int adx_bias_grad(const float* dc, float* db, int32_t B, int32_t C, int32_t L, adx_stream stream) {

@@ -14,6 +14,7 @@
 
 #include "tconv.h"
 
+#include "batch_ops.h"
 #include "unet_internal.h"
 
 namespace adx {
@@ -154,8 +155,9 @@ static int build(adx_unet* u) {
   return rc;
 }
 
-static int copy_f(float* dst, const float* src, size_t n, hipStream_t s) {
-  ADX_CHECK_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+// queued: adx_unet_pack flushes the whole list as a handful of launches (batch_ops.h)
+static int copy_f(float* dst, const float* src, size_t n, hipStream_t) {
+  batch_copy_add(dst, src, n);
   return ADX_OK;
 }
 
@@ -244,6 +246,7 @@ int adx_unet_pack(adx_unet* u, const float* const* P, int32_t n_params, const fl
   for (auto& l : u->ups) if (rc == ADX_OK) rc = pack_layer(l, P, base, s);
   if (rc == ADX_OK) rc = pack_layer(u->head0, P, base, s);
   if (rc == ADX_OK) rc = pack_layer(u->head1, P, base, s);
+  if (rc == ADX_OK) rc = batch_copy_flush(s);      // the fused Linear below is packed from the concatenated copy
   if (rc == ADX_OK) rc = tconv_pack(&u->tlin.d, base + u->o_tlin_raw, base + u->tlin.o_w, s);
   if (rc == ADX_OK) rc = copy_f(base + u->o_freqs, freqs, dim / 2, s);
   if (rc == ADX_OK) rc = copy_f(base + u->o_t1w, P[u->p_t1w], (size_t)4 * dim * dim, s);
@@ -255,6 +258,10 @@ int adx_unet_pack(adx_unet* u, const float* const* P, int32_t n_params, const fl
     if (rc == ADX_OK) rc = copy_f(base + u->o_c0b, P[u->p_c0b], dim, s);
     if (rc == ADX_OK) rc = copy_f(base + u->o_c2w, P[u->p_c2w], (size_t)dim * dim, s);
     if (rc == ADX_OK) rc = copy_f(base + u->o_c2b, P[u->p_c2b], dim, s);
+  }
+  {
+    const int rf = batch_copy_flush(s);            // always drain the queue, also after an error
+    if (rc == ADX_OK) rc = rf;
   }
   if (rc == ADX_OK) u->packed_once = true;
   return rc;

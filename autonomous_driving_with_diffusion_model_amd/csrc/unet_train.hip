@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <unordered_map>
 
+#include "batch_ops.h"
 #include "unet_internal.h"
 
 namespace adx {
@@ -19,7 +20,7 @@ namespace adx {
 int gn_mish_backward_raw(const float* dy, int64_t sb, int64_t sc, int64_t sl, const float* pre, const float* stats,
                          const float* gamma, const float* beta, float* dc, float* dgamma, float* dbeta, float* dbias,
                          float* dtb, int64_t dtb_stride, int B, int C, int L, int groups, hipStream_t s);
-int tconv_wgrad(const adx_tconv_desc* d, const adx_tconv_io* io, const float* dc, float* dw, hipStream_t s);
+int tconv_wgrad(const adx_tconv_desc* d, const adx_tconv_io* io, const float* dc, float* dw, hipStream_t s, bool zero);
 int bias_grad(const float* dc, int64_t sb, int64_t sc, int64_t sl, float* db, int B, int C, int L, hipStream_t s);
 int add_strided(float* dst, const float* src, int64_t sb, int64_t sc, int64_t sl, int B, int C, int L, hipStream_t s);
 int embed_backward(const adx_embed_weights* w, int dim, const int64_t* t, int t_rows, const float* cond,
@@ -266,7 +267,19 @@ int adx_unet_backward(adx_unet* u, const void* packed, void* workspace, size_t w
   float* wscratch = ws.take(maxw);
   ADX_REQUIRE(ws.ok, "adx_unet_backward: workspace of %zu bytes too small", workspace_bytes);
 
-  int rc = ADX_OK;
+  // every small gradient tensor that is accumulated atomically (conv weights, GroupNorm affine, conv bias) is zeroed
+  // here in a handful of launches instead of one memset each inside the loop
+  for (const TapeOp& op : tape->ops) {
+    const ConvLayer& L = *op.L;
+    const adx_tconv_desc& d = L.d;
+    batch_fill_add(grads[L.p_w], (size_t)d.cout * (d.c0 + d.c1) * d.taps);
+    if (d.groups > 0) {
+      batch_fill_add(grads[L.p_g], d.cout);
+      batch_fill_add(grads[L.p_be], d.cout);
+      batch_fill_add(grads[L.p_b], d.cout);
+    }
+  }
+  int rc = batch_fill_flush(s);
   for (size_t oi = tape->ops.size(); oi-- > 0 && rc == ADX_OK;) {
     const TapeOp& op = tape->ops[oi];
     const ConvLayer& L = *op.L;
@@ -297,9 +310,6 @@ int adx_unet_backward(adx_unet* u, const void* packed, void* workspace, size_t w
     const float* dc = nullptr;
     if (d.groups > 0) {
       float* dg = grads[L.p_g]; float* dbe = grads[L.p_be]; float* dbi = grads[L.p_b];
-      ADX_CHECK_HIP(hipMemsetAsync(dg, 0, sizeof(float) * d.cout, s));
-      ADX_CHECK_HIP(hipMemsetAsync(dbe, 0, sizeof(float) * d.cout, s));
-      ADX_CHECK_HIP(hipMemsetAsync(dbi, 0, sizeof(float) * d.cout, s));
       rc = gn_mish_backward_raw(dy.p, dy.sb, dy.sc, dy.sl, op.pre, op.stats, base + L.o_g, base + L.o_be, dc_buf, dg,
                                 dbe, dbi, op.tb_off >= 0 ? dtb + op.tb_off : nullptr, u->sum_c, rows, d.cout, d.lout,
                                 d.groups, s);
@@ -327,7 +337,7 @@ int adx_unet_backward(adx_unet* u, const void* packed, void* workspace, size_t w
       if (d.kind == 0) {
         wio.x0 = op.x0.p; wio.x0_sb = op.x0.sb; wio.x0_sc = op.x0.sc; wio.x0_sl = op.x0.sl;
         if (op.has_x1) { wio.x1 = op.x1.p; wio.x1_sb = op.x1.sb; wio.x1_sc = op.x1.sc; wio.x1_sl = op.x1.sl; }
-        rc = tconv_wgrad(&d, &wio, dc, grads[L.p_w], s);
+        rc = tconv_wgrad(&d, &wio, dc, grads[L.p_w], s, false);
       } else {
         // ConvTranspose1d weight [cin][cout][k]: dW = wgrad of the mirrored strided conv with x and dy swapped
         adx_tconv_desc m{};
@@ -335,7 +345,7 @@ int adx_unet_backward(adx_unet* u, const void* packed, void* workspace, size_t w
         m.c0 = d.cout; m.c1 = 0; m.cout = cin; m.lin = d.lout; m.lout = d.lin; m.groups = 0; m.eps = d.eps;
         wio.x0 = dc; wio.x0_sb = (int64_t)d.cout * d.lout; wio.x0_sc = d.lout; wio.x0_sl = 1;
         ADX_REQUIRE(op.x0.dense(), "adx_unet_backward: transposed conv input must be dense");
-        rc = tconv_wgrad(&m, &wio, op.x0.p, grads[L.p_w], s);
+        rc = tconv_wgrad(&m, &wio, op.x0.p, grads[L.p_w], s, false);
       }
       if (rc != ADX_OK) break;
     }
@@ -393,7 +403,7 @@ int adx_unet_backward(adx_unet* u, const void* packed, void* workspace, size_t w
     memset(&wio, 0, sizeof(wio));
     wio.x0 = tape->mc; wio.x0_sb = 2 * dim; wio.x0_sc = 1; wio.x0_sl = 0;
     wio.batch = rows;
-    rc = tconv_wgrad(&u->tlin.d, &wio, dtb, dwcat, s);
+    rc = tconv_wgrad(&u->tlin.d, &wio, dtb, dwcat, s, true);
     if (rc != ADX_OK) return rc;
     rc = bias_grad(dtb, u->sum_c, 1, 0, dbcat, rows, u->sum_c, 1, s);
     if (rc != ADX_OK) return rc;
