@@ -124,7 +124,7 @@ def conv2d_roofline(dev, reps=10):
             "achieved_note": "fp16 MFMA flops issued = 3 x algorithmic conv flops, / HIP-event launch time",
             "fp32_equivalent_tflops": round(equiv, 1), "fp32_mfma_peak_tflops": PEAK_F32_TFLOPS,
             "traffic": pmc_traffic("conv2d_hs3x3_kernel"),
-            "traffic_note": "bytes/launch, FETCH_SIZE+WRITE_SIZE from profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc passes)",
+            "traffic_note": "bytes/launch, 2 x FETCH_SIZE (gfx950 correction, calibrated: tools/micro/fetch_calib.hip) + WRITE_SIZE from profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc passes)",
             "avg_launch_ms": round(avg_ms, 4), "launches_per_step": count,
             "algorithmic_gflop_per_launch": round(tot_fl / count / 1e9, 2),
             "mfma_gflop_per_launch": round(3 * tot_fl / count / 1e9, 2),
