@@ -5,12 +5,19 @@ them is the bar of fp32 arithmetic: the max error against fp64 may not exceed 1.
 (CPU oneDNN and ROCm MIOpen, whichever is worse; they differ only in summation order) show on the same inputs,
 + 1e-7 relative slack.  Measured (tools/conv_err.py, K = 4608): split-fp16 rms 4.2e-7, exact-fp32 MFMA chain
 1.2e-6, MIOpen fp32 5.8e-7, oneDNN 2.3e-7."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+# ADX_CONV_EXACT=1 routes every conv to the exact-fp32 MFMA kernels (one sequential fp32 chain over K): their bar is
+# the looser one of test_exact_fp32_mfma_conv_shapes
+EXACT = os.environ.get("ADX_CONV_EXACT") == "1" or os.environ.get("ADX_WGRAD_EXACT") == "1"
+BAR = 4.0 if EXACT else 1.5
+split_only = pytest.mark.skipif(EXACT, reason="property of the split-fp16 kernels; ADX_CONV_EXACT=1 selects the exact ones")
 
 
 def _ops():
@@ -44,9 +51,10 @@ def test_conv3x3_s1_split_fp16_is_fp32_grade(cin, cout, h, w, n):
     x, wt = _case(cin, cout, 3, h, w, n, seed=cin + h)
     y, _ = _ops().conv2d(x.to(DEV), wt.to(DEV), stride=1, pad=1)
     e_hip, e_f32 = _errs(y, x, wt, 1, 1)
-    assert e_hip <= 1.5 * e_f32 + 1e-7, (e_hip, e_f32)
+    assert e_hip <= BAR * e_f32 + 1e-7, (e_hip, e_f32)
 
 
+@split_only
 @pytest.mark.parametrize("xscale,wscale", [(2e-3, 1e-2), (300.0, 0.05), (1.0, 30.0), (0.05, 0.002)])
 def test_conv3x3_split_keeps_relative_accuracy_across_magnitudes(xscale, wscale):
     """hi + 2^-11 lo keeps 22 significant bits for every operand with 2^-14 <= |x| < 65504 (fp16's normal range);
@@ -56,9 +64,10 @@ def test_conv3x3_split_keeps_relative_accuracy_across_magnitudes(xscale, wscale)
     y, _ = _ops().conv2d(x.to(DEV), wt.to(DEV), stride=1, pad=1)
     e_hip, e_f32 = _errs(y, x, wt, 1, 1)
     assert torch.isfinite(y).all()
-    assert e_hip <= 1.5 * e_f32 + 1e-7, (e_hip, e_f32)
+    assert e_hip <= BAR * e_f32 + 1e-7, (e_hip, e_f32)
 
 
+@split_only
 def test_conv3x3_split_degrades_gracefully_below_fp16_normal_range():
     """A tensor whose EVERY element is below fp16's normal range (|x| ~ 3e-6) loses bits gradually (hi is an fp16
     subnormal), it does not flush: the result is still well inside the 1e-4 parity bar."""
@@ -78,7 +87,7 @@ def test_conv3x3_fused_bn_residual_relu_epilogue():
     post = lambda c: torch.relu(c * scale.to(c.dtype)[None, :, None, None] + shift.to(c.dtype)[None, :, None, None]  # noqa: E731
                                 + res.to(c.dtype))
     e_hip, e_f32 = _errs(y, x, wt, 1, 1, post)
-    assert e_hip <= 1.5 * e_f32 + 2e-7, (e_hip, e_f32)
+    assert e_hip <= BAR * e_f32 + 2e-7, (e_hip, e_f32)
 
 
 @pytest.mark.parametrize("cin,cout,h,w", [(64, 128, 64, 225), (256, 512, 16, 57), (128, 256, 9, 31), (64, 64, 7, 8)])
@@ -86,7 +95,7 @@ def test_conv3x3_s2_split_fp16_is_fp32_grade(cin, cout, h, w):
     x, wt = _case(cin, cout, 3, h, w, 2, seed=cin + w)
     y, _ = _ops().conv2d(x.to(DEV), wt.to(DEV), stride=2, pad=1)
     e_hip, e_f32 = _errs(y, x, wt, 2, 1)
-    assert e_hip <= 1.5 * e_f32 + 1e-7, (e_hip, e_f32)
+    assert e_hip <= BAR * e_f32 + 1e-7, (e_hip, e_f32)
 
 
 @pytest.mark.parametrize("h,w,n", [(64, 96, 2), (256, 900, 1), (37, 45, 3), (32, 32, 1)])
@@ -97,7 +106,7 @@ def test_stem_7x7_s2_split_fp16_is_fp32_grade(h, w, n):
     y, _ = _ops().conv2d(x.to(DEV), wt.to(DEV), stride=2, pad=3, scale=scale.to(DEV), shift=shift.to(DEV), relu=True)
     post = lambda c: torch.relu(c * scale.to(c.dtype)[None, :, None, None] + shift.to(c.dtype)[None, :, None, None])  # noqa: E731
     e_hip, e_f32 = _errs(y, x, wt, 2, 3, post)
-    assert e_hip <= 1.5 * e_f32 + 2e-7, (e_hip, e_f32)
+    assert e_hip <= BAR * e_f32 + 2e-7, (e_hip, e_f32)
 
 
 @pytest.mark.parametrize("cin,cout,k,stride,pad,h,w", [(64, 128, 1, 2, 0, 64, 225), (128, 64, 1, 1, 0, 9, 33)])
@@ -109,6 +118,7 @@ def test_exact_fp32_mfma_conv_shapes(cin, cout, k, stride, pad, h, w):
     assert e_hip <= 4 * e_f32 + 1e-7, (e_hip, e_f32)
 
 
+@split_only
 def test_conv_non_finite_inputs_stay_loud():
     x, wt = _case(64, 64, 3, 8, 32, 1, seed=2)
     x[0, 3, 4, 5] = float("nan")
@@ -139,7 +149,7 @@ def test_conv3x3_weight_gradient_split_fp16(cin, cout, h, w, n, dyscale, stride)
     dw = _ops().conv2d_weight_grad(x.to(DEV), dy.to(DEV), 3, stride=stride, pad=1)
     den = ref.abs().max().item()
     err = lambda t: (t.double().cpu() - ref).abs().max().item() / den  # noqa: E731
-    assert err(dw) <= 1.5 * max(err(f32), err(g32)) + 2e-7, (err(dw), err(f32), err(g32))
+    assert err(dw) <= BAR * max(err(f32), err(g32)) + 2e-7, (err(dw), err(f32), err(g32))
 
 
 @pytest.mark.parametrize("cin,cout,k,stride,pad,h,w", [(32, 64, 3, 2, 1, 32, 57), (64, 128, 1, 2, 0, 32, 57),
