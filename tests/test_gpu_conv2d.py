@@ -46,7 +46,7 @@ def _errs(y_hip, x, wt, stride, pad, post=None):
 
 @pytest.mark.parametrize("cin,cout,h,w,n", [(64, 64, 64, 225, 2), (128, 128, 32, 113, 2), (256, 256, 16, 57, 3),
                                             (512, 512, 8, 29, 2), (64, 128, 13, 37, 1), (16, 64, 5, 3, 2),
-                                            (32, 192, 9, 70, 1)])
+                                            (32, 192, 9, 70, 1), (48, 64, 11, 33, 2), (80, 128, 17, 20, 1)])
 def test_conv3x3_s1_split_fp16_is_fp32_grade(cin, cout, h, w, n):
     x, wt = _case(cin, cout, 3, h, w, n, seed=cin + h)
     y, _ = _ops().conv2d(x.to(DEV), wt.to(DEV), stride=1, pad=1)
