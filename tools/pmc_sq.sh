@@ -6,12 +6,16 @@ rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_A
 done
 python3 - <<'PY'
 import csv, glob
+res = {}
 for d in sorted(glob.glob("gpurun_out/pmc[AB]_*")):
     f = glob.glob(d + "/*/*counter_collection.csv")
     if not f: print(d, "no csv"); continue
     acc = {}
     for r in csv.DictReader(open(f[0])):
-        if "conv2d_hs_kernel<1" in r["Kernel_Name"]:
+        if "conv2d_hs3x3_kernel" in r["Kernel_Name"]:
             acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-    print(d, {k: round(sum(v[1:]) / max(1, len(v) - 1)) for k, v in acc.items()})
+    res[d.split("/")[-1]] = {k: round(sum(v[1:]) / max(1, len(v) - 1)) for k, v in acc.items()}
+    print(d, res[d.split("/")[-1]])
+import json
+json.dump({"source": "bash tools/pmc_sq.sh: rocprofv3 --kernel-trace --pmc <8 counters> -- python3 tools/pmc_one.py <cin> <h> <w> (B = 64, one 3x3 stride-1 conv with BN + residual + ReLU, per launch, averaged over 4 launches); pmcA / pmcB = the two counter sets", "kernel": "conv2d_hs3x3_kernel", "counters": res}, open("gpurun_out/r01_sq_counters.json", "w"), indent=1)
 PY
