@@ -24,6 +24,7 @@
 // weight slab arrives pre-split from adx_*_pack as [tap][plane][k-half][cout] cells (the A fragment), so every
 // operand read is one conflict-free ds_read_b128.  Global loads of the next stage are issued before the MFMAs
 // of the current one and land in the other LDS buffer after them (one barrier per stage).  Epilogue as conv2d.hip: BN scale/shift, residual, ReLU, NCHW stores.
+#include <type_traits>
 #include <stdlib.h>
 
 #include "adx_common.h"
@@ -345,6 +346,26 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
 //      MODE 0: 4 waves,  8 rows x 32 columns x  64 channels (two per CU)  19.5 KB per 36 MFMAs/wave
 //      MODE 1: 8 waves, 16 rows x 32 columns x  64 channels               25.4 KB per 2 x 36   (-35 %)
 //      MODE 2: 8 waves,  8 rows x 32 columns x 128 channels               31.9 KB per 2 x 36   (-18 %; 8-row maps)
+#ifdef ADX_HS_TRACE
+// diagnostic build (-DADX_HS_TRACE): every workgroup of conv2d_hs3x3_kernel leaves the shader clock at its phase
+// boundaries and the hardware slot it ran on; tools/hs_trace.py reads them back through adx_hs_trace_read
+__device__ unsigned long long g_hs_trace[8 * 16384];
+__device__ __forceinline__ void hs_trace(int slot) {
+  if (threadIdx.x == 0 && blockIdx.x < 16384) g_hs_trace[blockIdx.x * 8 + slot] = __builtin_readcyclecounter();
+}
+__device__ __forceinline__ void hs_trace_id() {
+  if (threadIdx.x == 0 && blockIdx.x < 16384) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_hs_trace[blockIdx.x * 8 + 7] = ((unsigned long long)xcc << 32) | hw;
+  }
+}
+#define HS_TRACE(slot) hs_trace(slot)
+#else
+#define HS_TRACE(slot)
+#endif
+
 template <int MODE>
 __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(const Conv2dArgs a) {
   constexpr int NT = MODE == 0 ? 256 : 512;            // threads
@@ -363,6 +384,10 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rowpair = MODE == 2 ? (wave & 3) : wave, slab = MODE == 2 ? (wave >> 2) : 0;
+#ifdef ADX_HS_TRACE
+  hs_trace_id();
+#endif
+  HS_TRACE(0);
   int bid = blockIdx.x;
   {
     const int per = gridDim.x >> 3;
@@ -408,10 +433,13 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
     wsrc_off[k] = ok ? sl * nchunks * NW + within : 0;
     wdst[k] = ok ? e : -1;
   }
+  // BN scale / shift of this workgroup's channels: requested now, parked in LDS after the first stage's data (a wait
+  // here would put one more memory round trip in front of the first patch load)
+  float ssv = 0.f;
   if (tid < 2 * 64 * CT) {
     const int half = tid / (64 * CT), cc = tid - half * 64 * CT;
     const int c = ct * CT * kHsCout + cc;
-    ss[tid] = a.scale == nullptr ? (half == 0 ? 1.f : 0.f) : (half == 0 ? a.scale[c] : a.shift[c]);
+    ssv = a.scale == nullptr ? (half == 0 ? 1.f : 0.f) : (half == 0 ? a.scale[c] : a.shift[c]);
   }
   float xs = 1.f, xs_inv = 1.f;
   if (a.x_amax != nullptr) {
@@ -485,8 +513,11 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
 #pragma unroll
   for (int k = 0; k < PIT; ++k) { load_p(0, k, 0); store_p(0, k, 0); }
   load_w(1, 1);                 // nchunks is even (>= 2): stage 1 and chunk 1 exist
+  if (tid < 2 * 64 * CT) ss[tid] = ssv;
   load_p(1, 0, 1);
+  HS_TRACE(1);
   __syncthreads();
+  HS_TRACE(2);
 
   for (int cp = 0; cp < nchunks; cp += 2) {
 #pragma unroll
@@ -529,41 +560,62 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
     }
   }
 
+  HS_TRACE(3);
+  // epilogue through buffer descriptors: one instruction per access (wave-uniform channel offset in an SGPR, the
+  // lane's pixel in one 32-bit VGPR); lanes outside the map carry the out-of-range offset, so their loads return 0
+  // and their stores are dropped; without a residual the descriptor is empty and every load returns 0
   const int ox = ox0 + l31;
+  const uint32_t plane_ob = (uint32_t)(a.OH * a.OW) * (uint32_t)sizeof(float);
   const size_t img = (size_t)n * a.Cout * a.OH * a.OW;
-  const size_t plane_o = (size_t)a.OH * a.OW;
+  const int img_bytes = (int)(a.Cout * plane_ob);
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + img, 0, img_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.res != nullptr ? a.res + img : a.y), 0, a.res != nullptr ? img_bytes : 0, 0x00020000);
   const float* sst = ss + slab * 64;
+  const uint32_t cbase_o = (uint32_t)cout0 * plane_ob;
+  uint32_t voff[2];
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const int oy = oy0 + rowpair * 2 + rr;
+    voff[rr] = (oy < a.OH && ox < a.OW) ? (uint32_t)(oy * a.OW + ox) * 4u + (uint32_t)(4 * khalf) * plane_ob : kOutside;
+  }
   float rv[2][2][16];
 #pragma unroll
-  for (int rr = 0; rr < 2; ++rr) {
-    const int oy = oy0 + rowpair * 2 + rr;
-    const bool ok = a.res != nullptr && oy < a.OH && ox < a.OW;
-    const size_t pix = (size_t)oy * a.OW + ox;
+  for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
     for (int half = 0; half < 2; ++half)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int cl = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        rv[rr][half][r] = ok ? a.res[img + (size_t)(cout0 + cl) * plane_o + pix] : 0.f;
+        const int cu = half * 32 + (r & 3) + 8 * (r >> 2);     // + 4 * khalf, which rides in voff
+        rv[rr][half][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, voff[rr], cbase_o + cu * plane_ob, 0));
       }
-  }
+#ifdef ADX_HS_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  HS_TRACE(6);
+#endif
+  auto finish = [&](auto relu) {       // two copies of the store loop: the ReLU is one v_max, not a compare + select
 #pragma unroll
-  for (int rr = 0; rr < 2; ++rr) {
-    const int oy = oy0 + rowpair * 2 + rr;
-    if (oy >= a.OH || ox >= a.OW) continue;
-    const size_t pix = (size_t)oy * a.OW + ox;
+    for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-    for (int half = 0; half < 2; ++half)
+      for (int half = 0; half < 2; ++half)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int cl = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        float v = (accm[rr][half][r] + accl[rr][half][r] * (1.f / kLoScale)) * xs_inv;
-        v = v * sst[cl] + sst[64 * CT + cl];
-        v += rv[rr][half][r];
-        if (a.relu) v = v > 0.f ? v : 0.f;
-        a.y[img + (size_t)(cout0 + cl) * plane_o + pix] = v;
-      }
-  }
+        for (int r = 0; r < 16; ++r) {
+          const int cu = half * 32 + (r & 3) + 8 * (r >> 2);
+          const int cl = cu + 4 * khalf;
+          float v = (accm[rr][half][r] + accl[rr][half][r] * (1.f / kLoScale)) * xs_inv;
+          v = v * sst[cl] + sst[64 * CT + cl];
+          v += rv[rr][half][r];
+          if (decltype(relu)::value) v = __builtin_fmaxf(v, 0.f);   // a NaN becomes 0, like `v > 0 ? v : 0` did
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yrsrc, voff[rr], cbase_o + cu * plane_ob, 0);
+        }
+  };
+  if (a.relu) finish(std::true_type{}); else finish(std::false_type{});
+  HS_TRACE(4);
+#ifdef ADX_HS_TRACE
+  __builtin_amdgcn_s_waitcnt(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  HS_TRACE(5);
+#endif
 }
 
 // ---- the stem: Conv2d(3, 64, 7, stride 2, padding 3), modeling/resnet.py:191 --------------------------------
@@ -971,6 +1023,7 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
   a.tiles_x = ceil_div(a.OW, kTileW); a.tiles_y = ceil_div(a.OH, TH); a.cout_tiles = a.Cout / (kHsCout * CT);
   const size_t grid = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y * a.N;
   ADX_REQUIRE(grid < (1u << 31), "conv2d_hs: grid too large");
+  ADX_REQUIRE((size_t)a.Cout * a.OH * a.OW * sizeof(float) < 0x7FFFFFFFu, "conv2d_hs: one image of the output exceeds the 32-bit byte offsets");
   conv2d_hs3x3_kernel<MODE><<<dim3((unsigned)grid), dim3(NT), lds, s>>>(a);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
@@ -1010,3 +1063,9 @@ int conv2d_hs_launch(const ConvSpec& L, Conv2dArgs a, hipStream_t s) {
 }
 
 }  // namespace adx
+
+#ifdef ADX_HS_TRACE
+extern "C" int adx_hs_trace_read(unsigned long long* host, int nwords) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(adx::g_hs_trace), (size_t)nwords * 8);
+}
+#endif
