@@ -288,45 +288,54 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
   // ---- epilogue: combine, BN scale/shift, residual, ReLU; lane = pixel column, register = channel ----
   // All residual loads of the tile are issued up front (the staging registers are dead by now): one exposed
   // latency per tile instead of one per 16 values.
+  // Buffer descriptors: one instruction per access (wave-uniform channel offset in an SGPR, the lane's pixel in one
+  // 32-bit VGPR); lanes outside the map carry the out-of-range offset (loads return 0, stores are dropped); without a
+  // residual the descriptor is empty and every load returns 0.
   const int ox = ox0 + l31;
+  const uint32_t plane_ob = (uint32_t)(a.OH * a.OW) * (uint32_t)sizeof(float);
   const size_t img = (size_t)n * a.Cout * a.OH * a.OW;
-  const size_t plane_o = (size_t)a.OH * a.OW;
-  float rv[ROWS][2][16];
+  const int img_bytes = (int)(a.Cout * plane_ob);
+  constexpr uint32_t kOut = 0xC0000000u;
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + img, 0, img_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(DS ? a.y_ds + img : a.y, 0, DS ? img_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.res != nullptr ? a.res + img : a.y), 0, a.res != nullptr ? img_bytes : 0, 0x00020000);
+  const uint32_t cbase_o = (uint32_t)cout0 * plane_ob;
+  uint32_t voff[ROWS];
 #pragma unroll
   for (int rr = 0; rr < ROWS; ++rr) {
     const int oy = oy0 + wave * ROWS + rr;
-    const bool ok = a.res != nullptr && oy < a.OH && ox < a.OW;
-    const size_t pix = (size_t)oy * a.OW + ox;
+    voff[rr] = (oy < a.OH && ox < a.OW) ? (uint32_t)(oy * a.OW + ox) * 4u + (uint32_t)(4 * khalf) * plane_ob : kOut;
+  }
+  float rv[ROWS][2][16];
+#pragma unroll
+  for (int rr = 0; rr < ROWS; ++rr)
 #pragma unroll
     for (int half = 0; half < 2; ++half)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int cl = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        rv[rr][half][r] = ok ? a.res[img + (size_t)(cout0 + cl) * plane_o + pix] : 0.f;
+        const int cu = half * 32 + (r & 3) + 8 * (r >> 2);     // + 4 * khalf, which rides in voff
+        rv[rr][half][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, voff[rr], cbase_o + cu * plane_ob, 0));
       }
-  }
 #pragma unroll
-  for (int rr = 0; rr < ROWS; ++rr) {
-    const int oy = oy0 + wave * ROWS + rr;
-    if (oy >= a.OH || ox >= a.OW) continue;
-    const size_t pix = (size_t)oy * a.OW + ox;
+  for (int rr = 0; rr < ROWS; ++rr)
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < 2; ++half)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int cl = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        const int cu = half * 32 + (r & 3) + 8 * (r >> 2);
+        const int cl = cu + 4 * khalf;
         float v = (accm[rr][half][r] + accl[rr][half][r] * (1.f / kLoScale)) * xs_inv;
         v = v * ss[cl] + ss[kHsCout + cl];
         v += rv[rr][half][r];
         if (a.relu) v = v > 0.f ? v : 0.f;
-        a.y[img + (size_t)(cout0 + cl) * plane_o + pix] = v;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yrsrc, voff[rr], cbase_o + cu * plane_ob, 0);
         if (DS) {    // downsample branch: BN only (resnet.py:230-231), no ReLU, no residual
-          float d = (adm[rr][half][r] + adl[rr][half][r] * (1.f / kLoScale)) * xs_inv;
-          a.y_ds[img + (size_t)(cout0 + cl) * plane_o + pix] = d * ss[2 * kHsCout + cl] + ss[3 * kHsCout + cl];
+          const float d = (adm[rr][half][r] + adl[rr][half][r] * (1.f / kLoScale)) * xs_inv;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, d * ss[2 * kHsCout + cl] + ss[3 * kHsCout + cl]),
+                                                drsrc, voff[rr], cbase_o + cu * plane_ob, 0);
         }
       }
-    }
-  }
 }
 
 // ---- 3x3 stride-1, deferred-store pipeline ---------------------------------------------------------------------
@@ -738,7 +747,9 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_stem_kernel(const Conv2dArgs
   // output geometry: the stem map (a.OH x a.OW) or, pooled, its MaxPool2d(3, 2, 1) image
   const int PHo = POOL ? (a.OH - 1) / 2 + 1 : a.OH, PWo = POOL ? (a.OW - 1) / 2 + 1 : a.OW;
   const size_t img = (size_t)n * a.Cout * PHo * PWo;
-  const size_t plane_o = (size_t)PHo * PWo;
+  // stores through a buffer descriptor: channel offset in an SGPR, the lane's pixel in one VGPR (out of range = dropped)
+  const uint32_t plane_ob = (uint32_t)(PHo * PWo) * (uint32_t)sizeof(float);
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + img, 0, (int)(a.Cout * plane_ob), 0x00020000);
 
   load_p(0);
   store_p(0);
@@ -813,19 +824,18 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_stem_kernel(const Conv2dArgs
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr) {
           const int oy = oy0 + wave * 2 + rr;
-          if (oy < a.OH && ox < a.OW) {
-            const size_t pix = (size_t)oy * a.OW + ox;
+          const uint32_t voff = (oy < a.OH && ox < a.OW) ? (uint32_t)(oy * a.OW + ox) * 4u + (uint32_t)(4 * khalf) * plane_ob : kOutside;
 #pragma unroll
-            for (int half = 0; half < 2; ++half)
+          for (int half = 0; half < 2; ++half)
 #pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                const int cl = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                float v = accm[rr][half][r] + accl[rr][half][r] * (1.f / kLoScale);
-                v = v * ss[cl] + ss[kHsCout + cl];
-                if (a.relu) v = v > 0.f ? v : 0.f;
-                a.y[img + (size_t)cl * plane_o + pix] = v;
-              }
-          }
+            for (int r = 0; r < 16; ++r) {
+              const int cu = half * 32 + (r & 3) + 8 * (r >> 2);
+              const int cl = cu + 4 * khalf;
+              float v = accm[rr][half][r] + accl[rr][half][r] * (1.f / kLoScale);
+              v = v * ss[cl] + ss[kHsCout + cl];
+              if (a.relu) v = v > 0.f ? v : 0.f;
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yrsrc, voff, cu * plane_ob, 0);
+            }
         }
       } else {
         // BN + ReLU; rows / columns outside the stem map are the pool's padding
@@ -847,6 +857,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_stem_kernel(const Conv2dArgs
       // horizontal: pooled column 16 tx + i sits on lane 2 i; left neighbour of lane 0 = previous tile's lane 31
       const int pr = ty * 4 + wave, pq = tx * 16 + (l31 >> 1);
       const bool st = pr < PHo && (l31 & 1) == 0 && pq < PWo;
+      const uint32_t voff = st ? (uint32_t)(pr * PWo + pq) * 4u + (uint32_t)(4 * khalf) * plane_ob : kOutside;
 #pragma unroll
       for (int half = 0; half < 2; ++half)
 #pragma unroll
@@ -856,8 +867,8 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_stem_kernel(const Conv2dArgs
           const float right = l31 == 31 ? -INFINITY : dn;
           const float m = pool_max3(left, vm[half][r], right);
           if (l31 == 31) cbuf[2 * (half * 16 + r)] = vm[half][r];
-          const int cl = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-          if (st) a.y[img + (size_t)cl * plane_o + (size_t)pr * PWo + pq] = m;
+          const int cu = half * 32 + (r & 3) + 8 * (r >> 2);       // + 4 * khalf, which rides in voff
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, m), yrsrc, voff, cu * plane_ob, 0);
         }
     }
     if (tx + 1 < a.tiles_x) {
@@ -957,6 +968,7 @@ static int hs_launch_t(Conv2dArgs a, hipStream_t s) {
   a.tiles_x = ceil_div(a.OW, kTileW); a.tiles_y = ceil_div(a.OH, TH); a.cout_tiles = a.Cout / kHsCout;
   const size_t grid = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y * a.N;
   ADX_REQUIRE(grid < (1u << 31), "conv2d_hs: grid too large");
+  ADX_REQUIRE((size_t)a.Cout * a.OH * a.OW * sizeof(float) < 0x7FFFFFFFu, "conv2d_hs: one image of the output exceeds the 32-bit byte offsets");
   conv2d_hs_kernel<STRIDE, K, ROWS, PBUF, DS><<<dim3((unsigned)grid), dim3(256), lds, s>>>(a);
   ADX_LAUNCH_CHECK();
   return ADX_OK;

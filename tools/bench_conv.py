@@ -8,7 +8,8 @@ DEV = "cuda:0"
 SHAPES = [(64, 64, 3, 1, 1, 64, 225), (128, 128, 3, 1, 1, 32, 113), (256, 256, 3, 1, 1, 16, 57), (512, 512, 3, 1, 1, 8, 29),
           (64, 128, 3, 2, 1, 64, 225), (128, 256, 3, 2, 1, 32, 113), (256, 512, 3, 2, 1, 16, 57),
           (64, 128, 1, 2, 0, 64, 225), (3, 64, 7, 2, 3, 256, 900)]
-B = 64
+import os
+B = int(os.environ.get("B", "64"))
 for cin, cout, k, s, p, h, w in SHAPES:
     x = torch.randn(B, cin, h, w, device=DEV)
     wt = torch.randn(cout, cin, k, k, device=DEV) * 0.05
