@@ -427,7 +427,7 @@ extern "C" {
 size_t adx_conv2d_packed_bytes(const adx_conv2d_desc* d) {
   ConvSpec L;
   if (spec_from_desc(d, &L) != ADX_OK) return 0;
-  return sizeof(float) * (size_t)L.k * L.k * L.cin_pad * L.cout;
+  return sizeof(float) * (conv2d_hs_eligible(L) ? conv2d_packed_floats(L) : (size_t)L.k * L.k * L.cin_pad * L.cout);
 }
 
 int adx_conv2d_pack(const adx_conv2d_desc* d, const float* w, float* packed, adx_stream stream) {
@@ -469,7 +469,7 @@ int adx_resnet_create(int32_t out_dim, adx_resnet** out) {
     L.cc = cin >= 16 ? 16 : 4;
     L.cin_pad = round_up(cin, L.cc);
     L.fuse_with = -1;
-    L.o_w = off; off = align64f(off + (size_t)k * k * L.cin_pad * cout);
+    L.o_w = off; off = align64f(off + (conv2d_hs_eligible(L) ? conv2d_packed_floats(L) : (size_t)k * k * L.cin_pad * cout));
     L.o_scale = off; off = align64f(off + cout);
     L.o_shift = off; off = align64f(off + cout);
     r->convs.push_back(L);

@@ -38,6 +38,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kHsCout = 64;          // output channels per workgroup
 constexpr int kHsCC = 16;            // channels per chunk = K of one MFMA
 constexpr float kLoScale = 2048.f;   // 2^11
+constexpr int kF23Default = 0;       // Winograd F(2,3) path of the 3x3 stride-1 convs: opt-in (ADX_HS_F23=1)
 
 __device__ __forceinline__ void split8(const float* v, float xs, u32x4& hi, u32x4& lo) {
   f16x8 h, l;
@@ -627,6 +628,280 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
 #endif
 }
 
+// ---- 3x3 stride-1 in Winograd F(2,3) form along the row -----------------------------------------------------------
+// Two adjacent output columns (2t, 2t+1) of a row come from FOUR products instead of six: with the input columns
+// d0..d3 = x[2t-1 .. 2t+2] and the kernel row g0 g1 g2,
+//     v0 = d0 - d2   v1 = d1 + d2   v2 = d2 - d1   v3 = d1 - d3          (input transform: additions only)
+//     u0 = g0   u1 = (g0 + g1 + g2) / 2   u2 = (g0 - g1 + g2) / 2   u3 = g2   (packed once: conv2d_hs_f23_pack_kernel)
+//     m_p = sum over (input channel, kernel row) of u_p * v_p ;   y[2t] = m0 + m1 + m2 ;   y[2t+1] = m1 - m2 - m3
+// so per (16-channel chunk, kernel row) a wave issues 4 x 3 split-fp16 MFMAs for 32 column PAIRS where the direct
+// kernel issues 2 x 3 x 3 for the same 64 outputs: a third of the matrix work goes away.  The GEMM per transform
+// position p is  [cout] x [column pair]  over k = (channel, kernel row); each position has its own accumulator pair,
+// so the register tile is 1 row x 32 pairs x 32 channels (4 positions x main/low = the 128 accumulator registers of
+// the direct tile) -- and that is what makes this form LOSE on this chip for now (0.26-0.42 ms against 0.21-0.31 ms
+// for the direct kernel on the 256/128/64-channel layers, results equal to 1e-7): with a 1 x 1 tile per position no
+// operand fragment is reused, 4 ds_read_b128 feed 3 MFMAs (1.33 KB of LDS reads per MFMA against 0.67 KB), and a
+// chunk needs ~3.1 k cycles of LDS bandwidth for 2.3 k cycles of MFMA.  It needs the single-accumulator variant
+// (a 2 x 1 tile per position in 128 registers) before it can pay.  Opt-in: ADX_HS_F23=1 (tools/f23_check.py).
+// Workgroup = 8 waves = 4 rows x 64 columns x 64 channels (wave = row, channel half), one per CU:
+//   LDS  V image  2 x [k-half][plane][position][6 rows][32 pairs] 16-byte cells  (transformed, split patch; 2 x 48 KB)
+//        U slab   [kernel row][position][plane][k-half][64 channels] cells       (one chunk; 48 KB, single copy)
+// A stage is a whole 16-channel chunk: 36 MFMAs per wave between barriers.  The patch of chunk c+1 (requested one
+// chunk earlier: 4 columns x 8 channels per thread) is transformed, split and stored into the other V copy under the
+// MFMAs of chunk c; the weights of chunk c+1 are requested right after (before the next patch request -- loads
+// complete in order, and the weights come from L2) and copied into the single U slab between two barriers at the
+// chunk's end, the only time the matrix pipe waits.
+__global__ void __launch_bounds__(512, 2) conv2d_hs3x3_f23_kernel(const Conv2dArgs a) {
+  constexpr int NT = 512, TR = 4, TT = 32, PR = TR + 2;
+  constexpr int VPOS = PR * TT;                   // cells of one (k-half, plane, position) image
+  constexpr int VBUF = 2 * 2 * 4 * VPOS;          // cells per V copy
+  constexpr int WCH = 3 * 4 * 2 * 2 * 64;         // weight cells per chunk
+  constexpr int WIT = WCH / NT;                   // 6
+  constexpr int NITEM = PR * TT * 2;              // staging items: (row, pair, k-half)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32x4* vimg = reinterpret_cast<u32x4*>(smem_raw);
+  u32x4* wl = vimg + 2 * VBUF;
+  float* ss = reinterpret_cast<float*>(wl + WCH);           // 2 x {scale[64], shift[64]}
+  u32x4* dummy = reinterpret_cast<u32x4*>(ss + 4 * 64);     // 8 cells for the idle staging threads
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r4 = wave & 3, mh = wave >> 2;
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const size_t hw = (size_t)a.H * a.W;
+  const int nchunks = a.cin_pad / kHsCC;          // even (checked by the host): a chunk's V copy is its parity
+  constexpr uint32_t kOutside = 0xC0000000u;
+  // one descriptor for the whole input (a lane's offset carries its image): the look-ahead of a tile's last chunks
+  // already fetches the first chunks of the workgroup's next tile, possibly in another image
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x), 0, (int)(uint32_t)((size_t)a.N * a.Cin * hw * sizeof(float)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.w), 0, (int)(uint32_t)((size_t)a.cout_tiles * nchunks * WCH * 16), 0x00020000);
+  const uint32_t plane_bytes = (uint32_t)(hw * sizeof(float));
+
+  // persistent workgroups (one per CU): every XCD walks one contiguous eighth of the tile space
+  const bool by_xcd = (a.ntiles & 7) == 0 && (gridDim.x & 7) == 0;
+  const int t_step = by_xcd ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  const int t_end = by_xcd ? (int)((blockIdx.x & 7) + 1) * (a.ntiles >> 3) : a.ntiles;
+  int tile = by_xcd ? (int)(blockIdx.x & 7) * (a.ntiles >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  int tnext = tile + t_step;
+  struct Tile { int ct, n, oy0, ox0; };
+  auto decode = [&](int t) {
+    Tile r;
+    r.ct = t % a.cout_tiles; t /= a.cout_tiles;
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    r.n = t / a.tiles_y;
+    r.oy0 = ty * TR; r.ox0 = tx * (2 * TT);
+    return r;
+  };
+  // staging item of this thread: patch row, column pair, 8-channel group; its four input columns
+  const bool stager = tid < NITEM;
+  const int st_t = tid & 31, st_h = (tid >> 5) & 1, st_row = stager ? tid >> 6 : 0;
+  auto patch_offsets = [&](const Tile& T, uint32_t (&g)[4]) {
+    const uint32_t img_off = (uint32_t)((size_t)T.n * a.Cin * hw * sizeof(float));
+    const int iy = T.oy0 - 1 + st_row;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ix = T.ox0 - 1 + 2 * st_t + j;
+      const bool ok = stager && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      g[j] = ok ? img_off + (uint32_t)((st_h * 8 * hw + (size_t)iy * a.W + ix) * sizeof(float)) : kOutside;
+    }
+  };
+  auto weights_of = [&](const Tile& T) { return (uint32_t)T.ct * (uint32_t)nchunks * (WCH * 16); };
+  auto load_ss = [&](const Tile& T) {
+    float v = 0.f;
+    if (tid < 128) {
+      const int c = T.ct * kHsCout + (tid & 63);
+      v = a.scale == nullptr ? (tid < 64 ? 1.f : 0.f) : (tid < 64 ? a.scale[c] : a.shift[c]);
+    }
+    return v;
+  };
+  Tile cur = decode(tile);
+  Tile nxt = decode(tnext < t_end ? tnext : tile);
+  uint32_t goff[4], goff_n[4];
+  patch_offsets(cur, goff);
+  patch_offsets(nxt, goff_n);
+  uint32_t wtile = weights_of(cur), wtile_n = weights_of(nxt);
+  const float ssv = load_ss(cur);
+  // first V cell of the item: position p and plane add p * VPOS and 4 * VPOS
+  const int vcell = st_h * 2 * 4 * VPOS + st_row * TT + st_t;
+
+  u32x4 wv[WIT];
+  float pv[4][8];
+  auto load_w = [&](uint32_t slab, int chunk) {
+    const uint32_t so = slab + (uint32_t)chunk * (WCH * 16);
+#pragma unroll
+    for (int k = 0; k < WIT; ++k) wv[k] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (uint32_t)(tid + NT * k) * 16u, so, 0);
+  };
+  auto store_w = [&]() {
+#pragma unroll
+    for (int k = 0; k < WIT; ++k) wl[tid + NT * k] = wv[k];
+  };
+  auto load_p = [&](const uint32_t (&g)[4], const uint32_t (&gn)[4], bool use_n, int chunk) {
+    const uint32_t cbase = (uint32_t)chunk * kHsCC * plane_bytes;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t off = use_n ? gn[j] : g[j];
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        pv[j][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, off, cbase + c * plane_bytes, 0));
+    }
+  };
+  auto store_p = [&](int buf) {
+    float v[4][8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      v[0][c] = pv[0][c] - pv[2][c];
+      v[1][c] = pv[1][c] + pv[2][c];
+      v[2][c] = pv[2][c] - pv[1][c];
+      v[3][c] = pv[1][c] - pv[3][c];
+    }
+    u32x4* base = vimg + buf * VBUF + vcell;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      u32x4 hi, lo;
+      split8(v[p], 1.f, hi, lo);
+      u32x4* d0 = stager ? base + p * VPOS : dummy + 2 * p;
+      u32x4* d1 = stager ? base + (4 + p) * VPOS : dummy + 2 * p + 1;
+      *d0 = hi;
+      *d1 = lo;
+    }
+  };
+
+  const int vb_lane = khalf * 2 * 4 * VPOS + r4 * TT + l31;
+  const u32x4* wa0 = wl + khalf * 64 + mh * 32 + l31;
+
+  // prologue (first tile only): chunk 0 complete in LDS, the patch of chunk 1 in flight
+  load_w(wtile, 0);
+  load_p(goff, goff_n, false, 0);
+  store_w();
+  store_p(0);
+  load_p(goff, goff_n, false, 1);
+  if (tid < 128) ss[tid] = ssv;
+  __syncthreads();
+
+  int par = 0;
+  for (;;) {
+    const bool has_next = tnext < t_end;
+    const float ssn = load_ss(nxt);
+    f32x16 accm[4], accl[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { accm[p][i] = 0.f; accl[p][i] = 0.f; }
+
+    for (int c = 0; c < nchunks; ++c) {
+      const u32x4* vb0 = vimg + (c & 1) * VBUF + vb_lane;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const f16x8 A0 = __builtin_bit_cast(f16x8, wa0[((kh * 4 + p) * 2 + 0) * 128]);
+          const f16x8 A1 = __builtin_bit_cast(f16x8, wa0[((kh * 4 + p) * 2 + 1) * 128]);
+          const f16x8 B0 = __builtin_bit_cast(f16x8, vb0[p * VPOS + kh * TT]);
+          const f16x8 B1 = __builtin_bit_cast(f16x8, vb0[(4 + p) * VPOS + kh * TT]);
+          accm[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, B0, accm[p], 0, 0, 0);
+          accl[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, B1, accl[p], 0, 0, 0);
+          accl[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, B0, accl[p], 0, 0, 0);
+          if (kh == 0 && p == 0) {
+            // the patch requested one chunk ago goes to the other V copy under this chunk's MFMAs; then the next
+            // requests: weights first (needed at this chunk's end), patch after (needed one chunk from now).  Past
+            // the tile's end these are the first chunks of the next tile (selects, no branches).
+            store_p((c + 1) & 1);
+            const bool wn = c + 1 >= nchunks;
+            load_w(wn ? wtile_n : wtile, wn ? c + 1 - nchunks : c + 1);
+            const bool pn = c + 2 >= nchunks;
+            load_p(goff, goff_n, pn, pn ? c + 2 - nchunks : c + 2);
+          }
+        }
+      }
+      __syncthreads();      // every wave is done with the U slab
+      store_w();
+      __syncthreads();
+    }
+
+    // epilogue: inverse transform, BN, residual, ReLU; lane = column pair, register = channel.  The next tile's first
+    // chunk is already in LDS and its second patch in flight.
+    {
+      const int oy = cur.oy0 + r4;
+      const int ox = cur.ox0 + 2 * l31;
+      const uint32_t plane_ob = (uint32_t)(a.OH * a.OW) * (uint32_t)sizeof(float);
+      const size_t img = (size_t)cur.n * a.Cout * a.OH * a.OW;
+      const int img_bytes = (int)(a.Cout * plane_ob);
+      const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + img, 0, img_bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(a.res != nullptr ? a.res + img : a.y), 0, a.res != nullptr ? img_bytes : 0, 0x00020000);
+      const uint32_t cbase_o = (uint32_t)(cur.ct * kHsCout + mh * 32) * plane_ob;
+      uint32_t voff[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        voff[q] = (oy < a.OH && ox + q < a.OW) ? (uint32_t)(oy * a.OW + ox + q) * 4u + (uint32_t)(4 * khalf) * plane_ob : kOutside;
+      float y0[16], y1[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float m0 = accm[0][r] + accl[0][r] * (1.f / kLoScale), m1 = accm[1][r] + accl[1][r] * (1.f / kLoScale);
+        const float m2 = accm[2][r] + accl[2][r] * (1.f / kLoScale), m3 = accm[3][r] + accl[3][r] * (1.f / kLoScale);
+        y0[r] = m0 + m1 + m2;
+        y1[r] = m1 - m2 - m3;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      float rv[2][16];
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          rv[q][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, voff[q], cbase_o + ((r & 3) + 8 * (r >> 2)) * plane_ob, 0));
+      const float* sst = ss + par * 128 + mh * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cu = (r & 3) + 8 * (r >> 2);
+        const int cl = cu + 4 * khalf;
+        float v0 = y0[r] * sst[cl] + sst[64 + cl] + rv[0][r];
+        float v1 = y1[r] * sst[cl] + sst[64 + cl] + rv[1][r];
+        if (a.relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v0), yrsrc, voff[0], cbase_o + cu * plane_ob, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v1), yrsrc, voff[1], cbase_o + cu * plane_ob, 0);
+      }
+    }
+    if (!has_next) break;
+    if (tid < 128) ss[(par ^ 1) * 128 + tid] = ssn;     // read by the next epilogue, a tile of barriers from now
+    par ^= 1;
+    cur = nxt;
+    wtile = wtile_n;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) goff[j] = goff_n[j];
+    tile = tnext;
+    tnext += t_step;
+    nxt = decode(tnext < t_end ? tnext : tile);
+    wtile_n = weights_of(nxt);
+    patch_offsets(nxt, goff_n);
+  }
+}
+
+// fp32 [cout][cin][3][3] -> U image [cout/64][cin/16][kernel row][position][plane][k-half][64][8] fp16
+__global__ void conv2d_hs_f23_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ p, int cout, int cin, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;   // over [cout/64][cin/16][kh][position][k-half][64][8]
+  if (idx >= total) return;
+  const int j = idx & 7;
+  const int ml = (idx >> 3) & 63;
+  const int h = (idx >> 9) & 1;
+  const int pos = (idx >> 10) & 3;
+  size_t rest = idx >> 12;
+  const int kh = rest % 3; rest /= 3;
+  const int nchunks = cin / kHsCC;
+  const int chunk = rest % nchunks;
+  const int ct = rest / nchunks;
+  const int m = ct * 64 + ml, kc = chunk * kHsCC + h * 8 + j;
+  const float* g = w + ((size_t)m * cin + kc) * 9 + kh * 3;
+  const double g0 = g[0], g1 = g[1], g2 = g[2];
+  const float v = pos == 0 ? (float)g0 : (pos == 1 ? (float)(0.5 * (g0 + g1 + g2)) : (pos == 2 ? (float)(0.5 * (g0 - g1 + g2)) : (float)g2));
+  const _Float16 hi = (_Float16)v;
+  const _Float16 lo = (_Float16)((v - (float)hi) * kLoScale);
+  const size_t cell = (((((size_t)(ct * nchunks + chunk) * 3 + kh) * 4 + pos) * 2 + 0) * 2 + h) * 64 + ml;
+  p[cell * 8 + j] = hi;
+  p[(cell + 128) * 8 + j] = lo;     // plane 1 is 2 * 64 cells further
+}
+
 // ---- the stem: Conv2d(3, 64, 7, stride 2, padding 3), modeling/resnet.py:191 --------------------------------
 // K = 3 channels x 7 x 7 = 147 has no 16-channel chunks, so the GEMM's k axis is laid out as 21 (channel, kernel
 // row) "combos" x 8 kernel columns (7 real + one zero weight): a lane's B fragment -- 8 consecutive k for one
@@ -939,6 +1214,22 @@ bool conv2d_hs_eligible(const ConvSpec& L) {
   return L.k == 3 && (L.stride == 1 || L.stride == 2);
 }
 
+// the layers that ALSO carry a Winograd F(2,3) weight image behind the direct one (conv2d_hs3x3_f23_kernel); which of
+// the two kernels runs is decided per launch from the map width.  ADX_HS_F23=0|1 switches the path.
+bool conv2d_hs_f23_eligible(const ConvSpec& L) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("ADX_HS_F23");
+    on = e != nullptr ? (e[0] == '1' ? 1 : 0) : kF23Default;
+  }
+  return on && !L.dgrad && L.k == 3 && L.stride == 1 && L.pad == 1 && conv2d_hs_eligible(L) && (L.cin_pad / kHsCC) % 2 == 0;
+}
+
+size_t conv2d_packed_floats(const ConvSpec& L) {
+  const size_t direct = (size_t)L.k * L.k * L.cin_pad * L.cout;
+  return direct + (conv2d_hs_f23_eligible(L) ? (size_t)12 * L.cin_pad * L.cout : 0);
+}
+
 int conv2d_hs_pack(const ConvSpec& c, const float* w, void* packed, int dgrad, hipStream_t s) {
   if (hs_is_stem(c) && !dgrad) {
     conv2d_hs_stem_pack_kernel<<<dim3(ceil_div(kStemSteps * 2 * 64 * 8, 256)), dim3(256), 0, s>>>(w, (_Float16*)packed);
@@ -949,6 +1240,12 @@ int conv2d_hs_pack(const ConvSpec& c, const float* w, void* packed, int dgrad, h
   conv2d_hs_pack_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
       w, (_Float16*)packed, c.cout, c.cin_pad, c.cin, c.k * c.k, dgrad, total);
   ADX_LAUNCH_CHECK();
+  if (!dgrad && conv2d_hs_f23_eligible(c)) {
+    const size_t tf = (size_t)c.cout * c.cin_pad * 12;     // (kernel row, position) per weight pair, 8 per thread group
+    conv2d_hs_f23_pack_kernel<<<dim3((unsigned)((tf + 255) / 256)), dim3(256), 0, s>>>(
+        w, (_Float16*)((float*)packed + total), c.cout, c.cin_pad, tf);
+    ADX_LAUNCH_CHECK();
+  }
   return ADX_OK;
 }
 
@@ -1041,6 +1338,34 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
   return ADX_OK;
 }
 
+static int hs3x3_f23_launch(Conv2dArgs a, hipStream_t s) {
+  constexpr size_t lds = (size_t)2 * (2 * 2 * 4 * 6 * 32) * 16 + (size_t)3072 * 16 + 256 * sizeof(float) + 8 * 16;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static bool attr = false;
+  if (!attr) {
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_f23_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  a.tiles_x = ceil_div(a.OW, 64); a.tiles_y = ceil_div(a.OH, 4); a.cout_tiles = a.Cout / kHsCout;
+  const size_t ntiles = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y * a.N;
+  ADX_REQUIRE(ntiles < (1u << 31), "conv2d_hs: too many tiles");
+  ADX_REQUIRE((size_t)a.Cout * a.OH * a.OW * sizeof(float) < 0x7FFFFFFFu, "conv2d_hs: one image of the output exceeds the 32-bit byte offsets");
+  a.ntiles = (int)ntiles;
+  static int slots = 0;        // persistent workgroups: one per CU
+  if (slots == 0) {
+    const char* e = getenv("ADX_HS_SLOTS");
+    int dev = 0, cus = 0;
+    ADX_CHECK_HIP(hipGetDevice(&dev));
+    ADX_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    slots = e != nullptr && atoi(e) > 0 ? atoi(e) : (cus > 0 ? cus : 256);
+  }
+  const size_t grid = ntiles < (size_t)slots ? ntiles : (size_t)slots;
+  conv2d_hs3x3_f23_kernel<<<dim3((unsigned)grid), dim3(512), lds, s>>>(a);
+  ADX_LAUNCH_CHECK();
+  return ADX_OK;
+}
+
 int conv2d_hs_launch(const ConvSpec& L, Conv2dArgs a, hipStream_t s) {
   ADX_REQUIRE((size_t)L.cin * a.H * a.W * sizeof(float) < 0xC0000000u, "conv2d_hs: one image of the input exceeds the 32-bit byte offsets");
   const bool ds = a.w_ds != nullptr;
@@ -1049,6 +1374,12 @@ int conv2d_hs_launch(const ConvSpec& L, Conv2dArgs a, hipStream_t s) {
     return hs_stem_launch<false>(a, s);
   }
   if (L.k == 3 && L.stride == 1 && !ds) {
+    // Winograd F(2,3) form where 64-column tiles waste no more of the map than 32-column tiles do
+    if (conv2d_hs_f23_eligible(L) && a.x_amax == nullptr && ceil_div(a.OW, 64) * 64 <= ceil_div(a.OW, 32) * 32 &&
+        (size_t)a.N * a.Cin * a.H * a.W * sizeof(float) < 0xC0000000u) {
+      a.w += (size_t)9 * L.cin_pad * L.cout;
+      return hs3x3_f23_launch(a, s);
+    }
     static int pipe = -1;
     if (pipe < 0) {
       const char* e = getenv("ADX_HS_PIPE");      // ADX_HS_PIPE=0: the one-stage-ahead kernel for every 3x3 conv

@@ -33,7 +33,7 @@ struct Conv2dArgs {
   int x_amax_n;
   int N, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, relu;
   int cin_pad, cc;      // channels padded to the chunk size, chunk size (16, or 4 for the stem)
-  int tiles_x, tiles_y, cout_tiles;
+  int tiles_x, tiles_y, cout_tiles, ntiles;
   int PH, PW, PWp;      // staged patch rows, columns, padded row pitch
 };
 
@@ -66,6 +66,8 @@ int conv2d_pack_raw(const float* w, float* packed, int cout, int cin, int k, int
 int conv2d_pack_spec(const ConvSpec& consumer, const float* w, float* packed, int dgrad, hipStream_t s);
 // conv2d_hs.hip: fp32-equivalent convolution on the fp16 matrix cores (hi/lo split operands, 3 MFMAs per product)
 bool conv2d_hs_eligible(const ConvSpec& L);
+// floats a layer's packed weight image takes (direct image, plus the Winograd F(2,3) image where that path applies)
+size_t conv2d_packed_floats(const ConvSpec& L);
 int conv2d_hs_pack(const ConvSpec& consumer, const float* w, void* packed, int dgrad, hipStream_t s);
 int conv2d_hs_launch(const ConvSpec& L, Conv2dArgs a, hipStream_t s);
 // stem conv + BN + ReLU + MaxPool2d(3, 2, 1) in one pass: writes only the pooled map [N][64][PH][PW]
