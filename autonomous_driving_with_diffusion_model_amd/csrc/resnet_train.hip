@@ -48,18 +48,34 @@ __global__ void __launch_bounds__(256) channel_sums_kernel(const float* __restri
   const float mu = MODE == 1 ? mean[c] : 0.f, rs = MODE == 1 ? rstd[c] : 0.f;
   float sc = 0.f, sh = 0.f;
   if (MODE == 1 && relu_mask == 2) bn_affine(gamma[c], beta[c], mu, rs, sc, sh);
-  for (int i = tid; i < HW; i += 256) {
-    float v = a[base + i];
+  auto one = [&](float v, float rw, float o) {
     if (MODE == 0) {
       s0 += v;
       s1 += (double)v * v;
     } else {
-      const float rw = raw[base + i];
-      if (relu_mask == 1 && !(out[base + i] > 0.f)) v = 0.f;
+      if (relu_mask == 1 && !(o > 0.f)) v = 0.f;
       if (relu_mask == 2 && !(bn_eval(rw, sc, sh) > 0.f)) v = 0.f;
       s0 += v;
       s1 += (double)v * (double)((rw - mu) * rs);
     }
+  };
+  const bool vec = (HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(a) | (MODE == 1 ? reinterpret_cast<uintptr_t>(raw) : 0) |
+                                      (MODE == 1 && relu_mask == 1 ? reinterpret_cast<uintptr_t>(out) : 0)) & 15) == 0;
+  if (vec) {     // 16-byte loads: a plane starts on a 16-byte boundary when HW % 4 == 0
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a + base);
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(raw + base);
+    const f32x4* o4 = reinterpret_cast<const f32x4*>(out + base);
+    for (int i = tid; i < (HW >> 2); i += 256) {
+      const f32x4 v = a4[i];
+      f32x4 rw = f32x4{0.f, 0.f, 0.f, 0.f}, o = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (MODE == 1) rw = r4[i];
+      if (MODE == 1 && relu_mask == 1) o = o4[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) one(v[k], rw[k], o[k]);
+    }
+  } else {
+    for (int i = tid; i < HW; i += 256)
+      one(a[base + i], MODE == 1 ? raw[base + i] : 0.f, MODE == 1 && relu_mask == 1 ? out[base + i] : 0.f);
   }
   __shared__ double red[8];
   s0 = wave_sum_d(s0);
@@ -109,6 +125,45 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__
   out[i] = v;
 }
 
+// plane kernels apply when a plane is a whole number of 16-byte quads and every tensor involved starts on one
+static bool bn_planes_ok(int HW, const void* a, const void* b, const void* c) {
+  return (HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
+}
+
+// The same pass for maps with HW % 4 == 0 (every ResNet-34 map at 256x900): one wave per (image, channel) plane, the
+// channel's constants in scalars, 16-byte loads and stores, no per-element index arithmetic.  Workgroup w takes the
+// planes 4w .. 4w+3, 4w + 4 gridDim ...
+__global__ void __launch_bounds__(256) bn_apply_planes_kernel(const float* __restrict__ raw, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, const float* __restrict__ res,
+                                                               float* __restrict__ out, int C, int HW, int planes, int relu) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hw4 = HW >> 2;
+  for (int pl = blockIdx.x * 4 + wave; pl < planes; pl += gridDim.x * 4) {
+    const int c = pl % C;
+    const float sc = scale[c], sh = shift[c];
+    const size_t base = (size_t)pl * hw4;
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(raw) + base;
+    const f32x4* i4 = reinterpret_cast<const f32x4*>(res) + base;
+    f32x4* o4 = reinterpret_cast<f32x4*>(out) + base;
+    for (int i = lane; i < hw4; i += 64) {
+      const f32x4 rw = r4[i];
+      f32x4 v;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = bn_eval(rw[k], sc, sh);
+      if (res != nullptr) {
+        const f32x4 id = i4[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += id[k];
+      }
+      if (relu) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+      }
+      o4[i] = v;
+    }
+  }
+}
+
 constexpr size_t kAmaxPartials = 4096;   // workgroups of bn_bwd_apply_kernel = partial maxima handed to the dgrad conv
 
 // draw = gamma*rstd * (dz - m1 - xhat*m2); also d gamma / d beta (one thread per channel does that part)
@@ -148,6 +203,70 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
     b = o > b ? o : b;
   }
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = b;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t m01 = red[0] > red[1] ? red[0] : red[1], m23 = red[2] > red[3] ? red[2] : red[3];
+    amax[blockIdx.x] = m01 > m23 ? m01 : m23;
+  }
+}
+
+// plane form of bn_bwd_apply_kernel (HW % 4 == 0): one wave per plane, channel constants (including the two fp64
+// divisions) once per plane, 16-byte accesses; amax[blockIdx.x] as above
+__global__ void __launch_bounds__(256) bn_bwd_apply_planes_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                                   const float* __restrict__ raw, const float* __restrict__ mean,
+                                                                   const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                   const double* __restrict__ sums, float* __restrict__ draw,
+                                                                   float* __restrict__ dz_out, int C, int HW, int planes,
+                                                                   double count, int relu_mask, uint32_t* __restrict__ amax,
+                                                                   const float* __restrict__ beta) {
+  __shared__ uint32_t red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hw4 = HW >> 2;
+  uint32_t b = 0;
+  for (int pl = blockIdx.x * 4 + wave; pl < planes; pl += gridDim.x * 4) {
+    const int c = pl % C;
+    const float mu = mean[c], rs = rstd[c], ga = gamma[c];
+    float sc = 0.f, sh = 0.f;
+    if (relu_mask == 2) bn_affine(ga, beta[c], mu, rs, sc, sh);
+    const float m1 = (float)(sums[2 * c] / count), m2 = (float)(sums[2 * c + 1] / count);
+    const size_t base = (size_t)pl * hw4;
+    const f32x4* d4 = reinterpret_cast<const f32x4*>(dout) + base;
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(raw) + base;
+    const f32x4* o4 = reinterpret_cast<const f32x4*>(out) + base;
+    f32x4* w4 = reinterpret_cast<f32x4*>(draw) + base;
+    f32x4* z4 = reinterpret_cast<f32x4*>(dz_out) + base;
+    for (int i = lane; i < hw4; i += 64) {
+      f32x4 dz = d4[i];
+      const f32x4 rw = r4[i];
+      if (relu_mask == 1) {
+        const f32x4 o = o4[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (!(o[k] > 0.f)) dz[k] = 0.f;
+      }
+      if (relu_mask == 2) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (!(bn_eval(rw[k], sc, sh) > 0.f)) dz[k] = 0.f;
+      }
+      if (dz_out != nullptr) z4[i] = dz;
+      f32x4 v;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float xh = (rw[k] - mu) * rs;
+        v[k] = ga * rs * (dz[k] - m1 - xh * m2);
+        const uint32_t vb = __builtin_bit_cast(uint32_t, v[k]) & 0x7FFFFFFFu;
+        b = vb > b ? vb : b;
+      }
+      w4[i] = v;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)b, off, 64);
+    b = o > b ? o : b;
+  }
+  if (lane == 0) red[wave] = b;
   __syncthreads();
   if (threadIdx.x == 0) {
     const uint32_t m01 = red[0] > red[1] ? red[0] : red[1], m23 = red[2] > red[3] ? red[2] : red[3];
@@ -267,31 +386,45 @@ __global__ void __launch_bounds__(256) maxpool_bwd_gather_kernel(const uint8_t* 
   }
 }
 
-// avgpool + fc backward; one workgroup per image.  pooled is recomputed.
+// avgpool + fc backward.  Grid = (image, channel slice): each workgroup recomputes the pooled values of its 64 channels
+// (one wave per 16 of them), forms their share of d(pooled) and of the fc weight gradient, and broadcasts d(pooled) over
+// the map with row-contiguous stores.
+constexpr int kPoolSlice = 64;
 __global__ void __launch_bounds__(256) avgpool_fc_bwd_kernel(const float* __restrict__ x, const float* __restrict__ fw,
                                                               const float* __restrict__ dfeat, float* __restrict__ dx,
                                                               float* __restrict__ dfw, float* __restrict__ dfb, int C,
                                                               int HW, int out_dim) {
-  __shared__ float pooled[512];
-  __shared__ float dpool[512];
-  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* src = x + (size_t)n * C * HW;
+  __shared__ float pooled[kPoolSlice];
+  __shared__ float dpool[kPoolSlice];
+  const int nslice = C / kPoolSlice;
+  const int n = blockIdx.x / nslice, c0 = (blockIdx.x % nslice) * kPoolSlice;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* src = x + ((size_t)n * C + c0) * HW;
+  const float* df = dfeat + (size_t)n * out_dim;
   const float inv = 1.0f / (float)HW;
-  for (int c = wave; c < C; c += 4) {
+  for (int c = wave; c < kPoolSlice; c += 4) {
     float s = 0.f;
     for (int i = lane; i < HW; i += 64) s += src[(size_t)c * HW + i];
     s = wave_sum(s);
     if (lane == 0) pooled[c] = s * inv;
   }
-  for (int c = tid; c < C; c += 256) {
+  if (tid < kPoolSlice) {
     float s = 0.f;
-    for (int j = 0; j < out_dim; ++j) s += dfeat[(size_t)n * out_dim + j] * fw[(size_t)j * C + c];
-    dpool[c] = s * inv;
+    for (int j = 0; j < out_dim; ++j) s += df[j] * fw[(size_t)j * C + c0 + tid];
+    dpool[tid] = s * inv;
   }
   __syncthreads();
-  for (int i = tid; i < C * HW; i += 256) dx[(size_t)n * C * HW + i] = dpool[i / HW];
-  for (int i = tid; i < out_dim * C; i += 256) atomicAdd(dfw + i, dfeat[(size_t)n * out_dim + i / C] * pooled[i % C]);
-  for (int j = tid; j < out_dim; j += 256) atomicAdd(dfb + j, dfeat[(size_t)n * out_dim + j]);
+  float* dst = dx + ((size_t)n * C + c0) * HW;
+  for (int c = wave; c < kPoolSlice; c += 4) {
+    const float v = dpool[c];
+    for (int i = lane; i < HW; i += 64) dst[(size_t)c * HW + i] = v;
+  }
+  for (int i = tid; i < out_dim * kPoolSlice; i += 256) {
+    const int j = i / kPoolSlice, c = i - j * kPoolSlice;
+    atomicAdd(dfw + (size_t)j * C + c0 + c, df[j] * pooled[c]);
+  }
+  if (c0 == 0)
+    for (int j = tid; j < out_dim; j += 256) atomicAdd(dfb + j, df[j]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -660,8 +793,14 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
     bn_finalize_kernel<<<dim3(ceil_div(L.cout, 256)), dim3(256), 0, s>>>(
         sums, T[L.t_g], T[L.t_b], scale, shift, rec.mean, rec.rstd, update_running ? const_cast<float*>(T[L.t_m]) : nullptr,
         update_running ? const_cast<float*>(T[L.t_v]) : nullptr, L.cout, (double)batch * HW);
-    bn_apply_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(rec.raw, scale, shift, identity, rec.out,
-                                                                          L.cout, HW, n, relu);
+    if (bn_planes_ok(HW, rec.raw, identity, rec.out)) {
+      const int planes = batch * L.cout;
+      bn_apply_planes_kernel<<<dim3(std::min(ceil_div(planes, 4), 8192)), dim3(256), 0, s>>>(rec.raw, scale, shift, identity,
+                                                                                            rec.out, L.cout, HW, planes, relu);
+    } else {
+      bn_apply_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(rec.raw, scale, shift, identity, rec.out,
+                                                                            L.cout, HW, n, relu);
+    }
     tape->recs.push_back(rec);
     return rec.out;
   };
@@ -730,7 +869,7 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
     const int HW = tape->fh * tape->fw_;
     ADX_CHECK_HIP(hipMemsetAsync(G[r->t_fcw], 0, sizeof(float) * (size_t)r->out_dim * 512, s));
     ADX_CHECK_HIP(hipMemsetAsync(G[r->t_fcb], 0, sizeof(float) * r->out_dim, s));
-    avgpool_fc_bwd_kernel<<<dim3(batch), dim3(256), 0, s>>>(tape->final_map, T[r->t_fcw], d_feature, g_cur, G[r->t_fcw],
+    avgpool_fc_bwd_kernel<<<dim3(batch * (512 / kPoolSlice)), dim3(256), 0, s>>>(tape->final_map, T[r->t_fcw], d_feature, g_cur, G[r->t_fcw],
                                                             G[r->t_fcb], 512, HW, r->out_dim);
     ADX_LAUNCH_CHECK();
   }
@@ -747,9 +886,17 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
     const int mask = !rec.relu ? 0 : (rec.identity != nullptr ? 1 : 2);
     channel_sums_kernel<1><<<dim3(batch * L.cout), dim3(256), 0, s>>>(dout, rec.out, rec.raw, rec.mean, rec.rstd, sums,
                                                                       L.cout, HW, mask, T[L.t_g], T[L.t_b]);
-    const int n_amax = (int)std::min<size_t>(kAmaxPartials, (n + 255) / 256);
-    bn_bwd_apply_kernel<<<dim3(n_amax), dim3(256), 0, s>>>(
-        dout, rec.out, rec.raw, rec.mean, rec.rstd, T[L.t_g], sums, draw, dz_keep, L.cout, HW, n, count, mask, amax, T[L.t_b]);
+    int n_amax;
+    if (bn_planes_ok(HW, dout, rec.raw, draw) && bn_planes_ok(HW, rec.out, dz_keep, nullptr)) {
+      const int planes = batch * L.cout;
+      n_amax = (int)std::min<size_t>(kAmaxPartials, (size_t)ceil_div(planes, 4));
+      bn_bwd_apply_planes_kernel<<<dim3(n_amax), dim3(256), 0, s>>>(dout, rec.out, rec.raw, rec.mean, rec.rstd, T[L.t_g], sums,
+                                                                    draw, dz_keep, L.cout, HW, planes, count, mask, amax, T[L.t_b]);
+    } else {
+      n_amax = (int)std::min<size_t>(kAmaxPartials, (n + 255) / 256);
+      bn_bwd_apply_kernel<<<dim3(n_amax), dim3(256), 0, s>>>(
+          dout, rec.out, rec.raw, rec.mean, rec.rstd, T[L.t_g], sums, draw, dz_keep, L.cout, HW, n, count, mask, amax, T[L.t_b]);
+    }
     bn_param_grad_kernel<<<dim3(ceil_div(L.cout, 256)), dim3(256), 0, s>>>(sums, G[L.t_g], G[L.t_b], L.cout);
     ADX_LAUNCH_CHECK();
     int rc2 = conv2d_wgrad(rec.x, draw, G[L.t_w], batch, L.cin, rec.H, rec.W, L.cout, L.k, L.stride, L.pad, s, amax, n_amax, false);
