@@ -634,23 +634,23 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
 //     v0 = d0 - d2   v1 = d1 + d2   v2 = d2 - d1   v3 = d1 - d3          (input transform: additions only)
 //     u0 = g0   u1 = (g0 + g1 + g2) / 2   u2 = (g0 - g1 + g2) / 2   u3 = g2   (packed once: conv2d_hs_f23_pack_kernel)
 //     m_p = sum over (input channel, kernel row) of u_p * v_p ;   y[2t] = m0 + m1 + m2 ;   y[2t+1] = m1 - m2 - m3
-// so per (16-channel chunk, kernel row) a wave issues 4 x 3 split-fp16 MFMAs for 32 column PAIRS where the direct
-// kernel issues 2 x 3 x 3 for the same 64 outputs: a third of the matrix work goes away.  The GEMM per transform
-// position p is  [cout] x [column pair]  over k = (channel, kernel row); each position has its own accumulator pair,
-// so the register tile is 1 row x 32 pairs x 32 channels (4 positions x main/low = the 128 accumulator registers of
-// the direct tile) -- and that is what makes this form LOSE on this chip for now (0.26-0.42 ms against 0.21-0.31 ms
-// for the direct kernel on the 256/128/64-channel layers, results equal to 1e-7): with a 1 x 1 tile per position no
-// operand fragment is reused, 4 ds_read_b128 feed 3 MFMAs (1.33 KB of LDS reads per MFMA against 0.67 KB), and a
-// chunk needs ~3.1 k cycles of LDS bandwidth for 2.3 k cycles of MFMA.  It needs the single-accumulator variant
-// (a 2 x 1 tile per position in 128 registers) before it can pay.  Opt-in: ADX_HS_F23=1 (tools/f23_check.py).
-// Workgroup = 8 waves = 4 rows x 64 columns x 64 channels (wave = row, channel half), one per CU:
+// so a third of the matrix work of the direct form goes away.  The GEMM per transform position p is [cout] x [column
+// pair] over k = (channel, kernel row), and every position needs its own accumulator pair.  Mapping: a wave owns ONE
+// position (and one 32-channel half) for all 4 rows of the tile -- 4 x (main, low) accumulators = the 128 registers of
+// the direct tile; the U fragments of a kernel row feed 4 rows, 18-30 ds_read_b128 per 36 MFMAs.  The four positions of
+// an output therefore sit in four waves and meet in LDS in the epilogue, one output row at a time.
+// Workgroup = 8 waves = 4 rows x 64 columns x 64 channels, persistent, one per CU:
 //   LDS  V image  2 x [k-half][plane][position][6 rows][32 pairs] 16-byte cells  (transformed, split patch; 2 x 48 KB)
 //        U slab   [kernel row][position][plane][k-half][64 channels] cells       (one chunk; 48 KB, single copy)
-// A stage is a whole 16-channel chunk: 36 MFMAs per wave between barriers.  The patch of chunk c+1 (requested one
-// chunk earlier: 4 columns x 8 channels per thread) is transformed, split and stored into the other V copy under the
-// MFMAs of chunk c; the weights of chunk c+1 are requested right after (before the next patch request -- loads
-// complete in order, and the weights come from L2) and copied into the single U slab between two barriers at the
-// chunk's end, the only time the matrix pipe waits.
+// A stage is a whole 16-channel chunk (36 MFMAs per wave between barriers); the patch of chunk c+3 is requested when
+// chunk c starts (each element fetched once, neighbours by lane shuffle) and is transformed, split and stored under the
+// MFMAs of chunk c+2; the weights of chunk c+1 are copied into the U slab between two barriers at the chunk's end.  The
+// look-ahead runs on into the workgroup's next tile, so only the first tile has a prologue.
+// STATUS: correct (error against fp64 1.0-1.8e-7, tools/f23_check.py), not yet faster: 0.23 / 0.31 / 0.42 ms against
+// 0.20 / 0.24 / 0.31 ms for the direct kernel on the 256/128/64-channel layers.  With the staging compiled out the
+// matrix part alone runs in 0.12 / 0.15 / 0.24 ms; the patch path costs the difference (fetch 0.06 ms, transform +
+// split + store 0.04 ms on the 256-channel layer): 6 of the 8 waves spend ~1 k VALU cycles per chunk on it in lockstep,
+// and with one workgroup per CU nothing else fills the matrix pipe meanwhile.  Opt-in: ADX_HS_F23=1.
 __global__ void __launch_bounds__(512, 2) conv2d_hs3x3_f23_kernel(const Conv2dArgs a) {
   constexpr int NT = 512, TR = 4, TT = 32, PR = TR + 2;
   constexpr int VPOS = PR * TT;                   // cells of one (k-half, plane, position) image
@@ -665,7 +665,7 @@ __global__ void __launch_bounds__(512, 2) conv2d_hs3x3_f23_kernel(const Conv2dAr
   u32x4* dummy = reinterpret_cast<u32x4*>(ss + 4 * 64);     // 8 cells for the idle staging threads
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r4 = wave & 3, mh = wave >> 2;
+  const int pos = wave & 3, mh = wave >> 2;     // a wave owns ONE transform position (and one channel half) for all 4 rows
   const int l31 = lane & 31, khalf = lane >> 5;
   const size_t hw = (size_t)a.H * a.W;
   const int nchunks = a.cin_pad / kHsCC;          // even (checked by the host): a chunk's V copy is its parity
@@ -697,15 +697,20 @@ __global__ void __launch_bounds__(512, 2) conv2d_hs3x3_f23_kernel(const Conv2dAr
   // staging item of this thread: patch row, column pair, 8-channel group; its four input columns
   const bool stager = tid < NITEM;
   const int st_t = tid & 31, st_h = (tid >> 5) & 1, st_row = stager ? tid >> 6 : 0;
+  // Every input element is fetched once: a lane loads the columns 2t and 2t+1 of its pair (g[0], g[1]; one 8-byte
+  // load when both lie inside the row), its left / right neighbours come from the adjacent lanes, and only the lanes
+  // at the ends of the 32-pair row fetch an edge column (g[2]: column -1 for t = 0, column 64 for t = 31).
   auto patch_offsets = [&](const Tile& T, uint32_t (&g)[4]) {
     const uint32_t img_off = (uint32_t)((size_t)T.n * a.Cin * hw * sizeof(float));
     const int iy = T.oy0 - 1 + st_row;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int ix = T.ox0 - 1 + 2 * st_t + j;
-      const bool ok = stager && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      g[j] = ok ? img_off + (uint32_t)((st_h * 8 * hw + (size_t)iy * a.W + ix) * sizeof(float)) : kOutside;
-    }
+    const bool rok = stager && iy >= 0 && iy < a.H;
+    const uint32_t rowb = img_off + (uint32_t)((st_h * 8 * hw + (size_t)(rok ? iy : 0) * a.W) * sizeof(float));
+    const int x0 = T.ox0 + 2 * st_t;
+    g[0] = rok && x0 < a.W ? rowb + (uint32_t)x0 * 4u : kOutside;
+    g[1] = rok && x0 + 1 < a.W ? rowb + (uint32_t)(x0 + 1) * 4u : kOutside;
+    const int xe = st_t == 0 ? T.ox0 - 1 : T.ox0 + 64;
+    g[2] = rok && (st_t == 0 || st_t == 31) && xe >= 0 && xe < a.W ? rowb + (uint32_t)xe * 4u : kOutside;
+    g[3] = 0;
   };
   auto weights_of = [&](const Tile& T) { return (uint32_t)T.ct * (uint32_t)nchunks * (WCH * 16); };
   auto load_ss = [&](const Tile& T) {
@@ -727,7 +732,7 @@ __global__ void __launch_bounds__(512, 2) conv2d_hs3x3_f23_kernel(const Conv2dAr
   const int vcell = st_h * 2 * 4 * VPOS + st_row * TT + st_t;
 
   u32x4 wv[WIT];
-  float pv[4][8];
+  float pv[2][3][8];      // two patches in flight (own column pair + edge column): requested at chunk c, stored at c+2
   auto load_w = [&](uint32_t slab, int chunk) {
     const uint32_t so = slab + (uint32_t)chunk * (WCH * 16);
 #pragma unroll
@@ -737,24 +742,27 @@ __global__ void __launch_bounds__(512, 2) conv2d_hs3x3_f23_kernel(const Conv2dAr
 #pragma unroll
     for (int k = 0; k < WIT; ++k) wl[tid + NT * k] = wv[k];
   };
-  auto load_p = [&](const uint32_t (&g)[4], const uint32_t (&gn)[4], bool use_n, int chunk) {
+  auto load_p = [&](const uint32_t (&g)[4], const uint32_t (&gn)[4], bool use_n, int chunk, int set) {
     const uint32_t cbase = (uint32_t)chunk * kHsCC * plane_bytes;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 3; ++j) {
       const uint32_t off = use_n ? gn[j] : g[j];
 #pragma unroll
       for (int c = 0; c < 8; ++c)
-        pv[j][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, off, cbase + c * plane_bytes, 0));
+        pv[set][j][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, off, cbase + c * plane_bytes, 0));
     }
   };
-  auto store_p = [&](int buf) {
+  auto store_p = [&](int buf, int set) {
     float v[4][8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      v[0][c] = pv[0][c] - pv[2][c];
-      v[1][c] = pv[1][c] + pv[2][c];
-      v[2][c] = pv[2][c] - pv[1][c];
-      v[3][c] = pv[1][c] - pv[3][c];
+      const float d1 = pv[set][0][c], d2 = pv[set][1][c], e = pv[set][2][c];
+      const float up = __shfl_up(d2, 1, 32), dn = __shfl_down(d1, 1, 32);
+      const float d0 = st_t == 0 ? e : up, d3 = st_t == 31 ? e : dn;
+      v[0][c] = d0 - d2;
+      v[1][c] = d1 + d2;
+      v[2][c] = d2 - d1;
+      v[3][c] = d1 - d3;
     }
     u32x4* base = vimg + buf * VBUF + vcell;
 #pragma unroll
@@ -768,15 +776,16 @@ __global__ void __launch_bounds__(512, 2) conv2d_hs3x3_f23_kernel(const Conv2dAr
     }
   };
 
-  const int vb_lane = khalf * 2 * 4 * VPOS + r4 * TT + l31;
+  const int vb_lane = khalf * 2 * 4 * VPOS + pos * VPOS + l31;
   const u32x4* wa0 = wl + khalf * 64 + mh * 32 + l31;
 
   // prologue (first tile only): chunk 0 complete in LDS, the patch of chunk 1 in flight
   load_w(wtile, 0);
-  load_p(goff, goff_n, false, 0);
+  load_p(goff, goff_n, false, 0, 0);
   store_w();
-  store_p(0);
-  load_p(goff, goff_n, false, 1);
+  store_p(0, 0);
+  load_p(goff, goff_n, false, 1, 1);                      // chunk 1 -> set 1 (stored at chunk 0)
+  load_p(goff, goff_n, false, 2, 0);                      // chunk 2 -> set 0 (stored at chunk 1); nchunks >= 4
   if (tid < 128) ss[tid] = ssv;
   __syncthreads();
 
@@ -784,83 +793,93 @@ __global__ void __launch_bounds__(512, 2) conv2d_hs3x3_f23_kernel(const Conv2dAr
   for (;;) {
     const bool has_next = tnext < t_end;
     const float ssn = load_ss(nxt);
-    f32x16 accm[4], accl[4];
+    f32x16 accm[4], accl[4];      // per output row of the tile
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { accm[p][i] = 0.f; accl[p][i] = 0.f; }
+      for (int i = 0; i < 16; ++i) { accm[r][i] = 0.f; accl[r][i] = 0.f; }
 
-    for (int c = 0; c < nchunks; ++c) {
-      const u32x4* vb0 = vimg + (c & 1) * VBUF + vb_lane;
+    for (int c2 = 0; c2 < nchunks; c2 += 2) {
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
+      for (int u = 0; u < 2; ++u) {
+        const int c = c2 + u;                       // c & 1 == u: chunk parity = V copy = 1 - register set to store
+        const u32x4* vb0 = vimg + u * VBUF + vb_lane;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const f16x8 A0 = __builtin_bit_cast(f16x8, wa0[((kh * 4 + p) * 2 + 0) * 128]);
-          const f16x8 A1 = __builtin_bit_cast(f16x8, wa0[((kh * 4 + p) * 2 + 1) * 128]);
-          const f16x8 B0 = __builtin_bit_cast(f16x8, vb0[p * VPOS + kh * TT]);
-          const f16x8 B1 = __builtin_bit_cast(f16x8, vb0[(4 + p) * VPOS + kh * TT]);
-          accm[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, B0, accm[p], 0, 0, 0);
-          accl[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, B1, accl[p], 0, 0, 0);
-          accl[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, B0, accl[p], 0, 0, 0);
-          if (kh == 0 && p == 0) {
-            // the patch requested one chunk ago goes to the other V copy under this chunk's MFMAs; then the next
-            // requests: weights first (needed at this chunk's end), patch after (needed one chunk from now).  Past
-            // the tile's end these are the first chunks of the next tile (selects, no branches).
-            store_p((c + 1) & 1);
-            const bool wn = c + 1 >= nchunks;
-            load_w(wn ? wtile_n : wtile, wn ? c + 1 - nchunks : c + 1);
-            const bool pn = c + 2 >= nchunks;
-            load_p(goff, goff_n, pn, pn ? c + 2 - nchunks : c + 2);
+        for (int kh = 0; kh < 3; ++kh) {
+          const f16x8 A0 = __builtin_bit_cast(f16x8, wa0[((kh * 4 + pos) * 2 + 0) * 128]);
+          const f16x8 A1 = __builtin_bit_cast(f16x8, wa0[((kh * 4 + pos) * 2 + 1) * 128]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const f16x8 B0 = __builtin_bit_cast(f16x8, vb0[(r + kh) * TT]);
+            const f16x8 B1 = __builtin_bit_cast(f16x8, vb0[4 * VPOS + (r + kh) * TT]);
+            accm[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, B0, accm[r], 0, 0, 0);
+            accl[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, B1, accl[r], 0, 0, 0);
+            accl[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, B0, accl[r], 0, 0, 0);
+            if (kh == 0 && r == 0) {
+              // the patch requested two chunks ago goes to the other V copy under this chunk's MFMAs; then the next
+              // requests: weights first (needed at this chunk's end), then the patch of chunk c+3 into the register
+              // set just freed.  Past the tile's end these belong to the next tile (selects, no branches).
+              store_p(1 - u, 1 - u);
+              const bool wn = c + 1 >= nchunks;
+              load_w(wn ? wtile_n : wtile, wn ? c + 1 - nchunks : c + 1);
+              const bool pn = c + 3 >= nchunks;
+              load_p(goff, goff_n, pn, pn ? c + 3 - nchunks : c + 3, 1 - u);
+            }
           }
         }
+        __syncthreads();      // every wave is done with the U slab
+        store_w();
+        __syncthreads();
       }
-      __syncthreads();      // every wave is done with the U slab
-      store_w();
-      __syncthreads();
     }
 
-    // epilogue: inverse transform, BN, residual, ReLU; lane = column pair, register = channel.  The next tile's first
-    // chunk is already in LDS and its second patch in flight.
+    // epilogue.  The four positions of an output sit in four different waves: one output row at a time they meet in
+    // LDS (the V copy of odd chunks is idle now: the last chunk was odd, the next tile's first chunk is in copy 0),
+    // X[position][channel][pair]; then wave w finishes channels 8w .. 8w+7 of that row: inverse transform, BN,
+    // residual, ReLU, store.  The next tile's second patch is in flight meanwhile.
     {
-      const int oy = cur.oy0 + r4;
-      const int ox = cur.ox0 + 2 * l31;
+      float* X = reinterpret_cast<float*>(vimg + VBUF);
       const uint32_t plane_ob = (uint32_t)(a.OH * a.OW) * (uint32_t)sizeof(float);
       const size_t img = (size_t)cur.n * a.Cout * a.OH * a.OW;
       const int img_bytes = (int)(a.Cout * plane_ob);
       const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + img, 0, img_bytes, 0x00020000);
       const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<float*>(a.res != nullptr ? a.res + img : a.y), 0, a.res != nullptr ? img_bytes : 0, 0x00020000);
-      const uint32_t cbase_o = (uint32_t)(cur.ct * kHsCout + mh * 32) * plane_ob;
-      uint32_t voff[2];
+      const int ox = cur.ox0 + 2 * l31;
+      const int cw0 = wave * 8;                                  // this wave's channels in the output phase
+      const uint32_t cbase_o = (uint32_t)(cur.ct * kHsCout + cw0) * plane_ob;
+      const float* sst = ss + par * 128 + cw0 + 4 * khalf;
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
-        voff[q] = (oy < a.OH && ox + q < a.OW) ? (uint32_t)(oy * a.OW + ox + q) * 4u + (uint32_t)(4 * khalf) * plane_ob : kOutside;
-      float y0[16], y1[16];
+      for (int r = 0; r < 4; ++r) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float m0 = accm[0][r] + accl[0][r] * (1.f / kLoScale), m1 = accm[1][r] + accl[1][r] * (1.f / kLoScale);
-        const float m2 = accm[2][r] + accl[2][r] * (1.f / kLoScale), m3 = accm[3][r] + accl[3][r] * (1.f / kLoScale);
-        y0[r] = m0 + m1 + m2;
-        y1[r] = m1 - m2 - m3;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      float rv[2][16];
+        for (int i = 0; i < 16; ++i) {
+          const int co = mh * 32 + (i & 3) + 8 * (i >> 2) + 4 * khalf;
+          X[(pos * 64 + co) * TT + l31] = accm[r][i] + accl[r][i] * (1.f / kLoScale);
+        }
+        __syncthreads();
+        const int oy = cur.oy0 + r;
+        uint32_t voff[2];
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < 2; ++q)
+          voff[q] = (oy < a.OH && ox + q < a.OW) ? (uint32_t)(oy * a.OW + ox + q) * 4u + (uint32_t)(4 * khalf) * plane_ob : kOutside;
+        float rv[2][4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          rv[q][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, voff[q], cbase_o + ((r & 3) + 8 * (r >> 2)) * plane_ob, 0));
-      const float* sst = ss + par * 128 + mh * 32;
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int cu = (r & 3) + 8 * (r >> 2);
-        const int cl = cu + 4 * khalf;
-        float v0 = y0[r] * sst[cl] + sst[64 + cl] + rv[0][r];
-        float v1 = y1[r] * sst[cl] + sst[64 + cl] + rv[1][r];
-        if (a.relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v0), yrsrc, voff[0], cbase_o + cu * plane_ob, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v1), yrsrc, voff[1], cbase_o + cu * plane_ob, 0);
+          for (int kk = 0; kk < 4; ++kk)
+            rv[q][kk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, voff[q], cbase_o + kk * plane_ob, 0));
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int co = cw0 + 4 * khalf + kk;
+          const float m0 = X[(0 * 64 + co) * TT + l31], m1 = X[(1 * 64 + co) * TT + l31];
+          const float m2 = X[(2 * 64 + co) * TT + l31], m3 = X[(3 * 64 + co) * TT + l31];
+          float v0 = (m0 + m1 + m2) * sst[kk] + sst[64 + kk] + rv[0][kk];
+          float v1 = (m1 - m2 - m3) * sst[kk] + sst[64 + kk] + rv[1][kk];
+          if (a.relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v0), yrsrc, voff[0], cbase_o + kk * plane_ob, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v1), yrsrc, voff[1], cbase_o + kk * plane_ob, 0);
+        }
+        __syncthreads();      // X is rewritten by the next row (and by the next tile's second patch)
       }
     }
     if (!has_next) break;
@@ -1222,7 +1241,8 @@ bool conv2d_hs_f23_eligible(const ConvSpec& L) {
     const char* e = getenv("ADX_HS_F23");
     on = e != nullptr ? (e[0] == '1' ? 1 : 0) : kF23Default;
   }
-  return on && !L.dgrad && L.k == 3 && L.stride == 1 && L.pad == 1 && conv2d_hs_eligible(L) && (L.cin_pad / kHsCC) % 2 == 0;
+  return on && !L.dgrad && L.k == 3 && L.stride == 1 && L.pad == 1 && conv2d_hs_eligible(L) && (L.cin_pad / kHsCC) % 2 == 0 &&
+         L.cin_pad / kHsCC >= 4;     // the look-ahead spans three chunks
 }
 
 size_t conv2d_packed_floats(const ConvSpec& L) {
