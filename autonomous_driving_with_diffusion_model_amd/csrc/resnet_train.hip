@@ -575,11 +575,29 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(const WgradArgs2 a) {
   }
 }
 
+// dw[i] += dw9[9 i + 4]: the centre tap of a 3x3 gradient is the gradient of the 1x1 conv at the same stride
+__global__ void centre_tap_add_kernel(float* __restrict__ dw, const float* __restrict__ dw9, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dw[i] += dw9[(size_t)i * 9 + 4];
+}
+
+// scratch9 (optional, Cout * Cin * 9 floats): lets the 1x1 stride-2 downsample convs ride on the split-fp16 3x3
+// stride-2 kernel -- x[2 oy][2 ox] is exactly that kernel's centre tap -- which is twice as fast as the exact-fp32 1x1
+// kernel even though eight of its nine taps are thrown away
 int conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, int k, int stride,
-                 int pad, hipStream_t s, const uint32_t* dy_amax = nullptr, int dy_amax_n = 0, bool zero = true) {
+                 int pad, hipStream_t s, const uint32_t* dy_amax = nullptr, int dy_amax_n = 0, bool zero = true,
+                 float* scratch9 = nullptr) {
   ADX_REQUIRE(x && dy && dw, "conv2d_wgrad: null tensor");
   // zero = false: the caller has already cleared dw (the training executor clears every weight gradient in one batch)
   if (zero) ADX_CHECK_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cout * Cin * k * k, s));
+  if (scratch9 != nullptr && k == 1 && stride == 2 && pad == 0 && conv2d_wgrad_hs_eligible(Cin, Cout, 3, 2, 1)) {
+    ADX_CHECK_HIP(hipMemsetAsync(scratch9, 0, sizeof(float) * (size_t)Cout * Cin * 9, s));
+    const int rc = conv2d_wgrad_hs(x, dy, scratch9, N, Cin, H, W, Cout, 2, dy_amax, dy_amax_n, s);
+    if (rc != ADX_OK) return rc;
+    centre_tap_add_kernel<<<dim3(ceil_div(Cout * Cin, 256)), dim3(256), 0, s>>>(dw, scratch9, Cout * Cin);
+    ADX_LAUNCH_CHECK();
+    return ADX_OK;
+  }
   if (conv2d_wgrad_hs_eligible(Cin, Cout, k, stride, pad))
     return conv2d_wgrad_hs(x, dy, dw, N, Cin, H, W, Cout, stride, dy_amax, dy_amax_n, s);
   WgradArgs2 a;
@@ -748,7 +766,7 @@ size_t adx_resnet_train_workspace_bytes(const adx_resnet* r, int32_t batch, int3
     conv(c2, OH, OW);
     H = OH; W = OW;
   }
-  f += al64(r->convs.size() * 2 * 512 * 2) + al64(kAmaxPartials) + 5 * al64(big) + al64(wmax);   // backward: sums, amax, 5 gradient buffers, dgrad weights
+  f += al64(r->convs.size() * 2 * 512 * 2) + al64(kAmaxPartials) + al64((size_t)512 * 256 * 9) + 5 * al64(big) + al64(wmax);   // backward: sums, amax, 3x3 image of a 1x1 gradient, 5 gradient buffers, dgrad weights
   return (f + 1024) * sizeof(float);
 }
 
@@ -849,6 +867,7 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
     if (rf != ADX_OK) return rf;
   }
   uint32_t* amax = reinterpret_cast<uint32_t*>(ws.take(kAmaxPartials));   // per-workgroup max |draw| of the conv being differentiated
+  float* wgrad9 = ws.take((size_t)512 * 256 * 9);     // 3x3 image of the largest 1x1 downsample gradient (conv2d_wgrad)
   size_t big = 0, wmax = 0;
   for (auto& rec : tape->recs) {
     big = std::max(big, (size_t)batch * rec.L->cout * rec.OH * rec.OW);
@@ -899,7 +918,7 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
     }
     bn_param_grad_kernel<<<dim3(ceil_div(L.cout, 256)), dim3(256), 0, s>>>(sums, G[L.t_g], G[L.t_b], L.cout);
     ADX_LAUNCH_CHECK();
-    int rc2 = conv2d_wgrad(rec.x, draw, G[L.t_w], batch, L.cin, rec.H, rec.W, L.cout, L.k, L.stride, L.pad, s, amax, n_amax, false);
+    int rc2 = conv2d_wgrad(rec.x, draw, G[L.t_w], batch, L.cin, rec.H, rec.W, L.cout, L.k, L.stride, L.pad, s, amax, n_amax, false, wgrad9);
     if (rc2 != ADX_OK || !need_dx) return rc2;
     // data gradient
     ConvSpec g{};
