@@ -635,50 +635,48 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
 //     u0 = g0   u1 = (g0 + g1 + g2) / 2   u2 = (g0 - g1 + g2) / 2   u3 = g2   (packed once: conv2d_hs_f23_pack_kernel)
 //     m_p = sum over (input channel, kernel row) of u_p * v_p ;   y[2t] = m0 + m1 + m2 ;   y[2t+1] = m1 - m2 - m3
 // so a third of the matrix work of the direct form goes away.  The GEMM per transform position p is [cout] x [column
-// pair] over k = (channel, kernel row), and every position needs its own accumulator pair.  Mapping: a wave owns ONE
-// position (and one 32-channel half) for all 4 rows of the tile -- 4 x (main, low) accumulators = the 128 registers of
-// the direct tile; the U fragments of a kernel row feed 4 rows, 18-30 ds_read_b128 per 36 MFMAs.  The four positions of
-// an output therefore sit in four waves and meet in LDS in the epilogue, one output row at a time.
-// Workgroup = 8 waves = 4 rows x 64 columns x 64 channels, persistent, one per CU:
-//   LDS  V image  2 x [k-half][plane][position][6 rows][32 pairs] 16-byte cells  (transformed, split patch; 2 x 48 KB)
-//        U slab   [kernel row][position][plane][k-half][64 channels] cells       (one chunk; 48 KB, single copy)
-// A stage is a whole 16-channel chunk (36 MFMAs per wave between barriers); the patch of chunk c+3 is requested when
-// chunk c starts (each element fetched once, neighbours by lane shuffle) and is transformed, split and stored under the
-// MFMAs of chunk c+2; the weights of chunk c+1 are copied into the U slab between two barriers at the chunk's end.  The
-// look-ahead runs on into the workgroup's next tile, so only the first tile has a prologue.
-// STATUS: correct (error against fp64 1.0-1.8e-7, tools/f23_check.py), not yet faster: 0.23 / 0.31 / 0.42 ms against
-// 0.20 / 0.24 / 0.31 ms for the direct kernel on the 256/128/64-channel layers.  With the staging compiled out the
-// matrix part alone runs in 0.12 / 0.15 / 0.24 ms; the patch path costs the difference (fetch 0.06 ms, transform +
-// split + store 0.04 ms on the 256-channel layer): 6 of the 8 waves spend ~1 k VALU cycles per chunk on it in lockstep,
-// and with one workgroup per CU nothing else fills the matrix pipe meanwhile.  Opt-in: ADX_HS_F23=1.
-__global__ void __launch_bounds__(512, 2) conv2d_hs3x3_f23_kernel(const Conv2dArgs a) {
-  constexpr int NT = 512, TR = 4, TT = 32, PR = TR + 2;
+// pair] over k = (channel, kernel row), and every position needs its own accumulator pair: a wave owns ONE position, so
+// the four positions of an output sit in four waves and meet in LDS in the epilogue.
+// STATUS: correct (error against fp64 1.0-1.8e-7, tools/f23_check.py), not yet faster: 0.24 / 0.30 / 0.42 ms against
+// 0.21 / 0.25 / 0.31 ms for the direct kernel on the 256/128/64-channel layers -- and three structurally different
+// versions (one row per wave; one position per wave in an 8-wave workgroup with the staging under the MFMAs; this one)
+// all land on the same times, while with the staging compiled out the matrix part alone runs in 0.12 / 0.15 / 0.24 ms.
+// The patch path (4 transformed values per 2 input columns: 2.3x the split / LDS-store work of the direct kernel per
+// output) costs what the saved MFMAs gain.  Opt-in: ADX_HS_F23=1.
+// Workgroup = 4 waves = 2 rows x 64 columns x 64 channels (wave = position; 2 rows x 2 channel halves x (main, low)
+// accumulators = 128 registers), persistent, TWO per CU so that one workgroup's staging phase runs under the other's
+// MFMAs (a workgroup cannot overlap the two itself: its waves move in lockstep and the staging is VALU work):
+//   LDS  V image  [k-half][plane][position][4 rows][32 pairs] 16-byte cells      (transformed, split patch; 32 KB, single)
+//        U slab   2 x [position][plane][k-half][64 channels] cells               (one kernel row of a chunk; 2 x 16 KB)
+// Per 16-channel chunk: three kernel-row stages (weights two stages ahead in two register sets, stored under the
+// MFMAs, one barrier each; 8 ds_read_b128 per 12 MFMAs), then, all waves being done with the V image, the staging
+// phase: the patch of the next chunk (requested one chunk earlier, every element fetched once, neighbours by lane
+// shuffle) is transformed, split and stored, and the patch after it is requested.  The look-ahead runs on into the
+// workgroup's next tile.
+__global__ void __launch_bounds__(256, 2) conv2d_hs3x3_f23_kernel(const Conv2dArgs a) {
+  constexpr int NT = 256, TR = 2, TT = 32, PR = TR + 2;
   constexpr int VPOS = PR * TT;                   // cells of one (k-half, plane, position) image
-  constexpr int VBUF = 2 * 2 * 4 * VPOS;          // cells per V copy
-  constexpr int WCH = 3 * 4 * 2 * 2 * 64;         // weight cells per chunk
-  constexpr int WIT = WCH / NT;                   // 6
-  constexpr int NITEM = PR * TT * 2;              // staging items: (row, pair, k-half)
+  constexpr int VBUF = 2 * 2 * 4 * VPOS;          // cells of the V image
+  constexpr int WST = 4 * 2 * 2 * 64;             // weight cells per stage (kernel row of a chunk)
+  constexpr int WIT = WST / NT;                   // 4
+  static_assert(PR * TT * 2 == NT, "one staging item (row, pair, 8-channel group) per thread");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32x4* vimg = reinterpret_cast<u32x4*>(smem_raw);
-  u32x4* wl = vimg + 2 * VBUF;
-  float* ss = reinterpret_cast<float*>(wl + WCH);           // 2 x {scale[64], shift[64]}
-  u32x4* dummy = reinterpret_cast<u32x4*>(ss + 4 * 64);     // 8 cells for the idle staging threads
+  u32x4* wl = vimg + VBUF;
+  float* ss = reinterpret_cast<float*>(wl + 2 * WST);       // 2 x {scale[64], shift[64]}
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int pos = wave & 3, mh = wave >> 2;     // a wave owns ONE transform position (and one channel half) for all 4 rows
+  const int pos = __builtin_amdgcn_readfirstlane(tid >> 6);  // a wave owns ONE transform position
   const int l31 = lane & 31, khalf = lane >> 5;
   const size_t hw = (size_t)a.H * a.W;
-  const int nchunks = a.cin_pad / kHsCC;          // even (checked by the host): a chunk's V copy is its parity
+  const int nchunks = a.cin_pad / kHsCC;          // even, >= 4 (checked by the host)
+  const int nstages = nchunks * 3;
   constexpr uint32_t kOutside = 0xC0000000u;
-  // one descriptor for the whole input (a lane's offset carries its image): the look-ahead of a tile's last chunks
-  // already fetches the first chunks of the workgroup's next tile, possibly in another image
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.x), 0, (int)(uint32_t)((size_t)a.N * a.Cin * hw * sizeof(float)), 0x00020000);
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.w), 0, (int)(uint32_t)((size_t)a.cout_tiles * nchunks * WCH * 16), 0x00020000);
+      const_cast<float*>(a.w), 0, (int)(uint32_t)((size_t)a.cout_tiles * nstages * WST * 16), 0x00020000);
   const uint32_t plane_bytes = (uint32_t)(hw * sizeof(float));
 
-  // persistent workgroups (one per CU): every XCD walks one contiguous eighth of the tile space
   const bool by_xcd = (a.ntiles & 7) == 0 && (gridDim.x & 7) == 0;
   const int t_step = by_xcd ? (int)(gridDim.x >> 3) : (int)gridDim.x;
   const int t_end = by_xcd ? (int)((blockIdx.x & 7) + 1) * (a.ntiles >> 3) : a.ntiles;
@@ -694,25 +692,23 @@ __global__ void __launch_bounds__(512, 2) conv2d_hs3x3_f23_kernel(const Conv2dAr
     r.oy0 = ty * TR; r.ox0 = tx * (2 * TT);
     return r;
   };
-  // staging item of this thread: patch row, column pair, 8-channel group; its four input columns
-  const bool stager = tid < NITEM;
-  const int st_t = tid & 31, st_h = (tid >> 5) & 1, st_row = stager ? tid >> 6 : 0;
-  // Every input element is fetched once: a lane loads the columns 2t and 2t+1 of its pair (g[0], g[1]; one 8-byte
-  // load when both lie inside the row), its left / right neighbours come from the adjacent lanes, and only the lanes
-  // at the ends of the 32-pair row fetch an edge column (g[2]: column -1 for t = 0, column 64 for t = 31).
-  auto patch_offsets = [&](const Tile& T, uint32_t (&g)[4]) {
+  // staging item of this thread: patch row, column pair, 8-channel group
+  const int st_t = tid & 31, st_h = (tid >> 5) & 1, st_row = tid >> 6;
+  // Every input element is fetched once: a lane loads the columns 2t and 2t+1 of its pair (g[0], g[1]), its left /
+  // right neighbours come from the adjacent lanes, and only the lanes at the ends of the 32-pair row fetch an edge
+  // column (g[2]: column -1 for t = 0, column 64 for t = 31).
+  auto patch_offsets = [&](const Tile& T, uint32_t (&g)[3]) {
     const uint32_t img_off = (uint32_t)((size_t)T.n * a.Cin * hw * sizeof(float));
     const int iy = T.oy0 - 1 + st_row;
-    const bool rok = stager && iy >= 0 && iy < a.H;
+    const bool rok = iy >= 0 && iy < a.H;
     const uint32_t rowb = img_off + (uint32_t)((st_h * 8 * hw + (size_t)(rok ? iy : 0) * a.W) * sizeof(float));
     const int x0 = T.ox0 + 2 * st_t;
     g[0] = rok && x0 < a.W ? rowb + (uint32_t)x0 * 4u : kOutside;
     g[1] = rok && x0 + 1 < a.W ? rowb + (uint32_t)(x0 + 1) * 4u : kOutside;
     const int xe = st_t == 0 ? T.ox0 - 1 : T.ox0 + 64;
     g[2] = rok && (st_t == 0 || st_t == 31) && xe >= 0 && xe < a.W ? rowb + (uint32_t)xe * 4u : kOutside;
-    g[3] = 0;
   };
-  auto weights_of = [&](const Tile& T) { return (uint32_t)T.ct * (uint32_t)nchunks * (WCH * 16); };
+  auto weights_of = [&](const Tile& T) { return (uint32_t)T.ct * (uint32_t)nstages * (WST * 16); };
   auto load_ss = [&](const Tile& T) {
     float v = 0.f;
     if (tid < 128) {
@@ -723,40 +719,39 @@ __global__ void __launch_bounds__(512, 2) conv2d_hs3x3_f23_kernel(const Conv2dAr
   };
   Tile cur = decode(tile);
   Tile nxt = decode(tnext < t_end ? tnext : tile);
-  uint32_t goff[4], goff_n[4];
+  uint32_t goff[3], goff_n[3];
   patch_offsets(cur, goff);
   patch_offsets(nxt, goff_n);
   uint32_t wtile = weights_of(cur), wtile_n = weights_of(nxt);
   const float ssv = load_ss(cur);
-  // first V cell of the item: position p and plane add p * VPOS and 4 * VPOS
-  const int vcell = st_h * 2 * 4 * VPOS + st_row * TT + st_t;
+  const int vcell = st_h * 2 * 4 * VPOS + st_row * TT + st_t;   // position p and plane add p * VPOS and 4 * VPOS
 
-  u32x4 wv[WIT];
-  float pv[2][3][8];      // two patches in flight (own column pair + edge column): requested at chunk c, stored at c+2
-  auto load_w = [&](uint32_t slab, int chunk) {
-    const uint32_t so = slab + (uint32_t)chunk * (WCH * 16);
+  u32x4 wv[2][WIT];
+  float pv[3][8];
+  auto load_w = [&](uint32_t slab, int stage, int set) {
+    const uint32_t so = slab + (uint32_t)stage * (WST * 16);
 #pragma unroll
-    for (int k = 0; k < WIT; ++k) wv[k] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (uint32_t)(tid + NT * k) * 16u, so, 0);
+    for (int k = 0; k < WIT; ++k) wv[set][k] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (uint32_t)(tid + NT * k) * 16u, so, 0);
   };
-  auto store_w = [&]() {
+  auto store_w = [&](int set, int buf) {
 #pragma unroll
-    for (int k = 0; k < WIT; ++k) wl[tid + NT * k] = wv[k];
+    for (int k = 0; k < WIT; ++k) wl[buf * WST + tid + NT * k] = wv[set][k];
   };
-  auto load_p = [&](const uint32_t (&g)[4], const uint32_t (&gn)[4], bool use_n, int chunk, int set) {
+  auto load_p = [&](bool use_n, int chunk) {
     const uint32_t cbase = (uint32_t)chunk * kHsCC * plane_bytes;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const uint32_t off = use_n ? gn[j] : g[j];
+      const uint32_t off = use_n ? goff_n[j] : goff[j];
 #pragma unroll
       for (int c = 0; c < 8; ++c)
-        pv[set][j][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, off, cbase + c * plane_bytes, 0));
+        pv[j][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, off, cbase + c * plane_bytes, 0));
     }
   };
-  auto store_p = [&](int buf, int set) {
+  auto store_p = [&]() {
     float v[4][8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      const float d1 = pv[set][0][c], d2 = pv[set][1][c], e = pv[set][2][c];
+      const float d1 = pv[0][c], d2 = pv[1][c], e = pv[2][c];
       const float up = __shfl_up(d2, 1, 32), dn = __shfl_down(d1, 1, 32);
       const float d0 = st_t == 0 ? e : up, d3 = st_t == 31 ? e : dn;
       v[0][c] = d0 - d2;
@@ -764,28 +759,26 @@ __global__ void __launch_bounds__(512, 2) conv2d_hs3x3_f23_kernel(const Conv2dAr
       v[2][c] = d2 - d1;
       v[3][c] = d1 - d3;
     }
-    u32x4* base = vimg + buf * VBUF + vcell;
+    u32x4* base = vimg + vcell;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       u32x4 hi, lo;
       split8(v[p], 1.f, hi, lo);
-      u32x4* d0 = stager ? base + p * VPOS : dummy + 2 * p;
-      u32x4* d1 = stager ? base + (4 + p) * VPOS : dummy + 2 * p + 1;
-      *d0 = hi;
-      *d1 = lo;
+      base[p * VPOS] = hi;
+      base[(4 + p) * VPOS] = lo;
     }
   };
 
-  const int vb_lane = khalf * 2 * 4 * VPOS + pos * VPOS + l31;
-  const u32x4* wa0 = wl + khalf * 64 + mh * 32 + l31;
+  const u32x4* vb0 = vimg + khalf * 2 * 4 * VPOS + pos * VPOS + l31;
+  const int wa_lane = (pos * 2 * 2 + khalf) * 64 + l31;       // + plane * 128, + mh * 32
 
-  // prologue (first tile only): chunk 0 complete in LDS, the patch of chunk 1 in flight
-  load_w(wtile, 0);
-  load_p(goff, goff_n, false, 0, 0);
-  store_w();
-  store_p(0, 0);
-  load_p(goff, goff_n, false, 1, 1);                      // chunk 1 -> set 1 (stored at chunk 0)
-  load_p(goff, goff_n, false, 2, 0);                      // chunk 2 -> set 0 (stored at chunk 1); nchunks >= 4
+  // prologue (first tile only): chunk 0 in the V image, stage 0 in U copy 0, stage 1 and the patch of chunk 1 in flight
+  load_w(wtile, 0, 0);
+  load_p(false, 0);
+  store_w(0, 0);
+  store_p();
+  load_w(wtile, 1, 1);
+  load_p(false, 1);
   if (tid < 128) ss[tid] = ssv;
   __syncthreads();
 
@@ -793,52 +786,62 @@ __global__ void __launch_bounds__(512, 2) conv2d_hs3x3_f23_kernel(const Conv2dAr
   for (;;) {
     const bool has_next = tnext < t_end;
     const float ssn = load_ss(nxt);
-    f32x16 accm[4], accl[4];      // per output row of the tile
+    f32x16 accm[2][2], accl[2][2];      // [row][channel half]
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < 2; ++r)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { accm[r][i] = 0.f; accl[r][i] = 0.f; }
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { accm[r][m][i] = 0.f; accl[r][m][i] = 0.f; }
 
     for (int c2 = 0; c2 < nchunks; c2 += 2) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int c = c2 + u;                       // c & 1 == u: chunk parity = V copy = 1 - register set to store
-        const u32x4* vb0 = vimg + u * VBUF + vb_lane;
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-          const f16x8 A0 = __builtin_bit_cast(f16x8, wa0[((kh * 4 + pos) * 2 + 0) * 128]);
-          const f16x8 A1 = __builtin_bit_cast(f16x8, wa0[((kh * 4 + pos) * 2 + 1) * 128]);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const f16x8 B0 = __builtin_bit_cast(f16x8, vb0[(r + kh) * TT]);
-            const f16x8 B1 = __builtin_bit_cast(f16x8, vb0[4 * VPOS + (r + kh) * TT]);
-            accm[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, B0, accm[r], 0, 0, 0);
-            accl[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, B1, accl[r], 0, 0, 0);
-            accl[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, B0, accl[r], 0, 0, 0);
-            if (kh == 0 && r == 0) {
-              // the patch requested two chunks ago goes to the other V copy under this chunk's MFMAs; then the next
-              // requests: weights first (needed at this chunk's end), then the patch of chunk c+3 into the register
-              // set just freed.  Past the tile's end these belong to the next tile (selects, no branches).
-              store_p(1 - u, 1 - u);
-              const bool wn = c + 1 >= nchunks;
-              load_w(wn ? wtile_n : wtile, wn ? c + 1 - nchunks : c + 1);
-              const bool pn = c + 3 >= nchunks;
-              load_p(goff, goff_n, pn, pn ? c + 3 - nchunks : c + 3, 1 - u);
-            }
-          }
+      for (int i = 0; i < 6; ++i) {
+        const int s = 3 * c2 + i;                 // stage within the tile; s & 1 == i & 1
+        const int kh = i % 3;
+        const u32x4* wa0 = wl + (i & 1) * WST + wa_lane;
+        // weights of stage s+2 into the set consumed last stage (past the tile's end: the next tile's first stages)
+        {
+          const bool wn = s + 2 >= nstages;
+          load_w(wn ? wtile_n : wtile, wn ? s + 2 - nstages : s + 2, i & 1);
         }
-        __syncthreads();      // every wave is done with the U slab
-        store_w();
+        __builtin_amdgcn_sched_barrier(0);
+        f16x8 A[2][2], B[2][2];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+          for (int m = 0; m < 2; ++m) A[pl][m] = __builtin_bit_cast(f16x8, wa0[pl * 128 + m * 32]);
+#pragma unroll
+          for (int r = 0; r < 2; ++r) B[pl][r] = __builtin_bit_cast(f16x8, vb0[pl * 4 * VPOS + (r + kh) * TT]);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            accm[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][m], B[0][r], accm[r][m], 0, 0, 0);
+            accl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][m], B[1][r], accl[r][m], 0, 0, 0);
+            accl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][m], B[0][r], accl[r][m], 0, 0, 0);
+            if (r == 0 && m == 0) store_w((i + 1) & 1, (i + 1) & 1);     // stage s+1, under this stage's MFMAs
+          }
         __syncthreads();
+        if (kh == 2) {
+          // staging phase: every wave is done with the V image of this chunk.  The patch requested one chunk ago is
+          // transformed / split / stored, the one after it requested (past the tile's end: the next tile's).
+          const int c = c2 + i / 3;
+          store_p();
+          const bool pn = c + 2 >= nchunks;
+          load_p(pn, pn ? c + 2 - nchunks : c + 2);
+          __syncthreads();
+        }
       }
     }
 
-    // epilogue.  The four positions of an output sit in four different waves: one output row at a time they meet in
-    // LDS (the V copy of odd chunks is idle now: the last chunk was odd, the next tile's first chunk is in copy 0),
-    // X[position][channel][pair]; then wave w finishes channels 8w .. 8w+7 of that row: inverse transform, BN,
-    // residual, ReLU, store.  The next tile's second patch is in flight meanwhile.
+    // epilogue.  The four positions of an output sit in the four waves: they meet in LDS, one (row, 32-channel half) at
+    // a time, X[position][channel][pair] in U copy 1 (idle: the last stage read it, the next tile's stage 1 is still in
+    // registers; the V image already holds the next tile's first chunk); then wave w finishes channels 8w .. 8w+7 of
+    // that half: inverse transform, BN, residual, ReLU, store.
     {
-      float* X = reinterpret_cast<float*>(vimg + VBUF);
+      float* X = reinterpret_cast<float*>(wl + WST);
       const uint32_t plane_ob = (uint32_t)(a.OH * a.OW) * (uint32_t)sizeof(float);
       const size_t img = (size_t)cur.n * a.Cout * a.OH * a.OW;
       const int img_bytes = (int)(a.Cout * plane_ob);
@@ -846,49 +849,51 @@ __global__ void __launch_bounds__(512, 2) conv2d_hs3x3_f23_kernel(const Conv2dAr
       const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<float*>(a.res != nullptr ? a.res + img : a.y), 0, a.res != nullptr ? img_bytes : 0, 0x00020000);
       const int ox = cur.ox0 + 2 * l31;
-      const int cw0 = wave * 8;                                  // this wave's channels in the output phase
-      const uint32_t cbase_o = (uint32_t)(cur.ct * kHsCout + cw0) * plane_ob;
-      const float* sst = ss + par * 128 + cw0 + 4 * khalf;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int co = mh * 32 + (i & 3) + 8 * (i >> 2) + 4 * khalf;
-          X[(pos * 64 + co) * TT + l31] = accm[r][i] + accl[r][i] * (1.f / kLoScale);
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int co = (i & 3) + 8 * (i >> 2) + 4 * khalf;
+            X[(pos * 32 + co) * TT + l31] = accm[r][m][i] + accl[r][m][i] * (1.f / kLoScale);
+          }
+          __syncthreads();
+          const int oy = cur.oy0 + r;
+          const int cw0 = m * 32 + pos * 8;                        // this wave's channels in the output phase
+          const uint32_t cbase_o = (uint32_t)(cur.ct * kHsCout + cw0) * plane_ob;
+          const float* sst = ss + par * 128 + cw0 + 4 * khalf;
+          uint32_t voff[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            voff[q] = (oy < a.OH && ox + q < a.OW) ? (uint32_t)(oy * a.OW + ox + q) * 4u + (uint32_t)(4 * khalf) * plane_ob : kOutside;
+          float rv[2][4];
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+              rv[q][kk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, voff[q], cbase_o + kk * plane_ob, 0));
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const int co = pos * 8 + 4 * khalf + kk;
+            const float m0 = X[(0 * 32 + co) * TT + l31], m1 = X[(1 * 32 + co) * TT + l31];
+            const float m2 = X[(2 * 32 + co) * TT + l31], m3 = X[(3 * 32 + co) * TT + l31];
+            float v0 = (m0 + m1 + m2) * sst[kk] + sst[64 + kk] + rv[0][kk];
+            float v1 = (m1 - m2 - m3) * sst[kk] + sst[64 + kk] + rv[1][kk];
+            if (a.relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v0), yrsrc, voff[0], cbase_o + kk * plane_ob, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v1), yrsrc, voff[1], cbase_o + kk * plane_ob, 0);
+          }
+          __syncthreads();      // X is rewritten by the next pass / by the next tile's stage-1 weights
         }
-        __syncthreads();
-        const int oy = cur.oy0 + r;
-        uint32_t voff[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-          voff[q] = (oy < a.OH && ox + q < a.OW) ? (uint32_t)(oy * a.OW + ox + q) * 4u + (uint32_t)(4 * khalf) * plane_ob : kOutside;
-        float rv[2][4];
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk)
-            rv[q][kk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, voff[q], cbase_o + kk * plane_ob, 0));
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const int co = cw0 + 4 * khalf + kk;
-          const float m0 = X[(0 * 64 + co) * TT + l31], m1 = X[(1 * 64 + co) * TT + l31];
-          const float m2 = X[(2 * 64 + co) * TT + l31], m3 = X[(3 * 64 + co) * TT + l31];
-          float v0 = (m0 + m1 + m2) * sst[kk] + sst[64 + kk] + rv[0][kk];
-          float v1 = (m1 - m2 - m3) * sst[kk] + sst[64 + kk] + rv[1][kk];
-          if (a.relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v0), yrsrc, voff[0], cbase_o + kk * plane_ob, 0);
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v1), yrsrc, voff[1], cbase_o + kk * plane_ob, 0);
-        }
-        __syncthreads();      // X is rewritten by the next row (and by the next tile's second patch)
-      }
     }
     if (!has_next) break;
-    if (tid < 128) ss[(par ^ 1) * 128 + tid] = ssn;     // read by the next epilogue, a tile of barriers from now
+    if (tid < 128) ss[(par ^ 1) * 128 + tid] = ssn;
     par ^= 1;
     cur = nxt;
     wtile = wtile_n;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) goff[j] = goff_n[j];
+    for (int j = 0; j < 3; ++j) goff[j] = goff_n[j];
     tile = tnext;
     tnext += t_step;
     nxt = decode(tnext < t_end ? tnext : tile);
@@ -1359,29 +1364,29 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
 }
 
 static int hs3x3_f23_launch(Conv2dArgs a, hipStream_t s) {
-  constexpr size_t lds = (size_t)2 * (2 * 2 * 4 * 6 * 32) * 16 + (size_t)3072 * 16 + 256 * sizeof(float) + 8 * 16;
-  static_assert(lds <= 160 * 1024, "LDS budget");
+  constexpr size_t lds = (size_t)(2 * 2 * 4 * 4 * 32) * 16 + (size_t)2 * 1024 * 16 + 256 * sizeof(float);
+  static_assert(lds <= 80 * 1024, "two workgroups per CU");
   static bool attr = false;
   if (!attr) {
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_f23_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = true;
   }
-  a.tiles_x = ceil_div(a.OW, 64); a.tiles_y = ceil_div(a.OH, 4); a.cout_tiles = a.Cout / kHsCout;
+  a.tiles_x = ceil_div(a.OW, 64); a.tiles_y = ceil_div(a.OH, 2); a.cout_tiles = a.Cout / kHsCout;
   const size_t ntiles = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y * a.N;
   ADX_REQUIRE(ntiles < (1u << 31), "conv2d_hs: too many tiles");
   ADX_REQUIRE((size_t)a.Cout * a.OH * a.OW * sizeof(float) < 0x7FFFFFFFu, "conv2d_hs: one image of the output exceeds the 32-bit byte offsets");
   a.ntiles = (int)ntiles;
-  static int slots = 0;        // persistent workgroups: one per CU
+  static int slots = 0;        // persistent workgroups: two per CU
   if (slots == 0) {
     const char* e = getenv("ADX_HS_SLOTS");
     int dev = 0, cus = 0;
     ADX_CHECK_HIP(hipGetDevice(&dev));
     ADX_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    slots = e != nullptr && atoi(e) > 0 ? atoi(e) : (cus > 0 ? cus : 256);
+    slots = e != nullptr && atoi(e) > 0 ? atoi(e) : 2 * (cus > 0 ? cus : 256);
   }
   const size_t grid = ntiles < (size_t)slots ? ntiles : (size_t)slots;
-  conv2d_hs3x3_f23_kernel<<<dim3((unsigned)grid), dim3(512), lds, s>>>(a);
+  conv2d_hs3x3_f23_kernel<<<dim3((unsigned)grid), dim3(256), lds, s>>>(a);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
 }
