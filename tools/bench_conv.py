@@ -13,6 +13,8 @@ B = int(os.environ.get("B", "64"))
 for cin, cout, k, s, p, h, w in SHAPES:
     x = torch.randn(B, cin, h, w, device=DEV)
     wt = torch.randn(cout, cin, k, k, device=DEV) * 0.05
+    if os.environ.get("ZERO") == "1":     # all-zero operands: same instruction stream, no toggling in the matrix pipe
+        x.zero_(); wt.zero_()
     y, packed = ops.conv2d(x, wt, stride=s, pad=p)
     res = None if k == 7 else torch.randn_like(y)
     sc, sh = torch.rand(cout, device=DEV), torch.rand(cout, device=DEV)
