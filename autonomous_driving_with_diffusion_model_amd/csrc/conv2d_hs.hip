@@ -352,7 +352,9 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
 //    effective 1.98 GHz, i.e. ~1040 TFLOP/s of fp16 MFMA; ONE workgroup per CU is as fast as two, removing the LDS
 //    fragment reads changes 7 %, and tiles that move 18-35 % fewer operand bytes per MFMA (MODE 1 / 2) change
 //    nothing: the loop runs at the MFMA rate the chip sustains on random data (MI355X_MICROARCH.md quotes 1247
-//    TFLOP/s for a tuned bf16 GEMM at 1.9-1.95 GHz), not at a rate set by operand delivery.  Tile modes:
+//    TFLOP/s for a tuned bf16 GEMM at 1.9-1.95 GHz), not at a rate set by operand delivery.  With all-zero operands
+//    the same launches are 22-25 % faster (ZERO=1 tools/bench_conv.py): the limit is power, i.e. data-dependent
+//    clock-down, and what shortens a launch is fewer MFMAs / instructions / bytes, not fewer stalls.  Tile modes:
 //      MODE 0: 4 waves,  8 rows x 32 columns x  64 channels (two per CU)  19.5 KB per 36 MFMAs/wave
 //      MODE 1: 8 waves, 16 rows x 32 columns x  64 channels               25.4 KB per 2 x 36   (-35 %)
 //      MODE 2: 8 waves,  8 rows x 32 columns x 128 channels               31.9 KB per 2 x 36   (-18 %; 8-row maps)
