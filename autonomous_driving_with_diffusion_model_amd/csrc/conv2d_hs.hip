@@ -991,6 +991,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_stem_kernel(const Conv2dArgs
   }
   // POOL: vertical maxima of the previous tile's last column (left neighbour of lane 0): [wave][32 registers][k-half]
   float* cbuf = ss + 2 * kHsCout + wave * 64 + khalf;
+  float* cpark = l31 == 31 ? cbuf : ss + 2 * kHsCout + 4 * 64 + (lane & 1);   // 64 dummy words behind the four waves' columns
   if (POOL && l31 == 0) {
 #pragma unroll
     for (int i = 0; i < 32; ++i) cbuf[2 * i] = -INFINITY;
@@ -1052,10 +1053,22 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_stem_kernel(const Conv2dArgs
   const uint32_t plane_ob = (uint32_t)(PHo * PWo) * (uint32_t)sizeof(float);
   const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + img, 0, (int)(a.Cout * plane_ob), 0x00020000);
 
+#ifdef ADX_HS_TRACE
+  // phase totals of this workgroup (tools/stem_trace.py); its records sit behind those of the 3x3 kernel
+  long long tr_c = 0, tr_e = 0, tr_s = 0, tr_t = 0;
+  unsigned long long* tr = g_hs_trace + (size_t)(8192 + (blockIdx.x & 8191)) * 8;
+  if (threadIdx.x == 0) tr[0] = __builtin_readcyclecounter();
+#endif
   load_p(0);
   store_p(0);
   __syncthreads();
+#ifdef ADX_HS_TRACE
+  if (threadIdx.x == 0) tr[1] = __builtin_readcyclecounter();
+#endif
   for (int tx = 0; tx < a.tiles_x; ++tx) {
+#ifdef ADX_HS_TRACE
+    tr_t = (long long)__builtin_readcyclecounter();
+#endif
     if (tx + 1 < a.tiles_x) load_p(tx + 1);
     const int ox = tx * kTileW + l31;
     float vm[2][16];                 // POOL: running vertical maximum of this wave's pooled row
@@ -1154,6 +1167,9 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_stem_kernel(const Conv2dArgs
           }
       }
     }
+#ifdef ADX_HS_TRACE
+    { const long long t = (long long)__builtin_readcyclecounter(); tr_c += t - tr_t; tr_t = t; }
+#endif
     if (POOL) {
       // horizontal: pooled column 16 tx + i sits on lane 2 i; left neighbour of lane 0 = previous tile's lane 31
       const int pr = ty * 4 + wave, pq = tx * 16 + (l31 >> 1);
@@ -1163,21 +1179,38 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_stem_kernel(const Conv2dArgs
       for (int half = 0; half < 2; ++half)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float up = __shfl_up(vm[half][r], 1, 32), dn = __shfl_down(vm[half][r], 1, 32);
+          // neighbours by DPP wavefront shifts (one VALU op each; the 32-lane groups' ends are overridden below)
+          const int vi = __builtin_bit_cast(int, vm[half][r]);
+          const float up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, vi, 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+          const float dn = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, vi, 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
           const float left = l31 == 0 ? cbuf[2 * (half * 16 + r)] : up;     // written by lane 31 one tile ago
           const float right = l31 == 31 ? -INFINITY : dn;
           const float m = pool_max3(left, vm[half][r], right);
-          if (l31 == 31) cbuf[2 * (half * 16 + r)] = vm[half][r];
+          cpark[2 * (half * 16 + r)] = vm[half][r];      // lane 31 parks its column for the next tile, the others hit a dummy row
           const int cu = half * 32 + (r & 3) + 8 * (r >> 2);       // + 4 * khalf, which rides in voff
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, m), yrsrc, voff, cu * plane_ob, 0);
         }
     }
+#ifdef ADX_HS_TRACE
+    { const long long t = (long long)__builtin_readcyclecounter(); tr_e += t - tr_t; tr_t = t; }
+#endif
     if (tx + 1 < a.tiles_x) {
       if (PBUF == 1) __syncthreads();        // every wave is done with the only patch copy
       store_p(PBUF == 2 ? (tx + 1) & 1 : 0);
     }
     __syncthreads();
+#ifdef ADX_HS_TRACE
+    { const long long t = (long long)__builtin_readcyclecounter(); tr_s += t - tr_t; tr_t = t; }
+#endif
   }
+#ifdef ADX_HS_TRACE
+  if (threadIdx.x == 0) {
+    tr[2] = (unsigned long long)tr_c;
+    tr[3] = (unsigned long long)tr_e;
+    tr[4] = (unsigned long long)tr_s;
+    tr[5] = __builtin_readcyclecounter();
+  }
+#endif
 }
 
 // [64][3][7][7] fp32 -> [step][plane][k-half][64][8] fp16 with k = (combo = 2*step + k-half -> channel combo/7,
@@ -1302,7 +1335,7 @@ template <bool POOL>
 static int hs_stem_launch(Conv2dArgs a, hipStream_t s) {
   constexpr int PH = POOL ? 25 : 21, PBUF = POOL ? 1 : 2;
   constexpr size_t lds = (size_t)kStemSteps * 4096 + (size_t)PBUF * 4 * 3 * PH * kStemPP + 2 * kHsCout * sizeof(float) +
-                         (POOL ? 4 * 64 * sizeof(float) : 0);
+                         (POOL ? (4 * 64 + 2) * sizeof(float) : 0);     // parked columns + the dummy words of the other lanes
   static_assert(lds <= 80 * 1024, "two workgroups per CU need <= 80 KB each");
   static bool attr = false;
   if (!attr) {
