@@ -754,7 +754,9 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs3x3_f23_kernel(const Conv2dAr
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const float d1 = pv[0][c], d2 = pv[1][c], e = pv[2][c];
-      const float up = __shfl_up(d2, 1, 32), dn = __shfl_down(d1, 1, 32);
+      // neighbours by DPP wavefront shifts (the ends of the 32-lane rows take the edge column instead)
+      const float up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d2), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+      const float dn = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d1), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
       const float d0 = st_t == 0 ? e : up, d3 = st_t == 31 ? e : dn;
       v[0][c] = d0 - d2;
       v[1][c] = d1 + d2;
