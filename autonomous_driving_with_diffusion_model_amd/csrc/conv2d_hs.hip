@@ -649,23 +649,23 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
 // accumulators = 128 registers), persistent, TWO per CU so that one workgroup's staging phase runs under the other's
 // MFMAs (a workgroup cannot overlap the two itself: its waves move in lockstep and the staging is VALU work):
 //   LDS  V image  [k-half][plane][position][4 rows][32 pairs] 16-byte cells      (transformed, split patch; 32 KB, single)
-//        U slab   2 x [position][plane][k-half][64 channels] cells               (one kernel row of a chunk; 2 x 16 KB)
-// Per 16-channel chunk: three kernel-row stages (weights two stages ahead in two register sets, stored under the
-// MFMAs, one barrier each; 8 ds_read_b128 per 12 MFMAs), then, all waves being done with the V image, the staging
-// phase: the patch of the next chunk (requested one chunk earlier, every element fetched once, neighbours by lane
-// shuffle) is transformed, split and stored, and the patch after it is requested.  The look-ahead runs on into the
-// workgroup's next tile.
+//        X        [position][32 channels][32 pairs] floats                      (epilogue exchange, 16 KB)
+// The U (weight) fragments never touch LDS: a wave needs only its own position's slice and takes it straight from L2
+// into a three-set register ring, two kernel-row stages ahead.  Per 16-channel chunk: three kernel-row stages without
+// a barrier between them (4 ds_read_b128 per 12 MFMAs), then, all waves being done with the V image, the staging
+// phase between two barriers: the patch of the next chunk (requested one chunk earlier, every element fetched once,
+// neighbours by DPP shifts) is transformed, split and stored, and the patch after it is requested.  The look-ahead
+// runs on into the workgroup's next tile.
 __global__ void __launch_bounds__(256, 2) conv2d_hs3x3_f23_kernel(const Conv2dArgs a) {
   constexpr int NT = 256, TR = 2, TT = 32, PR = TR + 2;
   constexpr int VPOS = PR * TT;                   // cells of one (k-half, plane, position) image
   constexpr int VBUF = 2 * 2 * 4 * VPOS;          // cells of the V image
   constexpr int WST = 4 * 2 * 2 * 64;             // weight cells per stage (kernel row of a chunk)
-  constexpr int WIT = WST / NT;                   // 4
   static_assert(PR * TT * 2 == NT, "one staging item (row, pair, 8-channel group) per thread");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32x4* vimg = reinterpret_cast<u32x4*>(smem_raw);
-  u32x4* wl = vimg + VBUF;
-  float* ss = reinterpret_cast<float*>(wl + 2 * WST);       // 2 x {scale[64], shift[64]}
+  float* X = reinterpret_cast<float*>(vimg + VBUF);         // epilogue exchange [position][32 channels][32 pairs]
+  float* ss = X + 4 * 32 * TT;                              // 2 x {scale[64], shift[64]}
   const int tid = threadIdx.x, lane = tid & 63;
   const int pos = __builtin_amdgcn_readfirstlane(tid >> 6);  // a wave owns ONE transform position
   const int l31 = lane & 31, khalf = lane >> 5;
@@ -728,16 +728,19 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs3x3_f23_kernel(const Conv2dAr
   const float ssv = load_ss(cur);
   const int vcell = st_h * 2 * 4 * VPOS + st_row * TT + st_t;   // position p and plane add p * VPOS and 4 * VPOS
 
-  u32x4 wv[2][WIT];
+  // U fragments straight from L2 into registers: a wave needs only its own position's slice ([plane][channel half] =
+  // 4 x 16 bytes per lane and kernel row), nothing is fetched twice and no barrier guards a weight buffer; three
+  // register sets: the set of stage s+2 is requested when stage s starts
+  u32x4 ar[3][4];
   float pv[3][8];
-  auto load_w = [&](uint32_t slab, int stage, int set) {
+  const uint32_t a_lane = (uint32_t)(((pos * 2 * 2 + khalf) * 64 + l31) * 16);      // + plane * 128 cells, + mh * 32 cells
+  auto load_a = [&](uint32_t slab, int stage, int set) {
     const uint32_t so = slab + (uint32_t)stage * (WST * 16);
 #pragma unroll
-    for (int k = 0; k < WIT; ++k) wv[set][k] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (uint32_t)(tid + NT * k) * 16u, so, 0);
-  };
-  auto store_w = [&](int set, int buf) {
+    for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-    for (int k = 0; k < WIT; ++k) wl[buf * WST + tid + NT * k] = wv[set][k];
+      for (int m = 0; m < 2; ++m)
+        ar[set][pl * 2 + m] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, a_lane + (uint32_t)((pl * 128 + m * 32) * 16), so, 0);
   };
   auto load_p = [&](bool use_n, int chunk) {
     const uint32_t cbase = (uint32_t)chunk * kHsCC * plane_bytes;
@@ -774,14 +777,12 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs3x3_f23_kernel(const Conv2dAr
   };
 
   const u32x4* vb0 = vimg + khalf * 2 * 4 * VPOS + pos * VPOS + l31;
-  const int wa_lane = (pos * 2 * 2 + khalf) * 64 + l31;       // + plane * 128, + mh * 32
 
   // prologue (first tile only): chunk 0 in the V image, stage 0 in U copy 0, stage 1 and the patch of chunk 1 in flight
-  load_w(wtile, 0, 0);
+  load_a(wtile, 0, 0);
+  load_a(wtile, 1, 1);
   load_p(false, 0);
-  store_w(0, 0);
   store_p();
-  load_w(wtile, 1, 1);
   load_p(false, 1);
   if (tid < 128) ss[tid] = ssv;
   __syncthreads();
@@ -801,34 +802,30 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs3x3_f23_kernel(const Conv2dAr
     for (int c2 = 0; c2 < nchunks; c2 += 2) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        const int s = 3 * c2 + i;                 // stage within the tile; s & 1 == i & 1
+        const int s = 3 * c2 + i;                 // stage within the tile; s % 3 == i % 3 because c2 is even
         const int kh = i % 3;
-        const u32x4* wa0 = wl + (i & 1) * WST + wa_lane;
-        // weights of stage s+2 into the set consumed last stage (past the tile's end: the next tile's first stages)
+        // U fragments of stage s+2 into the set consumed at stage s-1 (past the tile's end: the next tile's first stages)
         {
           const bool wn = s + 2 >= nstages;
-          load_w(wn ? wtile_n : wtile, wn ? s + 2 - nstages : s + 2, i & 1);
+          load_a(wn ? wtile_n : wtile, wn ? s + 2 - nstages : s + 2, (i + 2) % 3);
         }
         __builtin_amdgcn_sched_barrier(0);
-        f16x8 A[2][2], B[2][2];
+        f16x8 B[2][2];
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-#pragma unroll
-          for (int m = 0; m < 2; ++m) A[pl][m] = __builtin_bit_cast(f16x8, wa0[pl * 128 + m * 32]);
+        for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
           for (int r = 0; r < 2; ++r) B[pl][r] = __builtin_bit_cast(f16x8, vb0[pl * 4 * VPOS + (r + kh) * TT]);
-        }
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
           for (int m = 0; m < 2; ++m) {
-            accm[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][m], B[0][r], accm[r][m], 0, 0, 0);
-            accl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][m], B[1][r], accl[r][m], 0, 0, 0);
-            accl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][m], B[0][r], accl[r][m], 0, 0, 0);
-            if (r == 0 && m == 0) store_w((i + 1) & 1, (i + 1) & 1);     // stage s+1, under this stage's MFMAs
+            const f16x8 A0 = __builtin_bit_cast(f16x8, ar[i % 3][m]), A1 = __builtin_bit_cast(f16x8, ar[i % 3][2 + m]);
+            accm[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, B[0][r], accm[r][m], 0, 0, 0);
+            accl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, B[1][r], accl[r][m], 0, 0, 0);
+            accl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, B[0][r], accl[r][m], 0, 0, 0);
           }
-        __syncthreads();
         if (kh == 2) {
+          __syncthreads();
           // staging phase: every wave is done with the V image of this chunk.  The patch requested one chunk ago is
           // transformed / split / stored, the one after it requested (past the tile's end: the next tile's).
           const int c = c2 + i / 3;
@@ -845,7 +842,6 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs3x3_f23_kernel(const Conv2dAr
     // registers; the V image already holds the next tile's first chunk); then wave w finishes channels 8w .. 8w+7 of
     // that half: inverse transform, BN, residual, ReLU, store.
     {
-      float* X = reinterpret_cast<float*>(wl + WST);
       const uint32_t plane_ob = (uint32_t)(a.OH * a.OW) * (uint32_t)sizeof(float);
       const size_t img = (size_t)cur.n * a.Cout * a.OH * a.OW;
       const int img_bytes = (int)(a.Cout * plane_ob);
@@ -1401,7 +1397,7 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
 }
 
 static int hs3x3_f23_launch(Conv2dArgs a, hipStream_t s) {
-  constexpr size_t lds = (size_t)(2 * 2 * 4 * 4 * 32) * 16 + (size_t)2 * 1024 * 16 + 256 * sizeof(float);
+  constexpr size_t lds = (size_t)(2 * 2 * 4 * 4 * 32) * 16 + (size_t)4 * 32 * 32 * sizeof(float) + 256 * sizeof(float);
   static_assert(lds <= 80 * 1024, "two workgroups per CU");
   static bool attr = false;
   if (!attr) {
