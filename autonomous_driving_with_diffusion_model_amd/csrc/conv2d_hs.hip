@@ -639,12 +639,11 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
 // so a third of the matrix work of the direct form goes away.  The GEMM per transform position p is [cout] x [column
 // pair] over k = (channel, kernel row), and every position needs its own accumulator pair: a wave owns ONE position, so
 // the four positions of an output sit in four waves and meet in LDS in the epilogue.
-// STATUS: correct (error against fp64 1.0-1.8e-7, tools/f23_check.py), not yet faster: 0.24 / 0.30 / 0.42 ms against
-// 0.21 / 0.25 / 0.31 ms for the direct kernel on the 256/128/64-channel layers -- and three structurally different
-// versions (one row per wave; one position per wave in an 8-wave workgroup with the staging under the MFMAs; this one)
-// all land on the same times, while with the staging compiled out the matrix part alone runs in 0.12 / 0.15 / 0.24 ms.
-// The patch path (4 transformed values per 2 input columns: 2.3x the split / LDS-store work of the direct kernel per
-// output) costs what the saved MFMAs gain.  Opt-in: ADX_HS_F23=1.
+// STATUS: correct (error against fp64 1.0-1.8e-7, tools/f23_check.py); at parity with the direct kernel on the
+// 256-channel layers, slower on the shallow ones: 0.21 / 0.27 / 0.41 ms against 0.21 / 0.26 / 0.32 ms on the
+// 256/128/64-channel layers.  With the staging compiled out the matrix part alone runs in 0.12 / 0.15 / 0.24 ms: the
+// patch path (4 transformed values per 2 input columns: 2.3x the split / LDS-store work of the direct kernel per
+// output) costs what the saved MFMAs gain.  History of the versions in DESIGN.md section 8.  Opt-in: ADX_HS_F23=1.
 // Workgroup = 4 waves = 2 rows x 64 columns x 64 channels (wave = position; 2 rows x 2 channel halves x (main, low)
 // accumulators = 128 registers), persistent, TWO per CU so that one workgroup's staging phase runs under the other's
 // MFMAs (a workgroup cannot overlap the two itself: its waves move in lockstep and the staging is VALU work):
