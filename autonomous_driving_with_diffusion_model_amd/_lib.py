@@ -62,6 +62,7 @@ class StepCoef(C.Structure):
 _SIGS = {
     "adx_version": (i32, []),
     "adx_last_error": (C.c_char_p, []),
+    "adx_source_hash": (C.c_char_p, []),
     "adx_tconv_packed_bytes": (C.c_size_t, [C.POINTER(TConvDesc)]),
     "adx_tconv_pack": (i32, [C.POINTER(TConvDesc), vp, vp, vp]),
     "adx_tconv_forward": (i32, [C.POINTER(TConvDesc), C.POINTER(TConvIO), vp]),

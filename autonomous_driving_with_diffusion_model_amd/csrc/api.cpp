@@ -31,7 +31,13 @@ int image_normalize(const uint8_t* src, float* dst, int n, int h, int w, const f
 
 extern "C" {
 
-int adx_version(void) { return 1; }
+#ifndef ADX_SRC_HASH
+#define ADX_SRC_HASH "unknown"
+#endif
+int adx_version(void) { return 2; }
+// the "ADX_SRC_HASH=" tag lets a build script read the hash out of the file without loading the library
+static const char kSrcHash[] = "ADX_SRC_HASH=" ADX_SRC_HASH;
+const char* adx_source_hash(void) { return kSrcHash + 13; }
 const char* adx_last_error(void) { return adx::g_err; }
 
 size_t adx_tconv_packed_bytes(const adx_tconv_desc* d) {

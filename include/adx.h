@@ -29,6 +29,8 @@ extern "C" {
 typedef void* adx_stream;      /* hipStream_t */
 
 int adx_version(void);
+/* sha256 (first 32 hex digits) of the sources this library was built from (csrc/build.sh); "unknown" for ad-hoc builds */
+const char* adx_source_hash(void);
 const char* adx_last_error(void);
 
 /* ------------------------------------------------------------------------------------

@@ -24,3 +24,15 @@ def close(a, b, atol, rtol=0.0):
     err = (a - b).abs()
     tol = atol + rtol * b.abs()
     assert bool((err <= tol).all()), f"max err {err.max().item():.3e} (atol {atol}, rtol {rtol})"
+
+
+def close_traj(a, b, tol=1e-4, magic=23.315):
+    """A caller-level trajectory [.., 7] as generate_traj returns it: x, y were multiplied by magic_num after the clamp
+    (interact.py:167), the other five channels were not, so the north_star bound of 1e-4 on the normalised trajectory is
+    magic * tol on channels 0-1 and tol on channels 2-6."""
+    a = torch.as_tensor(a, dtype=torch.float32)
+    b = torch.as_tensor(b, dtype=torch.float32)
+    assert a.shape == b.shape and a.shape[-1] >= 2, (a.shape, b.shape)
+    close(a[..., :2], b[..., :2], magic * tol)
+    if a.shape[-1] > 2:
+        close(a[..., 2:], b[..., 2:], tol)
