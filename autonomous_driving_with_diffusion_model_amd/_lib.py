@@ -144,6 +144,26 @@ def lib() -> C.CDLL:
     return _lib
 
 
+class NativeTape:
+    """Owner of one native training tape (adx_*_tape_create / _destroy).  The handle is destroyed exactly once: by
+    `release()` after the backward pass, or by the finalizer when the autograd node that holds it is dropped without a
+    backward (a train-mode forward under no_grad, a loss that is never back-propagated)."""
+
+    def __init__(self, create, destroy, what: str):
+        import weakref
+        h = vp()
+        check(create(C.byref(h)), what)
+        self.handle = h
+        self._fin = weakref.finalize(self, destroy, h)
+
+    @property
+    def alive(self) -> bool:
+        return self._fin.alive
+
+    def release(self) -> None:
+        self._fin()          # idempotent
+
+
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = lib().adx_last_error().decode(errors="replace")

@@ -29,15 +29,14 @@ class _PerceptionTrainFn(torch.autograd.Function):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=img.device)
         pk = L.lib().adx_resnet_packed_bytes(h)
         packed = torch.empty(pk, dtype=torch.uint8, device=img.device)
-        tape = L.vp()
-        L.check(L.lib().adx_resnet_tape_create(C.byref(tape)), "adx_resnet_tape_create")
+        tape = L.NativeTape(L.lib().adx_resnet_tape_create, L.lib().adx_resnet_tape_destroy, "adx_resnet_tape_create")
         out = torch.empty((B, module.out_dim), dtype=torch.float32, device=img.device)
         try:
             L.check(L.lib().adx_resnet_forward_train(h, L.ptr_array(ts), len(ts), packed.data_ptr(), ws.data_ptr(), nbytes,
-                                                     img.data_ptr(), B, H, W, out.data_ptr(), tape, 1,
+                                                     img.data_ptr(), B, H, W, out.data_ptr(), tape.handle, 1,
                                                      L.stream_ptr(img.device)), "adx_resnet_forward_train")
         except Exception:
-            L.lib().adx_resnet_tape_destroy(tape)
+            tape.release()
             raise
         for b in module.buffers():
             if b.dtype == torch.int64:
@@ -49,6 +48,9 @@ class _PerceptionTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         module = ctx.module
+        if not ctx.tape.alive:
+            raise RuntimeError("the perception tape was consumed by an earlier backward (retain_graph / a second backward "
+                               "through the same forward is not supported: run the forward again)")
         g = L.require_gpu_f32(grad_out, "grad_out")
         named = dict(module.named_parameters())
         entries = [e for e in module._entries if e.dtype == "f32"]
@@ -64,11 +66,11 @@ class _PerceptionTrainFn(torch.autograd.Function):
             garr[i] = None if t is None else t.data_ptr()
         try:
             L.check(L.lib().adx_resnet_backward(module._native(), L.ptr_array(ctx.ts), garr, len(slots), ctx.ws.data_ptr(),
-                                                ctx.nbytes, ctx.tape, g.data_ptr(), L.stream_ptr(g.device)),
+                                                ctx.nbytes, ctx.tape.handle, g.data_ptr(), L.stream_ptr(g.device)),
                     "adx_resnet_backward")
         finally:
-            L.lib().adx_resnet_tape_destroy(ctx.tape)
-            ctx.tape = None
+            ctx.tape.release()
+            ctx.ws = None            # 27 GB of taped activations at B = 64: free them with the tape
         return (None, None, *[grads[k] for k, _ in module.named_parameters()])
 
 

@@ -44,8 +44,7 @@ class _UnetTrainFn(torch.autograd.Function):
         module._ensure_packed(x.device)
         nbytes = L.lib().adx_unet_train_workspace_bytes(h, rows)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        tape = L.vp()
-        L.check(L.lib().adx_unet_tape_create(C.byref(tape)), "adx_unet_tape_create")
+        tape = L.NativeTape(L.lib().adx_unet_tape_create, L.lib().adx_unet_tape_destroy, "adx_unet_tape_create")
         classifier = module.use_cond == GuidanceType.CLASSIFIER_GUIDANCE
         out = torch.empty((rows, module.horizon, 3 if classifier else module.transition_dim), dtype=torch.float32,
                           device=x.device)
@@ -56,10 +55,10 @@ class _UnetTrainFn(torch.autograd.Function):
         io.t, io.t_rows, io.cond, io.rows = time.data_ptr(), time.shape[0], L.ptr(cond), rows
         io.out, io.time_embed = out.data_ptr(), te.data_ptr()
         try:
-            L.check(L.lib().adx_unet_forward_train(h, module._packed.data_ptr(), ws.data_ptr(), nbytes, C.byref(io), tape,
-                                                   L.stream_ptr(x.device)), "adx_unet_forward_train")
+            L.check(L.lib().adx_unet_forward_train(h, module._packed.data_ptr(), ws.data_ptr(), nbytes, C.byref(io),
+                                                   tape.handle, L.stream_ptr(x.device)), "adx_unet_forward_train")
         except Exception:
-            L.lib().adx_unet_tape_destroy(tape)
+            tape.release()
             raise
         ctx.module, ctx.tape, ctx.ws, ctx.nbytes = module, tape, ws, nbytes
         ctx.keep = (x, feat_c, time, cond)          # the tape holds raw pointers into these
@@ -70,6 +69,9 @@ class _UnetTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out, grad_te):
         module, params = ctx.module, ctx.params
+        if not ctx.tape.alive:
+            raise RuntimeError("the temporal stack's tape was consumed by an earlier backward (retain_graph / a second "
+                               "backward through the same forward is not supported: run the forward again)")
         if module._pack_key != ctx.pack_key:
             raise RuntimeError("parameters changed between forward and backward")
         h = module._native()
@@ -81,12 +83,12 @@ class _UnetTrainFn(torch.autograd.Function):
         pa = L.ptr_array([p.detach() for p in params])
         ga = L.ptr_array(grads)
         try:
-            L.check(L.lib().adx_unet_backward(h, module._packed.data_ptr(), ctx.ws.data_ptr(), ctx.nbytes, ctx.tape,
-                                              g.data_ptr(), L.ptr(gte), d_feat.data_ptr(), pa, ga, len(grads),
-                                              L.stream_ptr(g.device)), "adx_unet_backward")
+            L.check(L.lib().adx_unet_backward(h, module._packed.data_ptr(), ctx.ws.data_ptr(), ctx.nbytes,
+                                              ctx.tape.handle, g.data_ptr(), L.ptr(gte), d_feat.data_ptr(), pa, ga,
+                                              len(grads), L.stream_ptr(g.device)), "adx_unet_backward")
         finally:
-            L.lib().adx_unet_tape_destroy(ctx.tape)
-            ctx.tape = None
+            ctx.tape.release()
+            ctx.ws = None            # the tape's activations are dead with it
         return (None, d_feat, None, None, None, *grads)
 
 

@@ -156,6 +156,16 @@ class GraphedSampler:
         with torch.cuda.graph(self._graph):
             self._out = run()
         self.model._feat_cache = None          # the memo now points at the static frame buffer: drop it
+        self._pointers = self._model_pointers()
+
+    def _model_pointers(self):
+        """Addresses of the model-owned buffers the captured launches read and write (workspaces and packed weight
+        images).  The model re-allocates them lazily (a later eager forward at a larger batch or image size, a weight
+        re-pack); a replay over stale addresses would touch freed memory, so `__call__` re-captures when any moved."""
+        m = self.model
+        owners = [m, getattr(m, "perception", None), getattr(m, "state_pred", None)]
+        return tuple(None if t is None else t.data_ptr()
+                     for o in owners if o is not None for t in (getattr(o, "_ws", None), getattr(o, "_packed", None)))
 
     def reset(self) -> None:
         """Forget the captured graph (call after the model's weights changed: the weight images are packed outside
@@ -170,7 +180,7 @@ class GraphedSampler:
                                      device=image.device)
         key = (tuple(image.shape), None if target is None else tuple(target.shape), tuple(init_trajs.shape), image.device,
                self.cfg.EVAL.SAMPLE_STEPS, self.cfg.GUIDANCE.USE_COND)
-        if key != self._key:
+        if key != self._key or self._graph is None or self._pointers != self._model_pointers():
             self._capture(image, target, init_trajs)
             self._key = key
         else:

@@ -362,8 +362,78 @@ def gen_train():
         for k in keys:
             put(f"train.{name}.gradnorm.{k}", named[k].grad.norm())
         put(f"train.{name}.grad.final_bias", named[[k for k in named if k.endswith("_conv.1.bias")][0]].grad)
+        # whole gradient tensors (a norm hides permuted or sign-flipped entries); the large ones as a leading slice
+        for k in keys + ["perception.bn1.weight", "perception.layer2.0.downsample.0.weight", "mid_block2.blocks.0.block.2.bias"]:
+            gfull = named[k].grad
+            put(f"train.{name}.gradfull.{k}", gfull if gfull.numel() <= 70000 else gfull.reshape(-1)[:70000])
         put(f"train.{name}.n_params", np.array(sum(p.numel() for p in m.parameters())))
         put(f"train.{name}.n_state", np.array(len(m.state_dict())))
+
+
+# ------------------------------------------------------------------ (6) checkpoint written by the reference's objects
+def gen_ckpt():
+    """Two optimizer steps of train.py:221-261 with the reference model and the objects train.py builds (torch AdamW,
+    the LambdaLR that get_constant_schedule_with_warmup returns, an EMA with diffusers' update rule), then the
+    dict of train.py:288-294 is written with torch.save, read back, and described: key lists and layouts as JSON, a
+    handful of tensors as arrays (the whole file would be 600 MB)."""
+    import json
+    import tempfile
+    H, warm = 16, 10
+    data = P.synthetic_batch(2, H, image_hw=IMG_SMALL, seed=51)
+    sch = DB.DDPMScheduler(**SCHED_KW)
+    m = ref_model("NO_GUIDANCE", H).train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, betas=(0.95, 0.999), eps=1e-7)               # train.py:170
+    lrs = torch.optim.lr_scheduler.LambdaLR(opt, lambda k: DB.constant_with_warmup_lr(k, warm))   # train.py:171
+    ema_kw = dict(update_after_step=0, inv_gamma=1.0, power=0.75, max_decay=0.9999)
+    shadow = [p.detach().clone() for p in m.parameters()]
+    n_steps = 2
+    for it in range(n_steps):
+        noisy = sch.add_noise(data["trajs"], data["noise"], data["t"])
+        noisy[..., 0, :3] = 0
+        loss = torch.nn.functional.mse_loss(m(noisy, data["imgs"], data["t"]).float(), data["trajs"].float())
+        loss.backward()
+        for prm in m.parameters():
+            torch.nan_to_num(prm.grad, nan=0, posinf=1e5, neginf=-1e5, out=prm.grad)
+        opt.step()
+        lrs.step()
+        opt.zero_grad()
+        decay = DB.ema_decay(it + 1, **ema_kw)          # EMAModel.step: optimization_step += 1, then get_decay
+        with torch.no_grad():
+            for sp, prm in zip(shadow, m.parameters()):
+                sp.sub_((1 - decay) * (sp - prm))
+        put(f"ckpt.loss.{it}", loss)
+    ck = {"state_dict": m.state_dict(), "optimizer": opt.state_dict(), "lr_scheduler": lrs.state_dict(), "iter": n_steps,
+          "ema_state_dict": {"decay": ema_kw["max_decay"], "min_decay": 0.0, "optimization_step": n_steps,
+                             "update_after_step": 0, "use_ema_warmup": True, "inv_gamma": 1.0, "power": 0.75,
+                             "shadow_params": shadow}}
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "checkpoint_2.pth")
+        torch.save(ck, path)
+        size = os.path.getsize(path)
+        ck = torch.load(path, map_location="cpu", weights_only=True)     # tensors, lists, dicts, scalars only
+    names = [k for k, _ in m.named_parameters()]
+    spec = {"keys": list(ck), "iter": ck["iter"], "file_bytes": size,
+            "state_dict_keys": list(ck["state_dict"]),
+            "optimizer_param_groups": [{k: (list(v) if isinstance(v, tuple) else v) for k, v in g.items()}
+                                       for g in ck["optimizer"]["param_groups"]],
+            "optimizer_state_entry": {k: [str(v.dtype), list(v.shape)] for k, v in ck["optimizer"]["state"][0].items()},
+            "optimizer_state_len": len(ck["optimizer"]["state"]),
+            "lr_scheduler": ck["lr_scheduler"],
+            "ema_keys": {k: (v if not isinstance(v, list) else len(v)) for k, v in ck["ema_state_dict"].items()},
+            "warmup": warm, "ema_kw": ema_kw, "parameter_names": names}
+    with open(os.path.join(HERE, "ckpt_spec.json"), "w") as f:
+        json.dump(spec, f)
+    for k in ("perception.conv1.weight", "perception.bn1.weight", "perception.fc.weight", "time_mlp.1.weight",
+              "downs.0.0.blocks.0.block.0.weight", "mid_block1.blocks.0.block.2.bias", "ups.2.3.conv.weight",
+              "final_conv.1.weight", "final_conv.1.bias"):
+        i = names.index(k)
+        put(f"ckpt.param.{k}", ck["state_dict"][k])
+        put(f"ckpt.exp_avg.{k}", ck["optimizer"]["state"][i]["exp_avg"])
+        put(f"ckpt.exp_avg_sq.{k}", ck["optimizer"]["state"][i]["exp_avg_sq"])
+        put(f"ckpt.shadow.{k}", ck["ema_state_dict"]["shadow_params"][i])
+    put("ckpt.step", ck["optimizer"]["state"][0]["step"])
+    put("ckpt.bn_running_mean", ck["state_dict"]["perception.bn1.running_mean"])
+    put("ckpt.bn_num_batches", ck["state_dict"]["perception.bn1.num_batches_tracked"])
 
 
 def gen_control():
@@ -401,7 +471,7 @@ if __name__ == "__main__":
         gen_spec()
         sys.exit(0)
     groups = {"ops": gen_ops, "unet": gen_unet, "sched": gen_sched, "loop": gen_loops, "train": gen_train,
-              "control": gen_control}
+              "control": gen_control, "ckpt": gen_ckpt}
     which = sys.argv[1:] or list(groups)
     for gname in which:
         out.clear()

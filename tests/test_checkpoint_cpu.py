@@ -3,6 +3,7 @@ names identical to the reference's, positional EMA list in parameters() order.""
 import json
 import os
 
+import pytest
 import torch
 
 from autonomous_driving_with_diffusion_model_amd.checkpoint import load_checkpoint, save_checkpoint
@@ -20,8 +21,11 @@ def test_roundtrip_and_reference_key_layout(tmp_path):
     P.load_procedural(m, 3)
     shadow = [p.detach() * 0.5 for p in m.parameters()]
     path = str(tmp_path / "checkpoint_1.pth")
-    save_checkpoint(path, m, optimizer=None, iteration=7, shadow_params=shadow)
-    ck = torch.load(path, weights_only=False)
+    with pytest.raises(ValueError):
+        save_checkpoint(path, m, optimizer=None, iteration=7)          # a placeholder entry would break train.py's resume
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, betas=(0.95, 0.999), eps=1e-7)
+    save_checkpoint(path, m, optimizer=opt, iteration=7, shadow_params=shadow)
+    ck = torch.load(path, weights_only=True)
     assert set(ck) == {"state_dict", "optimizer", "lr_scheduler", "iter", "ema_state_dict"} and ck["iter"] == 7
     spec = json.load(open(os.path.join(HERE, "golden", "state_spec.json")))["FREE_GUIDANCE"]
     assert list(ck["state_dict"].keys()) == [r[0] for r in spec["state_dict"]]
@@ -34,6 +38,58 @@ def test_roundtrip_and_reference_key_layout(tmp_path):
         assert torch.equal(b, b0), k
     load_checkpoint(path, m2, use_ema=False)
     assert all(torch.equal(a, b) for a, b in zip(m2.parameters(), m.parameters()))
+
+
+def test_fused_optimizer_state_in_the_reference_readers_layout(tmp_path):
+    """FusedAdamWEMA's state goes out in the layouts train.py's resume reads (train.py:197-201: EMAModel, AdamW,
+    LambdaLR.load_state_dict) -- compared key by key with the checkpoint the reference's objects wrote
+    (tests/golden/ckpt_spec.json) -- loads into torch's AdamW/LambdaLR, and comes back through resume_training."""
+    from autonomous_driving_with_diffusion_model_amd.checkpoint import resume_training
+    from autonomous_driving_with_diffusion_model_amd.optim import FusedAdamWEMA
+    spec = json.load(open(os.path.join(HERE, "golden", "ckpt_spec.json")))
+    cfg = create_cfg()
+    m = build_model(cfg)
+    P.load_procedural(m, 5)
+    opt = FusedAdamWEMA(m.parameters(), lr=1e-4, warmup_steps=10, ema_update_after_step=0, lr_ticks_per_step=2)
+    gen = torch.Generator().manual_seed(0)
+    opt.step_count = 3                                   # as if three steps had run (state only; step() needs the GPU)
+    for a, b, s_ in zip(opt.exp_avg, opt.exp_avg_sq, opt.shadow_params):
+        a.copy_(torch.randn(a.shape, generator=gen) * 1e-3)
+        b.copy_(torch.rand(b.shape, generator=gen) * 1e-6)
+        s_.mul_(0.75)
+    path = str(tmp_path / "checkpoint_3.pth")
+    save_checkpoint(path, m, opt, iteration=3)
+    ck = torch.load(path, weights_only=True)
+    assert list(ck) == spec["keys"]
+    assert set(ck["optimizer"]["param_groups"][0]) == set(spec["optimizer_param_groups"][0])
+    assert set(ck["lr_scheduler"]) == set(spec["lr_scheduler"]) and ck["lr_scheduler"]["lr_lambdas"] == [None]
+    assert ck["lr_scheduler"]["last_epoch"] == 6 and ck["lr_scheduler"]["_step_count"] == 7      # 2 ticks per step
+    assert set(ck["ema_state_dict"]) == set(spec["ema_keys"])
+    assert {k: [str(v.dtype), list(v.shape)] for k, v in ck["optimizer"]["state"][0].items()} == spec["optimizer_state_entry"]
+    # torch's own objects read it
+    ps = [torch.nn.Parameter(p.detach().clone()) for p in m.parameters()]
+    ref_opt = torch.optim.AdamW(ps, lr=1e-4, betas=(0.95, 0.999), eps=1e-7)
+    ref_lrs = torch.optim.lr_scheduler.LambdaLR(ref_opt, lambda k: min(1.0, k / 10))
+    ref_opt.load_state_dict(ck["optimizer"])
+    ref_lrs.load_state_dict(ck["lr_scheduler"])
+    assert ref_lrs.last_epoch == 6 and ref_opt.param_groups[0]["lr"] == pytest.approx(0.6e-4)
+    st = ref_opt.state[ps[5]]
+    assert torch.equal(st["exp_avg"], opt.exp_avg[5]) and float(st["step"]) == 3.0
+    # ... and what torch's objects write comes back into a fresh FusedAdamWEMA
+    torch.save({"state_dict": m.state_dict(), "optimizer": ref_opt.state_dict(), "lr_scheduler": ref_lrs.state_dict(),
+                "iter": 3, "ema_state_dict": ck["ema_state_dict"]}, path)
+    m2 = build_model(cfg)
+    opt2 = FusedAdamWEMA(m2.parameters(), lr=1.0, warmup_steps=10, ema_update_after_step=7, lr_ticks_per_step=2)
+    assert resume_training(path, m2, opt2) == 4
+    assert opt2.step_count == 3 and opt2.lr == pytest.approx(1e-4) and opt2.ema_kw["update_after_step"] == 0
+    assert opt2.current_lr() == pytest.approx(0.6e-4)
+    for i in (0, 5, 100, 305):
+        assert torch.equal(opt2.exp_avg[i], opt.exp_avg[i]) and torch.equal(opt2.exp_avg_sq[i], opt.exp_avg_sq[i])
+        assert torch.equal(opt2.shadow_params[i], opt.shadow_params[i])
+    assert all(torch.equal(a, b) for a, b in zip(m2.parameters(), m.parameters()))
+    bad = dict(ck["lr_scheduler"], last_epoch=4)
+    with pytest.raises(ValueError):
+        opt2.load_lr_scheduler_state_dict(bad)
 
 
 def test_config_yaml_inheritance(tmp_path):

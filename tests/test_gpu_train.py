@@ -297,6 +297,99 @@ def test_training_step_vs_golden(golden, use_cond):
             got = named[k[len(pre):]].grad.norm().item()
             assert abs(got - ref) <= 2e-3 * max(1.0, abs(ref)), (k, got, ref)
     assert all(p.grad is not None for p in m.parameters())
+    # whole gradient tensors of the REAL reference (leading 70,000 elements of the large ones): element-wise, so a
+    # permuted, transposed or sign-flipped gradient cannot hide behind a matching norm.  Bar: relative L2 error 1e-3
+    # (the reference's own fp32 CPU backward differs from an fp64 one by 1e-4..5e-4 on the perception tensors: batch-
+    # statistics BatchNorm over B = 2 amplifies rounding) and every element within 2e-3 of the tensor's largest.
+    pre = f"train.{use_cond}.gradfull."
+    checked = 0
+    for k in g.files:
+        if not k.startswith(pre):
+            continue
+        ref = torch.from_numpy(g[k]).float()
+        got = named[k[len(pre):]].grad.detach().cpu()
+        got = got if got.numel() <= 70000 else got.reshape(-1)[:70000]
+        assert got.shape == ref.shape, (k, got.shape, ref.shape)
+        e = ((got - ref).norm() / (ref.norm() + 1e-30)).item()
+        assert e <= 1e-3, (k, e)
+        assert (got - ref).abs().max().item() <= 2e-3 * ref.abs().max().item() + 1e-9, k
+        checked += 1
+    assert checked >= 12
+
+
+def test_two_optimizer_steps_and_checkpoint_vs_reference_written_fixture(golden, tmp_path):
+    """tests/golden/ckpt.npz + ckpt_spec.json describe a checkpoint the REFERENCE's objects wrote (reference model, torch
+    AdamW, the LambdaLR of get_constant_schedule_with_warmup, EMA rule of diffusers) after two iterations of
+    train.py:221-261.  The same two iterations run here on the HIP path with FusedAdamWEMA; the file save_checkpoint
+    writes must have the same layout and the same numbers, and must load into the reference's readers."""
+    import json
+    import os
+    from autonomous_driving_with_diffusion_model_amd import scheduler as S
+    from autonomous_driving_with_diffusion_model_amd.checkpoint import save_checkpoint
+    from autonomous_driving_with_diffusion_model_amd.optim import FusedAdamWEMA
+    from helpers import SCHED_KW
+    from test_gpu_model import make_model
+    g = golden("ckpt")
+    spec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ckpt_spec.json")))
+    m, _ = make_model("NO_GUIDANCE", 16)
+    m.train()
+    kw = spec["ema_kw"]
+    opt = FusedAdamWEMA(m.parameters(), lr=1e-4, warmup_steps=spec["warmup"], ema_update_after_step=kw["update_after_step"],
+                        ema_power=kw["power"], ema_inv_gamma=kw["inv_gamma"], ema_max_decay=kw["max_decay"])
+    d = {k: v.to(DEV) for k, v in P.synthetic_batch(2, 16, image_hw=(64, 96), seed=51).items()}
+    sch = S.DDPMScheduler(**SCHED_KW)
+    for it in range(spec["iter"]):
+        noisy = sch.add_noise(d["trajs"], d["noise"], d["t"], zero_first=True)
+        loss = F.mse_loss(m(noisy, d["imgs"], d["t"]), d["trajs"])
+        assert abs(loss.item() - float(g[f"ckpt.loss.{it}"])) < 2e-5, it
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+    path = str(tmp_path / "checkpoint_2.pth")
+    save_checkpoint(path, m, opt, iteration=spec["iter"])
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    # layout
+    assert list(ck) == spec["keys"] and ck["iter"] == spec["iter"]
+    assert list(ck["state_dict"]) == spec["state_dict_keys"]
+    assert abs(os.path.getsize(path) - spec["file_bytes"]) < 0.01 * spec["file_bytes"]
+    assert len(ck["optimizer"]["state"]) == spec["optimizer_state_len"]
+    want_group = spec["optimizer_param_groups"][0]
+    got_group = ck["optimizer"]["param_groups"][0]
+    assert set(got_group) == set(want_group)
+    for k, v in want_group.items():
+        gv = got_group[k]
+        assert (list(gv) if isinstance(gv, tuple) else gv) == (pytest.approx(v) if isinstance(v, float) else v), k
+    assert {k: [str(v.dtype), list(v.shape)] for k, v in ck["optimizer"]["state"][0].items()} == spec["optimizer_state_entry"]
+    assert set(ck["lr_scheduler"]) == set(spec["lr_scheduler"])
+    for k, v in spec["lr_scheduler"].items():
+        assert ck["lr_scheduler"][k] == (pytest.approx(v) if k in ("_last_lr", "base_lrs") else v), k
+    assert {k: (v if not isinstance(v, list) else len(v)) for k, v in ck["ema_state_dict"].items()} == spec["ema_keys"]
+    # numbers: weights after two AdamW steps, both moments, EMA shadow, BatchNorm buffers
+    names = spec["parameter_names"]
+    assert float(ck["optimizer"]["state"][0]["step"]) == float(g["ckpt.step"])
+    for k in g.files:
+        kind, _, name = k.partition(".")[2].partition(".")
+        if kind not in ("param", "exp_avg", "exp_avg_sq", "shadow"):
+            continue
+        ref = torch.from_numpy(g[k])
+        i = names.index(name)
+        got = {"param": lambda: ck["state_dict"][name], "exp_avg": lambda: ck["optimizer"]["state"][i]["exp_avg"],
+               "exp_avg_sq": lambda: ck["optimizer"]["state"][i]["exp_avg_sq"],
+               "shadow": lambda: ck["ema_state_dict"]["shadow_params"][i]}[kind]()
+        if kind in ("param", "shadow"):
+            close(got, ref, 2e-6, rtol=1e-6)          # two steps at lr <= 2e-5: weights move by <= 4e-5
+        else:
+            e = ((got - ref).norm() / (ref.norm() + 1e-30)).item()
+            assert e <= (2e-3 if kind == "exp_avg_sq" else 1e-3), (k, e)
+    close(ck["state_dict"]["perception.bn1.running_mean"], g["ckpt.bn_running_mean"], 1e-5)
+    assert int(ck["state_dict"]["perception.bn1.num_batches_tracked"]) == int(g["ckpt.bn_num_batches"])
+    # the reference's readers accept the file (train.py:197-201): AdamW, LambdaLR
+    cpu = [torch.nn.Parameter(p.detach().cpu()) for p in m.parameters()]
+    ref_opt = torch.optim.AdamW(cpu, lr=1e-4, betas=(0.95, 0.999), eps=1e-7)
+    ref_lrs = torch.optim.lr_scheduler.LambdaLR(ref_opt, lambda k_: min(1.0, k_ / spec["warmup"]))
+    ref_opt.load_state_dict(ck["optimizer"])
+    ref_lrs.load_state_dict(ck["lr_scheduler"])
+    assert ref_lrs.last_epoch == spec["iter"] and ref_opt.param_groups[0]["lr"] == pytest.approx(2e-5)
 
 
 def test_fused_adamw_ema_matches_torch_adamw():
