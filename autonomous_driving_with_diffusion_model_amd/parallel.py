@@ -135,6 +135,73 @@ class GradientAverager:
                 off += g.numel()
 
 
+class BufferBroadcaster:
+    """DDP's `broadcast_buffers=True` (the reference's setting: accelerate builds `DistributedDataParallel(model)` with
+    torch's defaults, train.py:176-178): before EVERY training forward rank 0's buffers overwrite everybody's, i.e. the
+    BatchNorm running statistics of ranks > 0 are discarded each step and rank 0's -- computed from rank 0's batches
+    only, never averaged -- are what a checkpoint holds.  108 buffers, 68 KB for the ResNet-34: they travel as ONE flat
+    fp32 broadcast plus one int64 broadcast (num_batches_tracked) instead of 108 collectives."""
+
+    def __init__(self, module: torch.nn.Module, src: int = 0, group=None):
+        self.module, self.src, self.group = module, src, group
+        bufs = list(module.buffers())
+        self._float = [b for b in bufs if b.is_floating_point()]
+        self._int = [b for b in bufs if not b.is_floating_point()]
+        self._flat_f: Optional[torch.Tensor] = None
+        self._flat_i: Optional[torch.Tensor] = None
+
+    @torch.no_grad()
+    def sync(self) -> int:
+        """Returns the number of collectives issued (0 on a single rank)."""
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return 0
+        n = 0
+        for bufs, attr, dtype in ((self._float, "_flat_f", torch.float32), (self._int, "_flat_i", torch.int64)):
+            if not bufs:
+                continue
+            total = sum(b.numel() for b in bufs)
+            flat = getattr(self, attr)
+            if flat is None or flat.numel() != total or flat.device != bufs[0].device:
+                flat = torch.empty(total, dtype=dtype, device=bufs[0].device)
+                setattr(self, attr, flat)
+            if dist.get_rank(self.group) == self.src:
+                torch.cat([b.reshape(-1).to(dtype) for b in bufs], out=flat)
+            dist.broadcast(flat, src=self.src, group=self.group)
+            n += 1
+            if dist.get_rank(self.group) != self.src:
+                off = 0
+                for b in bufs:
+                    b.copy_(flat[off:off + b.numel()].view_as(b))
+                    off += b.numel()
+        if n and dist.get_rank(self.group) != self.src and hasattr(self.module, "refresh_weights"):
+            self.module.refresh_weights()       # eval-mode weight images fold the running statistics
+        return n
+
+
+class DataParallel(torch.nn.Module):
+    """This package's counterpart of `DistributedDataParallel(model)` as accelerate builds it (train.py:176-178):
+    construction broadcasts rank 0's parameters and buffers, every train-mode forward starts with the buffer broadcast
+    (`BufferBroadcaster`), gradients are averaged bucket by bucket from autograd hooks while backward is still running
+    (`GradientAverager.attach`).  After `loss.backward()` call `.synchronize()` (DDP does that inside backward; here it
+    is one explicit call so that the collective's wait sits where the trainer wants it), then the optimizer step.
+    `.module` is the wrapped model, like DDP's attribute that `accelerator.unwrap_model` reads."""
+
+    def __init__(self, module: torch.nn.Module, bucket_mb: float = 64.0, broadcast_buffers: bool = True, group=None):
+        super().__init__()
+        self.module = module
+        broadcast_parameters(module, src=0, group=group)
+        self.buffers_sync = BufferBroadcaster(module, src=0, group=group) if broadcast_buffers else None
+        self.averager = GradientAverager(module.parameters(), bucket_mb=bucket_mb, group=group).attach()
+
+    def forward(self, *args, **kwargs):
+        if self.buffers_sync is not None and self.module.training and torch.is_grad_enabled():
+            self.buffers_sync.sync()
+        return self.module(*args, **kwargs)
+
+    def synchronize(self) -> None:
+        self.averager.synchronize()
+
+
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:
     """What DDP's constructor does (train.py:176-178): rank `src`'s parameters and buffers win."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:

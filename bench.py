@@ -165,7 +165,18 @@ def tconv_roofline(model, dev, reps=20):
             "hbm_frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4)}
 
 
-def cpu_baseline(steps=2):
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(steps=3):
     """The oracle (CPU restatement of the reference, kind 'port') on the host cores of this box,
     same workload: one reference-faithful denoising step = ResNet-34 on 64 images + UNet on the
     2x64 CFG batch + DDIM step.  Bounded sample: 1 warm-up + `steps` timed steps."""
@@ -200,7 +211,8 @@ def cpu_baseline(steps=2):
         unet_s = (time.perf_counter() - t0) / 3
     timed = times[1:]
     per = sum(timed) / len(timed)
-    return {"value": round(1.0 / per, 4), "unit": "denoising-steps/sec", "cores": cores, "kind": "port",
+    return {"value": round(1.0 / per, 4), "unit": "denoising-steps/sec", "cores": cores, "cpu": cpu_model_name(),
+            "kind": "port", "per_step_s": [round(x, 3) for x in timed],
             "sample": f"{len(timed)} reference-faithful steps (ResNet-34 on 64x3x256x900 + UNet 2x64xH32 + DDIM step) "
                       f"after 1 warm-up, torch-CPU fp32, {cores} threads",
             "s_per_step": round(per, 3), "unet_only_steps_per_sec": round(1.0 / unet_s, 3)}
@@ -214,7 +226,7 @@ def train_leg(dev, world, steps=5, warm=3):
     from autonomous_driving_with_diffusion_model_amd.config import create_cfg
     from autonomous_driving_with_diffusion_model_amd.modeling import build_model
     from autonomous_driving_with_diffusion_model_amd.optim import FusedAdamWEMA
-    from autonomous_driving_with_diffusion_model_amd.parallel import GradientAverager
+    from autonomous_driving_with_diffusion_model_amd.parallel import DataParallel
     from autonomous_driving_with_diffusion_model_amd.utils import procedural as P
     torch.cuda.empty_cache()      # the sampling legs' workspaces go back to the driver before the 27 GB of tapes arrive
     cfg = create_cfg()
@@ -224,17 +236,20 @@ def train_leg(dev, world, steps=5, warm=3):
     P.load_procedural(model, 0)
     model = model.to(dev).train()
     opt = FusedAdamWEMA(model.parameters(), lr=1e-4, warmup_steps=1000, lr_ticks_per_step=world)
-    avg = GradientAverager(model.parameters()).attach() if world > 1 else None      # all-reduce overlaps backward
+    # rank 0's weights and buffers to everyone, per-forward BatchNorm-buffer broadcast, bucketed all-reduce from hooks
+    # during backward (the reference's DistributedDataParallel semantics, train.py:176-178)
+    dp = DataParallel(model) if world > 1 else None
+    fwd = dp if dp is not None else model
     sch = S.DDPMScheduler(**SCHED_KW)
-    d = {k: v.to(dev) for k, v in P.synthetic_batch(B, H, image_hw=IMG, seed=7).items()}
+    d = {k: v.to(dev) for k, v in P.synthetic_batch(B, H, image_hw=IMG, seed=7 + int(os.environ.get("RANK", "0"))).items()}
 
     def step():
         noisy = sch.add_noise(d["trajs"], d["noise"], d["t"], zero_first=True)
-        pred = model(noisy, d["imgs"], d["t"])
+        pred = fwd(noisy, d["imgs"], d["t"])
         loss = torch.nn.functional.mse_loss(pred, d["trajs"])
         loss.backward()
-        if avg is not None:
-            avg.synchronize()
+        if dp is not None:
+            dp.synchronize()
         opt.step()
         opt.zero_grad()
         return loss
@@ -262,6 +277,56 @@ def train_leg(dev, world, steps=5, warm=3):
             "steps": steps, "approx_tflops_per_gpu": round(flops * steps / dt / 1e12, 1), "final_loss": round(float(loss.detach()), 5)}
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher around it: start N copies of this script, one per GPU, with the
+    rendezvous variables torchrun would set.  The parent never touches a GPU (no HIP call before or after the spawn);
+    the first child that fails takes the others down and its exit code becomes the parent's."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()          # counts devices without initialising HIP on this image
+    if have < n and "--launch-check" not in sys.argv:
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this pool
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc, alive = 0, set(range(n))
+    while alive:
+        for i in sorted(alive):
+            r = procs[i].poll()
+            if r is None:
+                continue
+            alive.discard(i)
+            if r != 0 and rc == 0:
+                rc = r
+                print(f"bench.py: rank {i} exited with status {r}; stopping the other ranks", file=sys.stderr)
+                for j in alive:
+                    procs[j].terminate()
+        time.sleep(0.1)
+    return rc
+
+
+def launch_check(world: int, rank: int) -> None:
+    """`--launch-check`: the rendezvous plumbing alone (gloo, no GPU): every rank contributes its rank + 1 to an
+    all-reduce; rank 0 prints what the process group itself reports.  Used by the CPU test of the launcher."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    if os.environ.get("ADX_LAUNCH_CHECK_FAIL_RANK") == str(rank):
+        sys.exit(7)
+    if dist.get_rank() == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": dist.get_world_size(), "sum": t.item(),
+                          "env_world": world}))
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -270,15 +335,25 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))       # no launcher around us: become one (the parent stays off the GPU)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        sys.exit(2)
+    if args.launch_check:
+        return launch_check(world, rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        world = dist.get_world_size()           # what RCCL itself reports is what goes into n_gpus
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

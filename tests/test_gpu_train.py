@@ -392,6 +392,55 @@ def test_two_optimizer_steps_and_checkpoint_vs_reference_written_fixture(golden,
     assert ref_lrs.last_epoch == spec["iter"] and ref_opt.param_groups[0]["lr"] == pytest.approx(2e-5)
 
 
+@pytest.mark.parametrize("use_cond", ["FREE_GUIDANCE", "CLASSIFIER_GUIDANCE"])
+def test_model_under_torch_ddp_world1_nccl(use_cond):
+    """train.py:176-178: accelerate wraps the model in DistributedDataParallel with torch's defaults
+    (find_unused_parameters=False, broadcast_buffers=True).  The package's model is custom autograd nodes over a
+    parameter-holder module tree, which is exactly where DDP's reducer breaks if a parameter's gradient does not arrive
+    through its AccumulateGrad node: wrap it (RCCL, world_size 1), run two iterations, and require every parameter's
+    gradient to equal the unwrapped model's."""
+    import socket
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from autonomous_driving_with_diffusion_model_amd import scheduler as S
+    from helpers import SCHED_KW
+    from test_gpu_model import make_model
+    m, _ = make_model(use_cond, 16)
+    m.train()
+    if hasattr(m, "state_pred"):
+        m.state_pred.dropout_p = 0.0
+    d = {k: v.to(DEV) for k, v in P.synthetic_batch(3, 16, image_hw=(64, 96), seed=43).items()}
+    sch = S.DDPMScheduler(**SCHED_KW)
+    noisy = sch.add_noise(d["trajs"], d["noise"], d["t"], zero_first=True)
+    cond = d["target"] if use_cond == "FREE_GUIDANCE" else None
+
+    def grads_of(model):
+        for p in m.parameters():
+            p.grad = None
+        loss = F.mse_loss(model(noisy, d["imgs"], d["t"], cond=cond), d["trajs"])
+        loss.backward()
+        assert all(p.grad is not None for p in m.parameters())
+        return loss.item(), [p.grad.detach().clone() for p in m.parameters()]
+
+    loss0, g0 = grads_of(m)
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device(DEV))
+    try:
+        ddp = DDP(m, device_ids=[0])
+        for it in range(2):                 # a parameter left without a gradient makes DDP raise in the NEXT forward
+            loss1, g1 = grads_of(ddp)
+            assert abs(loss1 - loss0) < 1e-6
+            for (k, _), a, b in zip(m.named_parameters(), g1, g0):
+                # weight gradients are reduced with float atomics: run-to-run order differs in the last bits
+                assert rel_err(a, b.cpu()) <= 2e-5, (it, k)
+        assert int(m.perception.bn1.num_batches_tracked) == 3
+    finally:
+        dist.destroy_process_group()
+
+
 def test_fused_adamw_ema_matches_torch_adamw():
     """adx_adamw_ema_step vs torch.optim.AdamW(betas=(0.95, 0.999), eps=1e-7) + nan_to_num + EMA (train.py:252-261)."""
     from autonomous_driving_with_diffusion_model_amd.optim import FusedAdamWEMA, ema_decay

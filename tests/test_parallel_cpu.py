@@ -88,3 +88,99 @@ def test_gradient_averaging_and_broadcast_world2():
     assert [r[0] for r in res] == [0, 1]
     assert all(r[1] and r[2] for r in res), res
     assert res[0][3] > 1
+
+
+def _dp_worker(rank, world, port, out):
+    """The reference's DDP semantics on a small conv + BatchNorm net: per-forward buffer broadcast from rank 0
+    (statistics are NOT averaged), hook-driven gradient means, and the LR schedule that ticks `world` times per
+    optimizer step under accelerate (FusedAdamWEMA.lr_ticks_per_step)."""
+    from autonomous_driving_with_diffusion_model_amd.optim import FusedAdamWEMA
+    from autonomous_driving_with_diffusion_model_amd.parallel import DataParallel
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                       # different initial weights per rank: the wrapper must fix that
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.ReLU(),
+                              torch.nn.Conv2d(8, 4, 1))
+    dp = DataParallel(net, bucket_mb=1e-4)
+    fused = FusedAdamWEMA(net.parameters(), lr=1e-2, warmup_steps=8, lr_ticks_per_step=world, use_ema=False)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-2, betas=(0.95, 0.999), eps=1e-7)
+    ok = True
+    bn = net[1]
+    for step in range(3):
+        g = torch.Generator().manual_seed(1000 * step + rank)
+        x = torch.randn(4, 3, 6, 6, generator=g) + rank          # rank-dependent statistics
+        before = [torch.zeros_like(bn.running_mean) for _ in range(world)]
+        dist.all_gather(before, bn.running_mean.clone())
+        out_ = dp(x)
+        # the forward started from rank 0's buffers on every rank: new = 0.9 * rank0_old + 0.1 * own batch mean
+        pre = net[0](x)
+        want = 0.9 * before[0] + 0.1 * pre.mean(dim=(0, 2, 3))
+        ok = ok and torch.allclose(bn.running_mean, want, atol=1e-5)
+        ok = ok and int(bn.num_batches_tracked) == step + 1
+        out_.square().mean().backward()
+        local = [p.grad.clone() for p in net.parameters()]
+        dp.synchronize()
+        for p, l in zip(net.parameters(), local):
+            parts = [torch.zeros_like(l) for _ in range(world)]
+            dist.all_gather(parts, l)
+            ok = ok and torch.allclose(p.grad, sum(parts) / world, atol=1e-6)
+        lr = fused.current_lr()
+        ok = ok and abs(lr - 1e-2 * min(1.0, step * world / 8)) < 1e-12     # accelerate: `world` ticks per step
+        for grp in opt.param_groups:
+            grp["lr"] = lr
+        opt.step()
+        opt.zero_grad()
+        fused.step_count += 1
+    # identical averaged gradients + identical start => identical weights on every rank; statistics differ (not synced)
+    w = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    ws = [torch.zeros_like(w) for _ in range(world)]
+    dist.all_gather(ws, w)
+    ok = ok and all(torch.equal(ws[0], v) for v in ws)
+    rm = [torch.zeros_like(bn.running_mean) for _ in range(world)]
+    dist.all_gather(rm, bn.running_mean.clone())
+    stats_differ = not torch.allclose(rm[0], rm[1])
+    # an eval-mode forward issues no collective (DDP only syncs buffers when it will run a training forward)
+    net.eval()
+    n_before = dp.buffers_sync.sync.__self__ is dp.buffers_sync
+    with torch.no_grad():
+        dp(x)
+    out.put((rank, bool(ok), bool(stats_differ), bool(n_before)))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_wrapper_semantics_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+    assert all(r[2] for r in res), "BatchNorm statistics must stay per rank between broadcasts"
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` with no launcher around it must start N ranks itself (reference: `accelerate launch`,
+    train.py:115-117), report the world size the process group saw, and fail as a whole when one rank fails."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--launch-check"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines == [{"launch_check": True, "n_gpus": 3, "sum": 6.0, "env_world": 3}]
+    # a launcher that started a different number of ranks than --gpus is an error, not a silent single-rank run
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"],
+                       env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr
+    # one failing rank fails the run
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"],
+                       env=dict(env, ADX_LAUNCH_CHECK_FAIL_RANK="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 7, (r.returncode, r.stderr[-500:])
