@@ -33,9 +33,11 @@ def generate_traj(sd: SD, image: torch.Tensor, init_trajs: torch.Tensor, target:
                   classifier_scale: float = 0.1, guidance_steps: int = 1, dim: int = 64,
                   dim_mults: Sequence[int] = (1, 2, 4, 8), hoist_perception: bool = False,
                   step_noise: Optional[Callable[[int, tuple], torch.Tensor]] = None,
-                  sched_kw: Optional[dict] = None, scale_xy: bool = True) -> torch.Tensor:
+                  sched_kw: Optional[dict] = None, scale_xy: bool = True,
+                  img_feature: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The agent's sampling loop.  For CLASSIFIER guidance with B > 1 every sample is an
-    independent B = 1 problem (the reference only defines B = 1)."""
+    independent B = 1 problem (the reference only defines B = 1).  `img_feature` = the perception
+    output for `image` computed by the caller (oracle.resnet), to share one pass between tests."""
     kw = sched_kw or scheduler_kwargs()
     guided = use_cond == U.CLASSIFIER_GUIDANCE and target is not None
 
@@ -55,7 +57,8 @@ def generate_traj(sd: SD, image: torch.Tensor, init_trajs: torch.Tensor, target:
                                       scheduler=scheduler, free_scale=free_scale, classifier_scale=classifier_scale,
                                       guidance_steps=guidance_steps, dim=dim, dim_mults=dim_mults,
                                       hoist_perception=hoist_perception, step_noise=sn, sched_kw=sched_kw,
-                                      scale_xy=scale_xy))
+                                      scale_xy=scale_xy,
+                                      img_feature=None if img_feature is None else img_feature[b:b + 1]))
         return torch.cat(outs, dim=0)
 
     trajs = init_trajs.clone().detach()
@@ -63,7 +66,9 @@ def generate_traj(sd: SD, image: torch.Tensor, init_trajs: torch.Tensor, target:
     if target is not None and use_cond == U.FREE_GUIDANCE:
         tg = target if target.dim() > 1 else target.repeat(trajs.size(0), 1)
         cond = torch.cat([tg, torch.zeros_like(tg)], dim=0)
-    feat = resnet34_forward(sd, "perception.", image) if hoist_perception else None
+    feat = img_feature
+    if feat is None and hoist_perception:
+        feat = resnet34_forward(sd, "perception.", image)
     trajs[:, 0, :3] = 0.0
     sch.set_timesteps(n_steps)
     action = None
