@@ -59,7 +59,7 @@ def upsample(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
 
 def time_mlp(sd: SD, t: torch.Tensor, dim: int) -> torch.Tensor:
     """modeling/temporal.py:93-98."""
-    e = sinusoidal_pos_emb(t, dim)
+    e = sinusoidal_pos_emb(t, dim).to(sd["time_mlp.1.weight"].dtype)   # no-op in fp32; lets tests run the oracle in fp64
     e = F.linear(e, sd["time_mlp.1.weight"], sd["time_mlp.1.bias"])
     return F.linear(F.mish(e), sd["time_mlp.3.weight"], sd["time_mlp.3.bias"])
 
@@ -98,7 +98,7 @@ def traj_predict(sd: SD, p: str, action: torch.Tensor, time_embed: torch.Tensor,
     """
     hidden = sd[p + "input_proj.weight"].shape[0]
     T = action.shape[1]
-    pos = sinusoidal_pos_emb(torch.arange(T, device=action.device).float(), hidden)
+    pos = sinusoidal_pos_emb(torch.arange(T, device=action.device).float(), hidden).to(action.dtype)
     x = F.linear(action, sd[p + "input_proj.weight"], sd[p + "input_proj.bias"]) + pos[None] + time_embed[:, None, :]
     li = 0
     while (p + f"encoder_traj.layers.{li}.linear1.weight") in sd:
