@@ -15,8 +15,9 @@ __global__ void __launch_bounds__(256) embed_kernel(const adx_embed_weights w, c
                                                      const float* __restrict__ cond,
                                                      const float* __restrict__ feat, const int feat_rows,
                                                      float* __restrict__ time_embed, float* __restrict__ mish_cond) {
-  __shared__ float e[kMaxDim];
-  __shared__ float h[4 * kMaxDim];
+  __shared__ __attribute__((aligned(16))) float e[kMaxDim];
+  __shared__ __attribute__((aligned(16))) float h[4 * kMaxDim];
+  __shared__ float parts[4 * kMaxDim];
   __shared__ float te[kMaxDim];
   __shared__ float ch[kMaxDim];
   const int row = blockIdx.x, tid = threadIdx.x;
@@ -28,19 +29,35 @@ __global__ void __launch_bounds__(256) embed_kernel(const adx_embed_weights w, c
     e[i] = i < half ? sinf(arg) : cosf(arg);
   }
   __syncthreads();
+  // time_mlp.1: hid outputs, one per thread, 16-byte weight loads (dim % 4 == 0, rows are 16-byte aligned)
   for (int j = tid; j < hid; j += 256) {
-    float acc = w.b1[j];
-    const float* wr = w.w1 + (size_t)j * dim;
-    for (int i = 0; i < dim; ++i) acc += wr[i] * e[i];
-    h[j] = mish_f(acc);
+    const f32x4* wr = reinterpret_cast<const f32x4*>(w.w1 + (size_t)j * dim);
+    f32x4 a4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < dim / 4; ++i) {
+      const f32x4 wv = wr[i];
+      const f32x4 ev = *reinterpret_cast<const f32x4*>(e + 4 * i);
+      a4 += wv * ev;
+    }
+    h[j] = mish_f(w.b1[j] + ((a4[0] + a4[1]) + (a4[2] + a4[3])));
   }
   __syncthreads();
-  for (int j = tid; j < dim; j += 256) {
-    float acc = w.b3[j];
-    const float* wr = w.w3 + (size_t)j * hid;
-    for (int i = 0; i < hid; ++i) acc += wr[i] * h[i];
-    te[j] = acc;
+  // time_mlp.3: dim outputs x hid inputs; all 256 threads work: thread (j, part) sums a quarter of the row, the four
+  // parts meet in LDS and are added in a fixed order
+  for (int lin = tid; lin < 4 * dim; lin += 256) {
+    const int jj = lin % dim, pp = lin / dim;
+    const int seg = hid / 4;
+    const f32x4* wr = reinterpret_cast<const f32x4*>(w.w3 + (size_t)jj * hid + pp * seg);
+    f32x4 a4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < seg / 4; ++i) {
+      const f32x4 wv = wr[i];
+      const f32x4 hv = *reinterpret_cast<const f32x4*>(h + pp * seg + 4 * i);
+      a4 += wv * hv;
+    }
+    parts[lin] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
   }
+  __syncthreads();
+  for (int jj = tid; jj < dim; jj += 256)
+    te[jj] = w.b3[jj] + ((parts[jj] + parts[dim + jj]) + (parts[2 * dim + jj] + parts[3 * dim + jj]));
   if (w.cw0 != nullptr) {
     // FREE_GUIDANCE: time_embed += cond_mlp(cond); cond == None means zeros, whose embedding
     // is cond_mlp(0) and not 0 (temporal.py:207,212)
@@ -191,7 +208,9 @@ int embed_backward(const adx_embed_weights* w, int dim, const int64_t* t, int t_
 int embed_forward(const adx_embed_weights* w, int dim, const int64_t* t, int t_rows, const float* cond,
                   const float* feat, int feat_rows, int rows, float* time_embed, float* mish_cond, hipStream_t s) {
   ADX_REQUIRE(w != nullptr && w->freqs && w->w1 && w->b1 && w->w3 && w->b3, "embed: missing time_mlp weights");
-  ADX_REQUIRE(dim >= 4 && dim <= kMaxDim && dim % 2 == 0, "embed: dim %d unsupported (<= %d, even)", dim, kMaxDim);
+  ADX_REQUIRE(dim >= 4 && dim <= kMaxDim && dim % 4 == 0, "embed: dim %d unsupported (<= %d, multiple of 4)", dim, kMaxDim);
+  ADX_REQUIRE(((reinterpret_cast<uintptr_t>(w->w1) | reinterpret_cast<uintptr_t>(w->w3)) & 15) == 0,
+              "embed: time_mlp weights must be 16-byte aligned");
   ADX_REQUIRE(rows >= 1 && t_rows >= 1 && feat_rows >= 1, "embed: empty batch");
   ADX_REQUIRE(rows % t_rows == 0 && rows % feat_rows == 0, "embed: rows %d not a multiple of t_rows %d / feat_rows %d",
               rows, t_rows, feat_rows);

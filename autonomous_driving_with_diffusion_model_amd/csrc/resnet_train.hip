@@ -950,7 +950,10 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
 
   // BasicBlocks in reverse.  recs: [stem, (c1, [ds], c2) per block] in forward launch order
   size_t ri = tape->recs.size();
+  static const int dbg_stop = [] { const char* e = getenv("ADX_DBG_STOP_BLOCKS"); return e ? atoi(e) : -1; }();   // diagnostic: return after N blocks
+  int blocks_done = 0;
   for (size_t b = r->block_has_ds.size(); b-- > 0 && rc == ADX_OK;) {
+    if (dbg_stop >= 0 && blocks_done++ == dbg_stop) return ADX_OK;
     const bool ds = r->block_has_ds[b] != 0;
     const adx_resnet_tape::Rec& c2 = tape->recs[--ri];
     const adx_resnet_tape::Rec* dsr = ds ? &tape->recs[--ri] : nullptr;

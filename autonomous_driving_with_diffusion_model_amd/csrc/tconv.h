@@ -26,4 +26,11 @@ size_t tconv_packed_floats(const adx_tconv_desc* d);
 int tconv_pack(const adx_tconv_desc* d, const float* w, float* packed, hipStream_t s);
 int tconv_forward(const adx_tconv_desc* d, const adx_tconv_io* io, hipStream_t s);
 
+// split-fp16 MFMA implementation (tconv_hs.hip); tconv_pack / tconv_forward route to it when the geometry is
+// supported and the descriptor does not ask for the exact-fp32 kernel
+bool tconv_hs_supported(const adx_tconv_desc* d);
+size_t tconv_hs_packed_floats(const adx_tconv_desc* d);
+int tconv_hs_pack(const adx_tconv_desc* d, const float* w, float* packed, hipStream_t s);
+int tconv_hs_forward(const adx_tconv_desc* d, const adx_tconv_io* io, hipStream_t s);
+
 }  // namespace adx

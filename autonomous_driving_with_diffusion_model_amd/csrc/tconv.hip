@@ -24,20 +24,9 @@
 #include <map>
 #include <mutex>
 
-#include "tconv.h"
+#include "tconv_internal.h"
 
 namespace adx {
-
-struct TConvArgs {
-  adx_tconv_io io;
-  int kind, taps, stride, pad;
-  int c0, cin, cout, lin, lout, log2_lout;
-  int groups, cg;
-  float eps;
-  int ncb, nkb;
-  int bt, ct, log2_ct, pl, lp, rs, ck, ntiles, cin_pad;
-  int dense;  // both inputs are plain [B][C][L] tensors with lin % 4 == 0: 16-byte staging loads
-};
 
 __device__ __forceinline__ int tconv_in_pos(int kind, int l, int tap, int stride, int pad, bool& ok) {
   if (kind == 0) {
@@ -195,7 +184,7 @@ __global__ void __launch_bounds__(64 * NW) tconv_kernel(const TConvArgs a) {
     }
   }
 
-  // ---- epilogue: sum the 4 K-partials through LDS, laid out [sample][channel][pos] ----------
+  // ---- epilogue: sum the K-partials through LDS, laid out [sample][channel][pos] ----------
   __syncthreads();
   constexpr int tile_elems = 256 * MF * NF;  // bt * ct * lout
   float* P = smem;
@@ -212,115 +201,7 @@ __global__ void __launch_bounds__(64 * NW) tconv_kernel(const TConvArgs a) {
       }
     }
   __syncthreads();
-  const int n0 = nt * a.ct;
-  // Every thread owns EPT elements e = tid + NT*k of the output tile; 64 consecutive elements (one
-  // wave's worth) always belong to the same (sample, GroupNorm group) pair when n % 64 == 0.
-  constexpr int EPT = (tile_elems + NT - 1) / NT;
-  float v[EPT];
-#pragma unroll
-  for (int k = 0; k < EPT; ++k) {
-    const int e = tid + NT * k;
-    v[k] = 0.f;
-    if (e < tile_elems) {
-      float sum = P[e];
-#pragma unroll
-      for (int w = 1; w < NW; ++w) sum += P[e + w * tile_elems];  // fixed order: deterministic
-      const int c = n0 + ((e >> a.log2_lout) & (a.ct - 1));
-      if (a.io.bias != nullptr && c < a.cout) sum += a.io.bias[c];
-      v[k] = sum;
-      if (a.io.pre != nullptr) {
-        const int b = b0 + (e >> (a.log2_lout + a.log2_ct));
-        if (b < batch && c < a.cout)
-          a.io.pre[((int64_t)b * a.cout + c) * a.lout + (e & (a.lout - 1))] = sum;
-      }
-    }
-  }
-  const int n = a.cg << a.log2_lout;  // elements per (sample, group)
-  float* red = smem + NW * tile_elems; // 2 x (tile_elems / 64) partial sums, behind the K-partials
-  constexpr int NCH = tile_elems / 64;
-  const bool gn = a.groups > 0;
-  // issue every global load of the epilogue now; they land while the statistics are reduced
-  float gm[EPT], be[EPT], tb[EPT], rs_[EPT];
-  int64_t yoff[EPT];
-  bool live[EPT];
-#pragma unroll
-  for (int k = 0; k < EPT; ++k) {
-    const int e = tid + NT * k;
-    const int l = e & (a.lout - 1);
-    const int c = n0 + ((e >> a.log2_lout) & (a.ct - 1));
-    const int b = b0 + (e >> (a.log2_lout + a.log2_ct));
-    live[k] = e < tile_elems && b < batch && c < a.cout;
-    gm[k] = 1.f; be[k] = 0.f; tb[k] = 0.f; rs_[k] = 0.f; yoff[k] = 0;
-    if (live[k]) {
-      if (gn) { gm[k] = a.io.gamma[c]; be[k] = a.io.beta[c]; }
-      if (a.io.tbias != nullptr) tb[k] = a.io.tbias[(int64_t)b * a.io.tbias_stride + c];
-      if (a.io.res != nullptr)
-        rs_[k] = a.io.res[(int64_t)b * a.io.res_sb + (int64_t)c * a.io.res_sc + (int64_t)l * a.io.res_sl];
-      yoff[k] = (int64_t)b * a.io.y_sb + (int64_t)c * a.io.y_sc + (int64_t)l * a.io.y_sl;
-    }
-  }
-  if (gn) {
-    // two-pass mean / variance: wave shuffle, then the pair's n/64 wave partials through LDS
-    const int cpp = n >> 6;  // 64-element chunks per pair (n is a multiple of 64: checked on the host)
-    const float inv_n = 1.0f / (float)n;
-    float mean[EPT], rstd[EPT];
-#pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-      const float s = wave_sum(v[k]);
-      const int ch = wave + NW * k;
-      if (lane == 0 && ch < NCH) red[ch] = s;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-      const int ch = min(wave + NW * k, NCH - 1);
-      const int base = (ch / cpp) * cpp;
-      float s = 0.f;
-      for (int i = 0; i < cpp; ++i) s += red[base + i];
-      mean[k] = s * inv_n;
-      const float d = v[k] - mean[k];
-      const float q = wave_sum(d * d);
-      if (lane == 0 && wave + NW * k < NCH) red[NCH + wave + NW * k] = q;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-      const int ch = min(wave + NW * k, NCH - 1);
-      const int base = (ch / cpp) * cpp;
-      float q = 0.f;
-      for (int i = 0; i < cpp; ++i) q += red[NCH + base + i];
-      rstd[k] = 1.0f / sqrtf(q * inv_n + a.eps);
-      if (a.io.stats != nullptr && lane == 0 && wave + NW * k < NCH && (ch % cpp) == 0) {
-        const int e0 = (wave + NW * k) * 64;  // first element of this (sample, group) pair
-        const int b = b0 + (e0 >> (a.log2_lout + a.log2_ct));
-        const int g = (n0 + ((e0 >> a.log2_lout) & (a.ct - 1))) / a.cg;
-        if (b < batch) {
-          a.io.stats[((int64_t)b * a.groups + g) * 2] = mean[k];
-          a.io.stats[((int64_t)b * a.groups + g) * 2 + 1] = rstd[k];
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-      if (live[k]) {
-        float o = (v[k] - mean[k]) * (rstd[k] * gm[k]) + be[k];
-        o = mish_f(o);
-        if (a.io.tbias != nullptr) o += tb[k];
-        if (a.io.res != nullptr) o += rs_[k];
-        a.io.y[yoff[k]] = o;
-      }
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-      if (live[k]) {
-        float o = v[k];
-        if (a.io.tbias != nullptr) o += tb[k];
-        if (a.io.res != nullptr) o += rs_[k];
-        a.io.y[yoff[k]] = o;
-      }
-    }
-  }
+  tconv_epilogue<NT, NW, tile_elems>(a, smem, tid, lane, wave, nt, b0);
 }
 
 // weight image: [cout_pad/16][nkb][64 lanes][4]; element j of lane l in block (tap, cb) is
@@ -509,13 +390,16 @@ int tconv_tile(const adx_tconv_desc* d, int batch, TConvTile* t) {
 
 size_t tconv_packed_floats(const adx_tconv_desc* d) {
   const int cin_pad = round_up(d->c0 + d->c1, 16);
-  return (size_t)(round_up(d->cout, 16) / 16) * d->taps * (cin_pad / 16) * 256;
+  const size_t exact = (size_t)(round_up(d->cout, 16) / 16) * d->taps * (cin_pad / 16) * 256;
+  const size_t hs = tconv_hs_packed_floats(d);     // both images fit: the `exact` flag may flip between pack calls
+  return exact > hs ? exact : hs;
 }
 
 int tconv_pack(const adx_tconv_desc* d, const float* w, float* packed, hipStream_t s) {
   int rc = tconv_check(d);
   if (rc != ADX_OK) return rc;
   ADX_REQUIRE(w != nullptr && packed != nullptr, "tconv_pack: null pointer");
+  if (tconv_hs_supported(d)) return tconv_hs_pack(d, w, packed, s);
   const int cin = d->c0 + d->c1;
   const int ncb = round_up(cin, 16) / 16;
   const size_t total = tconv_packed_floats(d);
@@ -555,6 +439,7 @@ int tconv_forward(const adx_tconv_desc* d, const adx_tconv_io* io, hipStream_t s
   ADX_REQUIRE(io->x0 != nullptr && io->packed_w != nullptr && io->y != nullptr, "tconv_forward: null tensor");
   ADX_REQUIRE(d->c1 == 0 || io->x1 != nullptr, "tconv_forward: c1 > 0 but x1 is null");
   ADX_REQUIRE(d->groups == 0 || (io->gamma != nullptr && io->beta != nullptr), "tconv_forward: GroupNorm affine missing");
+  if (tconv_hs_supported(d)) return tconv_hs_forward(d, io, s);   // split-fp16 MFMA path (tconv_hs.hip)
   TConvArgs a;
   a.io = *io;
   a.kind = d->kind; a.taps = d->taps; a.stride = d->stride; a.pad = d->pad;

@@ -1,0 +1,514 @@
+// Temporal (1-D) convolution on the fp16 matrix cores of gfx950 with fp32-grade results ("split fp16").
+//
+// Same operator family and the same fused epilogue as tconv.hip (Conv1dBlock = Conv1d -> GroupNorm -> Mish
+// [+ time bias] [+ residual], Downsample1d, Upsample1d, 1x1 convs, the block Linears: modeling/helpers.py:77-112,
+// modeling/temporal.py:23-55), but the multiply runs as v_mfma_f32_32x32x16_f16 on operands split like the
+// perception convolutions (conv2d_hs.hip): x = hi + 2^-11 lo with hi = fp16(x), lo = fp16((x - hi) * 2^11); a product is
+// three MFMAs -- hi*hi into one fp32 accumulator, hi*lo + lo*hi into a second one that is scaled by 2^-11 at the end
+// (the dropped lo*lo term is 2^-22 relative).  fp16 x fp16 products are exact in the MFMA's fp32 datapath, so the
+// result carries fp32 accumulation error only.  One 32x32x16 MFMA retires 32768 MACs in 32 cycles against 1024 MACs
+// in 32 cycles for v_mfma_f32_16x16x4_f32: with 3 products per multiply the matrix time drops 10x, which turns these
+// kernels from matrix-bound into what they should be at 32..4096 rows: bound by streaming the weights once.
+//
+// GEMM view: rows m = (sample, position), 32 per workgroup (= bt whole samples, so every GroupNorm group the tile
+// touches is complete on chip); cols n = output channels, one or two 32-channel tiles (two when the GroupNorm group
+// is 64 wide); k = (tap, input channel), 16 per MFMA.
+//   A (activations): staged ONCE per workgroup into LDS as 16-byte cells of 8 consecutive channels of one position,
+//     hi cell next to lo cell, row pitch an odd number of 16-byte units => a lane's fragment is one ds_read_b128 per
+//     plane and the 32 rows of a read fall into distinct banks.  Only real positions are stored: a tap that falls
+//     outside the sample (zero padding, odd phase of the transposed conv) reads one shared all-zero row.
+//   B (weights): pre-split and pre-packed per (32-channel tile, K-step, plane) in fragment order, so a wave's load of
+//     one K-step is a contiguous 2 KB; NW waves split the K-steps and keep PF of them in flight in a register ring.
+//   The NW partial tiles meet in LDS in the output tensor's [sample][channel][pos] order and go through
+//   tconv_epilogue (shared with the exact kernel): fixed summation order, bit-reproducible.
+#include <array>
+#include <map>
+#include <mutex>
+
+#define ADX_TCONV_TRACE_TU
+#include "tconv_internal.h"
+
+namespace adx {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float kLoScale = 2048.0f;          // 2^11
+constexpr float kLoInv = 1.0f / 2048.0f;
+
+struct HsArgs {
+  TConvArgs t;          // geometry + io (ct, log2_ct, bt, ntiles, ck, cin_pad, ncb, nkb as in TConvArgs)
+  int pitch16;          // LDS row pitch in 16-byte units (odd)
+  int nrows;            // staged input rows per workgroup = bt * lin; row index nrows is the all-zero row
+  int vec_stage;        // 16-byte staging loads (dense [B][C][L] inputs and enough items to occupy the workgroup)
+  int fast_epi;         // hs_epilogue4 applies (lout >= 4, GroupNorm group of 64..256 elements or none)
+  int pc;               // floats per (sample, channel) line of a partial tile: lout, or lout + 4 when that makes the
+                        // 16-byte accesses of 32 lanes (one channel each) bank-conflict free (fast epilogue only)
+  int ptile;            // floats per partial tile = bt * ct * pc
+  int log2_lin, log2_nrows;
+};
+
+__device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const _Float16 h = (_Float16)v[j];
+    hi[j] = h;
+    lo[j] = (_Float16)((v[j] - (float)h) * kLoScale);
+  }
+}
+
+// ---- sums over segments of 16 / 32 / 64 consecutive lanes: DPP inside a row of 16, LDS permute across rows ------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float seg_sum(float v, int lanes) {   // every lane of a segment receives the segment's sum
+  v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);   // row_half_mirror: the other quad of each 8
+  v += dpp_f<0x140>(v);   // row_mirror: the other half of the row
+  if (lanes >= 32) v += __shfl_xor(v, 16, 64);
+  if (lanes >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+// Mish with the hardware exp and reciprocal: e = 2^(x log2 e) (v_exp_f32, 1 ulp), n = e (e + 2), x n / (n + 2)
+// (same closed form as mish_f; ~3e-7 relative, far inside the 1e-4 trajectory budget)
+__device__ __forceinline__ float mish_fast(float x) {
+  if (x > 20.f) return x;
+  const float e = __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+  const float n = e * (e + 2.f);
+  return x * n * __builtin_amdgcn_rcpf(n + 2.f);
+}
+
+// Fused epilogue on the summed tile, four consecutive positions of one (sample, channel) per thread: no barrier, the
+// GroupNorm statistics are segment sums inside a wave (a group = cg * lout / 4 consecutive lanes, 16 / 32 / 64).
+// Valid when lout >= 4 and (no GroupNorm or 64 <= cg * lout <= 256); other geometries use tconv_epilogue.
+template <int NW, int TILE>
+__device__ __forceinline__ void hs_epilogue4(const TConvArgs& a, const float* P, int pc, int ptile, int tid, int nt,
+                                             int b0) {
+  if (tid >= TILE / 4) return;
+  const int e0 = 4 * tid;
+  const int l0 = e0 & (a.lout - 1);
+  const int c = nt * a.ct + ((e0 >> a.log2_lout) & (a.ct - 1));
+  const int b = b0 + (e0 >> (a.log2_lout + a.log2_ct));
+  const bool live = b < a.io.batch && c < a.cout;
+  // the loads of the epilogue first: they land while the partial tiles are summed
+  float bias = 0.f, gm = 1.f, be = 0.f, tb = 0.f;
+  f32x4 rs = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    if (a.io.bias != nullptr) bias = a.io.bias[c];
+    if (a.groups > 0) { gm = a.io.gamma[c]; be = a.io.beta[c]; }
+    if (a.io.tbias != nullptr) tb = a.io.tbias[(int64_t)b * a.io.tbias_stride + c];
+    if (a.io.res != nullptr) {
+      const float* rp = a.io.res + (int64_t)b * a.io.res_sb + (int64_t)c * a.io.res_sc + (int64_t)l0 * a.io.res_sl;
+      if (a.io.res_sl == 1 && ((a.io.res_sb | a.io.res_sc) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.io.res) & 15) == 0) {
+        rs = *reinterpret_cast<const f32x4*>(rp);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rs[q] = rp[(int64_t)q * a.io.res_sl];
+      }
+    }
+  }
+  const float* pp = P + (e0 >> a.log2_lout) * pc + l0;     // line (sample, channel) of the padded partial tile
+  f32x4 v = *reinterpret_cast<const f32x4*>(pp);
+#pragma unroll
+  for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4*>(pp + w * ptile);   // fixed order: deterministic
+  v += bias;
+  if (a.io.pre != nullptr && live)
+    *reinterpret_cast<f32x4*>(a.io.pre + ((int64_t)b * a.cout + c) * a.lout + l0) = v;
+  ADX_TSTAMP(5);
+  f32x4 o = v;
+  if (a.groups > 0) {
+    const int n = a.cg << a.log2_lout;          // elements per (sample, group); n / 4 consecutive lanes hold them
+    const float inv_n = 1.0f / (float)n;
+    const float mean = seg_sum((v[0] + v[1]) + (v[2] + v[3]), n >> 2) * inv_n;
+    const f32x4 d = v - mean;
+    const float q = seg_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]), n >> 2);
+    const float rstd = 1.0f / sqrtf(q * inv_n + a.eps);
+    if (a.io.stats != nullptr && live && (e0 & (n - 1)) == 0) {
+      float* st = a.io.stats + ((int64_t)b * a.groups + c / a.cg) * 2;
+      st[0] = mean;
+      st[1] = rstd;
+    }
+    const float sc = rstd * gm;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = mish_fast(d[k] * sc + be);
+  }
+  ADX_TSTAMP(7);
+  if (!live) return;
+  o += tb;
+  o += rs;
+  float* yp = a.io.y + (int64_t)b * a.io.y_sb + (int64_t)c * a.io.y_sc + (int64_t)l0 * a.io.y_sl;
+  if (a.io.y_sl == 1 && ((a.io.y_sb | a.io.y_sc) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.io.y) & 15) == 0) {
+    *reinterpret_cast<f32x4*>(yp) = o;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) yp[(int64_t)k * a.io.y_sl] = o[k];
+  }
+}
+
+template <int NF, int NW, int PF>
+__global__ void __launch_bounds__(64 * NW) tconv_hs_kernel(const HsArgs ha) {
+  constexpr int NT = 64 * NW;
+  const TConvArgs& a = ha.t;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  u32x4* cells = reinterpret_cast<u32x4*>(smem);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nt = blockIdx.x % a.ntiles;   // blocks b, b + 8 share an XCD: with ntiles | 8 or 8 | ntiles one XCD's L2 serves one weight slab
+  const int b0 = (blockIdx.x / a.ntiles) * a.bt;
+  const int batch = a.io.batch;
+  const int r = lane & 31, kg = lane >> 5;
+  const int bl = r >> a.log2_lout, l = r & (a.lout - 1);
+  const int pitch = ha.pitch16;
+  const int zrow = ha.nrows;
+
+  ADX_TSTAMP(0);
+  f32x16 accm[NF], accx[NF];
+#pragma unroll
+  for (int j = 0; j < NF; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { accm[j][i] = 0.f; accx[j][i] = 0.f; }
+
+  // weight image: [32-channel tile][K-step][plane][lane] x 16 bytes
+  const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(a.io.packed_w) + (size_t)nt * NF * a.nkb * 128 + lane;
+  const size_t tile_stride = (size_t)a.nkb * 128;
+  u32x4 wq[PF][NF][2];
+
+  for (int c0 = 0; c0 < a.cin_pad; c0 += a.ck) {
+    const int ckc = min(a.ck, a.cin_pad - c0);
+    const int ncbc = ckc >> 4;
+    const int nblk = a.taps * ncbc;
+    const int nbw = nblk > wave ? (nblk - wave + NW - 1) / NW : 0;   // K-steps of this wave in this chunk
+    const int cb0 = c0 >> 4;
+    // this wave's K-steps: i = wave, wave + NW, ...  (tap, 16-channel block) = (i / ncbc, i % ncbc)
+    int ltap = 0, lcb = wave;
+    while (lcb >= ncbc) { lcb -= ncbc; ++ltap; }
+    auto issue = [&](u32x4 (&dst)[NF][2]) {
+      const int tp = min(ltap, a.taps - 1);  // past-the-end slots re-read a valid block and are never used
+      const u32x4* src = wp + (size_t)(tp * a.ncb + cb0 + lcb) * 128;
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        dst[j][0] = src[j * tile_stride];
+        dst[j][1] = src[j * tile_stride + 64];
+      }
+      lcb += NW;
+      while (lcb >= ncbc) { lcb -= ncbc; ++ltap; }
+    };
+#pragma unroll
+    for (int s = 0; s < PF; ++s) issue(wq[s]);     // in flight while the activations are staged
+    ADX_TSTAMP(9);
+    if (c0 > 0) __syncthreads();
+    // ---- stage rows [0, nrows] x channels [c0, c0 + ckc) as split cells ---------------------------------------
+    {
+      const int ncell = ckc >> 3;
+      if (ha.vec_stage) {
+        // item = (sample, quad of 4 positions, 8-channel octet): eight 16-byte loads -> four (hi, lo) cell pairs
+        const int items = (ha.nrows >> 2) * ncell;
+        for (int it = tid; it < items; it += NT) {
+          const int rq = it & ((ha.nrows >> 2) - 1), oc = it >> (ha.log2_nrows - 2);  // row quads fastest
+          const int q = rq & ((a.lin >> 2) - 1), sb = rq >> (ha.log2_lin - 2);
+          const int b = b0 + sb;
+          f32x4 v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int ci = c0 + 8 * oc + j;
+            v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ci < a.cin && b < batch) {
+              const bool first = ci < a.c0;
+              const float* src = first ? a.io.x0 + (int64_t)ci * a.io.x0_sc + (int64_t)b * a.io.x0_sb
+                                       : a.io.x1 + (int64_t)(ci - a.c0) * a.io.x1_sc + (int64_t)b * a.io.x1_sb;
+              v[j] = *reinterpret_cast<const f32x4*>(src + 4 * q);
+            }
+          }
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            float t8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t8[j] = v[j][p];
+            h8 hi, lo;
+            split8(t8, hi, lo);
+            u32x4* dst = cells + (sb * a.lin + 4 * q + p) * pitch + 2 * oc;
+            dst[0] = __builtin_bit_cast(u32x4, hi);
+            dst[1] = __builtin_bit_cast(u32x4, lo);
+          }
+        }
+      } else {
+        // item = (row, 8-channel octet): eight 4-byte loads -> one (hi, lo) cell pair; rows fastest across lanes so that
+        // a wave's load instruction covers consecutive positions of one channel
+        const int nrows = ha.nrows;
+        const int items = nrows * ncell;
+        for (int it = tid; it < items; it += NT) {
+          const int row = it & (nrows - 1), oc = it >> ha.log2_nrows;      // nrows and lin are powers of two
+          const int sb = row >> ha.log2_lin, ip = row & (a.lin - 1);
+          const int b = b0 + sb;
+          float t8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int ci = c0 + 8 * oc + j;
+            t8[j] = 0.f;
+            if (ci < a.cin && b < batch) {
+              const bool first = ci < a.c0;
+              t8[j] = first ? a.io.x0[(int64_t)b * a.io.x0_sb + (int64_t)ci * a.io.x0_sc + (int64_t)ip * a.io.x0_sl]
+                            : a.io.x1[(int64_t)b * a.io.x1_sb + (int64_t)(ci - a.c0) * a.io.x1_sc + (int64_t)ip * a.io.x1_sl];
+            }
+          }
+          h8 hi, lo;
+          split8(t8, hi, lo);
+          ADX_TSTAMP(10);
+          u32x4* dst = cells + row * pitch + 2 * oc;
+          dst[0] = __builtin_bit_cast(u32x4, hi);
+          dst[1] = __builtin_bit_cast(u32x4, lo);
+        }
+      }
+      for (int it = tid; it < 2 * ncell; it += NT) cells[zrow * pitch + it] = u32x4{0u, 0u, 0u, 0u};
+    }
+    ADX_TSTAMP(11);
+    __syncthreads();
+    ADX_TSTAMP(1);
+    // ---- K loop over this wave's steps, PF-deep weight ring, activation fragments fetched one step ahead -------
+    int ctap = 0, ccb = wave;
+    while (ccb >= ncbc) { ccb -= ncbc; ++ctap; }
+    u32x4 ah, al;
+    auto fetch_a = [&]() {     // fragment of step (ctap, ccb); then advance to this wave's next step
+      int ip;
+      bool ok;
+      if (a.kind == 0) {
+        ip = l * a.stride + ctap - a.pad;
+        ok = ip >= 0 && ip < a.lin;
+      } else {  // ConvTranspose1d, stride 2: o = 2 i - pad + tap  <=>  i = (o + pad - tap) / 2 when even
+        const int v = l + a.pad - ctap;
+        ok = (v & 1) == 0 && v >= 0 && (v >> 1) < a.lin;
+        ip = v >> 1;
+      }
+      const int row = (ok && ctap < a.taps) ? bl * a.lin + ip : zrow;
+      const u32x4* xp = cells + row * pitch + 4 * ccb + 2 * kg;
+      ah = xp[0];
+      al = xp[1];
+      ccb += NW;
+      while (ccb >= ncbc) { ccb -= ncbc; ++ctap; }
+    };
+    if (nbw > 0) fetch_a();
+    auto compute = [&](const u32x4 (&w)[NF][2]) {
+      const h8 ch = __builtin_bit_cast(h8, ah);
+      const h8 cl = __builtin_bit_cast(h8, al);
+      fetch_a();                        // next step's fragment is in flight under this step's MFMAs
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const h8 wh = __builtin_bit_cast(h8, w[j][0]);
+        const h8 wl = __builtin_bit_cast(h8, w[j][1]);
+        accm[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, wh, accm[j], 0, 0, 0);
+        accx[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, wl, accx[j], 0, 0, 0);
+        accx[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl, wh, accx[j], 0, 0, 0);
+      }
+    };
+    int j0 = 0;
+    for (; j0 + PF <= nbw; j0 += PF) {  // full groups: branch-free, ring slots are compile-time indices
+#pragma unroll
+      for (int s = 0; s < PF; ++s) {
+        compute(wq[s]);
+        issue(wq[s]);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < PF; ++s)        // tail group: its weights are already in the ring
+      if (j0 + s < nbw) compute(wq[s]);
+  }
+
+  // ---- the NW partial tiles -> LDS, [wave][sample][channel][pos] ------------------------------------------------
+  ADX_TSTAMP(2);
+  __syncthreads();
+  ADX_TSTAMP(3);
+  constexpr int TILE = 32 * 32 * NF;
+  float* P = smem + wave * ha.ptile;
+#pragma unroll
+  for (int j = 0; j < NF; ++j) {
+    const int c = j * 32 + r;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int m0 = 8 * g + 4 * kg;                      // 4 consecutive rows m0 .. m0 + 3 in registers 4g .. 4g + 3
+      f32x4 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = accm[j][4 * g + q] + accx[j][4 * g + q] * kLoInv;
+      if (a.log2_lout >= 2) {                             // the 4 rows are 4 consecutive positions of one sample
+        const int sb = m0 >> a.log2_lout, l0 = m0 & (a.lout - 1);
+        *reinterpret_cast<f32x4*>(P + ((sb << a.log2_ct) + c) * ha.pc + l0) = o;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m = m0 + q;
+          const int sb = m >> a.log2_lout, lq = m & (a.lout - 1);
+          P[(((sb << a.log2_ct) + c) << a.log2_lout) + lq] = o[q];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  ADX_TSTAMP(4);
+  if (ha.fast_epi) {
+    hs_epilogue4<NW, TILE>(a, smem, ha.pc, ha.ptile, tid, nt, b0);
+    ADX_TSTAMP(8);
+  } else {
+    tconv_epilogue<NT, NW, TILE>(a, smem, tid, lane, wave, nt, b0);
+  }
+}
+
+// weight image [cout_pad32 / 32][nkb][2 planes][64 lanes][8 halfs]; element j of lane ln in K-step (tap, cb) is
+// W[n = 32 tile + (ln & 31)][ci = 16 cb + 8 (ln >> 5) + j][tap]  (B operand of 32x32x16)
+__global__ void tconv_hs_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ packed, int layout, int flip,
+                                     int taps, int cin, int cout, int ncb, int nkb, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;   // one (tile, K-step, lane, j) per thread, both planes
+  if (idx >= total) return;
+  const int j = idx & 7;
+  const int ln = (idx >> 3) & 63;
+  const size_t blk = idx >> 9;
+  const int kb = blk % nkb;
+  const int t32 = blk / nkb;
+  const int tap = kb / ncb, cb = kb - tap * ncb;
+  const int n = t32 * 32 + (ln & 31);
+  const int ci = cb * 16 + 8 * (ln >> 5) + j;
+  float v = 0.f;
+  const int ts = flip ? taps - 1 - tap : tap;
+  if (n < cout && ci < cin)
+    v = layout == 0 ? w[((size_t)n * cin + ci) * taps + ts] : w[((size_t)ci * cout + n) * taps + ts];
+  const _Float16 hi = (_Float16)v;
+  const _Float16 lo = (_Float16)((v - (float)hi) * kLoScale);
+  _Float16* dst = packed + blk * 1024 + ln * 8 + j;
+  dst[0] = hi;
+  dst[512] = lo;
+}
+
+static int ilog2_exact_hs(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return (1 << l) == v ? l : -1;
+}
+
+constexpr size_t kMaxHsLds = 144 * 1024;
+
+bool tconv_hs_supported(const adx_tconv_desc* d) {
+  static const bool force_exact = [] {
+    const char* e = getenv("ADX_TCONV_EXACT");
+    return e != nullptr && e[0] == '1';
+  }();
+  if (force_exact || d->exact != 0) return false;
+  if (d->lout > 32 || ilog2_exact_hs(d->lout) < 0 || ilog2_exact_hs(d->lin) < 0) return false;   // 32 rows per tile = whole samples
+  if (32 % d->lout != 0) return false;
+  if (d->groups > 0) {
+    const int cg = d->cout / d->groups;
+    if (cg > 64 || ilog2_exact_hs(cg) < 0) return false;
+  }
+  return true;
+}
+
+size_t tconv_hs_packed_floats(const adx_tconv_desc* d) {
+  const int cin_pad = round_up(d->c0 + d->c1, 16);
+  return (size_t)round_up(d->cout, 32) * d->taps * cin_pad;     // 2 halfs = 4 bytes per (padded) weight
+}
+
+int tconv_hs_pack(const adx_tconv_desc* d, const float* w, float* packed, hipStream_t s) {
+  const int cin = d->c0 + d->c1;
+  const int ncb = round_up(cin, 16) / 16;
+  const int nkb = d->taps * ncb;
+  const size_t total = (size_t)(round_up(d->cout, 32) / 32) * nkb * 512;
+  tconv_hs_pack_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
+      w, reinterpret_cast<_Float16*>(packed), d->kind == 1 ? 1 - d->w_layout : d->w_layout, d->w_flip, d->taps, cin,
+      d->cout, ncb, nkb, total);
+  ADX_LAUNCH_CHECK();
+  return ADX_OK;
+}
+
+struct HsTile {
+  int nf, nw, bt, ct, ntiles, ck, pitch16, nrows;
+  size_t lds_bytes;
+};
+
+static int hs_tile(const adx_tconv_desc* d, int batch, HsTile* t) {
+  const int cin_pad = round_up(d->c0 + d->c1, 16);
+  const int cout_pad = round_up(d->cout, 32);
+  t->bt = 32 / d->lout;
+  t->nf = 1;
+  if (d->groups > 0 && d->cout / d->groups == 64) t->nf = 2;
+  t->ct = 32 * t->nf;
+  ADX_REQUIRE(cout_pad % t->ct == 0, "tconv_hs: cout %d not divisible by the channel tile %d", d->cout, t->ct);
+  t->ntiles = cout_pad / t->ct;
+  t->nrows = t->bt * d->lin;
+  t->nw = 8;     // also where K is short: the staging and the epilogue are spread over 512 threads
+  // staged chunk: (nrows + 1) rows x (ck / 4 + 1) 16-byte units; keep it <= ~68 KB so two workgroups share a CU
+  const size_t budget = 70 * 1024;
+  int ck = cin_pad;
+  while ((size_t)(t->nrows + 1) * (ck / 4 + 1) * 16 > budget && ck > 16) ck = round_up(ck / 2, 16);
+  const int nchunks = ceil_div(cin_pad, ck);
+  t->ck = round_up(ceil_div(cin_pad, nchunks), 16);
+  t->pitch16 = t->ck / 4 + 1;
+  const size_t stage = (size_t)(t->nrows + 1) * t->pitch16 * 16;
+  const size_t epi = ((size_t)t->nw * 1024 * t->nf + 2 * 16 * t->nf) * sizeof(float);
+  t->lds_bytes = stage > epi ? stage : epi;
+  ADX_REQUIRE(t->lds_bytes <= kMaxHsLds, "tconv_hs: LDS tile of %zu bytes exceeds %zu", t->lds_bytes, kMaxHsLds);
+  (void)batch;
+  return ADX_OK;
+}
+
+template <int NF, int NW, int PF>
+static int hs_launch(const HsArgs& a, int grid, size_t lds, hipStream_t s) {
+  static bool attr_set = false;  // dynamic LDS above 64 KB must be opted into once per kernel
+  if (!attr_set) {
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_hs_kernel<NF, NW, PF>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxHsLds));
+    attr_set = true;
+  }
+  tconv_hs_kernel<NF, NW, PF><<<dim3(grid), dim3(64 * NW), lds, s>>>(a);
+  ADX_LAUNCH_CHECK();
+  return ADX_OK;
+}
+
+int tconv_hs_forward(const adx_tconv_desc* d, const adx_tconv_io* io, hipStream_t s) {
+  HsTile t;
+  int rc = hs_tile(d, io->batch, &t);
+  if (rc != ADX_OK) return rc;
+  HsArgs ha;
+  TConvArgs& a = ha.t;
+  a.io = *io;
+  a.kind = d->kind; a.taps = d->taps; a.stride = d->stride; a.pad = d->pad;
+  a.c0 = d->c0; a.cin = d->c0 + d->c1; a.cout = d->cout; a.lin = d->lin; a.lout = d->lout;
+  a.log2_lout = ilog2_exact_hs(d->lout);
+  a.groups = d->groups; a.cg = d->groups > 0 ? d->cout / d->groups : 1; a.eps = d->eps;
+  a.cin_pad = round_up(a.cin, 16);
+  a.ncb = a.cin_pad / 16; a.nkb = d->taps * a.ncb;
+  a.bt = t.bt; a.ct = t.ct; a.log2_ct = ilog2_exact_hs(t.ct); a.pl = 0; a.lp = 0; a.rs = 0; a.ck = t.ck;
+  a.ntiles = t.ntiles;
+  auto dense_src = [&](const float* p, int64_t sb, int64_t sc, int64_t sl) {
+    return sl == 1 && sc % 4 == 0 && sb % 4 == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+  };
+  a.dense = d->lin % 4 == 0 && dense_src(io->x0, io->x0_sb, io->x0_sc, io->x0_sl) &&
+            (d->c1 == 0 || dense_src(io->x1, io->x1_sb, io->x1_sc, io->x1_sl));
+  ha.pitch16 = t.pitch16;
+  ha.nrows = t.nrows;
+  ha.vec_stage = a.dense && t.bt * (d->lin / 4) * (t.ck / 8) >= 256;
+  const int n_gn = a.cg * d->lout;
+  ha.fast_epi = d->lout >= 4 && (d->groups == 0 || (n_gn >= 64 && n_gn <= 256));
+  ha.pc = (ha.fast_epi && d->lout >= 8) ? d->lout + 4 : d->lout;     // (lout + 4) / 4 is odd for lout = 8, 16, 32
+  ha.ptile = t.bt * t.ct * ha.pc;
+  ha.log2_lin = ilog2_exact_hs(d->lin);
+  ha.log2_nrows = ilog2_exact_hs(t.nrows);
+  ADX_REQUIRE(ha.log2_lin >= 0 && ha.log2_nrows >= 0, "tconv_hs: lin %d must be a power of two", d->lin);
+  const size_t epi_bytes = ((size_t)t.nw * ha.ptile + 2 * 16 * t.nf) * sizeof(float);
+  if (epi_bytes > t.lds_bytes) t.lds_bytes = epi_bytes;
+  ADX_REQUIRE(t.lds_bytes <= kMaxHsLds, "tconv_hs: LDS tile of %zu bytes exceeds %zu", t.lds_bytes, kMaxHsLds);
+  const int grid = ceil_div(io->batch, t.bt) * t.ntiles;
+  // a grid that fits the chip one workgroup per CU must not be packed two per CU (the dispatcher does that with
+  // 128 workgroups on 256 CUs): the two would share one CU's L2->L1 fill rate, which is what bounds the K loop
+  static const size_t min_lds = [] { const char* e = getenv("ADX_TCONV_MIN_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();   // measured: no gain, off by default
+  if (grid <= 256 && t.lds_bytes < min_lds) t.lds_bytes = min_lds;
+  return t.nf == 2 ? hs_launch<2, 8, 4>(ha, grid, t.lds_bytes, s) : hs_launch<1, 8, 6>(ha, grid, t.lds_bytes, s);
+}
+
+#ifdef ADX_TCONV_TRACE
+extern "C" int adx_debug_tconv_trace(unsigned long long* host_dst, int n) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_tconv_trace), sizeof(unsigned long long) * n);
+}
+#endif
+
+}  // namespace adx

@@ -217,7 +217,17 @@ int adx_unet_create(const adx_unet_config* cfg, adx_unet** out) {
   return ADX_OK;
 }
 
-void adx_unet_destroy(adx_unet* u) { delete u; }
+void adx_unet_destroy(adx_unet* u) {
+  if (u == nullptr) return;
+  if (u->side_state == 1) {
+    for (int i = 0; i < 16; ++i) {
+      (void)hipEventDestroy(u->ev_fork[i]);
+      (void)hipEventDestroy(u->ev_join[i]);
+    }
+    (void)hipStreamDestroy(u->side);
+  }
+  delete u;
+}
 
 int adx_unet_num_params(const adx_unet* u) { return u ? u->n_params : 0; }
 
@@ -346,17 +356,44 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
   // the last conv of the block, after h and the 1x1-residual buffers of that block were taken).
   int nb = 0;
   auto next_buf = [&]() { float* p = bufs[nb]; nb = (nb + 1) % kRing; return p; };
+  if (u->side_state == 0) {
+    // Measured (round 2, B = 64 and B = 1): the fork/join costs more than the overlap gains -- 1664 -> 1244 steps/s
+    // eager, 1603 -> 1423 as a graph (cross-queue dependencies are several microseconds each) -- so the side stream is
+    // opt-in (ADX_UNET_SIDE=1) and the default issues R(x) in stream order.
+    const char* e = getenv("ADX_UNET_SIDE");
+    u->side_state = -1;
+    if (e != nullptr && e[0] == '1' && hipStreamCreateWithFlags(&u->side, hipStreamNonBlocking) == hipSuccess) {
+      bool ok = true;
+      for (int i = 0; i < 16 && ok; ++i)
+        ok = hipEventCreateWithFlags(&u->ev_fork[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&u->ev_join[i], hipEventDisableTiming) == hipSuccess;
+      if (ok) u->side_state = 1;
+    }
+    (void)hipGetLastError();
+  }
+  int n_fork = 0;
   auto run_block = [&](const ResBlock& B, const Act& x0, const Act* x1, float* dst) -> int {
     float* h = next_buf();
-    int r = run_conv(B.a, base, x0, x1, tb + B.tb_off, u->sum_c, nullptr, h, (int64_t)B.cout * B.len, B.len, 1, rows, s);
-    if (r != ADX_OK) return r;
     Act res = x0;  // identity residual (cin == cout, never a concat)
+    int r = ADX_OK, fork = -1;
     if (B.has_r) {
+      // R(x) beside block[0]: fork after the producer of x0, join before block[1] (whose epilogue adds R(x))
       float* rb = next_buf();
-      r = run_conv(B.r, base, x0, x1, nullptr, 0, nullptr, rb, (int64_t)B.cout * B.len, B.len, 1, rows, s);
+      hipStream_t rs = s;
+      if (u->side_state == 1 && n_fork < 16) {
+        fork = n_fork++;
+        ADX_CHECK_HIP(hipEventRecord(u->ev_fork[fork], s));
+        ADX_CHECK_HIP(hipStreamWaitEvent(u->side, u->ev_fork[fork], 0));
+        rs = u->side;
+      }
+      r = run_conv(B.r, base, x0, x1, nullptr, 0, nullptr, rb, (int64_t)B.cout * B.len, B.len, 1, rows, rs);
+      if (fork >= 0) ADX_CHECK_HIP(hipEventRecord(u->ev_join[fork], u->side));
       if (r != ADX_OK) return r;
       res = dense(rb, B.cout, B.len);
     }
+    r = run_conv(B.a, base, x0, x1, tb + B.tb_off, u->sum_c, nullptr, h, (int64_t)B.cout * B.len, B.len, 1, rows, s);
+    if (r != ADX_OK) return r;
+    if (fork >= 0) ADX_CHECK_HIP(hipStreamWaitEvent(s, u->ev_join[fork], 0));
     const Act hin = dense(h, B.cout, B.len);
     return run_conv(B.b, base, hin, nullptr, nullptr, 0, &res, dst, (int64_t)B.cout * B.len, B.len, 1, rows, s);
   };

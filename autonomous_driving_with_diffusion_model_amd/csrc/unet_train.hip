@@ -353,6 +353,7 @@ int adx_unet_backward(adx_unet* u, const void* packed, void* workspace, size_t w
     if (!op.need_dx) continue;
     adx_tconv_desc g{};
     g.groups = 0; g.eps = d.eps; g.c0 = d.cout; g.c1 = 0; g.cout = cin; g.lin = d.lout; g.lout = d.lin; g.taps = d.taps;
+    g.exact = 1;   // gradients span many binades (1e-9 .. 1): keep them off the fp16 operand path
     if (d.kind == 0 && d.stride == 1) {
       g.kind = 0; g.stride = 1; g.pad = d.taps - 1 - d.pad; g.w_layout = 1; g.w_flip = 1;
     } else if (d.kind == 0) {       // strided conv -> transposed conv with the conv's own weight
@@ -414,7 +415,7 @@ int adx_unet_backward(adx_unet* u, const void* packed, void* workspace, size_t w
     }
     adx_tconv_desc g{};
     g.kind = 0; g.taps = 1; g.stride = 1; g.pad = 0; g.c0 = u->sum_c; g.c1 = 0; g.cout = 2 * dim; g.lin = 1; g.lout = 1;
-    g.groups = 0; g.eps = 1e-5f; g.w_layout = 1; g.w_flip = 0;
+    g.groups = 0; g.eps = 1e-5f; g.w_layout = 1; g.w_flip = 0; g.exact = 1;
     rc = tconv_pack(&g, base + u->o_tlin_raw, wscratch, s);
     if (rc != ADX_OK) return rc;
     adx_tconv_io gio;

@@ -54,6 +54,9 @@ typedef struct adx_tconv_desc {
    * convolution is again a convolution of this family with the SAME weight tensor read differently:
    *   w_layout 0: w[cout][cin][taps]   1: w[cin][cout][taps];   w_flip 1: taps reversed.          */
   int32_t w_layout, w_flip;
+  /* 0 (default): split-fp16 MFMA where the geometry allows it (fp32-grade result, csrc/tconv_hs.hip);
+   * 1: the exact-fp32 MFMA kernel (used for gradient-sized operands whose range fp16 cannot hold). */
+  int32_t exact;
 } adx_tconv_desc;
 
 /* Size (bytes) of the packed weight image for a conv of this geometry. */

@@ -1,0 +1,44 @@
+"""Per-tensor gradient error of one training step (B = 2, H = 16, 64x96 image, the train.npz fixture's inputs) against the
+oracle in fp64; prints the worst tensors.  ADX_CONV_EXACT=1 / ADX_TCONV_EXACT=1 select the exact-fp32 kernels for A/B."""
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+from oracle import sampling as OS  # noqa: E402
+from autonomous_driving_with_diffusion_model_amd import scheduler as S  # noqa: E402
+from autonomous_driving_with_diffusion_model_amd.modeling.spec import unet_entries  # noqa: E402
+from autonomous_driving_with_diffusion_model_amd.utils import procedural as P  # noqa: E402
+from helpers import SCHED_KW, oracle_sd  # noqa: E402
+from test_gpu_model import make_model  # noqa: E402
+
+DEV = "cuda:0"
+use_cond = "NO_GUIDANCE"
+m, _ = make_model(use_cond, 16)
+m.train()
+d = P.synthetic_batch(2, 16, image_hw=(64, 96), seed=41)
+dd = {k: v.to(DEV) for k, v in d.items()}
+sch = S.DDPMScheduler(**SCHED_KW)
+noisy = sch.add_noise(dd["trajs"], dd["noise"], dd["t"], zero_first=True)
+loss = F.mse_loss(m(noisy, dd["imgs"], dd["t"]), dd["trajs"])
+loss.backward()
+got = {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+pkeys = [e.key for e in unet_entries(use_cond) if not e.is_buffer]
+
+
+def og(dtype):
+    sd = {k: (v.to(dtype).requires_grad_(k in pkeys) if v.is_floating_point() else v) for k, v in oracle_sd(use_cond).items()}
+    c = lambda t: t.to(dtype) if t.is_floating_point() else t  # noqa: E731
+    OS.training_loss(sd, c(d["imgs"]), c(d["trajs"]), c(d["target"]), d["t"], c(d["noise"]), use_cond=use_cond).backward()
+    return {k: sd[k].grad for k in pkeys}
+
+
+g64, g32 = og(torch.float64), og(torch.float32)
+rel = lambda a, b: ((a.double() - b).norm() / (b.norm() + 1e-300)).item()  # noqa: E731
+rows = sorted(((rel(got[k], g64[k]), rel(g32[k], g64[k]), k) for k in pkeys), reverse=True)
+for e_hip, e_ref, k in rows[:25]:
+    print(f"{k:50s} e_hip {e_hip:.2e}  e_oracle_fp32 {e_ref:.2e}  ratio {e_hip / max(e_ref, 1e-12):8.1f}")
+bad = [r for r in rows if r[0] > 3 * r[1] + 1e-3]
+print(f"{len(bad)} of {len(rows)} tensors beyond 3 e_ref + 1e-3")

@@ -1,0 +1,65 @@
+"""Phase times of the temporal-conv kernel from a -DADX_TCONV_TRACE build:
+    ADX_OUT=../libadx_trace.so ADX_OBJDIR=build_trace bash autonomous_driving_with_diffusion_model_amd/csrc/build.sh -DADX_TCONV_TRACE
+    ADX_LIB=autonomous_driving_with_diffusion_model_amd/libadx_trace.so python tools/tconv_trace.py
+Every workgroup's thread 0 stamps s_memtime at: 0 start, 1 activations staged, 2 K loop done, 3 barrier, 4 partial tiles in
+LDS, 5 partials summed (+bias), 6 GroupNorm pass 1, 7 pass 2, 8 end.  Prints the median over workgroups of each interval."""
+import ctypes as C
+import os
+import statistics
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from autonomous_driving_with_diffusion_model_amd import _lib as L  # noqa: E402
+
+DEV = torch.device("cuda:0")
+ROWS = int(os.environ.get("ROWS", "128"))
+LAYERS = {"64x64L32": (0, 5, 1, 2, 64, 0, 64, 32, 32, 8), "512x512L4": (0, 5, 1, 2, 512, 0, 512, 4, 4, 8),
+          "head64x7": (0, 1, 1, 0, 64, 0, 7, 32, 32, 0), "256x256L8": (0, 5, 1, 2, 256, 0, 256, 8, 8, 8),
+          "1024x256L4": (0, 5, 1, 2, 512, 512, 256, 4, 4, 8)}
+lib = L.lib()
+dbg = C.CDLL(L.LIB_PATH).adx_debug_tconv_trace
+s = L.stream_ptr(DEV)
+NAMES = ["stage", "kloop", "barrier", "partials->lds", "sum partials", "gn pass1", "gn pass2", "normalise+store"]
+for name, (kind, taps, stride, pad, c0, c1, cout, lin, lout, groups) in LAYERS.items():
+    d = L.TConvDesc(kind, taps, stride, pad, c0, c1, cout, lin, lout, groups, 1e-5, 0, 0, 0)
+    cin = c0 + c1
+    w = torch.randn((cout, cin, taps), device=DEV) * (1.0 / (taps * cin)) ** 0.5
+    packed = torch.empty(lib.adx_tconv_packed_bytes(C.byref(d)) // 4, device=DEV)
+    L.check(lib.adx_tconv_pack(C.byref(d), w.data_ptr(), packed.data_ptr(), s))
+    x0 = torch.randn((ROWS, c0, lin), device=DEV)
+    x1 = torch.randn((ROWS, c1, lin), device=DEV) if c1 else None
+    y = torch.empty((ROWS, cout, lout), device=DEV)
+    b, g, be = (torch.randn(cout, device=DEV) * 0.1 for _ in range(3))
+    io = L.TConvIO()
+    io.x0, io.x0_sb, io.x0_sc, io.x0_sl = x0.data_ptr(), c0 * lin, lin, 1
+    if x1 is not None:
+        io.x1, io.x1_sb, io.x1_sc, io.x1_sl = x1.data_ptr(), c1 * lin, lin, 1
+    io.packed_w, io.bias = packed.data_ptr(), b.data_ptr()
+    if groups:
+        io.gamma, io.beta = g.data_ptr(), be.data_ptr()
+    io.y, io.y_sb, io.y_sc, io.y_sl, io.batch = y.data_ptr(), cout * lout, lout, 1, ROWS
+    for _ in range(5):
+        L.check(lib.adx_tconv_forward(C.byref(d), C.byref(io), s))
+    torch.cuda.synchronize()
+    nwg = 256
+    buf = (C.c_ulonglong * (16 * nwg))()
+    assert dbg(buf, 16 * nwg) == 0
+    rows = [[buf[i * 16 + k] for k in range(9)] for i in range(nwg)]
+    rows = [r for r in rows if r[0] and r[8] >= r[0]]
+    t0 = min(r[0] for r in rows)
+    print(f"{name}: {len(rows)} workgroups stamped; grid span {max(r[8] for r in rows) - t0} ticks; "
+          f"first start..last start {max(r[0] for r in rows) - t0}")
+    for k in range(8):
+        dl = [r[k + 1] - r[k] for r in rows if r[k + 1] >= r[k]]
+        if dl:
+            print(f"   {NAMES[k]:18s} median {statistics.median(dl):8.0f}  max {max(dl):8.0f} ticks")
+    full = [[buf[i * 16 + k] for k in range(12)] for i in range(nwg)]
+    full = [r for r in full if r[0] and r[9] >= r[0]]
+    for nm, k0, k1 in (("  start->weights issued", 0, 9), ("  ->first item loaded+split", 9, 10), ("  ->all cells written", 10, 11),
+                       ("  ->barrier passed", 11, 1)):
+        dl = [r[k1] - r[k0] for r in full if r[k1] >= r[k0]]
+        if dl:
+            print(f"   {nm:28s} median {statistics.median(dl):8.0f}  max {max(dl):8.0f}")
+    print(f"   whole workgroup    median {statistics.median([r[8] - r[0] for r in rows]):8.0f}")
