@@ -398,7 +398,10 @@ def test_two_optimizer_steps_and_checkpoint_vs_reference_written_fixture(golden,
                "exp_avg_sq": lambda: ck["optimizer"]["state"][i]["exp_avg_sq"],
                "shadow": lambda: ck["ema_state_dict"]["shadow_params"][i]}[kind]()
         if kind in ("param", "shadow"):
-            close(got, ref, 2e-6, rtol=1e-6)          # two steps at lr <= 2e-5: weights move by <= 4e-5
+            # warm-up: the first step runs at lr = 0, the second at 1e-5, and Adam's normalised update m / sqrt(v) is
+            # O(1) whatever the gradient's size -- an element whose gradient is ~0 can take either sign in two fp32
+            # implementations, so individual weights may differ by up to ~2 lr = 2e-5 (measured: 4e-6)
+            close(got, ref, 2e-5, rtol=1e-6)
         else:
             e = ((got - ref).norm() / (ref.norm() + 1e-30)).item()
             assert e <= (2e-3 if kind == "exp_avg_sq" else 1e-3), (k, e)
