@@ -38,7 +38,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kHsCout = 64;          // output channels per workgroup
 constexpr int kHsCC = 16;            // channels per chunk = K of one MFMA
 constexpr float kLoScale = 2048.f;   // 2^11
-constexpr int kF23Default = 0;       // Winograd F(2,3) path of the 3x3 stride-1 convs: opt-in (ADX_HS_F23=1)
 
 __device__ __forceinline__ void split8(const float* v, float xs, u32x4& hi, u32x4& lo) {
   f16x8 h, l;
@@ -630,301 +629,6 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
 #endif
 }
 
-// ---- 3x3 stride-1 in Winograd F(2,3) form along the row -----------------------------------------------------------
-// Two adjacent output columns (2t, 2t+1) of a row come from FOUR products instead of six: with the input columns
-// d0..d3 = x[2t-1 .. 2t+2] and the kernel row g0 g1 g2,
-//     v0 = d0 - d2   v1 = d1 + d2   v2 = d2 - d1   v3 = d1 - d3          (input transform: additions only)
-//     u0 = g0   u1 = (g0 + g1 + g2) / 2   u2 = (g0 - g1 + g2) / 2   u3 = g2   (packed once: conv2d_hs_f23_pack_kernel)
-//     m_p = sum over (input channel, kernel row) of u_p * v_p ;   y[2t] = m0 + m1 + m2 ;   y[2t+1] = m1 - m2 - m3
-// so a third of the matrix work of the direct form goes away.  The GEMM per transform position p is [cout] x [column
-// pair] over k = (channel, kernel row), and every position needs its own accumulator pair: a wave owns ONE position, so
-// the four positions of an output sit in four waves and meet in LDS in the epilogue.
-// STATUS: correct (error against fp64 1.0-1.8e-7, tools/f23_check.py); at parity with the direct kernel on the
-// 256-channel layers, slower on the shallow ones: 0.21 / 0.27 / 0.41 ms against 0.21 / 0.26 / 0.32 ms on the
-// 256/128/64-channel layers.  With the staging compiled out the matrix part alone runs in 0.12 / 0.15 / 0.24 ms: the
-// patch path (4 transformed values per 2 input columns: 2.3x the split / LDS-store work of the direct kernel per
-// output) costs what the saved MFMAs gain.  History of the versions in DESIGN.md section 8.  Opt-in: ADX_HS_F23=1.
-// Workgroup = 4 waves = 2 rows x 64 columns x 64 channels (wave = position; 2 rows x 2 channel halves x (main, low)
-// accumulators = 128 registers), persistent, TWO per CU so that one workgroup's staging phase runs under the other's
-// MFMAs (a workgroup cannot overlap the two itself: its waves move in lockstep and the staging is VALU work):
-//   LDS  V image  [k-half][plane][position][4 rows][32 pairs] 16-byte cells      (transformed, split patch; 32 KB, single)
-//        X        [position][32 channels][32 pairs] floats                      (epilogue exchange, 16 KB)
-// The U (weight) fragments never touch LDS: a wave needs only its own position's slice and takes it straight from L2
-// into a three-set register ring, two kernel-row stages ahead.  Per 16-channel chunk: three kernel-row stages without
-// a barrier between them (4 ds_read_b128 per 12 MFMAs), then, all waves being done with the V image, the staging
-// phase between two barriers: the patch of the next chunk (requested one chunk earlier, every element fetched once,
-// neighbours by DPP shifts) is transformed, split and stored, and the patch after it is requested.  The look-ahead
-// runs on into the workgroup's next tile.
-__global__ void __launch_bounds__(256, 2) conv2d_hs3x3_f23_kernel(const Conv2dArgs a) {
-  constexpr int NT = 256, TR = 2, TT = 32, PR = TR + 2;
-  constexpr int VPOS = PR * TT;                   // cells of one (k-half, plane, position) image
-  constexpr int VBUF = 2 * 2 * 4 * VPOS;          // cells of the V image
-  constexpr int WST = 4 * 2 * 2 * 64;             // weight cells per stage (kernel row of a chunk)
-  static_assert(PR * TT * 2 == NT, "one staging item (row, pair, 8-channel group) per thread");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  u32x4* vimg = reinterpret_cast<u32x4*>(smem_raw);
-  float* X = reinterpret_cast<float*>(vimg + VBUF);         // epilogue exchange [position][32 channels][32 pairs]
-  float* ss = X + 4 * 32 * TT;                              // 2 x {scale[64], shift[64]}
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int pos = __builtin_amdgcn_readfirstlane(tid >> 6);  // a wave owns ONE transform position
-  const int l31 = lane & 31, khalf = lane >> 5;
-  const size_t hw = (size_t)a.H * a.W;
-  const int nchunks = a.cin_pad / kHsCC;          // even, >= 4 (checked by the host)
-  const int nstages = nchunks * 3;
-  constexpr uint32_t kOutside = 0xC0000000u;
-  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.x), 0, (int)(uint32_t)((size_t)a.N * a.Cin * hw * sizeof(float)), 0x00020000);
-  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.w), 0, (int)(uint32_t)((size_t)a.cout_tiles * nstages * WST * 16), 0x00020000);
-  const uint32_t plane_bytes = (uint32_t)(hw * sizeof(float));
-
-  const bool by_xcd = (a.ntiles & 7) == 0 && (gridDim.x & 7) == 0;
-  const int t_step = by_xcd ? (int)(gridDim.x >> 3) : (int)gridDim.x;
-  const int t_end = by_xcd ? (int)((blockIdx.x & 7) + 1) * (a.ntiles >> 3) : a.ntiles;
-  int tile = by_xcd ? (int)(blockIdx.x & 7) * (a.ntiles >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-  int tnext = tile + t_step;
-  struct Tile { int ct, n, oy0, ox0; };
-  auto decode = [&](int t) {
-    Tile r;
-    r.ct = t % a.cout_tiles; t /= a.cout_tiles;
-    const int tx = t % a.tiles_x; t /= a.tiles_x;
-    const int ty = t % a.tiles_y;
-    r.n = t / a.tiles_y;
-    r.oy0 = ty * TR; r.ox0 = tx * (2 * TT);
-    return r;
-  };
-  // staging item of this thread: patch row, column pair, 8-channel group
-  const int st_t = tid & 31, st_h = (tid >> 5) & 1, st_row = tid >> 6;
-  // Every input element is fetched once: a lane loads the columns 2t and 2t+1 of its pair (g[0], g[1]), its left /
-  // right neighbours come from the adjacent lanes, and only the lanes at the ends of the 32-pair row fetch an edge
-  // column (g[2]: column -1 for t = 0, column 64 for t = 31).
-  auto patch_offsets = [&](const Tile& T, uint32_t (&g)[3]) {
-    const uint32_t img_off = (uint32_t)((size_t)T.n * a.Cin * hw * sizeof(float));
-    const int iy = T.oy0 - 1 + st_row;
-    const bool rok = iy >= 0 && iy < a.H;
-    const uint32_t rowb = img_off + (uint32_t)((st_h * 8 * hw + (size_t)(rok ? iy : 0) * a.W) * sizeof(float));
-    const int x0 = T.ox0 + 2 * st_t;
-    g[0] = rok && x0 < a.W ? rowb + (uint32_t)x0 * 4u : kOutside;
-    g[1] = rok && x0 + 1 < a.W ? rowb + (uint32_t)(x0 + 1) * 4u : kOutside;
-    const int xe = st_t == 0 ? T.ox0 - 1 : T.ox0 + 64;
-    g[2] = rok && (st_t == 0 || st_t == 31) && xe >= 0 && xe < a.W ? rowb + (uint32_t)xe * 4u : kOutside;
-  };
-  auto weights_of = [&](const Tile& T) { return (uint32_t)T.ct * (uint32_t)nstages * (WST * 16); };
-  auto load_ss = [&](const Tile& T) {
-    float v = 0.f;
-    if (tid < 128) {
-      const int c = T.ct * kHsCout + (tid & 63);
-      v = a.scale == nullptr ? (tid < 64 ? 1.f : 0.f) : (tid < 64 ? a.scale[c] : a.shift[c]);
-    }
-    return v;
-  };
-  Tile cur = decode(tile);
-  Tile nxt = decode(tnext < t_end ? tnext : tile);
-  uint32_t goff[3], goff_n[3];
-  patch_offsets(cur, goff);
-  patch_offsets(nxt, goff_n);
-  uint32_t wtile = weights_of(cur), wtile_n = weights_of(nxt);
-  const float ssv = load_ss(cur);
-  const int vcell = st_h * 2 * 4 * VPOS + st_row * TT + st_t;   // position p and plane add p * VPOS and 4 * VPOS
-
-  // U fragments straight from L2 into registers: a wave needs only its own position's slice ([plane][channel half] =
-  // 4 x 16 bytes per lane and kernel row), nothing is fetched twice and no barrier guards a weight buffer; three
-  // register sets: the set of stage s+2 is requested when stage s starts
-  u32x4 ar[3][4];
-  float pv[3][8];
-  const uint32_t a_lane = (uint32_t)(((pos * 2 * 2 + khalf) * 64 + l31) * 16);      // + plane * 128 cells, + mh * 32 cells
-  auto load_a = [&](uint32_t slab, int stage, int set) {
-    const uint32_t so = slab + (uint32_t)stage * (WST * 16);
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-        ar[set][pl * 2 + m] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, a_lane + (uint32_t)((pl * 128 + m * 32) * 16), so, 0);
-  };
-  auto load_p = [&](bool use_n, int chunk) {
-    const uint32_t cbase = (uint32_t)chunk * kHsCC * plane_bytes;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const uint32_t off = use_n ? goff_n[j] : goff[j];
-#pragma unroll
-      for (int c = 0; c < 8; ++c)
-        pv[j][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, off, cbase + c * plane_bytes, 0));
-    }
-  };
-  auto store_p = [&]() {
-    float v[4][8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const float d1 = pv[0][c], d2 = pv[1][c], e = pv[2][c];
-      // neighbours by DPP wavefront shifts (the ends of the 32-lane rows take the edge column instead)
-      const float up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d2), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
-      const float dn = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d1), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
-      const float d0 = st_t == 0 ? e : up, d3 = st_t == 31 ? e : dn;
-      v[0][c] = d0 - d2;
-      v[1][c] = d1 + d2;
-      v[2][c] = d2 - d1;
-      v[3][c] = d1 - d3;
-    }
-    u32x4* base = vimg + vcell;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      u32x4 hi, lo;
-      split8(v[p], 1.f, hi, lo);
-      base[p * VPOS] = hi;
-      base[(4 + p) * VPOS] = lo;
-    }
-  };
-
-  const u32x4* vb0 = vimg + khalf * 2 * 4 * VPOS + pos * VPOS + l31;
-
-  // prologue (first tile only): chunk 0 in the V image, stage 0 in U copy 0, stage 1 and the patch of chunk 1 in flight
-  load_a(wtile, 0, 0);
-  load_a(wtile, 1, 1);
-  load_p(false, 0);
-  store_p();
-  load_p(false, 1);
-  if (tid < 128) ss[tid] = ssv;
-  __syncthreads();
-
-  int par = 0;
-  for (;;) {
-    const bool has_next = tnext < t_end;
-    const float ssn = load_ss(nxt);
-    f32x16 accm[2][2], accl[2][2];      // [row][channel half]
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { accm[r][m][i] = 0.f; accl[r][m][i] = 0.f; }
-
-    for (int c2 = 0; c2 < nchunks; c2 += 2) {
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const int s = 3 * c2 + i;                 // stage within the tile; s % 3 == i % 3 because c2 is even
-        const int kh = i % 3;
-        // U fragments of stage s+2 into the set consumed at stage s-1 (past the tile's end: the next tile's first stages)
-        {
-          const bool wn = s + 2 >= nstages;
-          load_a(wn ? wtile_n : wtile, wn ? s + 2 - nstages : s + 2, (i + 2) % 3);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        f16x8 B[2][2];
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-          for (int r = 0; r < 2; ++r) B[pl][r] = __builtin_bit_cast(f16x8, vb0[pl * 4 * VPOS + (r + kh) * TT]);
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            const f16x8 A0 = __builtin_bit_cast(f16x8, ar[i % 3][m]), A1 = __builtin_bit_cast(f16x8, ar[i % 3][2 + m]);
-            accm[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, B[0][r], accm[r][m], 0, 0, 0);
-            accl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, B[1][r], accl[r][m], 0, 0, 0);
-            accl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, B[0][r], accl[r][m], 0, 0, 0);
-          }
-        if (kh == 2) {
-          __syncthreads();
-          // staging phase: every wave is done with the V image of this chunk.  The patch requested one chunk ago is
-          // transformed / split / stored, the one after it requested (past the tile's end: the next tile's).
-          const int c = c2 + i / 3;
-          store_p();
-          const bool pn = c + 2 >= nchunks;
-          load_p(pn, pn ? c + 2 - nchunks : c + 2);
-          __syncthreads();
-        }
-      }
-    }
-
-    // epilogue.  The four positions of an output sit in the four waves: they meet in LDS, one (row, 32-channel half) at
-    // a time, X[position][channel][pair] in U copy 1 (idle: the last stage read it, the next tile's stage 1 is still in
-    // registers; the V image already holds the next tile's first chunk); then wave w finishes channels 8w .. 8w+7 of
-    // that half: inverse transform, BN, residual, ReLU, store.
-    {
-      const uint32_t plane_ob = (uint32_t)(a.OH * a.OW) * (uint32_t)sizeof(float);
-      const size_t img = (size_t)cur.n * a.Cout * a.OH * a.OW;
-      const int img_bytes = (int)(a.Cout * plane_ob);
-      const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + img, 0, img_bytes, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<float*>(a.res != nullptr ? a.res + img : a.y), 0, a.res != nullptr ? img_bytes : 0, 0x00020000);
-      const int ox = cur.ox0 + 2 * l31;
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int co = (i & 3) + 8 * (i >> 2) + 4 * khalf;
-            X[(pos * 32 + co) * TT + l31] = accm[r][m][i] + accl[r][m][i] * (1.f / kLoScale);
-          }
-          __syncthreads();
-          const int oy = cur.oy0 + r;
-          const int cw0 = m * 32 + pos * 8;                        // this wave's channels in the output phase
-          const uint32_t cbase_o = (uint32_t)(cur.ct * kHsCout + cw0) * plane_ob;
-          const float* sst = ss + par * 128 + cw0 + 4 * khalf;
-          uint32_t voff[2];
-#pragma unroll
-          for (int q = 0; q < 2; ++q)
-            voff[q] = (oy < a.OH && ox + q < a.OW) ? (uint32_t)(oy * a.OW + ox + q) * 4u + (uint32_t)(4 * khalf) * plane_ob : kOutside;
-          float rv[2][4];
-#pragma unroll
-          for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-              rv[q][kk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, voff[q], cbase_o + kk * plane_ob, 0));
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
-            const int co = pos * 8 + 4 * khalf + kk;
-            const float m0 = X[(0 * 32 + co) * TT + l31], m1 = X[(1 * 32 + co) * TT + l31];
-            const float m2 = X[(2 * 32 + co) * TT + l31], m3 = X[(3 * 32 + co) * TT + l31];
-            float v0 = (m0 + m1 + m2) * sst[kk] + sst[64 + kk] + rv[0][kk];
-            float v1 = (m1 - m2 - m3) * sst[kk] + sst[64 + kk] + rv[1][kk];
-            if (a.relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v0), yrsrc, voff[0], cbase_o + kk * plane_ob, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v1), yrsrc, voff[1], cbase_o + kk * plane_ob, 0);
-          }
-          __syncthreads();      // X is rewritten by the next pass / by the next tile's stage-1 weights
-        }
-    }
-    if (!has_next) break;
-    if (tid < 128) ss[(par ^ 1) * 128 + tid] = ssn;
-    par ^= 1;
-    cur = nxt;
-    wtile = wtile_n;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) goff[j] = goff_n[j];
-    tile = tnext;
-    tnext += t_step;
-    nxt = decode(tnext < t_end ? tnext : tile);
-    wtile_n = weights_of(nxt);
-    patch_offsets(nxt, goff_n);
-  }
-}
-
-// fp32 [cout][cin][3][3] -> U image [cout/64][cin/16][kernel row][position][plane][k-half][64][8] fp16
-__global__ void conv2d_hs_f23_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ p, int cout, int cin, size_t total) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;   // over [cout/64][cin/16][kh][position][k-half][64][8]
-  if (idx >= total) return;
-  const int j = idx & 7;
-  const int ml = (idx >> 3) & 63;
-  const int h = (idx >> 9) & 1;
-  const int pos = (idx >> 10) & 3;
-  size_t rest = idx >> 12;
-  const int kh = rest % 3; rest /= 3;
-  const int nchunks = cin / kHsCC;
-  const int chunk = rest % nchunks;
-  const int ct = rest / nchunks;
-  const int m = ct * 64 + ml, kc = chunk * kHsCC + h * 8 + j;
-  const float* g = w + ((size_t)m * cin + kc) * 9 + kh * 3;
-  const double g0 = g[0], g1 = g[1], g2 = g[2];
-  const float v = pos == 0 ? (float)g0 : (pos == 1 ? (float)(0.5 * (g0 + g1 + g2)) : (pos == 2 ? (float)(0.5 * (g0 - g1 + g2)) : (float)g2));
-  const _Float16 hi = (_Float16)v;
-  const _Float16 lo = (_Float16)((v - (float)hi) * kLoScale);
-  const size_t cell = (((((size_t)(ct * nchunks + chunk) * 3 + kh) * 4 + pos) * 2 + 0) * 2 + h) * 64 + ml;
-  p[cell * 8 + j] = hi;
-  p[(cell + 128) * 8 + j] = lo;     // plane 1 is 2 * 64 cells further
-}
-
 // ---- the stem: Conv2d(3, 64, 7, stride 2, padding 3), modeling/resnet.py:191 --------------------------------
 // K = 3 channels x 7 x 7 = 147 has no 16-channel chunks, so the GEMM's k axis is laid out as 21 (channel, kernel
 // row) "combos" x 8 kernel columns (7 real + one zero weight): a lane's B fragment -- 8 consecutive k for one
@@ -1270,21 +974,9 @@ bool conv2d_hs_eligible(const ConvSpec& L) {
   return L.k == 3 && (L.stride == 1 || L.stride == 2);
 }
 
-// the layers that ALSO carry a Winograd F(2,3) weight image behind the direct one (conv2d_hs3x3_f23_kernel); which of
-// the two kernels runs is decided per launch from the map width.  ADX_HS_F23=0|1 switches the path.
-bool conv2d_hs_f23_eligible(const ConvSpec& L) {
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("ADX_HS_F23");
-    on = e != nullptr ? (e[0] == '1' ? 1 : 0) : kF23Default;
-  }
-  return on && !L.dgrad && L.k == 3 && L.stride == 1 && L.pad == 1 && conv2d_hs_eligible(L) && (L.cin_pad / kHsCC) % 2 == 0 &&
-         L.cin_pad / kHsCC >= 4;     // the look-ahead spans three chunks
-}
-
 size_t conv2d_packed_floats(const ConvSpec& L) {
   const size_t direct = (size_t)L.k * L.k * L.cin_pad * L.cout;
-  return direct + (conv2d_hs_f23_eligible(L) ? (size_t)12 * L.cin_pad * L.cout : 0);
+  return direct;
 }
 
 int conv2d_hs_pack(const ConvSpec& c, const float* w, void* packed, int dgrad, hipStream_t s) {
@@ -1297,12 +989,6 @@ int conv2d_hs_pack(const ConvSpec& c, const float* w, void* packed, int dgrad, h
   conv2d_hs_pack_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
       w, (_Float16*)packed, c.cout, c.cin_pad, c.cin, c.k * c.k, dgrad, total);
   ADX_LAUNCH_CHECK();
-  if (!dgrad && conv2d_hs_f23_eligible(c)) {
-    const size_t tf = (size_t)c.cout * c.cin_pad * 12;     // (kernel row, position) per weight pair, 8 per thread group
-    conv2d_hs_f23_pack_kernel<<<dim3((unsigned)((tf + 255) / 256)), dim3(256), 0, s>>>(
-        w, (_Float16*)((float*)packed + total), c.cout, c.cin_pad, tf);
-    ADX_LAUNCH_CHECK();
-  }
   return ADX_OK;
 }
 
@@ -1395,34 +1081,6 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
   return ADX_OK;
 }
 
-static int hs3x3_f23_launch(Conv2dArgs a, hipStream_t s) {
-  constexpr size_t lds = (size_t)(2 * 2 * 4 * 4 * 32) * 16 + (size_t)4 * 32 * 32 * sizeof(float) + 256 * sizeof(float);
-  static_assert(lds <= 80 * 1024, "two workgroups per CU");
-  static bool attr = false;
-  if (!attr) {
-    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_f23_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr = true;
-  }
-  a.tiles_x = ceil_div(a.OW, 64); a.tiles_y = ceil_div(a.OH, 2); a.cout_tiles = a.Cout / kHsCout;
-  const size_t ntiles = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y * a.N;
-  ADX_REQUIRE(ntiles < (1u << 31), "conv2d_hs: too many tiles");
-  ADX_REQUIRE((size_t)a.Cout * a.OH * a.OW * sizeof(float) < 0x7FFFFFFFu, "conv2d_hs: one image of the output exceeds the 32-bit byte offsets");
-  a.ntiles = (int)ntiles;
-  static int slots = 0;        // persistent workgroups: two per CU
-  if (slots == 0) {
-    const char* e = getenv("ADX_HS_SLOTS");
-    int dev = 0, cus = 0;
-    ADX_CHECK_HIP(hipGetDevice(&dev));
-    ADX_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    slots = e != nullptr && atoi(e) > 0 ? atoi(e) : 2 * (cus > 0 ? cus : 256);
-  }
-  const size_t grid = ntiles < (size_t)slots ? ntiles : (size_t)slots;
-  conv2d_hs3x3_f23_kernel<<<dim3((unsigned)grid), dim3(256), lds, s>>>(a);
-  ADX_LAUNCH_CHECK();
-  return ADX_OK;
-}
-
 int conv2d_hs_launch(const ConvSpec& L, Conv2dArgs a, hipStream_t s) {
   ADX_REQUIRE((size_t)L.cin * a.H * a.W * sizeof(float) < 0xC0000000u, "conv2d_hs: one image of the input exceeds the 32-bit byte offsets");
   const bool ds = a.w_ds != nullptr;
@@ -1431,12 +1089,6 @@ int conv2d_hs_launch(const ConvSpec& L, Conv2dArgs a, hipStream_t s) {
     return hs_stem_launch<false>(a, s);
   }
   if (L.k == 3 && L.stride == 1 && !ds) {
-    // Winograd F(2,3) form where 64-column tiles waste no more of the map than 32-column tiles do
-    if (conv2d_hs_f23_eligible(L) && a.x_amax == nullptr && ceil_div(a.OW, 64) * 64 <= ceil_div(a.OW, 32) * 32 &&
-        (size_t)a.N * a.Cin * a.H * a.W * sizeof(float) < 0xC0000000u) {
-      a.w += (size_t)9 * L.cin_pad * L.cout;
-      return hs3x3_f23_launch(a, s);
-    }
     static int pipe = -1;
     if (pipe < 0) {
       const char* e = getenv("ADX_HS_PIPE");      // ADX_HS_PIPE=0: the one-stage-ahead kernel for every 3x3 conv

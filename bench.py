@@ -69,16 +69,34 @@ def time_events(fn, reps, warm=2):
 
 
 def pmc_traffic(key):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json); rocprof cannot
+    """HBM bytes per launch from the newest committed rocprofv3 PMC passes (profiles/r*_pmc_traffic.json); rocprof cannot
     run inside this process, so the number is read back with its provenance."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        import glob
+        with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]) as f:
             for k, v in json.load(f)["kernels"].items():
                 if k.startswith(key):
                     return round(v["traffic"])
     except Exception:
         pass
     return None
+
+
+def rocprof_avg_ms(prefix):
+    """Launch-weighted average duration of the kernels whose name contains `prefix` in the newest committed
+    rocprofv3 --kernel-trace --stats summary of this command (profiles/r*_bench_kernel_stats.csv)."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")))
+    if not files:
+        return None
+    calls = tot = 0
+    with open(files[-1]) as f:
+        for row in csv.DictReader(f):
+            if prefix in row["Name"]:
+                calls += int(row["Calls"])
+                tot += int(row["TotalDurationNs"])
+    return round(tot / calls / 1e6, 4) if calls else None
 
 
 def conv2d_roofline(dev, reps=10):
@@ -121,7 +139,10 @@ def conv2d_roofline(dev, reps=10):
                       "from fp16 hi/lo split operands, 3 MFMA products per multiply-add)",
             "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_F16_TFLOPS, 4),
-            "achieved_note": "fp16 MFMA flops issued = 3 x algorithmic conv flops, / HIP-event launch time",
+            "frac_algorithmic": round(equiv / PEAK_F16_TFLOPS, 4),
+            "achieved_note": "fp16 MFMA flops issued = 3 x algorithmic conv flops, / HIP-event launch time; "
+                             "frac_algorithmic = algorithmic conv flops / the same time / the same fp16 peak",
+            "avg_launch_ms_rocprof": rocprof_avg_ms("conv2d_hs3x3_kernel"),
             "fp32_equivalent_tflops": round(equiv, 1), "fp32_mfma_peak_tflops": PEAK_F32_TFLOPS,
             "traffic": pmc_traffic("conv2d_hs3x3_kernel"),
             "traffic_note": "bytes/launch, 2 x FETCH_SIZE (gfx950 correction, calibrated: tools/micro/fetch_calib.hip) + WRITE_SIZE from profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc passes)",
@@ -156,13 +177,65 @@ def tconv_roofline(model, dev, reps=20):
     fl = 2.0 * rows * L * c * c * 5
     byts = 4.0 * (2 * x.numel() + w.numel())
     del fn
-    return {"kernel": "tconv_kernel<1,4> (Conv1d 512->512 k5 + GroupNorm + Mish, 128x4 positions)",
-            "bound": "mfma", "achieved": round(fl / ms / 1e9, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(fl / ms / 1e9 / PEAK_F32_TFLOPS, 4), "traffic": pmc_traffic("tconv_kernel<1,4"),
-            "avg_launch_ms": round(ms, 4),
+    return {"kernel": "tconv_hs_kernel<2,8,4> (Conv1d 512->512 k5 + GroupNorm + Mish, 128x4 positions; fp32-grade result "
+                      "from fp16 hi/lo split operands, 3 MFMA products per multiply-add)",
+            "bound": "mfma", "achieved": round(3 * fl / ms / 1e9, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(3 * fl / ms / 1e9 / PEAK_F16_TFLOPS, 4),
+            "frac_algorithmic": round(fl / ms / 1e9 / PEAK_F16_TFLOPS, 4),
+            "fp32_equivalent_tflops": round(fl / ms / 1e9, 2), "fp32_mfma_peak_tflops": PEAK_F32_TFLOPS,
+            "traffic": pmc_traffic("tconv_hs_kernel<2"), "avg_launch_ms": round(ms, 4),
+            "avg_launch_ms_rocprof": rocprof_avg_ms("tconv_hs_kernel<2"),
             "algorithmic_gflop_per_launch": round(fl / 1e9, 3), "algorithmic_mb_per_launch": round(byts / 1e6, 2),
             "hbm_gbs_at_algorithmic_bytes": round(byts / ms / 1e6, 1),
-            "hbm_frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4)}
+            "hbm_frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4),
+            "note": "neither roofline binds at 512 rows: one workgroup streams a 655 KB weight slab through one CU's "
+                    "L2->L1 port (~64 B/clk) behind ~4 us of launch, staging and epilogue latency (DESIGN.md section 3)"}
+
+
+def deployed_leg(dev):
+    """The configuration the reference actually drives with (e2e_driving/diffusion_agent.py:179-232, interact.py:115-168):
+    ONE scene per tick, horizon 16, classifier-free guidance (UNet batch 2), 50 DDIM steps, the camera frame's
+    perception pass included, replayed as one HIP graph per tick (sampling.GraphedSampler)."""
+    import contextlib
+    from autonomous_driving_with_diffusion_model_amd import scheduler as S
+    from autonomous_driving_with_diffusion_model_amd.config import create_cfg
+    from autonomous_driving_with_diffusion_model_amd.modeling import build_model
+    from autonomous_driving_with_diffusion_model_amd.sampling import GraphedSampler, generate_traj
+    from autonomous_driving_with_diffusion_model_amd.utils import procedural as P
+    cfg = create_cfg()
+    cfg.MODEL.HORIZON = 16
+    cfg.TRAIN.USE_COND = cfg.GUIDANCE.USE_COND = "FREE_GUIDANCE"
+    cfg.GUIDANCE.FREE_SCALE, cfg.EVAL.SAMPLE_STEPS = FREE_SCALE, N_INFER
+    with contextlib.redirect_stdout(sys.stderr):
+        model = build_model(cfg)
+    P.load_procedural(model, 0)
+    model = model.to(dev).eval()
+    sch = S.GuidanceDDIMScheduler(cfg=cfg, thresholding=True, **SCHED_KW)
+    d = {k: v.to(dev) for k, v in P.synthetic_batch(1, 16, image_hw=IMG, seed=3).items()}
+    out = {}
+    with torch.no_grad():
+        for name, fn in (("eager", lambda: generate_traj(model, sch, cfg, d["imgs"].clone(), d["target"], d["init_trajs"])),
+                         ("graph", None)):
+            if fn is None:
+                gs = GraphedSampler(model, sch, cfg)
+                fn = lambda: gs(d["imgs"], d["target"], d["init_trajs"])  # noqa: E731
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            out[name] = (time.perf_counter() - t0) / 5
+    wbytes = 64.5e6            # UNet weights read once per denoising step (SURVEY 8d: B = 1, H = 16)
+    per_step = out["graph"] / N_INFER
+    return {"workload": "one scene per tick: B = 1 (UNet batch 2, classifier-free guidance 7.5), horizon 16, 50 DDIM steps, "
+                        "image 3x256x900, perception pass inside the tick",
+            "tick_ms_graph": round(1e3 * out["graph"], 3), "tick_ms_eager": round(1e3 * out["eager"], 3),
+            "denoising_steps_per_sec": round(N_INFER / out["graph"], 1), "us_per_step": round(1e6 * per_step, 1),
+            "hbm_frac_weights_once_per_step": round(wbytes / per_step / 1e9 / PEAK_HBM_GBS, 4),
+            "note": "bound by the chain of ~50 dependent launches per step (launch boundary + kernel prologue + one global "
+                    "round trip + epilogue each), not by HBM: DESIGN.md section 8"}
 
 
 def cpu_model_name():
@@ -467,6 +540,11 @@ def main():
         if not args.no_roofline:
             res["roofline"] = conv2d_roofline(dev)
             res["roofline_tconv"] = tconv_roofline(None, dev)
+        if world == 1:
+            try:
+                res["deployed_b1_h16"] = deployed_leg(dev)
+            except Exception as e:
+                res["deployed_b1_h16"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
             res["speedup_vs_cpu_baseline"] = round(res["value"] / res["cpu_baseline"]["value"], 1)

@@ -162,28 +162,3 @@ def test_other_weight_gradients(cin, cout, k, stride, pad, h, w):
     ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, k, k), dy.double(), stride=stride, padding=pad)
     dw = _ops().conv2d_weight_grad(x.to(DEV), dy.to(DEV), k, stride=stride, pad=pad)
     assert ((dw.double().cpu() - ref).abs().max() / ref.abs().max()).item() < 5e-6
-
-
-@pytest.mark.gpu
-@split_only
-def test_winograd_f23_variant_matches_fp64_in_a_subprocess():
-    """The opt-in F(2,3) form of the 3x3 stride-1 conv (ADX_HS_F23 is read once per process): same fp32-grade bar, and
-    the run really took the other kernel (its rounding differs from the direct kernel's)."""
-    import os
-    import re
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-    def run(flag):
-        out = subprocess.run([sys.executable, os.path.join(root, "tools", "f23_check.py")], cwd=root,
-                             env=dict(os.environ, ADX_HS_F23=flag), capture_output=True, text=True, timeout=600)
-        assert out.returncode == 0, out.stderr[-2000:]
-        rows = re.findall(r"err ([0-9.e+-]+) cpu fp32 err ([0-9.e+-]+)", out.stdout)
-        assert len(rows) >= 6, out.stdout
-        return rows
-
-    f23, direct = run("1"), run("0")
-    for e, e32 in f23:
-        assert float(e) <= BAR * float(e32) + 1e-7, (e, e32)
-    assert [r[0] for r in f23] != [r[0] for r in direct]
