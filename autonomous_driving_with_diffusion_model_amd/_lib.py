@@ -89,6 +89,7 @@ _SIGS = {
     "adx_resnet_pack": (i32, [vp, C.POINTER(vp), i32, vp, vp]),
     "adx_resnet_workspace_bytes": (C.c_size_t, [vp, i32, i32, i32]),
     "adx_resnet_forward": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp]),
+    "adx_resnet_forward_u8": (i32, [vp, vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float), i32, i32, i32, vp, vp]),
     "adx_resnet_tape_create": (i32, [C.POINTER(vp)]),
     "adx_resnet_tape_destroy": (None, [vp]),
     "adx_resnet_train_workspace_bytes": (C.c_size_t, [vp, i32, i32, i32]),
@@ -113,6 +114,7 @@ _SIGS = {
     "adx_optim_chunk": (i32, []),
     "adx_adamw_ema_step": (i32, [vp, vp, vp, i32, f32, f32, f32, f32, f32, i32, f32, i32, i32, vp]),
     "adx_image_normalize": (i32, [vp, vp, i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), vp]),
+    "adx_image_augment": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp]),
     "adx_ddim_step": (i32, [C.POINTER(StepCoef), vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "adx_ddpm_step": (i32, [C.POINTER(StepCoef), vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "adx_add_noise": (i32, [vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp]),

@@ -541,9 +541,28 @@ size_t adx_resnet_workspace_bytes(const adx_resnet* r, int32_t batch, int32_t h,
   return (stem + 3 * act) * sizeof(float);
 }
 
+static int resnet_forward_impl(adx_resnet* r, const void* packed, void* workspace, const float* img,
+                               const uint8_t* frames_u8, const float* mean, const float* stdv, int32_t batch, int32_t h,
+                               int32_t w, float* feature, adx_stream stream);
+
 int adx_resnet_forward(adx_resnet* r, const void* packed, void* workspace, const float* img, int32_t batch, int32_t h,
                        int32_t w, float* feature, adx_stream stream) {
-  ADX_REQUIRE(r && packed && workspace && img && feature, "adx_resnet_forward: null argument");
+  ADX_REQUIRE(img != nullptr, "adx_resnet_forward: null image");
+  return resnet_forward_impl(r, packed, workspace, img, nullptr, nullptr, nullptr, batch, h, w, feature, stream);
+}
+
+int adx_resnet_forward_u8(adx_resnet* r, const void* packed, void* workspace, const uint8_t* frames_hwc, const float* mean,
+                          const float* stdv, int32_t batch, int32_t h, int32_t w, float* feature, adx_stream stream) {
+  ADX_REQUIRE(frames_hwc && mean && stdv, "adx_resnet_forward_u8: null frames / mean / std");
+  ADX_REQUIRE(r != nullptr && !r->convs.empty() && conv2d_hs_eligible(r->convs[0]),
+              "adx_resnet_forward_u8: the uint8 front-end lives in the split-fp16 stem kernel (unavailable with ADX_CONV_EXACT=1)");
+  return resnet_forward_impl(r, packed, workspace, nullptr, frames_hwc, mean, stdv, batch, h, w, feature, stream);
+}
+
+static int resnet_forward_impl(adx_resnet* r, const void* packed, void* workspace, const float* img,
+                               const uint8_t* frames_u8, const float* mean, const float* stdv, int32_t batch, int32_t h,
+                               int32_t w, float* feature, adx_stream stream) {
+  ADX_REQUIRE(r && packed && workspace && (img || frames_u8) && feature, "adx_resnet_forward: null argument");
   if (!r->packed_once) {
     set_error("adx_resnet_forward: weights were never packed (call adx_resnet_pack first)");
     return ADX_ERR_STATE;
@@ -570,8 +589,9 @@ int adx_resnet_forward(adx_resnet* r, const void* packed, void* workspace, const
       const char* e = getenv("ADX_STEM_POOL");
       fuse = (e != nullptr && e[0] == '0') ? 0 : 1;
     }
-    if (fuse && conv2d_hs_eligible(c0)) {
-      rc = conv2d_hs_stem_pool(c0, img, base + c0.o_w, base + c0.o_scale, base + c0.o_shift, buf[0], batch, h, w, s);
+    if ((fuse || frames_u8 != nullptr) && conv2d_hs_eligible(c0)) {
+      rc = conv2d_hs_stem_pool(c0, img, base + c0.o_w, base + c0.o_scale, base + c0.o_shift, buf[0], batch, h, w, s,
+                               frames_u8, mean, stdv);
       if (rc != ADX_OK) return rc;
     } else {
       rc = conv2d_launch(c0, base, img, nullptr, stem, batch, h, w, 1, s);

@@ -656,7 +656,7 @@ constexpr int kStemPP = 72;                               // patch row pitch in 
 // removes); the horizontal maximum takes the neighbouring lanes (shuffles) and, at a tile's left edge, the last
 // column of the previous tile (parked in LDS while the workgroup walks its band).  One patch copy (the next tile
 // waits in registers), so two workgroups still fit a CU.
-template <bool POOL>
+template <bool POOL, bool U8>
 __global__ void __launch_bounds__(256, 2) conv2d_hs_stem_kernel(const Conv2dArgs a) {
   constexpr int NT = 256;
   constexpr int PH = POOL ? 25 : 21;                       // patch rows (9 / 8 stem rows)
@@ -679,7 +679,8 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_stem_kernel(const Conv2dArgs
   const float* xin = a.x + (size_t)n * 3 * hw;
   constexpr uint32_t kOutside = 0xC0000000u;
   const __amdgpu_buffer_rsrc_t xrsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0, (int)(3 * hw * sizeof(float)), 0x00020000);
+      U8 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.x_u8 + (size_t)n * 3 * hw), 0, (int)(3 * hw), 0x00020000)
+         : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0, (int)(3 * hw * sizeof(float)), 0x00020000);
 
   {
     const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.w);
@@ -717,11 +718,23 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_stem_kernel(const Conv2dArgs
       decode(k, c, py, pp);
       const int ix = ix0 + 2 * pp, iy = iy0 + py;
       const bool rok = tid + NT * k < ITEMS && iy >= 0 && iy < a.H;
-      const uint32_t grow = (uint32_t)(c * (int)hw + iy * a.W) * 4u;
-      const uint32_t o0 = (rok && ix >= 0 && ix < a.W) ? grow + (uint32_t)ix * 4u : kOutside;
-      const uint32_t o1 = (rok && ix + 1 >= 0 && ix + 1 < a.W) ? grow + (uint32_t)(ix + 1) * 4u : kOutside;
-      pv[k][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, o0, 0, 0));
-      pv[k][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, o1, 0, 0));
+      const bool ok0 = rok && ix >= 0 && ix < a.W, ok1 = rok && ix + 1 >= 0 && ix + 1 < a.W;
+      if (U8) {
+        // uint8 HWC frame: byte (iy, ix, c); outside the frame the NORMALISED tensor is zero-padded, so the value is 0
+        // there, not normalise(0).  Same operation order as image_normalize_kernel (IEEE division, no contraction).
+#pragma clang fp contract(off)
+        const uint32_t brow = (uint32_t)(iy * a.W) * 3u + (uint32_t)c;
+        const uint32_t b0 = __builtin_amdgcn_raw_buffer_load_b8(xrsrc, ok0 ? brow + (uint32_t)ix * 3u : kOutside, 0, 0);
+        const uint32_t b1 = __builtin_amdgcn_raw_buffer_load_b8(xrsrc, ok1 ? brow + (uint32_t)(ix + 1) * 3u : kOutside, 0, 0);
+        const float mean = c == 0 ? a.u8_mean[0] : (c == 1 ? a.u8_mean[1] : a.u8_mean[2]);
+        const float stdv = c == 0 ? a.u8_std[0] : (c == 1 ? a.u8_std[1] : a.u8_std[2]);
+        pv[k][0] = ok0 ? ((float)b0 / 255.0f - mean) / stdv : 0.f;
+        pv[k][1] = ok1 ? ((float)b1 / 255.0f - mean) / stdv : 0.f;
+      } else {
+        const uint32_t grow = (uint32_t)(c * (int)hw + iy * a.W) * 4u;
+        pv[k][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, ok0 ? grow + (uint32_t)ix * 4u : kOutside, 0, 0));
+        pv[k][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, ok1 ? grow + (uint32_t)(ix + 1) * 4u : kOutside, 0, 0));
+      }
     }
   };
   auto store_p = [&](int buf) {
@@ -1014,7 +1027,7 @@ static int hs_launch_t(Conv2dArgs a, hipStream_t s) {
   return ADX_OK;
 }
 
-template <bool POOL>
+template <bool POOL, bool U8 = false>
 static int hs_stem_launch(Conv2dArgs a, hipStream_t s) {
   constexpr int PH = POOL ? 25 : 21, PBUF = POOL ? 1 : 2;
   constexpr size_t lds = (size_t)kStemSteps * 4096 + (size_t)PBUF * 4 * 3 * PH * kStemPP + 2 * kHsCout * sizeof(float) +
@@ -1022,28 +1035,34 @@ static int hs_stem_launch(Conv2dArgs a, hipStream_t s) {
   static_assert(lds <= 80 * 1024, "two workgroups per CU need <= 80 KB each");
   static bool attr = false;
   if (!attr) {
-    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs_stem_kernel<POOL>),
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs_stem_kernel<POOL, U8>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = true;
   }
   a.tiles_x = ceil_div(a.OW, kTileW); a.cout_tiles = 1;
   a.tiles_y = POOL ? ceil_div((a.OH - 1) / 2 + 1, 4) : ceil_div(a.OH, 8);
-  conv2d_hs_stem_kernel<POOL><<<dim3((unsigned)(a.tiles_y * a.N)), dim3(256), lds, s>>>(a);
+  conv2d_hs_stem_kernel<POOL, U8><<<dim3((unsigned)(a.tiles_y * a.N)), dim3(256), lds, s>>>(a);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
 }
 
 int conv2d_hs_stem_pool(const ConvSpec& L, const float* x, const float* w, const float* scale, const float* shift,
-                        float* pooled, int N, int H, int W, hipStream_t s) {
-  ADX_REQUIRE(x && w && scale && shift && pooled, "conv2d_hs_stem_pool: null pointer");
+                        float* pooled, int N, int H, int W, hipStream_t s, const uint8_t* frames_u8, const float* mean,
+                        const float* stdv) {
+  ADX_REQUIRE((x || frames_u8) && w && scale && shift && pooled, "conv2d_hs_stem_pool: null pointer");
   ADX_REQUIRE((size_t)3 * H * W * sizeof(float) < 0xC0000000u, "conv2d_hs_stem_pool: image too large for 32-bit offsets");
   Conv2dArgs a{};
   a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.y = pooled;
+  if (frames_u8 != nullptr) {
+    ADX_REQUIRE(mean && stdv, "conv2d_hs_stem_pool: uint8 frames need mean / std");
+    a.x_u8 = frames_u8;
+    for (int c = 0; c < 3; ++c) { a.u8_mean[c] = mean[c]; a.u8_std[c] = stdv[c]; }
+  }
   a.N = N; a.Cin = 3; a.H = H; a.W = W; a.Cout = 64;
   a.OH = conv_out_dim(H, 7, 2, 3); a.OW = conv_out_dim(W, 7, 2, 3);
   a.KH = 7; a.KW = 7; a.stride = 2; a.pad = 3; a.relu = 1;
   a.cin_pad = L.cin_pad; a.cc = L.cc;
-  return hs_stem_launch<true>(a, s);
+  return frames_u8 != nullptr ? hs_stem_launch<true, true>(a, s) : hs_stem_launch<true>(a, s);
 }
 
 int conv2d_hs_launch_block_s2(const ConvSpec& c1, const ConvSpec& ds, const float* x, const float* w1, const float* scale1,

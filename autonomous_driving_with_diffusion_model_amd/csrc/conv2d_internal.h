@@ -31,6 +31,10 @@ struct Conv2dArgs {
   float* y_ds;
   const uint32_t* x_amax;  // optional: x_amax_n partial maxima of |x| as bit patterns (conv2d_hs rescales x by a power of two)
   int x_amax_n;
+  // stem only: the camera frames as uint8 [N][H][W][3]; ToTensor + Normalize ((v / 255 - mean) / std, the arithmetic of
+  // image_normalize_kernel) happen in the staging load and the fp32 NCHW tensor is never written (x is unused then)
+  const uint8_t* x_u8;
+  float u8_mean[3], u8_std[3];
   int N, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, relu;
   int cin_pad, cc;      // channels padded to the chunk size, chunk size (16, or 4 for the stem)
   int tiles_x, tiles_y, cout_tiles, ntiles;
@@ -72,7 +76,8 @@ int conv2d_hs_pack(const ConvSpec& consumer, const float* w, void* packed, int d
 int conv2d_hs_launch(const ConvSpec& L, Conv2dArgs a, hipStream_t s);
 // stem conv + BN + ReLU + MaxPool2d(3, 2, 1) in one pass: writes only the pooled map [N][64][PH][PW]
 int conv2d_hs_stem_pool(const ConvSpec& L, const float* x, const float* w, const float* scale, const float* shift,
-                        float* pooled, int N, int H, int W, hipStream_t s);
+                        float* pooled, int N, int H, int W, hipStream_t s, const uint8_t* frames_u8 = nullptr,
+                        const float* mean = nullptr, const float* stdv = nullptr);
 // conv1 (3x3 stride 2, +BN+ReLU) and the block's downsample (1x1 stride 2, +BN) in one pass over x; both must be
 // conv2d_hs_eligible (the downsample's weights packed with conv2d_hs_pack_ds)
 int conv2d_hs_launch_block_s2(const ConvSpec& c1, const ConvSpec& ds, const float* x, const float* w1, const float* scale1,

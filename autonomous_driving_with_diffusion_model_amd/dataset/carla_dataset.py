@@ -9,7 +9,9 @@ misc/data_collect.py:176-208):
 decoded with Pillow (the reference's cv2.imread + BGR->RGB gives the same bytes for PNG).  With `img_transforms=None`
 the frame is returned as a uint8 HWC tensor so that a whole batch can go through the package's GPU front-end
 (`ops.image_transform`, ToTensor + ImageNet Normalize in one kernel) instead of per-sample CPU transforms.
-The reference's imgaug pipeline (dataset/augment.py) is not reproduced: `augment` takes any callable
+The reference's imgaug pipeline (dataset/augment.py) runs per sample on the CPU; its stand-in here is batch-level and on
+the GPU (`dataset.augment.GpuAugmentor`: same seven operators and iteration schedule, applied to the uint8 batch where
+it lives, before `ops.image_transform`).  A per-sample CPU hook remains: `augment` takes any callable
 (HWC uint8 ndarray, access counter) -> ndarray.
 """
 from __future__ import annotations
@@ -38,8 +40,9 @@ class TrajDataset(torch.utils.data.Dataset):
     def __init__(self, root_path: str, img_transforms: Optional[Callable] = None, use_img_augmentor: bool = False,
                  augment: Optional[Callable] = None, horizon: int = 16):
         if use_img_augmentor and augment is None:
-            raise NotImplementedError("the imgaug pipeline of dataset/augment.py is not part of this package: pass "
-                                      "augment=callable(image_uint8_hwc, access_count) or TRAIN.USE_IMG_AUGMENTOR False")
+            raise NotImplementedError("imgaug is not part of this package: augment the uint8 batch on the GPU with "
+                                      "dataset.augment.GpuAugmentor (the stand-in for dataset/augment.py), or pass a "
+                                      "per-sample augment=callable(image_uint8_hwc, access_count)")
         self.root_path, self.img_transforms, self.augment = root_path, img_transforms, augment
         self.horizon = horizon
         self.count_access = 0

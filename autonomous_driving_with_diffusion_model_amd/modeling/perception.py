@@ -128,6 +128,32 @@ class PerceptionResNet34(nn.Module):
                 "adx_resnet_pack")
         self._pack_key = key
 
+    def forward_frames(self, frames_u8: torch.Tensor, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)) -> torch.Tensor:
+        """Eval-mode forward straight from uint8 camera frames [N, H, W, 3] (or [H, W, 3]): the agents'
+        `T.Compose([T.ToTensor(), T.Normalize(mean, std)])` (interact.py:73-78, e2e_driving/diffusion_agent.py:96-101)
+        runs inside the stem kernel's staging load, so the normalised fp32 image is never written or re-read.
+        Bit-identical to `self(ops.image_transform(frames_u8, mean, std))`."""
+        if self.training:
+            raise RuntimeError("forward_frames is the inference front-end (eval mode)")
+        if frames_u8.dim() == 3:
+            frames_u8 = frames_u8[None]
+        if not frames_u8.is_cuda or frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.shape[-1] != 3:
+            raise L.AdxError("forward_frames expects a uint8 [N, H, W, 3] tensor on the GPU")
+        f = frames_u8.contiguous()
+        self._ensure_packed()
+        h = self._native()
+        B, H, W, _ = f.shape
+        nbytes = L.lib().adx_resnet_workspace_bytes(h, B, H, W)
+        if nbytes == 0:
+            raise ValueError(f"image {H}x{W} too small for ResNet-34")
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != f.device:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=f.device)
+        out = torch.empty((B, self.out_dim), dtype=torch.float32, device=f.device)
+        m, s = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+        L.check(L.lib().adx_resnet_forward_u8(h, self._packed.data_ptr(), self._ws.data_ptr(), f.data_ptr(), m, s, B, H, W,
+                                              out.data_ptr(), L.stream_ptr(f.device)), "adx_resnet_forward_u8")
+        return out
+
     def forward(self, img: torch.Tensor) -> torch.Tensor:
         img = L.require_gpu_f32(img, "img")
         if img.dim() != 4 or img.shape[1] != 3:

@@ -178,6 +178,13 @@ int adx_resnet_pack(adx_resnet* r, const float* const* tensors, int32_t n, void*
 size_t adx_resnet_workspace_bytes(const adx_resnet* r, int32_t batch, int32_t h, int32_t w);
 int adx_resnet_forward(adx_resnet* r, const void* packed, void* workspace, const float* img /* NCHW */,
                        int32_t batch, int32_t h, int32_t w, float* feature /* [batch][out_dim] */, adx_stream s);
+/* The same with the agents' image front-end folded into the stem's staging load: frames_hwc = uint8 camera frames
+ * [batch][h][w][3] (RGB); ToTensor + Normalize(mean, std) (interact.py:73-78, e2e_driving/diffusion_agent.py:96-101) are
+ * applied on the fly -- (v / 255 - mean[c]) / std[c], the arithmetic of adx_image_normalize -- and the fp32 NCHW image
+ * is never materialised.  Bit-identical to adx_image_normalize followed by adx_resnet_forward. */
+int adx_resnet_forward_u8(adx_resnet* r, const void* packed, void* workspace, const uint8_t* frames_hwc,
+                          const float* mean /* [3] */, const float* stdv /* [3] */, int32_t batch, int32_t h, int32_t w,
+                          float* feature /* [batch][out_dim] */, adx_stream s);
 
 /* Op-level 2-D convolution used by the perception executor (one launch): NCHW fp32,
  * y = [relu]( conv(x, w) * scale[c] + shift[c] [+ res] ); scale/shift = eval-mode BatchNorm2d
@@ -315,6 +322,15 @@ int adx_add_noise(const float* x, const float* noise, const int64_t* t, const fl
  * [n][h][w][3] frames into fp32 [n][3][h][w]; mean/std are HOST pointers to 3 floats. */
 int adx_image_normalize(const uint8_t* frame_hwc, float* out_nchw, int32_t n, int32_t h, int32_t w, const float* mean,
                         const float* stdv, adx_stream s);
+
+/* Batch image augmentation on the GPU: stand-in for the reference's imgaug pipeline (dataset/augment.py:10-77, applied per
+ * sample in dataset/carla_dataset.py:24-31).  frames_hwc: uint8 [n][h][w][3], augmented IN PLACE; scratch: n*h*w*3 bytes
+ * (needed when any_blur != 0).  The host draws the plan (autonomous_driving_with_diffusion_model_amd/dataset/augment.py):
+ * plan [n][7][8] floats = per image seven operator slots in application order (row = code, p0..p3, per_channel, 0, 0;
+ * codes in csrc/augment.hip), seeds [n] for the per-pixel hash randomness, ranges [n][4] = the slot ranges applied before
+ * and after the image's blur, blur_sigma [n] (0 = no blur).  All four arrays live on the device. */
+int adx_image_augment(uint8_t* frames_hwc, uint8_t* scratch, int32_t n, int32_t h, int32_t w, const float* plan,
+                      const uint64_t* seeds, const int32_t* ranges, const float* blur_sigma, int32_t any_blur, adx_stream s);
 
 #ifdef __cplusplus
 }

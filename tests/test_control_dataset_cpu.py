@@ -98,3 +98,68 @@ def test_loader_batches(tmp_path):
     img, wp, tgt = batches[0]
     assert tuple(img.shape) == (3, 12, 20, 3) and img.dtype == torch.uint8
     assert tuple(wp.shape) == (3, 16, 7) and tuple(tgt.shape) == (3, 2)
+
+
+def test_augment_schedule_matches_the_reference_formulas_and_plans_are_well_formed():
+    """the iteration-dependent strengths of dataset/augment.py:10-27 (hand-evaluated known answers: imgaug is
+    absent, so the reference module cannot be imported) and the host-drawn plan of the GPU stand-in."""
+    import numpy as np
+    from autonomous_driving_with_diffusion_model_amd.dataset import augment as A
+    f0 = A.augment_factors(0)
+    assert f0 == pytest.approx({"frequency": 0.05, "color": 0.0, "dropout": 0.03856658, "blur": 0.5, "add": 10.0,
+                                "multiply_pos": 1.0, "multiply_neg": 1.0, "contrast_pos": 1.0, "contrast_neg": 1.0})
+    f = A.augment_factors(32 * 100000)            # iteration = image_iteration / 32 = 100000
+    assert f["frequency"] == pytest.approx(0.5) and f["color"] == pytest.approx(0.1) and f["add"] == pytest.approx(20.0)
+    assert f["multiply_pos"] == pytest.approx(2.25) and f["multiply_neg"] == pytest.approx(0.818)
+    assert f["contrast_pos"] == pytest.approx(1.1) and f["contrast_neg"] == pytest.approx(0.9)
+    assert f["dropout"] == pytest.approx(0.198667 + (0.03856658 - 0.198667) / (1 + (100000 / 196416.6) ** 1.863486))
+    assert A.augment_factors(32 * 10 ** 7)["color"] == 0.5 and A.augment_factors(32 * 10 ** 7)["blur"] == 0.5
+    rng = np.random.default_rng(0)
+    plan, seeds, ranges, sigma = A.sample_plan(32 * 400000 + np.arange(64), 48, 80, rng)
+    assert plan.shape == (64, 7, 8) and seeds.shape == (64,) and ranges.shape == (64, 4) and sigma.shape == (64,)
+    codes = plan[:, :, 0].astype(int)
+    for i in range(64):
+        active = codes[i][codes[i] > 0]
+        assert len(set(active)) == len(active)                       # every operator at most once per image
+        b = np.nonzero(codes[i] == A.BLUR)[0]
+        assert (len(b) == 1) == (sigma[i] > 0)
+        if len(b):
+            assert tuple(ranges[i]) == (0, b[0], b[0] + 1, 7) and 0 < sigma[i] <= 0.5
+        else:
+            assert ranges[i][1] == 7 and ranges[i][2] == 7
+    frac = (codes > 0).mean()
+    assert 0.35 < frac < 0.65                                        # Sometimes(0.5, ...) at this iteration
+    add_rows = plan[codes == A.ADD]
+    assert np.all(add_rows[:, 1:4] == np.round(add_rows[:, 1:4])) and np.abs(add_rows[:, 1:4]).max() <= 50 + 1e-6
+    shared = add_rows[add_rows[:, 5] == 0]
+    assert np.all(shared[:, 1] == shared[:, 2]) and np.all(shared[:, 2] == shared[:, 3])
+
+
+def test_augment_oracle_operator_semantics():
+    """The numpy restatement of the device operators (oracle/augment.py): uint8 saturation, dropout rates, blur mass."""
+    import numpy as np
+    from oracle import augment as OA
+    img = np.full((1, 32, 48, 3), 200, dtype=np.uint8)
+    z = np.zeros((1, 7, 8), dtype=np.float32)
+    seeds = np.array([12345], dtype=np.uint64)
+    rg = np.array([[0, 7, 7, 7]], dtype=np.int32)
+    p = z.copy(); p[0, 0] = (5, 100, -250, 3, 0, 1, 0, 0)            # add per channel: saturates both ways
+    out = OA.augment(img, p, seeds, rg, np.zeros(1, np.float32))
+    assert out[0, 0, 0].tolist() == [255, 0, 203]
+    p = z.copy(); p[0, 0] = (6, 1.3, 1.3, 1.3, 0, 0, 0, 0); p[0, 1] = (7, 0.5, 0.5, 0.5, 0, 0, 0, 0)   # 200*1.3 -> 255 -> 128+0.5*127 = 191.5 -> 192
+    assert OA.augment(img, p, seeds, rg, np.zeros(1, np.float32))[0, 5, 5].tolist() == [192, 192, 192]
+    p = z.copy(); p[0, 0] = (4, 0.25, 0, 0, 0, 0, 0, 0)
+    out = OA.augment(img, p, seeds, rg, np.zeros(1, np.float32))
+    dropped = (out[0, :, :, 0] == 0)
+    assert 0.15 < dropped.mean() < 0.35 and np.array_equal(out[0, :, :, 0], out[0, :, :, 1])     # shared mask across channels
+    p[0, 0, 5] = 1
+    out = OA.augment(img, p, seeds, rg, np.zeros(1, np.float32))
+    assert not np.array_equal(out[0, :, :, 0], out[0, :, :, 1])                                  # per-channel masks
+    p = z.copy(); p[0, 0] = (3, 0.5, 4, 6, 0, 0, 0, 0)
+    out = OA.augment(img, p, seeds, rg, np.zeros(1, np.float32))[0, :, :, 0]
+    blocks = out.reshape(4, 8, 6, 8)
+    assert all(len(np.unique(blocks[a, :, b, :])) == 1 for a in range(4) for b in range(6))     # constant on the coarse grid
+    ramp = np.tile(np.arange(48, dtype=np.uint8)[None, :, None] * 5, (32, 1, 3))[None]
+    p = z.copy(); p[0, 0] = (1, 0.5, 0, 0, 0, 0, 0, 0)
+    out = OA.augment(ramp, p, seeds, np.array([[0, 0, 1, 7]], dtype=np.int32), np.array([0.5], np.float32))
+    assert np.array_equal(out[0, :, 5:40], ramp[0, :, 5:40])                                    # a linear ramp is a fixed point of a symmetric blur
