@@ -1,5 +1,5 @@
 """Fold the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; tools/pmc_kernels.py under each) into
-profiles/r01_pmc_traffic.json: bytes per launch of the two roofline kernels.
+profiles/rNN_pmc_traffic.json: bytes per launch of the two roofline kernels.
 
 usage: python tools/pmc_to_json.py <FETCH_counter_collection.csv> <WRITE_counter_collection.csv> <out.json>"""
 import csv
@@ -61,10 +61,10 @@ def main():
         n += cnt
     res["kernels"]["conv2d_hs3x3_kernel<0|1|2>"] = {"per_shape": per_shape, "fetch": tf / n, "write": tw / n,
                                                          "traffic": (tf + tw) / n}
-    tname = next(k for k in fetch if "tconv_kernel<1, 4" in k)
+    tname = next(k for k in fetch if "tconv_hs_kernel<2" in k)
     fv = [v for g in fetch[tname].values() for v in g]
     wv = [v for g in write[tname].values() for v in g]
-    res["kernels"]["tconv_kernel<1,4,4,16> 512->512 k5, 128x4 positions"] = {
+    res["kernels"]["tconv_hs_kernel<2,8,4> 512->512 k5, 128x4 positions"] = {
         "fetch": sum(fv) / len(fv), "write": sum(wv) / len(wv), "traffic": sum(fv) / len(fv) + sum(wv) / len(wv)}
     with open(sys.argv[3], "w") as f:
         json.dump(res, f, indent=1)

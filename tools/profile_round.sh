@@ -1,7 +1,12 @@
+# Round profile (run on the GPU box through gpurun): kernel stats of the whole bench, PMC traffic of the two roofline
+# kernels (separate --pmc passes, --kernel-trace only), the per-layer timeline of the temporal stack, the default bench.
+R=${R:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r01b_stats -- python3 bench.py --steps 5 --warmup 1 > gpurun_out/r01b_bench_under_rocprof.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/r01b_pmc_fetch -- python3 tools/pmc_kernels.py > gpurun_out/r01b_pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/r01b_pmc_write -- python3 tools/pmc_kernels.py > gpurun_out/r01b_pmc_write.log 2>&1
-python bench.py > gpurun_out/r01b_bench_default.json 2> gpurun_out/r01b_bench_default.err
-ls gpurun_out/r01b_*/*/ | head -30
-tail -c 600 gpurun_out/r01b_bench_default.json
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/${R}_bench_under_rocprof.json 2> gpurun_out/${R}_bench_under_rocprof.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${R}_pmc_fetch -- python3 tools/pmc_kernels.py > gpurun_out/${R}_pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${R}_pmc_write -- python3 tools/pmc_kernels.py > gpurun_out/${R}_pmc_write.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${R}_tconv_trace -- python3 tools/bench_tconv.py > gpurun_out/${R}_tconv_layers_hostclock.log 2>&1
+python tools/trace_chunks.py gpurun_out/${R}_tconv_trace > gpurun_out/${R}_tconv_layers.txt
+python bench.py > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.err
+ls gpurun_out/${R}_*/*/ | head -30
+tail -c 400 gpurun_out/${R}_bench_default.json
