@@ -21,6 +21,7 @@
 //     one K-step is a contiguous 2 KB; NW waves split the K-steps and keep PF of them in flight in a register ring.
 //   The NW partial tiles meet in LDS in the output tensor's [sample][channel][pos] order and go through
 //   tconv_epilogue (shared with the exact kernel): fixed summation order, bit-reproducible.
+#include <algorithm>
 #include <array>
 #include <map>
 #include <mutex>
@@ -55,6 +56,80 @@ __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
     hi[j] = h;
     lo[j] = (_Float16)((v[j] - (float)h) * kLoScale);
   }
+}
+
+// Stage rows [0, nrows] x channels [c0, c0 + ckc) of this workgroup's samples into LDS as split cells.  Every global load
+// is UNCONDITIONAL (clamped address, value zeroed afterwards): a guarded load makes the compiler wait for it before the
+// next one is issued, i.e. eight dependent round trips per item instead of one.
+template <int NT>
+__device__ __forceinline__ void hs_stage(const TConvArgs& a, const HsArgs& ha, u32x4* cells, int c0, int ckc, int b0, int tid) {
+  const int batch = a.io.batch;
+  const int pitch = ha.pitch16;
+  const int ncell = ckc >> 3;
+  const int cmax = a.cin - 1, bmax = batch - 1;
+  if (ha.vec_stage) {
+    // item = (sample, quad of 4 positions, 8-channel octet): eight 16-byte loads -> four (hi, lo) cell pairs
+    const int items = (ha.nrows >> 2) * ncell;
+    for (int it = tid; it < items; it += NT) {
+      const int rq = it & ((ha.nrows >> 2) - 1), oc = it >> (ha.log2_nrows - 2);  // row quads fastest
+      const int q = rq & ((a.lin >> 2) - 1), sb = rq >> (ha.log2_lin - 2);
+      const int b = b0 + sb, bc = min(b, bmax);
+      f32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ci = c0 + 8 * oc + j, cc = min(ci, cmax);
+        const bool first = cc < a.c0;
+        const float* base = first ? a.io.x0 : a.io.x1;
+        const int64_t off = first ? (int64_t)cc * a.io.x0_sc + (int64_t)bc * a.io.x0_sb
+                                  : (int64_t)(cc - a.c0) * a.io.x1_sc + (int64_t)bc * a.io.x1_sb;
+        v[j] = *reinterpret_cast<const f32x4*>(base + off + 4 * q);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (!(c0 + 8 * oc + j < a.cin && b < batch)) v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        float t8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t8[j] = v[j][p];
+        h8 hi, lo;
+        split8(t8, hi, lo);
+        u32x4* dst = cells + (sb * a.lin + 4 * q + p) * pitch + 2 * oc;
+        dst[0] = __builtin_bit_cast(u32x4, hi);
+        dst[1] = __builtin_bit_cast(u32x4, lo);
+      }
+    }
+  } else {
+    // item = (row, 8-channel octet): eight 4-byte loads -> one (hi, lo) cell pair; rows fastest across lanes so that
+    // a wave's load instruction covers consecutive positions of one channel
+    const int nrows = ha.nrows;
+    const int items = nrows * ncell;
+    for (int it = tid; it < items; it += NT) {
+      const int row = it & (nrows - 1), oc = it >> ha.log2_nrows;      // nrows and lin are powers of two
+      const int sb = row >> ha.log2_lin, ip = row & (a.lin - 1);
+      const int b = b0 + sb, bc = min(b, bmax);
+      float t8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ci = c0 + 8 * oc + j, cc = min(ci, cmax);
+        const bool first = cc < a.c0;
+        const float* base = first ? a.io.x0 : a.io.x1;
+        const int64_t off = first ? (int64_t)bc * a.io.x0_sb + (int64_t)cc * a.io.x0_sc + (int64_t)ip * a.io.x0_sl
+                                  : (int64_t)bc * a.io.x1_sb + (int64_t)(cc - a.c0) * a.io.x1_sc + (int64_t)ip * a.io.x1_sl;
+        t8[j] = base[off];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (!(c0 + 8 * oc + j < a.cin && b < batch)) t8[j] = 0.f;
+      h8 hi, lo;
+      split8(t8, hi, lo);
+      ADX_TSTAMP(10);
+      u32x4* dst = cells + row * pitch + 2 * oc;
+      dst[0] = __builtin_bit_cast(u32x4, hi);
+      dst[1] = __builtin_bit_cast(u32x4, lo);
+    }
+  }
+  for (int it = tid; it < 2 * ncell; it += NT) cells[ha.nrows * pitch + it] = u32x4{0u, 0u, 0u, 0u};
 }
 
 // ---- sums over segments of 16 / 32 / 64 consecutive lanes: DPP inside a row of 16, LDS permute across rows ------------
@@ -159,7 +234,6 @@ __global__ void __launch_bounds__(64 * NW) tconv_hs_kernel(const HsArgs ha) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nt = blockIdx.x % a.ntiles;   // blocks b, b + 8 share an XCD: with ntiles | 8 or 8 | ntiles one XCD's L2 serves one weight slab
   const int b0 = (blockIdx.x / a.ntiles) * a.bt;
-  const int batch = a.io.batch;
   const int r = lane & 31, kg = lane >> 5;
   const int bl = r >> a.log2_lout, l = r & (a.lout - 1);
   const int pitch = ha.pitch16;
@@ -201,70 +275,7 @@ __global__ void __launch_bounds__(64 * NW) tconv_hs_kernel(const HsArgs ha) {
     for (int s = 0; s < PF; ++s) issue(wq[s]);     // in flight while the activations are staged
     ADX_TSTAMP(9);
     if (c0 > 0) __syncthreads();
-    // ---- stage rows [0, nrows] x channels [c0, c0 + ckc) as split cells ---------------------------------------
-    {
-      const int ncell = ckc >> 3;
-      if (ha.vec_stage) {
-        // item = (sample, quad of 4 positions, 8-channel octet): eight 16-byte loads -> four (hi, lo) cell pairs
-        const int items = (ha.nrows >> 2) * ncell;
-        for (int it = tid; it < items; it += NT) {
-          const int rq = it & ((ha.nrows >> 2) - 1), oc = it >> (ha.log2_nrows - 2);  // row quads fastest
-          const int q = rq & ((a.lin >> 2) - 1), sb = rq >> (ha.log2_lin - 2);
-          const int b = b0 + sb;
-          f32x4 v[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int ci = c0 + 8 * oc + j;
-            v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ci < a.cin && b < batch) {
-              const bool first = ci < a.c0;
-              const float* src = first ? a.io.x0 + (int64_t)ci * a.io.x0_sc + (int64_t)b * a.io.x0_sb
-                                       : a.io.x1 + (int64_t)(ci - a.c0) * a.io.x1_sc + (int64_t)b * a.io.x1_sb;
-              v[j] = *reinterpret_cast<const f32x4*>(src + 4 * q);
-            }
-          }
-#pragma unroll
-          for (int p = 0; p < 4; ++p) {
-            float t8[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) t8[j] = v[j][p];
-            h8 hi, lo;
-            split8(t8, hi, lo);
-            u32x4* dst = cells + (sb * a.lin + 4 * q + p) * pitch + 2 * oc;
-            dst[0] = __builtin_bit_cast(u32x4, hi);
-            dst[1] = __builtin_bit_cast(u32x4, lo);
-          }
-        }
-      } else {
-        // item = (row, 8-channel octet): eight 4-byte loads -> one (hi, lo) cell pair; rows fastest across lanes so that
-        // a wave's load instruction covers consecutive positions of one channel
-        const int nrows = ha.nrows;
-        const int items = nrows * ncell;
-        for (int it = tid; it < items; it += NT) {
-          const int row = it & (nrows - 1), oc = it >> ha.log2_nrows;      // nrows and lin are powers of two
-          const int sb = row >> ha.log2_lin, ip = row & (a.lin - 1);
-          const int b = b0 + sb;
-          float t8[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int ci = c0 + 8 * oc + j;
-            t8[j] = 0.f;
-            if (ci < a.cin && b < batch) {
-              const bool first = ci < a.c0;
-              t8[j] = first ? a.io.x0[(int64_t)b * a.io.x0_sb + (int64_t)ci * a.io.x0_sc + (int64_t)ip * a.io.x0_sl]
-                            : a.io.x1[(int64_t)b * a.io.x1_sb + (int64_t)(ci - a.c0) * a.io.x1_sc + (int64_t)ip * a.io.x1_sl];
-            }
-          }
-          h8 hi, lo;
-          split8(t8, hi, lo);
-          ADX_TSTAMP(10);
-          u32x4* dst = cells + row * pitch + 2 * oc;
-          dst[0] = __builtin_bit_cast(u32x4, hi);
-          dst[1] = __builtin_bit_cast(u32x4, lo);
-        }
-      }
-      for (int it = tid; it < 2 * ncell; it += NT) cells[zrow * pitch + it] = u32x4{0u, 0u, 0u, 0u};
-    }
+    hs_stage<NT>(a, ha, cells, c0, ckc, b0, tid);
     ADX_TSTAMP(11);
     __syncthreads();
     ADX_TSTAMP(1);
@@ -272,18 +283,14 @@ __global__ void __launch_bounds__(64 * NW) tconv_hs_kernel(const HsArgs ha) {
     int ctap = 0, ccb = wave;
     while (ccb >= ncbc) { ccb -= ncbc; ++ctap; }
     u32x4 ah, al;
+    const bool kind0 = a.kind == 0;
     auto fetch_a = [&]() {     // fragment of step (ctap, ccb); then advance to this wave's next step
-      int ip;
-      bool ok;
-      if (a.kind == 0) {
-        ip = l * a.stride + ctap - a.pad;
-        ok = ip >= 0 && ip < a.lin;
-      } else {  // ConvTranspose1d, stride 2: o = 2 i - pad + tap  <=>  i = (o + pad - tap) / 2 when even
-        const int v = l + a.pad - ctap;
-        ok = (v & 1) == 0 && v >= 0 && (v >> 1) < a.lin;
-        ip = v >> 1;
-      }
-      const int row = (ok && ctap < a.taps) ? bl * a.lin + ip : zrow;
+      // branch-free (a branch per K-step costs more than the MFMAs it guards): conv: ip = l stride + tap - pad;
+      // ConvTranspose1d, stride 2: o = 2 i - pad + tap  <=>  i = (o + pad - tap) / 2 when that is even
+      const int vt = l + a.pad - ctap;
+      const int ip = kind0 ? l * a.stride + ctap - a.pad : vt >> 1;
+      const bool ok = ((unsigned)ip < (unsigned)a.lin) & (kind0 | ((vt & 1) == 0)) & (ctap < a.taps);
+      const int row = ok ? bl * a.lin + ip : zrow;
       const u32x4* xp = cells + row * pitch + 4 * ccb + 2 * kg;
       ah = xp[0];
       al = xp[1];
@@ -295,6 +302,7 @@ __global__ void __launch_bounds__(64 * NW) tconv_hs_kernel(const HsArgs ha) {
       const h8 ch = __builtin_bit_cast(h8, ah);
       const h8 cl = __builtin_bit_cast(h8, al);
       fetch_a();                        // next step's fragment is in flight under this step's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < NF; ++j) {
         const h8 wh = __builtin_bit_cast(h8, w[j][0]);
@@ -355,6 +363,231 @@ __global__ void __launch_bounds__(64 * NW) tconv_hs_kernel(const HsArgs ha) {
   }
 }
 
+// ---- short-K variant: no K split --------------------------------------------------------------------------------
+// For the layers whose reduction is short (taps * cin <= 1536: every conv of the 64/128-channel levels, the 1x1 and
+// down/up-sampling convs, the block Linears -- 29 of the 47 launches of a forward) splitting K over the waves buys
+// nothing and costs the partial-tile round trip through LDS (write, barrier, 8-way sum: ~1800 cycles of a ~10000-cycle
+// workgroup).  Here every wave owns a 16 x 16 corner of the 32-row x 32-channel tile with the WHOLE reduction
+// (v_mfma_f32_16x16x32_f16: 4 accumulator registers = 4 consecutive rows = 4 consecutive positions of one channel), and
+// the epilogue runs straight from those registers.  K is the flattened sequence of 8-channel cells (tap-major), four
+// cells per MFMA step, so a step may straddle taps when cin < 32.  GroupNorm statistics: lane shuffles inside the wave,
+// one LDS exchange with the partner waves when a (sample, group) spans the tile's two row halves (lout = 32) or its two
+// channel halves (group width 32); two passes (mean, centred second moment), fixed summation order.
+struct HsdArgs {
+  HsArgs h;
+  int nsteps;           // MFMA steps = ceil(taps * cin_pad / 8 / 4)
+  int kcells;           // taps * cin_pad / 8
+  int log2_ncell;       // cells per tap = cin_pad / 8 (a power of two)
+  int red_off;          // float offset of the GroupNorm exchange area [2][4][64] behind the staged cells
+};
+
+template <int PF, bool UT>
+__global__ void __launch_bounds__(256) tconv_hsd_kernel(const HsdArgs da) {
+  constexpr int NT = 256;
+  const HsArgs& ha = da.h;
+  const TConvArgs& a = ha.t;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  u32x4* cells = reinterpret_cast<u32x4*>(smem);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave & 1, wc = wave >> 1;          // row half, channel half of the 32 x 32 tile
+  const int nt = blockIdx.x % a.ntiles;
+  const int b0 = (blockIdx.x / a.ntiles) * a.bt;
+  const int batch = a.io.batch;
+  const int r = lane & 15, kg = lane >> 4;
+  const int ma = 16 * wr + r;                       // this lane's row as an A operand
+  const int bl = ma >> a.log2_lout, l = ma & (a.lout - 1);
+  const int pitch = ha.pitch16;
+  const int zrow = ha.nrows;
+  ADX_TSTAMP(0);
+  // weight image: [16-channel tile][step][plane][lane] x 16 bytes
+  const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(a.io.packed_w) + (size_t)(nt * 2 + wc) * da.nsteps * 128 + lane;
+  u32x4 wq[PF][2];
+#pragma unroll
+  for (int s = 0; s < PF; ++s) {
+    const int st = min(s, da.nsteps - 1);
+    wq[s][0] = wp[(size_t)st * 128];
+    wq[s][1] = wp[(size_t)st * 128 + 64];
+  }
+  ADX_TSTAMP(9);
+  hs_stage<NT>(a, ha, cells, 0, a.cin_pad, b0, tid);     // the short-K layers fit one chunk
+  ADX_TSTAMP(11);
+  __syncthreads();
+  ADX_TSTAMP(1);
+  // ---- K loop: all steps on this wave's 16 x 16 corner, weights PF steps ahead, activations one step ahead ---------
+  f32x4 accm = f32x4{0.f, 0.f, 0.f, 0.f}, accx = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 ah, al;
+  const bool kind0 = a.kind == 0;
+  const int ncm1 = (1 << da.log2_ncell) - 1;
+  // UT (cin_pad >= 32): the four cells of a step lie in ONE tap, so the tap and the first cell are wave-uniform and move
+  // incrementally -- the lane's LDS row is recomputed only when the tap changes; otherwise (cin_pad = 16) each lane has
+  // its own (tap, cell) per step
+  int f_tap = 0, f_cell = 0;                         // UT: position of the NEXT fetch
+  int f_row = zrow;
+  auto row_of = [&](int tap) {
+    const int vt = l + a.pad - tap;
+    const int ip = kind0 ? l * a.stride + tap - a.pad : vt >> 1;
+    const bool ok = ((unsigned)ip < (unsigned)a.lin) & (kind0 | ((vt & 1) == 0)) & (tap < a.taps);
+    return ok ? bl * a.lin + ip : zrow;
+  };
+  if (UT) f_row = row_of(0);
+  auto fetch_a = [&](int step) {
+    const u32x4* xp;
+    if (UT) {
+      xp = cells + f_row * pitch + 2 * (f_cell + kg);
+      f_cell += 4;
+      if (f_cell > ncm1) {                           // uniform: next tap
+        f_cell = 0;
+        ++f_tap;
+        f_row = row_of(f_tap);
+      }
+    } else {
+      const int kc = 4 * step + kg;                  // flattened (tap, cell)
+      const int tap = kc >> da.log2_ncell, cell = kc & ncm1;
+      xp = cells + row_of(tap) * pitch + 2 * cell;
+    }
+    ah = xp[0];
+    al = xp[1];
+  };
+  fetch_a(0);
+  auto compute = [&](const u32x4 (&w)[2], int next_step) {
+    const h8 ch = __builtin_bit_cast(h8, ah);
+    const h8 cl = __builtin_bit_cast(h8, al);
+    fetch_a(next_step);
+    __builtin_amdgcn_sched_barrier(0);    // the next step's LDS reads stay in front of this step's MFMAs
+    const h8 wh = __builtin_bit_cast(h8, w[0]);
+    const h8 wl = __builtin_bit_cast(h8, w[1]);
+    accm = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, wh, accm, 0, 0, 0);
+    accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, wl, accx, 0, 0, 0);
+    accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl, wh, accx, 0, 0, 0);
+  };
+  int j0 = 0;
+  for (; j0 + PF <= da.nsteps; j0 += PF) {
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+      const int nxt = min(j0 + s + 1, da.nsteps - 1);
+      compute(wq[s], nxt);
+      const int st = min(j0 + s + PF, da.nsteps - 1);
+      wq[s][0] = wp[(size_t)st * 128];
+      wq[s][1] = wp[(size_t)st * 128 + 64];
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < PF; ++s)
+    if (j0 + s < da.nsteps) compute(wq[s], min(j0 + s + 1, da.nsteps - 1));
+  ADX_TSTAMP(2);
+
+  // ---- epilogue from the accumulators: lane = (channel lane & 15, four consecutive rows 4 kg .. 4 kg + 3) ------------
+  const int c = nt * a.ct + 16 * wc + r;
+  const int m0 = 16 * wr + 4 * kg;
+  const int sb = m0 >> a.log2_lout, l0 = m0 & (a.lout - 1);
+  const int b = b0 + sb;
+  const bool live = b < batch && c < a.cout;
+  float bias = 0.f, gm = 1.f, be = 0.f, tb = 0.f;
+  f32x4 rs = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    if (a.io.bias != nullptr) bias = a.io.bias[c];
+    if (a.groups > 0) { gm = a.io.gamma[c]; be = a.io.beta[c]; }
+    if (a.io.tbias != nullptr) tb = a.io.tbias[(int64_t)b * a.io.tbias_stride + c];
+    if (a.io.res != nullptr) {
+      const float* rp = a.io.res + (int64_t)b * a.io.res_sb + (int64_t)c * a.io.res_sc + (int64_t)l0 * a.io.res_sl;
+      if (a.io.res_sl == 1 && ((a.io.res_sb | a.io.res_sc) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.io.res) & 15) == 0) {
+        rs = *reinterpret_cast<const f32x4*>(rp);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rs[q] = rp[(int64_t)q * a.io.res_sl];
+      }
+    }
+  }
+  f32x4 v = accm + accx * kLoInv;
+  v += bias;
+  if (a.io.pre != nullptr && live) *reinterpret_cast<f32x4*>(a.io.pre + ((int64_t)b * a.cout + c) * a.lout + l0) = v;
+  ADX_TSTAMP(5);
+  f32x4 o = v;
+  if (a.groups > 0) {
+    // (sample, group) of this lane: channel lanes that share the group = bits 0..2 (and 3 when cg >= 16); row quads that
+    // share the sample = bit 4 when lout >= 8, bit 5 when lout >= 16; partner waves: wr ^ 1 when lout == 32, wc ^ 1 when cg == 32
+    float* red = smem + da.red_off;                  // behind the staged cells: [2 passes][4 waves][64 lanes]
+    const bool x_rows = a.lout == 32, x_ch = a.cg == 32;
+    auto group_sum = [&](float s, int pass) -> float {
+      s += dpp_f<0xB1>(s);
+      s += dpp_f<0x4E>(s);
+      s += dpp_f<0x141>(s);                          // bits 0..2: the 8 channel lanes
+      if (a.cg >= 16) s += dpp_f<0x140>(s);          // bit 3
+      if (a.lout >= 8) s += __shfl_xor(s, 16, 64);
+      if (a.lout >= 16) s += __shfl_xor(s, 32, 64);
+      if (x_rows || x_ch) {                          // uniform branch: same for every lane of the workgroup
+        float* rp = red + pass * 256;
+        rp[wave * 64 + lane] = s;
+        __syncthreads();
+        const int w0 = (x_rows ? 0 : wr) + 2 * (x_ch ? 0 : wc);     // lowest partner wave: canonical summation order
+        float t = rp[w0 * 64 + lane];
+        if (x_rows) t += rp[(w0 + 1) * 64 + lane];
+        if (x_ch) {
+          t += rp[(w0 + 2) * 64 + lane];
+          if (x_rows) t += rp[(w0 + 3) * 64 + lane];
+        }
+        s = t;
+      }
+      return s;
+    };
+    const int n = a.cg << a.log2_lout;
+    const float inv_n = 1.0f / (float)n;
+    const float mean = group_sum((v[0] + v[1]) + (v[2] + v[3]), 0) * inv_n;
+    const f32x4 d = v - mean;
+    const float q = group_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]), 1);
+    const float rstd = 1.0f / sqrtf(q * inv_n + a.eps);
+    if (a.io.stats != nullptr && live && l0 == 0 && (c & (a.cg - 1)) == 0) {
+      float* st = a.io.stats + ((int64_t)b * a.groups + c / a.cg) * 2;
+      st[0] = mean;
+      st[1] = rstd;
+    }
+    const float sc = rstd * gm;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = mish_fast(d[k] * sc + be);
+  }
+  ADX_TSTAMP(7);
+  if (live) {
+    o += tb;
+    o += rs;
+    float* yp = a.io.y + (int64_t)b * a.io.y_sb + (int64_t)c * a.io.y_sc + (int64_t)l0 * a.io.y_sl;
+    if (a.io.y_sl == 1 && ((a.io.y_sb | a.io.y_sc) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.io.y) & 15) == 0) {
+      *reinterpret_cast<f32x4*>(yp) = o;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) yp[(int64_t)k * a.io.y_sl] = o[k];
+    }
+  }
+  ADX_TSTAMP(8);
+}
+
+// weight image of the short-K variant: [cout_pad32 / 16][nsteps][2 planes][64 lanes][8 halfs]; element j of lane ln at
+// `step` is W[n = 16 tile + (ln & 15)][flattened cell kc = 4 step + (ln >> 4): tap = kc / ncell, ci = 8 (kc % ncell) + j]
+__global__ void tconv_hsd_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ packed, int layout, int flip,
+                                      int taps, int cin, int cout, int ncell, int nsteps, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int j = idx & 7;
+  const int ln = (idx >> 3) & 63;
+  const size_t blk = idx >> 9;
+  const int step = blk % nsteps;
+  const int t16 = blk / nsteps;
+  const int kc = 4 * step + (ln >> 4);
+  const int tap = kc / ncell, ci = 8 * (kc - tap * ncell) + j;
+  const int n = t16 * 16 + (ln & 15);
+  float v = 0.f;
+  if (tap < taps && n < cout && ci < cin) {
+    const int ts = flip ? taps - 1 - tap : tap;
+    v = layout == 0 ? w[((size_t)n * cin + ci) * taps + ts] : w[((size_t)ci * cout + n) * taps + ts];
+  }
+  const _Float16 hi = (_Float16)v;
+  const _Float16 lo = (_Float16)((v - (float)hi) * kLoScale);
+  _Float16* dst = packed + blk * 1024 + ln * 8 + j;
+  dst[0] = hi;
+  dst[512] = lo;
+}
+
 // weight image [cout_pad32 / 32][nkb][2 planes][64 lanes][8 halfs]; element j of lane ln in K-step (tap, cb) is
 // W[n = 32 tile + (ln & 31)][ci = 16 cb + 8 (ln >> 5) + j][tap]  (B operand of 32x32x16)
 __global__ void tconv_hs_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ packed, int layout, int flip,
@@ -403,12 +636,49 @@ bool tconv_hs_supported(const adx_tconv_desc* d) {
   return true;
 }
 
+// short-K variant (tconv_hsd_kernel): geometry it covers, decided from the descriptor alone so that pack and forward agree
+static bool hsd_geometry(const adx_tconv_desc* d, int* nsteps, int* kcells, int* log2_ncell) {
+  const int cin_pad = round_up(d->c0 + d->c1, 16);
+  const int ncell = cin_pad / 8;
+  const int lg = ilog2_exact_hs(ncell);
+  if (lg < 0 || d->lout < 4 || d->lout > 32) return false;
+  if (d->groups > 0) {
+    const int cg = d->cout / d->groups;
+    if (cg != 8 && cg != 16 && cg != 32) return false;
+  }
+  const int kc = d->taps * ncell, ns = ceil_div(kc, 4);
+  if (ns > 48) return false;                                                   // taps * cin_pad <= 1536
+  const int nrows = (32 / d->lout) * d->lin;
+  if ((size_t)(nrows + 1) * (cin_pad / 4 + 1) * 16 > 60 * 1024) return false;  // one staging chunk
+  *nsteps = ns; *kcells = kc; *log2_ncell = lg;
+  return true;
+}
+
+static bool hsd_enabled() {
+  static const bool on = [] { const char* e = getenv("ADX_TCONV_NO_DIRECT"); return !(e != nullptr && e[0] == '1'); }();
+  return on;
+}
+
 size_t tconv_hs_packed_floats(const adx_tconv_desc* d) {
   const int cin_pad = round_up(d->c0 + d->c1, 16);
-  return (size_t)round_up(d->cout, 32) * d->taps * cin_pad;     // 2 halfs = 4 bytes per (padded) weight
+  size_t f = (size_t)round_up(d->cout, 32) * d->taps * cin_pad;     // 2 halfs = 4 bytes per (padded) weight
+  int ns, kc, lg;
+  if (hsd_geometry(d, &ns, &kc, &lg)) f = std::max(f, (size_t)round_up(d->cout, 32) * ns * 32);
+  return f;
 }
 
 int tconv_hs_pack(const adx_tconv_desc* d, const float* w, float* packed, hipStream_t s) {
+  {
+    int ns, kc, lg;
+    if (hsd_enabled() && hsd_geometry(d, &ns, &kc, &lg)) {
+      const size_t total = (size_t)(round_up(d->cout, 32) / 16) * ns * 512;
+      tconv_hsd_pack_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
+          w, reinterpret_cast<_Float16*>(packed), d->kind == 1 ? 1 - d->w_layout : d->w_layout, d->w_flip, d->taps,
+          d->c0 + d->c1, d->cout, 1 << lg, ns, total);
+      ADX_LAUNCH_CHECK();
+      return ADX_OK;
+    }
+  }
   const int cin = d->c0 + d->c1;
   const int ncb = round_up(cin, 16) / 16;
   const int nkb = d->taps * ncb;
@@ -497,6 +767,34 @@ int tconv_hs_forward(const adx_tconv_desc* d, const adx_tconv_io* io, hipStream_
   const size_t epi_bytes = ((size_t)t.nw * ha.ptile + 2 * 16 * t.nf) * sizeof(float);
   if (epi_bytes > t.lds_bytes) t.lds_bytes = epi_bytes;
   ADX_REQUIRE(t.lds_bytes <= kMaxHsLds, "tconv_hs: LDS tile of %zu bytes exceeds %zu", t.lds_bytes, kMaxHsLds);
+  {
+    HsdArgs da;
+    if (hsd_enabled() && hsd_geometry(d, &da.nsteps, &da.kcells, &da.log2_ncell)) {
+      // short reduction: 32-row x 32-channel tiles, four waves with the whole K each (no partial tiles)
+      HsArgs& h = da.h;
+      h = ha;
+      h.t.ct = 32; h.t.log2_ct = 5; h.t.ntiles = round_up(d->cout, 32) / 32;
+      h.t.ck = a.cin_pad;
+      h.pitch16 = a.cin_pad / 4 + 1;
+      h.vec_stage = a.dense && (t.nrows / 4) * (a.cin_pad / 8) >= 128;
+      const size_t stage = (size_t)(t.nrows + 1) * h.pitch16 * 16;
+      da.red_off = (int)(round_up((int)stage, 16) / 4);
+      const size_t lds = (size_t)da.red_off * 4 + 2 * 4 * 64 * sizeof(float);
+      const int grid_d = ceil_div(io->batch, t.bt) * h.t.ntiles;
+      static bool attr_set = false;
+      if (!attr_set) {
+        ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_hsd_kernel<6, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_hsd_kernel<6, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        attr_set = true;
+      }
+      if (da.log2_ncell >= 2) tconv_hsd_kernel<6, true><<<dim3(grid_d), dim3(256), lds, s>>>(da);
+      else tconv_hsd_kernel<6, false><<<dim3(grid_d), dim3(256), lds, s>>>(da);
+      ADX_LAUNCH_CHECK();
+      return ADX_OK;
+    }
+  }
   const int grid = ceil_div(io->batch, t.bt) * t.ntiles;
   // a grid that fits the chip one workgroup per CU must not be packed two per CU (the dispatcher does that with
   // 128 workgroups on 256 CUs): the two would share one CU's L2->L1 fill rate, which is what bounds the K loop
