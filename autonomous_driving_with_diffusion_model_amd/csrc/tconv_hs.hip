@@ -481,6 +481,24 @@ __global__ void __launch_bounds__(256) tconv_hsd_kernel(const HsdArgs da) {
   // ---- epilogue from the accumulators: lane = (channel lane & 15, four consecutive rows 4 kg .. 4 kg + 3) ------------
   const int c = nt * a.ct + 16 * wc + r;
   const int m0 = 16 * wr + 4 * kg;
+  if (a.lout < 4) {
+    // rows are (sample, position) pairs with fewer than 4 positions per sample (the block Linears: lout = 1): the four
+    // accumulator rows belong to different samples; no GroupNorm on this path (hsd_geometry), one element at a time
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int m = m0 + q;
+      const int b = b0 + (m >> a.log2_lout), lq = m & (a.lout - 1);
+      if (b < batch && c < a.cout) {
+        float o = accm[q] + accx[q] * kLoInv;
+        if (a.io.bias != nullptr) o += a.io.bias[c];
+        if (a.io.pre != nullptr) a.io.pre[((int64_t)b * a.cout + c) * a.lout + lq] = o;
+        if (a.io.tbias != nullptr) o += a.io.tbias[(int64_t)b * a.io.tbias_stride + c];
+        if (a.io.res != nullptr) o += a.io.res[(int64_t)b * a.io.res_sb + (int64_t)c * a.io.res_sc + (int64_t)lq * a.io.res_sl];
+        a.io.y[(int64_t)b * a.io.y_sb + (int64_t)c * a.io.y_sc + (int64_t)lq * a.io.y_sl] = o;
+      }
+    }
+    return;
+  }
   const int sb = m0 >> a.log2_lout, l0 = m0 & (a.lout - 1);
   const int b = b0 + sb;
   const bool live = b < batch && c < a.cout;
@@ -641,10 +659,10 @@ static bool hsd_geometry(const adx_tconv_desc* d, int* nsteps, int* kcells, int*
   const int cin_pad = round_up(d->c0 + d->c1, 16);
   const int ncell = cin_pad / 8;
   const int lg = ilog2_exact_hs(ncell);
-  if (lg < 0 || d->lout < 4 || d->lout > 32) return false;
+  if (lg < 0 || d->lout > 32) return false;
   if (d->groups > 0) {
     const int cg = d->cout / d->groups;
-    if (cg != 8 && cg != 16 && cg != 32) return false;
+    if (d->lout < 4 || (cg != 8 && cg != 16 && cg != 32)) return false;   // lout < 4 (the block Linears: lout = 1) without GroupNorm only
   }
   const int kc = d->taps * ncell, ns = ceil_div(kc, 4);
   if (ns > 48) return false;                                                   // taps * cin_pad <= 1536
@@ -706,8 +724,10 @@ static int hs_tile(const adx_tconv_desc* d, int batch, HsTile* t) {
   t->ntiles = cout_pad / t->ct;
   t->nrows = t->bt * d->lin;
   t->nw = 8;     // also where K is short: the staging and the epilogue are spread over 512 threads
-  // staged chunk: (nrows + 1) rows x (ck / 4 + 1) 16-byte units; keep it <= ~68 KB so two workgroups share a CU
-  const size_t budget = 70 * 1024;
+  // staged chunk: (nrows + 1) rows x (ck / 4 + 1) 16-byte units; <= ~68 KB so that two workgroups share a CU, unless the
+  // grid puts at most one workgroup on a CU anyway: then one chunk of up to 140 KB saves the second staging phase
+  const bool one_per_cu = (size_t)ceil_div(batch, t->bt) * t->ntiles <= 256;
+  const size_t budget = (one_per_cu ? 140 : 70) * 1024;
   int ck = cin_pad;
   while ((size_t)(t->nrows + 1) * (ck / 4 + 1) * 16 > budget && ck > 16) ck = round_up(ck / 2, 16);
   const int nchunks = ceil_div(cin_pad, ck);
