@@ -10,6 +10,24 @@ namespace adx {
 
 constexpr int kMaxDim = 256;
 
+// sum over n (a multiple of 4) of w[i] * x[i]: w in global memory (16-byte aligned), x in LDS; eight 16-byte loads are
+// issued before the first is consumed, so a 64-long row costs one memory round trip instead of sixteen
+__device__ __forceinline__ float dot_f4(const float* __restrict__ w, const float* x, int n) {
+  const f32x4* w4 = reinterpret_cast<const f32x4*>(w);
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  const int n4 = n >> 2;
+  f32x4 a4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i0 = 0; i0 < n4; i0 += 8) {
+    f32x4 wv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) wv[u] = w4[min(i0 + u, n4 - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u < n4) a4 += wv[u] * x4[i0 + u];
+  }
+  return (a4[0] + a4[1]) + (a4[2] + a4[3]);
+}
+
 __global__ void __launch_bounds__(256) embed_kernel(const adx_embed_weights w, const int dim,
                                                      const int64_t* __restrict__ t, const int t_rows,
                                                      const float* __restrict__ cond,
@@ -19,7 +37,7 @@ __global__ void __launch_bounds__(256) embed_kernel(const adx_embed_weights w, c
   __shared__ __attribute__((aligned(16))) float h[4 * kMaxDim];
   __shared__ float parts[4 * kMaxDim];
   __shared__ float te[kMaxDim];
-  __shared__ float ch[kMaxDim];
+  __shared__ __attribute__((aligned(16))) float ch[kMaxDim];
   const int row = blockIdx.x, tid = threadIdx.x;
   const int half = dim / 2, hid = 4 * dim;
   const float tval = (float)t[row % t_rows];  // int64 * fp32 -> fp32 (helpers.py:71)
@@ -29,31 +47,15 @@ __global__ void __launch_bounds__(256) embed_kernel(const adx_embed_weights w, c
     e[i] = i < half ? sinf(arg) : cosf(arg);
   }
   __syncthreads();
-  // time_mlp.1: hid outputs, one per thread, 16-byte weight loads (dim % 4 == 0, rows are 16-byte aligned)
-  for (int j = tid; j < hid; j += 256) {
-    const f32x4* wr = reinterpret_cast<const f32x4*>(w.w1 + (size_t)j * dim);
-    f32x4 a4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int i = 0; i < dim / 4; ++i) {
-      const f32x4 wv = wr[i];
-      const f32x4 ev = *reinterpret_cast<const f32x4*>(e + 4 * i);
-      a4 += wv * ev;
-    }
-    h[j] = mish_f(w.b1[j] + ((a4[0] + a4[1]) + (a4[2] + a4[3])));
-  }
+  // time_mlp.1: hid outputs, one per thread
+  for (int j = tid; j < hid; j += 256) h[j] = mish_f(w.b1[j] + dot_f4(w.w1 + (size_t)j * dim, e, dim));
   __syncthreads();
   // time_mlp.3: dim outputs x hid inputs; all 256 threads work: thread (j, part) sums a quarter of the row, the four
   // parts meet in LDS and are added in a fixed order
   for (int lin = tid; lin < 4 * dim; lin += 256) {
     const int jj = lin % dim, pp = lin / dim;
     const int seg = hid / 4;
-    const f32x4* wr = reinterpret_cast<const f32x4*>(w.w3 + (size_t)jj * hid + pp * seg);
-    f32x4 a4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int i = 0; i < seg / 4; ++i) {
-      const f32x4 wv = wr[i];
-      const f32x4 hv = *reinterpret_cast<const f32x4*>(h + pp * seg + 4 * i);
-      a4 += wv * hv;
-    }
-    parts[lin] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+    parts[lin] = dot_f4(w.w3 + (size_t)jj * hid + pp * seg, h + pp * seg, seg);
   }
   __syncthreads();
   for (int jj = tid; jj < dim; jj += 256)
@@ -64,13 +66,16 @@ __global__ void __launch_bounds__(256) embed_kernel(const adx_embed_weights w, c
     const float c0 = cond != nullptr ? cond[2 * row] : 0.f;
     const float c1 = cond != nullptr ? cond[2 * row + 1] : 0.f;
     for (int j = tid; j < dim; j += 256) ch[j] = mish_f(w.cw0[2 * j] * c0 + w.cw0[2 * j + 1] * c1 + w.cb0[j]);
-    __syncthreads();
-    for (int j = tid; j < dim; j += 256) {
-      float acc = w.cb2[j];
-      const float* wr = w.cw2 + (size_t)j * dim;
-      for (int i = 0; i < dim; ++i) acc += wr[i] * ch[i];
-      te[j] += acc;  // same thread wrote te[j] above
+    __syncthreads();                       // also orders the reads of `parts` above before they are overwritten
+    // cond_mlp.2: dim x dim, four parts per output like time_mlp.3 (dim % 16 == 0)
+    for (int lin = tid; lin < 4 * dim; lin += 256) {
+      const int jj = lin % dim, pp = lin / dim;
+      const int seg = dim / 4;
+      parts[lin] = dot_f4(w.cw2 + (size_t)jj * dim + pp * seg, ch + pp * seg, seg);
     }
+    __syncthreads();
+    for (int jj = tid; jj < dim; jj += 256)   // same thread wrote te[jj] above
+      te[jj] += w.cb2[jj] + ((parts[jj] + parts[dim + jj]) + (parts[2 * dim + jj] + parts[3 * dim + jj]));
   }
   __syncthreads();
   for (int j = tid; j < dim; j += 256) {
@@ -208,7 +213,8 @@ int embed_backward(const adx_embed_weights* w, int dim, const int64_t* t, int t_
 int embed_forward(const adx_embed_weights* w, int dim, const int64_t* t, int t_rows, const float* cond,
                   const float* feat, int feat_rows, int rows, float* time_embed, float* mish_cond, hipStream_t s) {
   ADX_REQUIRE(w != nullptr && w->freqs && w->w1 && w->b1 && w->w3 && w->b3, "embed: missing time_mlp weights");
-  ADX_REQUIRE(dim >= 4 && dim <= kMaxDim && dim % 4 == 0, "embed: dim %d unsupported (<= %d, multiple of 4)", dim, kMaxDim);
+  ADX_REQUIRE(dim >= 16 && dim <= kMaxDim && dim % 16 == 0, "embed: dim %d unsupported (<= %d, multiple of 16)", dim, kMaxDim);
+  ADX_REQUIRE(w->cw2 == nullptr || (reinterpret_cast<uintptr_t>(w->cw2) & 15) == 0, "embed: cond_mlp.2 weight must be 16-byte aligned");
   ADX_REQUIRE(((reinterpret_cast<uintptr_t>(w->w1) | reinterpret_cast<uintptr_t>(w->w3)) & 15) == 0,
               "embed: time_mlp weights must be 16-byte aligned");
   ADX_REQUIRE(rows >= 1 && t_rows >= 1 && feat_rows >= 1, "embed: empty batch");
