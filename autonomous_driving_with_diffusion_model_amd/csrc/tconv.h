@@ -32,5 +32,8 @@ bool tconv_hs_supported(const adx_tconv_desc* d);
 size_t tconv_hs_packed_floats(const adx_tconv_desc* d);
 int tconv_hs_pack(const adx_tconv_desc* d, const float* w, float* packed, hipStream_t s);
 int tconv_hs_forward(const adx_tconv_desc* d, const adx_tconv_io* io, hipStream_t s);
+// two independent convolutions, in one launch where both run on the short-K kernel
+int tconv_hs_forward_pair(const adx_tconv_desc* da, const adx_tconv_io* ioa, const adx_tconv_desc* db,
+                          const adx_tconv_io* iob, hipStream_t s);
 
 }  // namespace adx

@@ -381,9 +381,20 @@ struct HsdArgs {
   int red_off;          // float offset of the GroupNorm exchange area [2][4][64] behind the staged cells
 };
 
+// Two independent short-K convolutions may share ONE launch (workgroups [0, n_a) run `a`, the rest run `b`): the 1x1
+// residual conv of a residual block and the block's first Conv1dBlock read the same input and nothing of each other
+// (modeling/temporal.py:51-55), so the pair costs one launch latency instead of two.
+struct HsdPair {
+  HsdArgs a, b;
+  int n_a;              // workgroups of `a`; a single conv has n_a = its whole grid
+};
+
 template <int PF, bool UT>
-__global__ void __launch_bounds__(256) tconv_hsd_kernel(const HsdArgs da) {
+__global__ void __launch_bounds__(256) tconv_hsd_kernel(const HsdPair pr) {
   constexpr int NT = 256;
+  const bool second = (int)blockIdx.x >= pr.n_a;                 // wave-uniform
+  const HsdArgs& da = second ? pr.b : pr.a;
+  const int bid = second ? (int)blockIdx.x - pr.n_a : (int)blockIdx.x;
   const HsArgs& ha = da.h;
   const TConvArgs& a = ha.t;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -392,8 +403,8 @@ __global__ void __launch_bounds__(256) tconv_hsd_kernel(const HsdArgs da) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave & 1, wc = wave >> 1;          // row half, channel half of the 32 x 32 tile
-  const int nt = blockIdx.x % a.ntiles;
-  const int b0 = (blockIdx.x / a.ntiles) * a.bt;
+  const int nt = bid % a.ntiles;
+  const int b0 = (bid / a.ntiles) * a.bt;
   const int batch = a.io.batch;
   const int r = lane & 15, kg = lane >> 4;
   const int ma = 16 * wr + r;                       // this lane's row as an A operand
@@ -754,11 +765,45 @@ static int hs_launch(const HsArgs& a, int grid, size_t lds, hipStream_t s) {
   return ADX_OK;
 }
 
-int tconv_hs_forward(const adx_tconv_desc* d, const adx_tconv_io* io, hipStream_t s) {
-  HsTile t;
+// short reduction: 32-row x 32-channel tiles, four waves with the whole K each (no partial tiles)
+static bool hsd_prepare(const adx_tconv_desc* d, const HsArgs& ha, const HsTile& t, HsdArgs* da, size_t* lds, int* grid) {
+  if (!hsd_enabled() || !hsd_geometry(d, &da->nsteps, &da->kcells, &da->log2_ncell)) return false;
+  const TConvArgs& a = ha.t;
+  HsArgs& h = da->h;
+  h = ha;
+  h.t.ct = 32; h.t.log2_ct = 5; h.t.ntiles = round_up(d->cout, 32) / 32;
+  h.t.ck = a.cin_pad;
+  h.pitch16 = a.cin_pad / 4 + 1;
+  h.vec_stage = a.dense && (t.nrows / 4) * (a.cin_pad / 8) >= 128;
+  const size_t stage = (size_t)(t.nrows + 1) * h.pitch16 * 16;
+  da->red_off = (int)(round_up((int)stage, 16) / 4);
+  *lds = (size_t)da->red_off * 4 + 2 * 4 * 64 * sizeof(float);
+  *grid = ceil_div(a.io.batch, t.bt) * h.t.ntiles;
+  return true;
+}
+
+static int hsd_launch(const HsdPair& pr, int grid, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_hsd_kernel<6, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_hsd_kernel<6, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    attr_set = true;
+  }
+  if (pr.a.log2_ncell >= 2) tconv_hsd_kernel<6, true><<<dim3(grid), dim3(256), lds, s>>>(pr);
+  else tconv_hsd_kernel<6, false><<<dim3(grid), dim3(256), lds, s>>>(pr);
+  ADX_LAUNCH_CHECK();
+  return ADX_OK;
+}
+
+static int hs_prepare(const adx_tconv_desc* d, const adx_tconv_io* io, HsTile* tp, HsArgs* hap);
+
+static int hs_prepare(const adx_tconv_desc* d, const adx_tconv_io* io, HsTile* tp, HsArgs* hap) {
+  HsTile& t = *tp;
   int rc = hs_tile(d, io->batch, &t);
   if (rc != ADX_OK) return rc;
-  HsArgs ha;
+  HsArgs& ha = *hap;
   TConvArgs& a = ha.t;
   a.io = *io;
   a.kind = d->kind; a.taps = d->taps; a.stride = d->stride; a.pad = d->pad;
@@ -787,32 +832,22 @@ int tconv_hs_forward(const adx_tconv_desc* d, const adx_tconv_io* io, hipStream_
   const size_t epi_bytes = ((size_t)t.nw * ha.ptile + 2 * 16 * t.nf) * sizeof(float);
   if (epi_bytes > t.lds_bytes) t.lds_bytes = epi_bytes;
   ADX_REQUIRE(t.lds_bytes <= kMaxHsLds, "tconv_hs: LDS tile of %zu bytes exceeds %zu", t.lds_bytes, kMaxHsLds);
+  return ADX_OK;
+}
+
+int tconv_hs_forward(const adx_tconv_desc* d, const adx_tconv_io* io, hipStream_t s) {
+  HsTile t;
+  HsArgs ha;
+  int rc = hs_prepare(d, io, &t, &ha);
+  if (rc != ADX_OK) return rc;
   {
     HsdArgs da;
-    if (hsd_enabled() && hsd_geometry(d, &da.nsteps, &da.kcells, &da.log2_ncell)) {
-      // short reduction: 32-row x 32-channel tiles, four waves with the whole K each (no partial tiles)
-      HsArgs& h = da.h;
-      h = ha;
-      h.t.ct = 32; h.t.log2_ct = 5; h.t.ntiles = round_up(d->cout, 32) / 32;
-      h.t.ck = a.cin_pad;
-      h.pitch16 = a.cin_pad / 4 + 1;
-      h.vec_stage = a.dense && (t.nrows / 4) * (a.cin_pad / 8) >= 128;
-      const size_t stage = (size_t)(t.nrows + 1) * h.pitch16 * 16;
-      da.red_off = (int)(round_up((int)stage, 16) / 4);
-      const size_t lds = (size_t)da.red_off * 4 + 2 * 4 * 64 * sizeof(float);
-      const int grid_d = ceil_div(io->batch, t.bt) * h.t.ntiles;
-      static bool attr_set = false;
-      if (!attr_set) {
-        ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_hsd_kernel<6, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_hsd_kernel<6, false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        attr_set = true;
-      }
-      if (da.log2_ncell >= 2) tconv_hsd_kernel<6, true><<<dim3(grid_d), dim3(256), lds, s>>>(da);
-      else tconv_hsd_kernel<6, false><<<dim3(grid_d), dim3(256), lds, s>>>(da);
-      ADX_LAUNCH_CHECK();
-      return ADX_OK;
+    size_t lds;
+    int grid_d;
+    if (hsd_prepare(d, ha, t, &da, &lds, &grid_d)) {
+      HsdPair pr;
+      pr.a = da; pr.b = da; pr.n_a = grid_d;
+      return hsd_launch(pr, grid_d, lds, s);
     }
   }
   const int grid = ceil_div(io->batch, t.bt) * t.ntiles;
@@ -828,5 +863,26 @@ extern "C" int adx_debug_tconv_trace(unsigned long long* host_dst, int n) {
   return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_tconv_trace), sizeof(unsigned long long) * n);
 }
 #endif
+
+// Two independent convolutions in one launch when both run on the short-K kernel with the same addressing variant;
+// otherwise two launches.  Same results either way.
+int tconv_hs_forward_pair(const adx_tconv_desc* da, const adx_tconv_io* ioa, const adx_tconv_desc* db,
+                          const adx_tconv_io* iob, hipStream_t s) {
+  static const bool pair_on = [] { const char* e = getenv("ADX_TCONV_NO_PAIR"); return !(e != nullptr && e[0] == '1'); }();
+  HsTile ta, tb;
+  HsArgs ha, hb;
+  HsdPair pr;
+  size_t la = 0, lb = 0;
+  int ga = 0, gb = 0;
+  if (pair_on && tconv_hs_supported(da) && tconv_hs_supported(db) && hs_prepare(da, ioa, &ta, &ha) == ADX_OK &&
+      hs_prepare(db, iob, &tb, &hb) == ADX_OK && hsd_prepare(da, ha, ta, &pr.a, &la, &ga) &&
+      hsd_prepare(db, hb, tb, &pr.b, &lb, &gb) && (pr.a.log2_ncell >= 2) == (pr.b.log2_ncell >= 2)) {
+    pr.n_a = ga;
+    return hsd_launch(pr, ga + gb, la > lb ? la : lb, s);
+  }
+  int rc = tconv_forward(da, ioa, s);
+  if (rc == ADX_OK) rc = tconv_forward(db, iob, s);
+  return rc;
+}
 
 }  // namespace adx

@@ -183,9 +183,18 @@ struct Act {  // an activation tensor [rows][c][len] with explicit strides
 
 static Act dense(float* p, int c, int len) { return Act{p, (int64_t)c * len, (int64_t)len, 1}; }
 
+static adx_tconv_io make_io(const ConvLayer& L, const float* base, const Act& x0, const Act* x1, const float* tbias,
+                            int64_t tb_stride, const Act* res, float* y, int64_t y_sb, int64_t y_sc, int64_t y_sl, int rows);
+
 static int run_conv(const ConvLayer& L, const float* base, const Act& x0, const Act* x1, const float* tbias,
                     int64_t tb_stride, const Act* res, float* y, int64_t y_sb, int64_t y_sc, int64_t y_sl, int rows,
                     hipStream_t s) {
+  const adx_tconv_io io = make_io(L, base, x0, x1, tbias, tb_stride, res, y, y_sb, y_sc, y_sl, rows);
+  return tconv_forward(&L.d, &io, s);
+}
+
+static adx_tconv_io make_io(const ConvLayer& L, const float* base, const Act& x0, const Act* x1, const float* tbias,
+                            int64_t tb_stride, const Act* res, float* y, int64_t y_sb, int64_t y_sc, int64_t y_sl, int rows) {
   adx_tconv_io io;
   memset(&io, 0, sizeof(io));
   io.x0 = x0.p; io.x0_sb = x0.sb; io.x0_sc = x0.sc; io.x0_sl = x0.sl;
@@ -195,7 +204,7 @@ static int run_conv(const ConvLayer& L, const float* base, const Act& x0, const 
   if (res != nullptr) { io.res = res->p; io.res_sb = res->sb; io.res_sc = res->sc; io.res_sl = res->sl; }
   io.y = y; io.y_sb = y_sb; io.y_sc = y_sc; io.y_sl = y_sl;
   io.batch = rows;
-  return tconv_forward(&L.d, &io, s);
+  return io;
 }
 
 }  // namespace adx
@@ -376,8 +385,20 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
     float* h = next_buf();
     Act res = x0;  // identity residual (cin == cout, never a concat)
     int r = ADX_OK, fork = -1;
+    if (B.has_r && u->side_state != 1) {
+      // R(x) and block[0] read the same input and nothing of each other: ONE launch where both run on the short-K
+      // kernel (tconv_hs_forward_pair), two otherwise
+      float* rb = next_buf();
+      const adx_tconv_io io_a = make_io(B.a, base, x0, x1, tb + B.tb_off, u->sum_c, nullptr, h, (int64_t)B.cout * B.len, B.len, 1, rows);
+      const adx_tconv_io io_r = make_io(B.r, base, x0, x1, nullptr, 0, nullptr, rb, (int64_t)B.cout * B.len, B.len, 1, rows);
+      r = tconv_hs_forward_pair(&B.a.d, &io_a, &B.r.d, &io_r, s);
+      if (r != ADX_OK) return r;
+      res = dense(rb, B.cout, B.len);
+      const Act hin2 = dense(h, B.cout, B.len);
+      return run_conv(B.b, base, hin2, nullptr, nullptr, 0, &res, dst, (int64_t)B.cout * B.len, B.len, 1, rows, s);
+    }
     if (B.has_r) {
-      // R(x) beside block[0]: fork after the producer of x0, join before block[1] (whose epilogue adds R(x))
+      // opt-in side stream (ADX_UNET_SIDE=1): R(x) beside block[0], fork after the producer of x0, join before block[1]
       float* rb = next_buf();
       hipStream_t rs = s;
       if (u->side_state == 1 && n_fork < 16) {
