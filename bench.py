@@ -514,6 +514,8 @@ def main():
         try:
             train = train_leg(dev, world)
         except Exception as e:   # the headline sampling metric must survive a failure of the secondary leg
+            if world > 1:
+                raise            # ... but not at the price of a hang: the other ranks are inside this leg's collectives
             train = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
