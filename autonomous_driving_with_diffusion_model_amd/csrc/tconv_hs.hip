@@ -390,11 +390,8 @@ struct HsdPair {
 };
 
 template <int PF, bool UT>
-__global__ void __launch_bounds__(256) tconv_hsd_kernel(const HsdPair pr) {
+__device__ __forceinline__ void tconv_hsd_body(const HsdArgs& da, const int bid) {
   constexpr int NT = 256;
-  const bool second = (int)blockIdx.x >= pr.n_a;                 // wave-uniform
-  const HsdArgs& da = second ? pr.b : pr.a;
-  const int bid = second ? (int)blockIdx.x - pr.n_a : (int)blockIdx.x;
   const HsArgs& ha = da.h;
   const TConvArgs& a = ha.t;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -591,6 +588,19 @@ __global__ void __launch_bounds__(256) tconv_hsd_kernel(const HsdPair pr) {
   ADX_TSTAMP(8);
 }
 
+template <int PF, bool UT>
+__global__ void __launch_bounds__(256) tconv_hsd_kernel(const HsdArgs da) {
+  tconv_hsd_body<PF, UT>(da, (int)blockIdx.x);
+}
+
+// the paired form: two bodies behind one wave-uniform branch, so that a workgroup loads only ITS argument block (selecting
+// between the two blocks field by field doubled the kernel-argument loads of every launch: +1 us each, measured)
+template <int PF, bool UT>
+__global__ void __launch_bounds__(256) tconv_hsd_pair_kernel(const HsdPair pr) {
+  if ((int)blockIdx.x < pr.n_a) tconv_hsd_body<PF, UT>(pr.a, (int)blockIdx.x);
+  else tconv_hsd_body<PF, UT>(pr.b, (int)blockIdx.x - pr.n_a);
+}
+
 // weight image of the short-K variant: [cout_pad32 / 16][nsteps][2 planes][64 lanes][8 halfs]; element j of lane ln at
 // `step` is W[n = 16 tile + (ln & 15)][flattened cell kc = 4 step + (ln >> 4): tap = kc / ncell, ci = 8 (kc % ncell) + j]
 __global__ void tconv_hsd_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ packed, int layout, int flip,
@@ -782,7 +792,7 @@ static bool hsd_prepare(const adx_tconv_desc* d, const HsArgs& ha, const HsTile&
   return true;
 }
 
-static int hsd_launch(const HsdPair& pr, int grid, size_t lds, hipStream_t s) {
+static int hsd_launch(const HsdArgs& da, int grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_hsd_kernel<6, true>),
@@ -791,8 +801,23 @@ static int hsd_launch(const HsdPair& pr, int grid, size_t lds, hipStream_t s) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     attr_set = true;
   }
-  if (pr.a.log2_ncell >= 2) tconv_hsd_kernel<6, true><<<dim3(grid), dim3(256), lds, s>>>(pr);
-  else tconv_hsd_kernel<6, false><<<dim3(grid), dim3(256), lds, s>>>(pr);
+  if (da.log2_ncell >= 2) tconv_hsd_kernel<6, true><<<dim3(grid), dim3(256), lds, s>>>(da);
+  else tconv_hsd_kernel<6, false><<<dim3(grid), dim3(256), lds, s>>>(da);
+  ADX_LAUNCH_CHECK();
+  return ADX_OK;
+}
+
+static int hsd_launch_pair(const HsdPair& pr, int grid, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_hsd_pair_kernel<6, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_hsd_pair_kernel<6, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    attr_set = true;
+  }
+  if (pr.a.log2_ncell >= 2) tconv_hsd_pair_kernel<6, true><<<dim3(grid), dim3(256), lds, s>>>(pr);
+  else tconv_hsd_pair_kernel<6, false><<<dim3(grid), dim3(256), lds, s>>>(pr);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
 }
@@ -844,11 +869,7 @@ int tconv_hs_forward(const adx_tconv_desc* d, const adx_tconv_io* io, hipStream_
     HsdArgs da;
     size_t lds;
     int grid_d;
-    if (hsd_prepare(d, ha, t, &da, &lds, &grid_d)) {
-      HsdPair pr;
-      pr.a = da; pr.b = da; pr.n_a = grid_d;
-      return hsd_launch(pr, grid_d, lds, s);
-    }
+    if (hsd_prepare(d, ha, t, &da, &lds, &grid_d)) return hsd_launch(da, grid_d, lds, s);
   }
   const int grid = ceil_div(io->batch, t.bt) * t.ntiles;
   // a grid that fits the chip one workgroup per CU must not be packed two per CU (the dispatcher does that with
@@ -878,7 +899,7 @@ int tconv_hs_forward_pair(const adx_tconv_desc* da, const adx_tconv_io* ioa, con
       hs_prepare(db, iob, &tb, &hb) == ADX_OK && hsd_prepare(da, ha, ta, &pr.a, &la, &ga) &&
       hsd_prepare(db, hb, tb, &pr.b, &lb, &gb) && (pr.a.log2_ncell >= 2) == (pr.b.log2_ncell >= 2)) {
     pr.n_a = ga;
-    return hsd_launch(pr, ga + gb, la > lb ? la : lb, s);
+    return hsd_launch_pair(pr, ga + gb, la > lb ? la : lb, s);
   }
   int rc = tconv_forward(da, ioa, s);
   if (rc == ADX_OK) rc = tconv_forward(db, iob, s);

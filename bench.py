@@ -408,6 +408,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--no-deployed", action="store_true")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -542,7 +543,7 @@ def main():
         if not args.no_roofline:
             res["roofline"] = conv2d_roofline(dev)
             res["roofline_tconv"] = tconv_roofline(None, dev)
-        if world == 1:
+        if world == 1 and not args.no_deployed:
             try:
                 res["deployed_b1_h16"] = deployed_leg(dev)
             except Exception as e:
