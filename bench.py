@@ -357,7 +357,7 @@ def launch_ranks(n: int) -> int:
     import socket
     import subprocess
     have = torch.cuda.device_count()          # counts devices without initialising HIP on this image
-    if have < n and "--launch-check" not in sys.argv:
+    if have < n and "--launch-check" not in sys.argv and os.environ.get("ADX_BENCH_SAME_DEVICE") != "1":
         print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
         return 2
     with socket.socket() as so:
@@ -422,11 +422,25 @@ def main():
         sys.exit(2)
     if args.launch_check:
         return launch_check(world, rank)
+    # the JSON line must be the ONLY thing on stdout: native libraries (gloo, RCCL with NCCL_DEBUG, the model's channel table)
+    # write to file descriptor 1 behind Python's back, so fd 1 is pointed at stderr for the run and the line goes to the saved fd
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    # Test hook for boxes with ONE GPU (RCCL refuses two ranks on one device): ADX_BENCH_SAME_DEVICE=1 puts every rank on
+    # cuda:0 and uses gloo for the collectives, so the multi-rank flow (launcher, DataParallel, bucketed all-reduce from
+    # autograd hooks, max-over-ranks timing) runs end to end on the real kernels.  The numbers of such a run mean nothing.
+    same_device = os.environ.get("ADX_BENCH_SAME_DEVICE") == "1"
+    if same_device:
+        local = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if same_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         world = dist.get_world_size()           # what RCCL itself reports is what goes into n_gpus
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -551,7 +565,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
             res["speedup_vs_cpu_baseline"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
-        print(json.dumps(res))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
     if world > 1:
         torch.distributed.destroy_process_group()
 
