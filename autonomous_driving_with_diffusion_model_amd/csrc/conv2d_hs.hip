@@ -1123,6 +1123,9 @@ int conv2d_hs_launch(const ConvSpec& L, Conv2dArgs a, hipStream_t s) {
       // random data paces all of them): short K loops take the small tile (better tail balance), long ones the
       // 8-wave tiles that move fewer operand bytes per MFMA.
       int mode = a.Cin < 256 ? 0 : (a.OH > 8 ? 1 : (a.Cout % 128 == 0 ? 2 : 0));
+      // small batches (the deployed case: one camera frame per tick): the 8-wave tiles leave most of the chip idle (512->512
+      // @8x29 at B = 1: four workgroups); the 4-wave tile doubles the workgroup count
+      if ((long)a.N * ceil_div(a.OH, 8) * ceil_div(a.OW, kTileW) * (a.Cout / kHsCout) <= 256) mode = 0;
       if (mode_env >= 0 && !(mode_env == 2 && a.Cout % 128 != 0)) mode = mode_env;
       return mode == 1 ? hs3x3_launch<1>(a, s) : (mode == 2 ? hs3x3_launch<2>(a, s) : hs3x3_launch<0>(a, s));
     }
