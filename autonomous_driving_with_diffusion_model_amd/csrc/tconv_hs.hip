@@ -163,35 +163,47 @@ template <int NW, int TILE>
 __device__ __forceinline__ void hs_epilogue4(const TConvArgs& a, const float* P, int pc, int ptile, int tid, int nt,
                                              int b0) {
   if (tid >= TILE / 4) return;
+  // four consecutive elements of the [sample][channel][pos] tile: with lout >= 4 they are 4 positions of ONE channel;
+  // with lout == 2 (the 512-channel level at horizon 16) they are 2 positions of channel cA and 2 of cA + 1, which lie in
+  // the same GroupNorm group and, in a plain [B][C][L] tensor, still form one 16-byte run
   const int e0 = 4 * tid;
+  const bool two = a.lout == 2;
   const int l0 = e0 & (a.lout - 1);
-  const int c = nt * a.ct + ((e0 >> a.log2_lout) & (a.ct - 1));
+  const int cA = nt * a.ct + ((e0 >> a.log2_lout) & (a.ct - 1));
+  const int cB = two ? cA + 1 : cA;
   const int b = b0 + (e0 >> (a.log2_lout + a.log2_ct));
-  const bool live = b < a.io.batch && c < a.cout;
+  const bool live = b < a.io.batch && cA < a.cout;
+  auto ch_of = [&](int k) { return (two && k >= 2) ? cB : cA; };
+  auto l_of = [&](int k) { return two ? (k & 1) : l0 + k; };
   // the loads of the epilogue first: they land while the partial tiles are summed
-  float bias = 0.f, gm = 1.f, be = 0.f, tb = 0.f;
+  float biasA = 0.f, biasB = 0.f, gmA = 1.f, gmB = 1.f, beA = 0.f, beB = 0.f, tbA = 0.f, tbB = 0.f;
   f32x4 rs = f32x4{0.f, 0.f, 0.f, 0.f};
   if (live) {
-    if (a.io.bias != nullptr) bias = a.io.bias[c];
-    if (a.groups > 0) { gm = a.io.gamma[c]; be = a.io.beta[c]; }
-    if (a.io.tbias != nullptr) tb = a.io.tbias[(int64_t)b * a.io.tbias_stride + c];
+    if (a.io.bias != nullptr) { biasA = a.io.bias[cA]; biasB = a.io.bias[cB]; }
+    if (a.groups > 0) { gmA = a.io.gamma[cA]; beA = a.io.beta[cA]; gmB = a.io.gamma[cB]; beB = a.io.beta[cB]; }
+    if (a.io.tbias != nullptr) {
+      tbA = a.io.tbias[(int64_t)b * a.io.tbias_stride + cA];
+      tbB = a.io.tbias[(int64_t)b * a.io.tbias_stride + cB];
+    }
     if (a.io.res != nullptr) {
-      const float* rp = a.io.res + (int64_t)b * a.io.res_sb + (int64_t)c * a.io.res_sc + (int64_t)l0 * a.io.res_sl;
-      if (a.io.res_sl == 1 && ((a.io.res_sb | a.io.res_sc) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.io.res) & 15) == 0) {
-        rs = *reinterpret_cast<const f32x4*>(rp);
+      const float* rb = a.io.res + (int64_t)b * a.io.res_sb;
+      const bool run = a.io.res_sl == 1 && a.io.res_sc == a.lout && (a.io.res_sb & 3) == 0 &&
+                       (reinterpret_cast<uintptr_t>(a.io.res) & 15) == 0;        // 4 elements = one aligned 16-byte run
+      if (run) {
+        rs = *reinterpret_cast<const f32x4*>(rb + (int64_t)cA * a.lout + l0);
       } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) rs[q] = rp[(int64_t)q * a.io.res_sl];
+        for (int q = 0; q < 4; ++q) rs[q] = rb[(int64_t)ch_of(q) * a.io.res_sc + (int64_t)l_of(q) * a.io.res_sl];
       }
     }
   }
-  const float* pp = P + (e0 >> a.log2_lout) * pc + l0;     // line (sample, channel) of the padded partial tile
+  const float* pp = P + (e0 >> a.log2_lout) * pc + l0;     // line (sample, channel) of the partial tile (pc == lout when lout < 8)
   f32x4 v = *reinterpret_cast<const f32x4*>(pp);
 #pragma unroll
   for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4*>(pp + w * ptile);   // fixed order: deterministic
-  v += bias;
-  if (a.io.pre != nullptr && live)
-    *reinterpret_cast<f32x4*>(a.io.pre + ((int64_t)b * a.cout + c) * a.lout + l0) = v;
+  v += f32x4{biasA, biasA, two ? biasB : biasA, two ? biasB : biasA};
+  if (a.io.pre != nullptr && live)          // dense [B][cout][lout]: the four elements are contiguous in both cases
+    *reinterpret_cast<f32x4*>(a.io.pre + ((int64_t)b * a.cout + cA) * a.lout + l0) = v;
   ADX_TSTAMP(5);
   f32x4 o = v;
   if (a.groups > 0) {
@@ -202,24 +214,27 @@ __device__ __forceinline__ void hs_epilogue4(const TConvArgs& a, const float* P,
     const float q = seg_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]), n >> 2);
     const float rstd = 1.0f / sqrtf(q * inv_n + a.eps);
     if (a.io.stats != nullptr && live && (e0 & (n - 1)) == 0) {
-      float* st = a.io.stats + ((int64_t)b * a.groups + c / a.cg) * 2;
+      float* st = a.io.stats + ((int64_t)b * a.groups + cA / a.cg) * 2;
       st[0] = mean;
       st[1] = rstd;
     }
-    const float sc = rstd * gm;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = mish_fast(d[k] * sc + be);
+    const float scA = rstd * gmA, scB = rstd * gmB;
+    o[0] = mish_fast(d[0] * scA + beA);
+    o[1] = mish_fast(d[1] * scA + beA);
+    o[2] = mish_fast(d[2] * (two ? scB : scA) + (two ? beB : beA));
+    o[3] = mish_fast(d[3] * (two ? scB : scA) + (two ? beB : beA));
   }
   ADX_TSTAMP(7);
   if (!live) return;
-  o += tb;
+  o += f32x4{tbA, tbA, two ? tbB : tbA, two ? tbB : tbA};
   o += rs;
-  float* yp = a.io.y + (int64_t)b * a.io.y_sb + (int64_t)c * a.io.y_sc + (int64_t)l0 * a.io.y_sl;
-  if (a.io.y_sl == 1 && ((a.io.y_sb | a.io.y_sc) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.io.y) & 15) == 0) {
-    *reinterpret_cast<f32x4*>(yp) = o;
+  float* yb = a.io.y + (int64_t)b * a.io.y_sb;
+  const bool run = a.io.y_sl == 1 && a.io.y_sc == a.lout && (a.io.y_sb & 3) == 0 && (reinterpret_cast<uintptr_t>(a.io.y) & 15) == 0;
+  if (run) {
+    *reinterpret_cast<f32x4*>(yb + (int64_t)cA * a.lout + l0) = o;
   } else {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) yp[(int64_t)k * a.io.y_sl] = o[k];
+    for (int k = 0; k < 4; ++k) yb[(int64_t)ch_of(k) * a.io.y_sc + (int64_t)l_of(k) * a.io.y_sl] = o[k];
   }
 }
 
@@ -848,7 +863,7 @@ static int hs_prepare(const adx_tconv_desc* d, const adx_tconv_io* io, HsTile* t
   ha.nrows = t.nrows;
   ha.vec_stage = a.dense && t.bt * (d->lin / 4) * (t.ck / 8) >= 256;
   const int n_gn = a.cg * d->lout;
-  ha.fast_epi = d->lout >= 4 && (d->groups == 0 || (n_gn >= 64 && n_gn <= 256));
+  ha.fast_epi = d->lout >= 2 && (d->groups == 0 || (n_gn >= 64 && n_gn <= 256)) && (d->lout >= 4 || d->cout % 2 == 0);
   ha.pc = (ha.fast_epi && d->lout >= 8) ? d->lout + 4 : d->lout;     // (lout + 4) / 4 is odd for lout = 8, 16, 32
   ha.ptile = t.bt * t.ct * ha.pc;
   ha.log2_lin = ilog2_exact_hs(d->lin);
