@@ -30,7 +30,8 @@ class TConvIO(C.Structure):
                 ("packed_w", vp), ("bias", vp), ("gamma", vp), ("beta", vp),
                 ("tbias", vp), ("tbias_stride", i64),
                 ("res", vp), ("res_sb", i64), ("res_sc", i64), ("res_sl", i64),
-                ("y", vp), ("y_sb", i64), ("y_sc", i64), ("y_sl", i64), ("batch", i32), ("pre", vp), ("stats", vp)]
+                ("y", vp), ("y_sb", i64), ("y_sc", i64), ("y_sl", i64), ("batch", i32), ("pre", vp), ("stats", vp),
+                ("scratch", vp), ("scratch_floats", i64)]
 
 
 class EmbedWeights(C.Structure):

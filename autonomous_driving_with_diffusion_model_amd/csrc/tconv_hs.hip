@@ -47,6 +47,12 @@ struct HsArgs {
                         // 16-byte accesses of 32 lanes (one channel each) bank-conflict free (fast epilogue only)
   int ptile;            // floats per partial tile = bt * ct * pc
   int log2_lin, log2_nrows;
+  // split of the reduction over workgroups (tiny batches: the grid of a 512-channel layer at B = 1 is 8 workgroups, each
+  // streaming a 655 KB slab through one CU).  ksplit workgroups per (row tile, channel slab) take cper input channels each
+  // and write their partial tile to `part`; tconv_hs_reduce_kernel sums them in a fixed order and runs the epilogue.  The
+  // ordering between the two is the kernel boundary: no fences, no counters, nothing to get wrong.
+  int ksplit, cper;
+  float* part;
 };
 
 __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
@@ -159,9 +165,9 @@ __device__ __forceinline__ float mish_fast(float x) {
 // Fused epilogue on the summed tile, four consecutive positions of one (sample, channel) per thread: no barrier, the
 // GroupNorm statistics are segment sums inside a wave (a group = cg * lout / 4 consecutive lanes, 16 / 32 / 64).
 // Valid when lout >= 4 and (no GroupNorm or 64 <= cg * lout <= 256); other geometries use tconv_epilogue.
-template <int NW, int TILE>
+template <int NW, int TILE>      // NW = number of partial tiles at P (compile time), or 0: `nparts` of them (run time)
 __device__ __forceinline__ void hs_epilogue4(const TConvArgs& a, const float* P, int pc, int ptile, int tid, int nt,
-                                             int b0) {
+                                             int b0, int nparts = 0) {
   if (tid >= TILE / 4) return;
   // four consecutive elements of the [sample][channel][pos] tile: with lout >= 4 they are 4 positions of ONE channel;
   // with lout == 2 (the 512-channel level at horizon 16) they are 2 positions of channel cA and 2 of cA + 1, which lie in
@@ -199,8 +205,12 @@ __device__ __forceinline__ void hs_epilogue4(const TConvArgs& a, const float* P,
   }
   const float* pp = P + (e0 >> a.log2_lout) * pc + l0;     // line (sample, channel) of the partial tile (pc == lout when lout < 8)
   f32x4 v = *reinterpret_cast<const f32x4*>(pp);
+  if (NW > 0) {
 #pragma unroll
-  for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4*>(pp + w * ptile);   // fixed order: deterministic
+    for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4*>(pp + w * ptile);   // fixed order: deterministic
+  } else {
+    for (int w = 1; w < nparts; ++w) v += *reinterpret_cast<const f32x4*>(pp + (size_t)w * ptile);
+  }
   v += f32x4{biasA, biasA, two ? biasB : biasA, two ? biasB : biasA};
   if (a.io.pre != nullptr && live)          // dense [B][cout][lout]: the four elements are contiguous in both cases
     *reinterpret_cast<f32x4*>(a.io.pre + ((int64_t)b * a.cout + cA) * a.lout + l0) = v;
@@ -248,7 +258,12 @@ __global__ void __launch_bounds__(64 * NW) tconv_hs_kernel(const HsArgs ha) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nt = blockIdx.x % a.ntiles;   // blocks b, b + 8 share an XCD: with ntiles | 8 or 8 | ntiles one XCD's L2 serves one weight slab
-  const int b0 = (blockIdx.x / a.ntiles) * a.bt;
+  const int rest = blockIdx.x / a.ntiles;
+  const int kpart = ha.ksplit > 1 ? rest % ha.ksplit : 0;
+  const int rowtile = ha.ksplit > 1 ? rest / ha.ksplit : rest;
+  const int b0 = rowtile * a.bt;
+  const int cbeg = ha.ksplit > 1 ? kpart * ha.cper : 0;
+  const int cend = ha.ksplit > 1 ? min(a.cin_pad, cbeg + ha.cper) : a.cin_pad;
   const int r = lane & 31, kg = lane >> 5;
   const int bl = r >> a.log2_lout, l = r & (a.lout - 1);
   const int pitch = ha.pitch16;
@@ -266,8 +281,8 @@ __global__ void __launch_bounds__(64 * NW) tconv_hs_kernel(const HsArgs ha) {
   const size_t tile_stride = (size_t)a.nkb * 128;
   u32x4 wq[PF][NF][2];
 
-  for (int c0 = 0; c0 < a.cin_pad; c0 += a.ck) {
-    const int ckc = min(a.ck, a.cin_pad - c0);
+  for (int c0 = cbeg; c0 < cend; c0 += a.ck) {
+    const int ckc = min(a.ck, cend - c0);
     const int ncbc = ckc >> 4;
     const int nblk = a.taps * ncbc;
     const int nbw = nblk > wave ? (nblk - wave + NW - 1) / NW : 0;   // K-steps of this wave in this chunk
@@ -289,7 +304,7 @@ __global__ void __launch_bounds__(64 * NW) tconv_hs_kernel(const HsArgs ha) {
 #pragma unroll
     for (int s = 0; s < PF; ++s) issue(wq[s]);     // in flight while the activations are staged
     ADX_TSTAMP(9);
-    if (c0 > 0) __syncthreads();
+    if (c0 > cbeg) __syncthreads();
     hs_stage<NT>(a, ha, cells, c0, ckc, b0, tid);
     ADX_TSTAMP(11);
     __syncthreads();
@@ -370,12 +385,35 @@ __global__ void __launch_bounds__(64 * NW) tconv_hs_kernel(const HsArgs ha) {
   }
   __syncthreads();
   ADX_TSTAMP(4);
+  if (ha.ksplit > 1) {
+    // this workgroup's share of the reduction: the 8 waves' partial tiles summed, written in the (padded) tile layout
+    if (tid < TILE / 4) {
+      const int e0 = 4 * tid;
+      const int off = (e0 >> a.log2_lout) * ha.pc + (e0 & (a.lout - 1));
+      f32x4 v = *reinterpret_cast<const f32x4*>(smem + off);
+#pragma unroll
+      for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4*>(smem + w * ha.ptile + off);
+      float* dst = ha.part + ((size_t)(rowtile * a.ntiles + nt) * ha.ksplit + kpart) * ha.ptile + off;
+      *reinterpret_cast<f32x4*>(dst) = v;
+    }
+    return;
+  }
   if (ha.fast_epi) {
     hs_epilogue4<NW, TILE>(a, smem, ha.pc, ha.ptile, tid, nt, b0);
     ADX_TSTAMP(8);
   } else {
     tconv_epilogue<NT, NW, TILE>(a, smem, tid, lane, wave, nt, b0);
   }
+}
+
+// second half of a split reduction (HsArgs::ksplit > 1): one workgroup per (row tile, channel slab)
+template <int NF>
+__global__ void __launch_bounds__(256 * NF) tconv_hs_reduce_kernel(const HsArgs ha) {
+  constexpr int TILE = 32 * 32 * NF;
+  const TConvArgs& a = ha.t;
+  const int nt = blockIdx.x % a.ntiles, rowtile = blockIdx.x / a.ntiles;
+  const float* P = ha.part + (size_t)blockIdx.x * ha.ksplit * ha.ptile;
+  hs_epilogue4<0, TILE>(a, P, ha.pc, ha.ptile, threadIdx.x, nt, rowtile * a.bt, ha.ksplit);
 }
 
 // ---- short-K variant: no K split --------------------------------------------------------------------------------
@@ -872,6 +910,7 @@ static int hs_prepare(const adx_tconv_desc* d, const adx_tconv_io* io, HsTile* t
   const size_t epi_bytes = ((size_t)t.nw * ha.ptile + 2 * 16 * t.nf) * sizeof(float);
   if (epi_bytes > t.lds_bytes) t.lds_bytes = epi_bytes;
   ADX_REQUIRE(t.lds_bytes <= kMaxHsLds, "tconv_hs: LDS tile of %zu bytes exceeds %zu", t.lds_bytes, kMaxHsLds);
+  ha.ksplit = 1; ha.cper = a.cin_pad; ha.part = nullptr;
   return ADX_OK;
 }
 
@@ -891,6 +930,30 @@ int tconv_hs_forward(const adx_tconv_desc* d, const adx_tconv_io* io, hipStream_
   // 128 workgroups on 256 CUs): the two would share one CU's L2->L1 fill rate, which is what bounds the K loop
   static const size_t min_lds = [] { const char* e = getenv("ADX_TCONV_MIN_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();   // measured: no gain, off by default
   if (grid <= 256 && t.lds_bytes < min_lds) t.lds_bytes = min_lds;
+  // tiny batches: split the input channels over up to 16 workgroups per (row tile, slab) + one reduce launch
+  static const bool split_on = [] { const char* e = getenv("ADX_TCONV_NO_KSPLIT"); return !(e != nullptr && e[0] == '1'); }();
+  const TConvArgs& a = ha.t;
+  // Measured at 2 rows, H = 16 (tools/bench_tconv.py, SCRATCH=1 vs 0): 512->512 x5 15.1 -> 10.9 us, 1024->256 x5 20.2 -> 9.6,
+  // 1024->256 x1 13.4 -> 8.8; but 512->128 x5 9.4 -> 10.5, 512->128 x1 5.7 -> 9.9, 256->256 x3 7.1 -> 8.5: the second launch
+  // costs ~4 us, so only reductions of >= 256 K-steps per workgroup (x2 fragments at 64 channels/group) or >= 1024 staged
+  // channels are split.
+  const bool worth = a.taps * a.ncb * t.nf >= 256 || a.cin_pad >= 1024;
+  if (split_on && worth && io->scratch != nullptr && ha.fast_epi && grid <= 32 && a.ncb >= 8) {
+    int S = 16;
+    while (S > 1 && (a.ncb % S != 0 || a.ncb / S < 2 || (size_t)grid * S * ha.ptile > (size_t)io->scratch_floats || grid * S > 512)) S >>= 1;
+    if (S > 1) {
+      ha.ksplit = S;
+      ha.cper = (a.ncb / S) * 16;
+      ha.part = io->scratch;
+      // the staged chunk now holds cper channels at most
+      rc = t.nf == 2 ? hs_launch<2, 8, 4>(ha, grid * S, t.lds_bytes, s) : hs_launch<1, 8, 6>(ha, grid * S, t.lds_bytes, s);
+      if (rc != ADX_OK) return rc;
+      if (t.nf == 2) tconv_hs_reduce_kernel<2><<<dim3(grid), dim3(512), 0, s>>>(ha);
+      else tconv_hs_reduce_kernel<1><<<dim3(grid), dim3(256), 0, s>>>(ha);
+      ADX_LAUNCH_CHECK();
+      return ADX_OK;
+    }
+  }
   return t.nf == 2 ? hs_launch<2, 8, 4>(ha, grid, t.lds_bytes, s) : hs_launch<1, 8, 6>(ha, grid, t.lds_bytes, s);
 }
 

@@ -186,6 +186,11 @@ static Act dense(float* p, int c, int len) { return Act{p, (int64_t)c * len, (in
 static adx_tconv_io make_io(const ConvLayer& L, const float* base, const Act& x0, const Act* x1, const float* tbias,
                             int64_t tb_stride, const Act* res, float* y, int64_t y_sb, int64_t y_sc, int64_t y_sl, int rows);
 
+// Split-reduction scratch of the forward call being enqueued on this thread (a region of ITS workspace; consumed in stream
+// order by the launches it is handed to, so two calls on different streams never share it).
+constexpr size_t kSplitScratchFloats = (size_t)2 << 20;
+static thread_local float* t_split_scratch = nullptr;
+
 static int run_conv(const ConvLayer& L, const float* base, const Act& x0, const Act* x1, const float* tbias,
                     int64_t tb_stride, const Act* res, float* y, int64_t y_sb, int64_t y_sc, int64_t y_sl, int rows,
                     hipStream_t s) {
@@ -204,6 +209,8 @@ static adx_tconv_io make_io(const ConvLayer& L, const float* base, const Act& x0
   if (res != nullptr) { io.res = res->p; io.res_sb = res->sb; io.res_sc = res->sc; io.res_sl = res->sl; }
   io.y = y; io.y_sb = y_sb; io.y_sc = y_sc; io.y_sl = y_sl;
   io.batch = rows;
+  io.scratch = t_split_scratch;
+  io.scratch_floats = t_split_scratch != nullptr ? (int64_t)kSplitScratchFloats : 0;
   return io;
 }
 
@@ -304,6 +311,7 @@ size_t adx_unet_workspace_bytes(const adx_unet* u, int32_t rows) {
   const int dim = u->cfg.dim;
   size_t f = align64((size_t)rows * dim) + align64((size_t)rows * 2 * dim) + align64((size_t)rows * u->sum_c);
   f += act_floats(u, rows) * (size_t)(kRing + u->n_levels);
+  f += kSplitScratchFloats;
   return f * sizeof(float);
 }
 
@@ -336,6 +344,10 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
   for (auto& b : bufs) b = take(af);
   std::vector<float*> skips(u->n_levels);
   for (auto& p : skips) p = take(af);
+  struct ScratchScope {   // handed to every conv of this call through make_io
+    explicit ScratchScope(float* p) { t_split_scratch = p; }
+    ~ScratchScope() { t_split_scratch = nullptr; }
+  } scratch_scope(take(kSplitScratchFloats));
 
   adx_embed_weights ew;
   memset(&ew, 0, sizeof(ew));

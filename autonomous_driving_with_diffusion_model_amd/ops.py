@@ -19,8 +19,11 @@ def tconv(x0: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
           kind: int = 0, stride: int = 1, pad: int = 0, gn_weight: Optional[torch.Tensor] = None,
           gn_bias: Optional[torch.Tensor] = None, groups: int = 0, eps: float = 1e-5,
           tbias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
-          out: Optional[torch.Tensor] = None) -> torch.Tensor:
+          out: Optional[torch.Tensor] = None, scratch: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Temporal conv (+bias) [-> GroupNorm(groups) -> Mish] [+ tbias[:, :, None]] [+ res].
+
+    scratch: optional float32 device buffer (adx_tconv_io::scratch) that allows a tiny-batch launch to split its
+    reduction over more workgroups.
 
     x0/x1: [B, C, L] views with arbitrary strides (x1 is concatenated after x0 along C);
     weight: Conv1d [Cout, Cin, k] (kind 0) or ConvTranspose1d [Cin, Cout, k] (kind 1)."""
@@ -61,6 +64,9 @@ def tconv(x0: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     io.y = y.data_ptr()
     io.y_sb, io.y_sc, io.y_sl = _strides3(y)
     io.batch = B
+    if scratch is not None:
+        assert scratch.is_cuda and scratch.dtype == torch.float32 and scratch.is_contiguous()
+        io.scratch, io.scratch_floats = scratch.data_ptr(), scratch.numel()
     L.check(L.lib().adx_tconv_forward(C.byref(d), C.byref(io), s), "adx_tconv_forward")
     return y
 

@@ -79,6 +79,9 @@ typedef struct adx_tconv_io {
   /* training only (NULL otherwise): conv+bias before GroupNorm, dense [B][cout][lout], and the
    * per-(sample, group) statistics [B][groups][2] = (mean, rstd) that the backward pass reuses */
   float* pre; float* stats;
+  /* optional device scratch (scratch_floats floats, contents irrelevant): lets a launch whose grid would occupy a few CUs
+   * only (tiny batches) split its reduction over more workgroups and finish with a reduce launch.  NULL: never split. */
+  float* scratch; int64_t scratch_floats;
 } adx_tconv_io;
 
 /* Conv (+bias) [-> GroupNorm -> Mish] [+ time bias] [+ residual], fp32 MFMA.

@@ -50,6 +50,32 @@ def test_conv1d_block(c0, c1, cout, L, B):
     close(y.cpu(), ref + tb[:, :, None] + res, 2e-5)
 
 
+@pytest.mark.parametrize("c0,c1,cout,L,B", [(512, 0, 512, 2, 1), (512, 0, 512, 2, 2), (512, 0, 512, 4, 1), (512, 512, 256, 2, 2),
+                                            (256, 256, 128, 4, 1), (256, 0, 512, 2, 2), (512, 0, 512, 4, 3), (256, 0, 256, 4, 2)])
+def test_conv1d_block_split_reduction_tiny_batch(c0, c1, cout, L, B):
+    """Deployed batch sizes (B = 1: 1 or 2 UNet rows, H = 16): with a scratch buffer the K-split kernel spreads the
+    input channels over more workgroups and a reduce launch runs the epilogue (tconv_hs.hip, HsArgs::ksplit).  Same
+    oracle, same bar as the unsplit launch; the two launches' results may differ by summation order only."""
+    name = f"blks.{c0}.{c1}.{cout}.{L}.{B}"
+    x0 = uni(name + ".x0", (B, c0, L))
+    x1 = uni(name + ".x1", (B, c1, L)) if c1 else None
+    cin = c0 + c1
+    w = uni(name + ".w", (cout, cin, 5), lo=-(3.0 / (5 * cin)) ** 0.5, hi=(3.0 / (5 * cin)) ** 0.5)
+    b, g, be = uni(name + ".b", (cout,), lo=-.1, hi=.1), uni(name + ".g", (cout,), lo=.9, hi=1.1), uni(name + ".be", (cout,), lo=-.1, hi=.1)
+    tb, res = uni(name + ".tb", (B, cout)), uni(name + ".res", (B, cout, L))
+    xin = x0 if x1 is None else torch.cat([x0, x1], 1)
+    ref = F.mish(F.group_norm(F.conv1d(xin, w, b, padding=2), 8, g, be, 1e-5)) + tb[:, :, None] + res
+    scratch = torch.full((2 << 20,), float("nan"), device=DEV)       # stale contents must never reach the output
+    kw = dict(x1=None if x1 is None else x1.to(DEV), pad=2, gn_weight=g.to(DEV), gn_bias=be.to(DEV), groups=8,
+              tbias=tb.to(DEV), res=res.to(DEV))
+    y_split = _ops().tconv(x0.to(DEV), w.to(DEV), b.to(DEV), scratch=scratch, **kw)
+    y_plain = _ops().tconv(x0.to(DEV), w.to(DEV), b.to(DEV), **kw)
+    close(y_split.cpu(), ref, 2e-5)
+    close(y_split.cpu(), y_plain.cpu(), 4e-6)
+    small = torch.full((1024,), float("nan"), device=DEV)            # too small for any split: falls back to one launch
+    assert torch.equal(_ops().tconv(x0.to(DEV), w.to(DEV), b.to(DEV), scratch=small, **kw), y_plain)
+
+
 @pytest.mark.parametrize("c,L,B", [(64, 32, 3), (128, 16, 5), (256, 8, 2), (64, 16, 4), (256, 4, 9)])
 def test_downsample(c, L, B):
     x, w, b = uni(f"dn.x.{c}", (B, c, L)), uni(f"dn.w.{c}", (c, c, 3), lo=-.1, hi=.1), uni(f"dn.b.{c}", (c,))

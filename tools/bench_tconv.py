@@ -13,6 +13,8 @@ DEV = torch.device("cuda:0")
 ROWS = int(os.environ.get("ROWS", "128"))
 EXACT = int(os.environ.get("EXACT", "0"))
 N = int(os.environ.get("N", "30"))
+SCRATCH = int(os.environ.get("SCRATCH", "1"))  # hand the launches a split-reduction scratch, as the UNet executor does
+HZ = int(os.environ.get("H", "32"))           # horizon: the layer lengths below are written for 32 and scaled
 # (kind, taps, stride, pad, c0, c1, cout, lin, lout, groups, count per forward)
 LAYERS = [(0, 5, 1, 2, 7, 0, 64, 32, 32, 8, 1), (0, 5, 1, 2, 64, 0, 64, 32, 32, 8, 4), (0, 1, 1, 0, 7, 0, 64, 32, 32, 0, 1),
           (0, 3, 2, 1, 64, 0, 64, 32, 16, 0, 1), (0, 5, 1, 2, 64, 0, 128, 16, 16, 8, 1), (0, 5, 1, 2, 128, 0, 128, 16, 16, 8, 3),
@@ -27,9 +29,12 @@ LAYERS = [(0, 5, 1, 2, 7, 0, 64, 32, 32, 8, 1), (0, 5, 1, 2, 64, 0, 64, 32, 32, 
           (0, 1, 1, 0, 128, 0, 3840, 1, 1, 0, 1)]
 lib = L.lib()
 s = L.stream_ptr(DEV)
+scratch = torch.empty(2 << 20, device=DEV) if SCRATCH else None
 tot = 0.0
 tot_w = 0.0
 for kind, taps, stride, pad, c0, c1, cout, lin, lout, groups, cnt in LAYERS:
+    if lin > 1 or lout > 1:
+        lin, lout = max(1, lin * HZ // 32), max(1, lout * HZ // 32)
     d = L.TConvDesc(kind, taps, stride, pad, c0, c1, cout, lin, lout, groups, 1e-5, 0, 0, EXACT)
     cin = c0 + c1
     w = torch.randn((cout, cin, taps) if kind == 0 else (cin, cout, taps), device=DEV) * (1.0 / (taps * cin)) ** 0.5
@@ -47,6 +52,8 @@ for kind, taps, stride, pad, c0, c1, cout, lin, lout, groups, cnt in LAYERS:
     if groups:
         io.gamma, io.beta = g.data_ptr(), be.data_ptr()
     io.y, io.y_sb, io.y_sc, io.y_sl, io.batch = y.data_ptr(), cout * lout, lout, 1, ROWS
+    if scratch is not None:
+        io.scratch, io.scratch_floats = scratch.data_ptr(), scratch.numel()
     run = lambda: L.check(lib.adx_tconv_forward(C.byref(d), C.byref(io), s))  # noqa: E731
     for _ in range(3):
         run()
