@@ -45,7 +45,7 @@ class UnetConfig(C.Structure):
 
 class UnetIO(C.Structure):
     _fields_ = [("x", vp), ("img_feature", vp), ("feat_rows", i32), ("t", vp), ("t_rows", i32), ("cond", vp),
-                ("rows", i32), ("out", vp), ("time_embed", vp)]
+                ("rows", i32), ("out", vp), ("time_embed", vp), ("x_rows", i32), ("time_bias", vp)]
 
 
 class Conv2dDesc(C.Structure):
@@ -75,6 +75,8 @@ _SIGS = {
     "adx_unet_pack": (i32, [vp, C.POINTER(vp), i32, vp, vp, vp]),
     "adx_unet_workspace_bytes": (C.c_size_t, [vp, i32]),
     "adx_unet_forward": (i32, [vp, vp, vp, C.POINTER(UnetIO), vp]),
+    "adx_unet_time_bias_width": (i32, [vp]),
+    "adx_unet_time_conditioning": (i32, [vp, vp, vp, C.POINTER(UnetIO), vp, vp, vp]),
     "adx_unet_tape_create": (i32, [C.POINTER(vp)]),
     "adx_unet_tape_destroy": (None, [vp]),
     "adx_unet_train_workspace_bytes": (C.c_size_t, [vp, i32]),

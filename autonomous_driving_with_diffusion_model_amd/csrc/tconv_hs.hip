@@ -426,6 +426,11 @@ __global__ void __launch_bounds__(256 * NF) tconv_hs_reduce_kernel(const HsArgs 
 // cells per MFMA step, so a step may straddle taps when cin < 32.  GroupNorm statistics: lane shuffles inside the wave,
 // one LDS exchange with the partner waves when a (sample, group) spans the tile's two row halves (lout = 32) or its two
 // channel halves (group width 32); two passes (mean, centred second moment), fixed summation order.
+#ifndef ADX_HSD_PF
+#define ADX_HSD_PF 6
+#endif
+constexpr int kHsdPF = ADX_HSD_PF;   // depth of the short-K kernel's weight-fragment ring
+
 struct HsdArgs {
   HsArgs h;
   int nsteps;           // MFMA steps = ceil(taps * cin_pad / 8 / 4)
@@ -848,14 +853,14 @@ static bool hsd_prepare(const adx_tconv_desc* d, const HsArgs& ha, const HsTile&
 static int hsd_launch(const HsdArgs& da, int grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_hsd_kernel<6, true>),
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_hsd_kernel<kHsdPF, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_hsd_kernel<6, false>),
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_hsd_kernel<kHsdPF, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     attr_set = true;
   }
-  if (da.log2_ncell >= 2) tconv_hsd_kernel<6, true><<<dim3(grid), dim3(256), lds, s>>>(da);
-  else tconv_hsd_kernel<6, false><<<dim3(grid), dim3(256), lds, s>>>(da);
+  if (da.log2_ncell >= 2) tconv_hsd_kernel<kHsdPF, true><<<dim3(grid), dim3(256), lds, s>>>(da);
+  else tconv_hsd_kernel<kHsdPF, false><<<dim3(grid), dim3(256), lds, s>>>(da);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
 }
@@ -863,14 +868,14 @@ static int hsd_launch(const HsdArgs& da, int grid, size_t lds, hipStream_t s) {
 static int hsd_launch_pair(const HsdPair& pr, int grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_hsd_pair_kernel<6, true>),
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_hsd_pair_kernel<kHsdPF, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_hsd_pair_kernel<6, false>),
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_hsd_pair_kernel<kHsdPF, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     attr_set = true;
   }
-  if (pr.a.log2_ncell >= 2) tconv_hsd_pair_kernel<6, true><<<dim3(grid), dim3(256), lds, s>>>(pr);
-  else tconv_hsd_pair_kernel<6, false><<<dim3(grid), dim3(256), lds, s>>>(pr);
+  if (pr.a.log2_ncell >= 2) tconv_hsd_pair_kernel<kHsdPF, true><<<dim3(grid), dim3(256), lds, s>>>(pr);
+  else tconv_hsd_pair_kernel<kHsdPF, false><<<dim3(grid), dim3(256), lds, s>>>(pr);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
 }

@@ -214,6 +214,42 @@ static adx_tconv_io make_io(const ConvLayer& L, const float* base, const Act& x0
   return io;
 }
 
+// time_embed [rows][dim], mish_cond [rows][2 dim] and the time-bias matrix tb[rows][sum_c] = all 16 block Linears at once
+// (temporal.py:206-216 + the `time_mlp` of every ResidualTemporalMapBlock, helpers.py:121-123)
+static int time_conditioning(adx_unet* u, const float* base, const adx_unet_io* io, int rows, float* te, float* mc, float* tb,
+                             hipStream_t s) {
+  const int dim = u->cfg.dim;
+  adx_embed_weights ew;
+  memset(&ew, 0, sizeof(ew));
+  ew.freqs = base + u->o_freqs;
+  ew.w1 = base + u->o_t1w; ew.b1 = base + u->o_t1b; ew.w3 = base + u->o_t3w; ew.b3 = base + u->o_t3b;
+  if (u->cfg.guidance == 1) {
+    ew.cw0 = base + u->o_c0w; ew.cb0 = base + u->o_c0b; ew.cw2 = base + u->o_c2w; ew.cb2 = base + u->o_c2b;
+  }
+  int rc = embed_forward(&ew, dim, io->t, io->t_rows, u->cfg.guidance == 1 ? io->cond : nullptr, io->img_feature,
+                         io->feat_rows, rows, te, mc, s);
+  if (rc != ADX_OK) return rc;
+  adx_tconv_io lio;
+  memset(&lio, 0, sizeof(lio));
+  lio.x0 = mc; lio.x0_sb = 2 * dim; lio.x0_sc = 1; lio.x0_sl = 0;
+  lio.packed_w = base + u->tlin.o_w; lio.bias = base + u->o_tlin_b;
+  lio.y = tb; lio.y_sb = u->sum_c; lio.y_sc = 1; lio.y_sl = 0;
+  lio.batch = rows;
+  return tconv_forward(&u->tlin.d, &lio, s);
+}
+
+static int check_conditioning_io(const adx_unet* u, const adx_unet_io* io, const char* who) {
+  const int rows = io->rows;
+  ADX_REQUIRE(io->img_feature && io->t, "%s: null tensor", who);
+  ADX_REQUIRE(io->t_rows >= 1 && rows % io->t_rows == 0 && io->feat_rows >= 1 && rows % io->feat_rows == 0,
+              "%s: rows %d must be a multiple of t_rows %d and feat_rows %d", who, rows, io->t_rows, io->feat_rows);
+  if (u->cfg.guidance != 1)
+    ADX_REQUIRE(io->t_rows == rows && io->feat_rows == rows,
+                "%s: time/img batch must equal the trajectory batch unless FREE_GUIDANCE "
+                "(the reference's torch.cat fails otherwise, temporal.py:213)", who);
+  return ADX_OK;
+}
+
 }  // namespace adx
 
 using namespace adx;
@@ -321,16 +357,17 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
     set_error("adx_unet_forward: weights were never packed (call adx_unet_pack first)");
     return ADX_ERR_STATE;
   }
-  ADX_REQUIRE(io->x && io->img_feature && io->t && io->out, "adx_unet_forward: null tensor");
+  ADX_REQUIRE(io->x && io->out, "adx_unet_forward: null tensor");
   const int rows = io->rows, dim = u->cfg.dim, H = u->cfg.horizon, D = u->cfg.transition_dim;
   ADX_REQUIRE(rows >= 1, "adx_unet_forward: rows must be >= 1");
-  ADX_REQUIRE(io->t_rows >= 1 && rows % io->t_rows == 0 && io->feat_rows >= 1 && rows % io->feat_rows == 0,
-              "adx_unet_forward: rows %d must be a multiple of t_rows %d and feat_rows %d", rows, io->t_rows,
-              io->feat_rows);
-  if (u->cfg.guidance != 1)
-    ADX_REQUIRE(io->t_rows == rows && io->feat_rows == rows,
-                "adx_unet_forward: time/img batch must equal the trajectory batch unless FREE_GUIDANCE "
-                "(the reference's torch.cat fails otherwise, temporal.py:213)");
+  if (io->time_bias == nullptr) {
+    const int rc0 = check_conditioning_io(u, io, "adx_unet_forward");
+    if (rc0 != ADX_OK) return rc0;
+  } else {
+    ADX_REQUIRE(io->time_embed == nullptr, "adx_unet_forward: with a precomputed time_bias the caller already holds time_embed");
+  }
+  const int x_rows = io->x_rows > 0 ? io->x_rows : rows;
+  ADX_REQUIRE(x_rows == rows || x_rows == 1, "adx_unet_forward: x_rows must be rows (%d) or 1, got %d", rows, x_rows);
   hipStream_t s = (hipStream_t)stream;
   const float* base = (const float*)packed;
   float* ws = (float*)workspace;
@@ -349,29 +386,17 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
     ~ScratchScope() { t_split_scratch = nullptr; }
   } scratch_scope(take(kSplitScratchFloats));
 
-  adx_embed_weights ew;
-  memset(&ew, 0, sizeof(ew));
-  ew.freqs = base + u->o_freqs;
-  ew.w1 = base + u->o_t1w; ew.b1 = base + u->o_t1b; ew.w3 = base + u->o_t3w; ew.b3 = base + u->o_t3b;
-  if (u->cfg.guidance == 1) {
-    ew.cw0 = base + u->o_c0w; ew.cb0 = base + u->o_c0b; ew.cw2 = base + u->o_c2w; ew.cb2 = base + u->o_c2b;
-  }
-  int rc = embed_forward(&ew, dim, io->t, io->t_rows, u->cfg.guidance == 1 ? io->cond : nullptr, io->img_feature,
-                         io->feat_rows, rows, te, mc, s);
-  if (rc != ADX_OK) return rc;
-  {  // all 16 block Linears at once: tb[rows][sum_c] = mc @ Wcat^T + bcat
-    adx_tconv_io lio;
-    memset(&lio, 0, sizeof(lio));
-    lio.x0 = mc; lio.x0_sb = 2 * dim; lio.x0_sc = 1; lio.x0_sl = 0;
-    lio.packed_w = base + u->tlin.o_w; lio.bias = base + u->o_tlin_b;
-    lio.y = tb; lio.y_sb = u->sum_c; lio.y_sc = 1; lio.y_sl = 0;
-    lio.batch = rows;
-    rc = tconv_forward(&u->tlin.d, &lio, s);
+  int rc = ADX_OK;
+  if (io->time_bias != nullptr) {
+    tb = const_cast<float*>(io->time_bias);     // one step's rows of adx_unet_time_conditioning's table (read only)
+  } else {
+    rc = time_conditioning(u, base, io, rows, te, mc, tb, s);
     if (rc != ADX_OK) return rc;
   }
 
   // x arrives as [rows][H][D]; the UNet works on [rows][D][H] (temporal.py:204): read with strides
-  Act cur{io->x, (int64_t)H * D, 1, (int64_t)D};
+  // x_rows == 1: every row reads the one trajectory (the CFG pair torch.cat([x, x]) of interact.py:131, never built)
+  Act cur{io->x, x_rows == rows ? (int64_t)H * D : 0, 1, (int64_t)D};
   // Six activation buffers used strictly round-robin.  A buffer is overwritten six takes after it
   // was handed out; the longest any tensor stays live is four takes (a block input is read by
   // the last conv of the block, after h and the 1x1-residual buffers of that block were taken).
@@ -490,6 +515,30 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
     ADX_CHECK_HIP(hipMemcpyAsync(io->time_embed, te, (size_t)rows * dim * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
   (void)D;
+  return ADX_OK;
+}
+
+int32_t adx_unet_time_bias_width(const adx_unet* u) { return u ? u->sum_c : 0; }
+
+int adx_unet_time_conditioning(adx_unet* u, const void* packed, void* workspace, const adx_unet_io* io, float* time_embed,
+                               float* time_bias, adx_stream stream) {
+  ADX_REQUIRE(u && packed && workspace && io && time_bias, "adx_unet_time_conditioning: null argument");
+  if (!u->packed_once) {
+    set_error("adx_unet_time_conditioning: weights were never packed (call adx_unet_pack first)");
+    return ADX_ERR_STATE;
+  }
+  const int rows = io->rows, dim = u->cfg.dim;
+  ADX_REQUIRE(rows >= 1, "adx_unet_time_conditioning: rows must be >= 1");
+  int rc = check_conditioning_io(u, io, "adx_unet_time_conditioning");
+  if (rc != ADX_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = (float*)workspace;                    // same front layout as adx_unet_forward: te, mc
+  float* te = ws;
+  float* mc = ws + align64((size_t)rows * dim);
+  rc = time_conditioning(u, (const float*)packed, io, rows, te, mc, time_bias, s);
+  if (rc != ADX_OK) return rc;
+  if (time_embed != nullptr)
+    ADX_CHECK_HIP(hipMemcpyAsync(time_embed, te, (size_t)rows * dim * sizeof(float), hipMemcpyDeviceToDevice, s));
   return ADX_OK;
 }
 

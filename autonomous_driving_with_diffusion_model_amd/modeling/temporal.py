@@ -233,15 +233,68 @@ class TemporalMapUnet(nn.Module):
         state = torch.cat([torch.zeros_like(state[:, :1]), state], dim=1)
         return torch.cat([state, action], dim=-1)
 
+    # -- sampling loops: everything that does not depend on the trajectory, once per loop -------------
+    def _workspace(self, rows: int, device):
+        nbytes = L.lib().adx_unet_workspace_bytes(self._native(), rows)
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self._ws
+
+    @torch.no_grad()
+    def time_conditioning(self, img, timesteps, cond=None, rows: Optional[int] = None) -> "TimeConditioning":
+        """The time MLP, the condition MLP and the 16 per-block time Linears (modeling/temporal.py:206-216,
+        modeling/helpers.py:121-123) for EVERY timestep of a sampling loop in one pass.
+
+        Inside the reference's loop (interact.py:128-166) they are recomputed each step from (t, target, image
+        feature), none of which changes during the loop: at one scene per tick that is 2 of ~50 dependent launches per
+        step.  `timesteps` int64 [n]; `cond` None or [rows, 2]; `rows` = rows of one step (default: cond's, else the
+        image batch).  Pass the result to `forward(..., time_cond=(tc, i))`; row-wise it equals what forward computes
+        itself (same kernels, each row independent of the batch it is in)."""
+        if self.training:
+            raise RuntimeError("time_conditioning is an inference-loop helper (eval mode)")
+        feat = self.image_feature(img)
+        dev = feat.device
+        free = self.use_cond == GuidanceType.FREE_GUIDANCE
+        cond = L.require_gpu_f32(cond, "cond") if (cond is not None and free) else None
+        if rows is None:
+            rows = cond.shape[0] if cond is not None else feat.shape[0]
+        if rows % feat.shape[0] != 0 or (cond is not None and tuple(cond.shape) != (rows, 2)):
+            raise ValueError(f"rows {rows} vs image batch {feat.shape[0]} / cond {None if cond is None else tuple(cond.shape)}")
+        ts = L.require_gpu_f32(timesteps.reshape(-1), "timesteps", torch.int64)
+        n = ts.shape[0]
+        total = n * rows
+        # row (step s, row r) of the table: t[s], cond[r], feature[r % image batch]
+        t_full = ts.repeat_interleave(rows).contiguous()
+        feat_full = feat.repeat(total // feat.shape[0], 1).contiguous()
+        cond_full = None if cond is None else cond.repeat(n, 1).contiguous()
+        self._ensure_packed(dev)
+        h = self._native()
+        width = L.lib().adx_unet_time_bias_width(h)
+        tb = torch.empty((n, rows, width), dtype=torch.float32, device=dev)
+        te = torch.empty((n, rows, self.dim), dtype=torch.float32, device=dev)
+        io = L.UnetIO()
+        io.img_feature, io.feat_rows = feat_full.data_ptr(), total
+        io.t, io.t_rows, io.cond, io.rows = t_full.data_ptr(), total, L.ptr(cond_full), total
+        L.check(L.lib().adx_unet_time_conditioning(h, self._packed.data_ptr(), self._workspace(total, dev).data_ptr(),
+                                                   C.byref(io), te.data_ptr(), tb.data_ptr(), L.stream_ptr(dev)),
+                "adx_unet_time_conditioning")
+        return TimeConditioning(tb, te, rows, self._weights_key())
+
     # -- forward ---------------------------------------------------------------------------------
-    def forward(self, x, img, time, cond=None, return_action_and_time_only=False):
-        """x [B, T, D]; img [B or 1, 3, H, W]; time int64 [B or 1]; cond None or [B, 2]."""
+    def forward(self, x, img, time, cond=None, return_action_and_time_only=False, *, time_cond=None):
+        """x [B, T, D]; img [B or 1, 3, H, W]; time int64 [B or 1]; cond None or [B, 2].
+
+        time_cond = (TimeConditioning, step index): use the loop's precomputed table instead of (img, time, cond),
+        which are then not read; x may be [1, T, D] for a table of more rows (every row reads the one trajectory: the
+        classifier-free pair of interact.py:131 without the torch.cat)."""
         if self.training:
             feat = self.perception(img)          # train-mode perception: batch-statistics BatchNorm, autograd node
             return self.unet_forward_train(x, feat, time, cond)
         x = L.require_gpu_f32(x, "x")
         if x.dim() != 3 or x.shape[1] != self.horizon or x.shape[2] != self.transition_dim:
             raise ValueError(f"x must be [B, {self.horizon}, {self.transition_dim}], got {tuple(x.shape)}")
+        if time_cond is not None:
+            return self._forward_precomputed(x, time_cond, return_action_and_time_only)
         rows = x.shape[0]
         feat = self.image_feature(img)
         time = L.require_gpu_f32(time.reshape(-1), "time", torch.int64)
@@ -257,9 +310,7 @@ class TemporalMapUnet(nn.Module):
                                "(torch.cat at modeling/temporal.py:213)")
         self._ensure_packed(x.device)
         h = self._native()
-        nbytes = L.lib().adx_unet_workspace_bytes(h, rows)
-        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != x.device:
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        self._workspace(rows, x.device)
         classifier = self.use_cond == GuidanceType.CLASSIFIER_GUIDANCE
         out_ch = 3 if classifier else self.transition_dim
         out = torch.empty((rows, self.horizon, out_ch), dtype=torch.float32, device=x.device)
@@ -270,7 +321,10 @@ class TemporalMapUnet(nn.Module):
         io.out, io.time_embed = out.data_ptr(), L.ptr(te)
         L.check(L.lib().adx_unet_forward(h, self._packed.data_ptr(), self._ws.data_ptr(), C.byref(io),
                                          L.stream_ptr(x.device)), "adx_unet_forward")
-        if not classifier:
+        return self._finish(out, te, return_action_and_time_only)
+
+    def _finish(self, out, te, return_action_and_time_only):
+        if self.use_cond != GuidanceType.CLASSIFIER_GUIDANCE:
             return out
         action = out
         if return_action_and_time_only:
@@ -279,6 +333,31 @@ class TemporalMapUnet(nn.Module):
         state = self.state_pred(action.detach()[:, :-1], te)
         state = torch.cat([torch.zeros_like(state[:, :1]), state], dim=1)
         return torch.cat([state, action], dim=-1)
+
+    def _forward_precomputed(self, x, time_cond, return_action_and_time_only):
+        tc, i = time_cond
+        rows = tc.rows
+        if x.shape[0] != rows and x.shape[0] != 1:
+            raise ValueError(f"x has {x.shape[0]} rows; the conditioning table was made for {rows} (or pass one row)")
+        if tc.weights_key != self._weights_key():
+            raise RuntimeError("the model's weights changed after time_conditioning() was computed")
+        self._ensure_packed(x.device)
+        classifier = self.use_cond == GuidanceType.CLASSIFIER_GUIDANCE
+        out = torch.empty((rows, self.horizon, 3 if classifier else self.transition_dim), dtype=torch.float32, device=x.device)
+        io = L.UnetIO()
+        io.x, io.x_rows, io.rows, io.out = x.data_ptr(), x.shape[0], rows, out.data_ptr()
+        io.time_bias = tc.time_bias[i].data_ptr()
+        L.check(L.lib().adx_unet_forward(self._native(), self._packed.data_ptr(), self._workspace(rows, x.device).data_ptr(),
+                                         C.byref(io), L.stream_ptr(x.device)), "adx_unet_forward")
+        return self._finish(out, tc.time_embed[i] if classifier else None, return_action_and_time_only)
+
+
+class TimeConditioning:
+    """Per-loop table of `TemporalMapUnet.time_conditioning`: time_bias [n_steps, rows, sum of block widths],
+    time_embed [n_steps, rows, dim]."""
+
+    def __init__(self, time_bias, time_embed, rows, weights_key):
+        self.time_bias, self.time_embed, self.rows, self.weights_key = time_bias, time_embed, rows, weights_key
 
 
 def build_model(cfg) -> TemporalMapUnet:

@@ -51,13 +51,25 @@ def generate_traj(model, scheduler, cfg, image: torch.Tensor, target: Optional[t
         scheduler.set_timesteps(cfg.EVAL.SAMPLE_STEPS, device=device)
     is_ddpm = not getattr(scheduler, "_is_ddim", False)
     action = None
+    # What the UNet derives from (t, target, image feature) alone does not change inside the loop: with the perception
+    # memo on (the product default) it is computed for all timesteps in one pass, and each step then starts at the first
+    # convolution.  The reference-faithful mode (cache_perception = False) keeps the reference's per-step recomputation.
+    tc = None
+    if fuse and getattr(model, "cache_perception", False) and hasattr(model, "time_conditioning"):
+        rows = 2 * B if use == GuidanceType.FREE_GUIDANCE else B
+        ts = scheduler.timesteps
+        ts = ts.tensor if hasattr(ts, "tensor") else torch.as_tensor(ts)
+        with torch.no_grad():
+            tc = model.time_conditioning(image, ts.to(device), cond=cond, rows=rows)
+    pair = (lambda x: x) if B == 1 and tc is not None else (lambda x: torch.cat([x, x], dim=0))
     for i, t in enumerate(scheduler.timesteps):
+        tck = None if tc is None else (tc, i)
         extra = {}
         if is_ddpm and step_noise is not None:
             extra["variance_noise"] = step_noise(i, tuple(trajs.shape)).to(device)
         if use == GuidanceType.FREE_GUIDANCE:
             with torch.no_grad():
-                out = model(torch.cat([trajs, trajs], dim=0), image, t.reshape(-1), cond=cond)
+                out = model(pair(trajs), image, t.reshape(-1), cond=cond, time_cond=tck)
             if fuse:
                 trajs = scheduler.step(out, t, trajs, cfg_scale=cfg.GUIDANCE.FREE_SCALE, zero_first=True,
                                        **extra).prev_sample
@@ -67,7 +79,8 @@ def generate_traj(model, scheduler, cfg, image: torch.Tensor, target: Optional[t
             trajs = scheduler.step(model_output, t, trajs, **extra).prev_sample
         elif use == GuidanceType.CLASSIFIER_GUIDANCE:
             with torch.no_grad():
-                action, time_embed = model(trajs, image, t.reshape(-1).repeat(B), return_action_and_time_only=True)
+                action, time_embed = model(trajs, image, t.reshape(-1).repeat(B), return_action_and_time_only=True,
+                                           time_cond=tck)
             guided = getattr(scheduler, "use_classifier_guidance", False) and tgt is not None
             if fuse and guided and scheduler.guidance_loss.guidance_step == 1:
                 # one launch: state_pred forward + TargetGuidance + its gradient through state_pred + update + clip
@@ -83,7 +96,7 @@ def generate_traj(model, scheduler, cfg, image: torch.Tensor, target: Optional[t
             trajs = scheduler.step(model_output, t, trajs, target=tgt, action=action, **extra).prev_sample.detach()
         else:
             with torch.no_grad():
-                model_output = model(trajs, image, t.reshape(-1).repeat(B))
+                model_output = model(trajs, image, t.reshape(-1).repeat(B), time_cond=tck)
             if fuse:
                 trajs = scheduler.step(model_output, t, trajs, zero_first=True, **extra).prev_sample
                 continue

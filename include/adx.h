@@ -137,8 +137,25 @@ typedef struct adx_unet_io {
   int32_t rows;
   float* out;                 /* [rows][horizon][transition_dim] (NO/FREE) or action [rows][horizon][3] (CLASSIFIER) */
   float* time_embed;          /* [rows][dim] or NULL (CLASSIFIER: returned to the caller, temporal.py:236-237) */
+  /* Optional (zero = absent), for sampling loops.
+   * x_rows: rows of `x` actually present: `rows` (default) or 1 -- every row then reads the one trajectory, which is the
+   *   classifier-free pair torch.cat([trajs, trajs]) of interact.py:131 at B = 1 without building it.
+   * time_bias: this call's [rows][adx_unet_time_bias_width] slice of a table made by adx_unet_time_conditioning; t, cond
+   *   and img_feature are then not read and time_embed must be NULL (the caller holds the table's time_embed). */
+  int32_t x_rows;
+  const float* time_bias;
 } adx_unet_io;
 int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx_unet_io* io, adx_stream s);
+/* Everything of the forward that depends on (t, cond, img_feature) only -- the time MLP, the condition MLP and the
+ * time_mlp Linear of all 16 residual blocks (modeling/temporal.py:206-216, modeling/helpers.py:121-123) -- for `rows`
+ * rows at once, e.g. all 50 timesteps of a sampling loop x the rows of one step: inside the loop
+ * (interact.py:128-166) these are the same launches every tick, and none of them depends on the trajectory.  Uses
+ * io->t, t_rows, cond, img_feature, feat_rows, rows (workspace sized by adx_unet_workspace_bytes(u, rows)).  Writes
+ * time_bias [rows][adx_unet_time_bias_width(u)] and, if not NULL, time_embed [rows][dim].  Row-wise identical to what
+ * adx_unet_forward computes internally. */
+int32_t adx_unet_time_bias_width(const adx_unet* u);
+int adx_unet_time_conditioning(adx_unet* u, const void* packed, void* workspace, const adx_unet_io* io, float* time_embed,
+                               float* time_bias, adx_stream s);
 
 /* ------------------------------------------------------------------------------------
  * Training step T1 (train.py:242-251), temporal stack: forward that keeps a tape, and backward.

@@ -272,3 +272,33 @@ def test_graphed_sampler_replays_the_eager_loop_bit_for_bit(use_cond, B):
         got = gs(d["imgs"], tgt, d["init_trajs"])
         want = generate_traj(m, sch, cfg, d["imgs"], tgt, d["init_trajs"])
         assert torch.equal(got, want), (seed, (got - want).abs().max().item())
+
+
+@pytest.mark.parametrize("use_cond,B", [("FREE_GUIDANCE", 1), ("FREE_GUIDANCE", 3), ("NO_GUIDANCE", 2), ("CLASSIFIER_GUIDANCE", 2)])
+def test_time_conditioning_table_equals_the_per_step_recomputation(use_cond, B):
+    """TemporalMapUnet.time_conditioning (adx_unet_time_conditioning): the time MLP, condition MLP and 16 block Linears
+    for all timesteps of a loop in one pass; a forward that starts from the table -- and, at one scene, reads the single
+    trajectory for both rows of the classifier-free pair -- must equal the reference-shaped forward bit for bit."""
+    m, _ = make_model(use_cond, 16)
+    d = {k: v.to(DEV) for k, v in P.synthetic_batch(B, 16, image_hw=IMG_SMALL, seed=31).items()}
+    free = use_cond == "FREE_GUIDANCE"
+    cond = torch.cat([d["target"], torch.zeros_like(d["target"])], 0) if free else None
+    rows = 2 * B if free else B
+    ts = torch.tensor([97, 50, 3, 0], dtype=torch.int64, device=DEV)
+    x = d["init_trajs"]
+    xin = torch.cat([x, x], 0) if free else x
+    with torch.no_grad():
+        tc = m.time_conditioning(d["imgs"], ts, cond=cond, rows=rows)
+        assert tc.time_bias.shape[:2] == (4, rows) and tc.time_embed.shape == (4, rows, m.dim)
+        for i in range(4):
+            t = ts[i].reshape(-1) if free else ts[i].reshape(-1).repeat(B)
+            kw = dict(return_action_and_time_only=True) if use_cond == "CLASSIFIER_GUIDANCE" else {}
+            want = m(xin, d["imgs"], t, cond=cond, **kw)
+            got = m(xin, None, None, time_cond=(tc, i), **kw)
+            if free and B == 1:
+                got1 = m(x, None, None, time_cond=(tc, i))          # one trajectory row feeds both rows of the pair
+                assert torch.equal(got1, want)
+            for g, w in zip(got if isinstance(got, tuple) else (got,), want if isinstance(want, tuple) else (want,)):
+                assert torch.equal(g, w), (i, (g - w).abs().max().item())
+    with pytest.raises(ValueError):
+        m(torch.zeros(rows + 1, 16, 7, device=DEV), None, None, time_cond=(tc, 0))

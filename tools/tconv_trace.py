@@ -18,6 +18,10 @@ ROWS = int(os.environ.get("ROWS", "128"))
 LAYERS = {"64x64L32": (0, 5, 1, 2, 64, 0, 64, 32, 32, 8), "512x512L4": (0, 5, 1, 2, 512, 0, 512, 4, 4, 8),
           "head64x7": (0, 1, 1, 0, 64, 0, 7, 32, 32, 0), "256x256L8": (0, 5, 1, 2, 256, 0, 256, 8, 8, 8),
           "1024x256L4": (0, 5, 1, 2, 512, 512, 256, 4, 4, 8)}
+if os.environ.get("SET") == "h16":     # the deployed horizon (lengths 16, 8, 4, 2)
+    LAYERS = {"64x64L16": (0, 5, 1, 2, 64, 0, 64, 16, 16, 8), "128x128L8": (0, 5, 1, 2, 128, 0, 128, 8, 8, 8),
+              "256x256L4": (0, 5, 1, 2, 256, 0, 256, 4, 4, 8), "512x512L2": (0, 5, 1, 2, 512, 0, 512, 2, 2, 8),
+              "res7x64L16": (0, 1, 1, 0, 7, 0, 64, 16, 16, 0), "down64L16": (0, 3, 2, 1, 64, 0, 64, 16, 8, 0)}
 lib = L.lib()
 dbg = C.CDLL(L.LIB_PATH).adx_debug_tconv_trace
 s = L.stream_ptr(DEV)

@@ -1,0 +1,71 @@
+"""Timeline of one deployed tick (B = 1, H = 16, CFG, 50 DDIM steps, one HIP graph replay).
+
+  rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tick_trace -- python3 tools/tick_timeline.py run
+  python tools/tick_timeline.py analyze gpurun_out/tick_trace
+
+`analyze` takes the last replay in the trace and prints, per kernel name, calls / total busy time / mean duration, and
+the total of the gaps between consecutive kernels (end of one to start of the next): what a tick is made of."""
+import contextlib
+import csv
+import glob
+import sys
+from collections import defaultdict
+
+
+def run():
+    import torch
+    sys.path.insert(0, ".")
+    import bench
+    from autonomous_driving_with_diffusion_model_amd import scheduler as S
+    from autonomous_driving_with_diffusion_model_amd.config import create_cfg
+    from autonomous_driving_with_diffusion_model_amd.modeling import build_model
+    from autonomous_driving_with_diffusion_model_amd.sampling import GraphedSampler
+    from autonomous_driving_with_diffusion_model_amd.utils import procedural as P
+    dev = torch.device("cuda:0")
+    cfg = create_cfg()
+    cfg.MODEL.HORIZON = 16
+    cfg.TRAIN.USE_COND = cfg.GUIDANCE.USE_COND = "FREE_GUIDANCE"
+    cfg.GUIDANCE.FREE_SCALE, cfg.EVAL.SAMPLE_STEPS = bench.FREE_SCALE, bench.N_INFER
+    with contextlib.redirect_stdout(sys.stderr):
+        model = build_model(cfg)
+    P.load_procedural(model, 0)
+    model = model.to(dev).eval()
+    sch = S.GuidanceDDIMScheduler(cfg=cfg, thresholding=True, **bench.SCHED_KW)
+    d = {k: v.to(dev) for k, v in P.synthetic_batch(1, 16, image_hw=bench.IMG, seed=3).items()}
+    gs = GraphedSampler(model, sch, cfg)
+    with torch.no_grad():
+        for _ in range(4):
+            gs(d["imgs"], d["target"], d["init_trajs"])
+            torch.cuda.synchronize()
+
+
+def analyze(d):
+    path = glob.glob(f"{d}/**/*kernel_trace.csv", recursive=True)[0]
+    rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
+    # a tick starts at the stem kernel of the perception pass; take the last one
+    starts = [i for i, r in enumerate(rows) if "stem" in r["Kernel_Name"] and "pack" not in r["Kernel_Name"]]
+    rows = rows[starts[-1]:]
+    # ... and ends with the last scheduler step kernel
+    last = max(i for i, r in enumerate(rows) if "step_kernel" in r["Kernel_Name"])
+    rows = rows[:last + 1]
+    t0, t1 = int(rows[0]["Start_Timestamp"]), int(rows[-1]["End_Timestamp"])
+    busy, calls = defaultdict(float), defaultdict(int)
+    gaps = 0.0
+    for a, b in zip(rows, rows[1:]):
+        gaps += max(0, int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e3
+    for r in rows:
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("adx::", "")[:48]
+        busy[name] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        calls[name] += 1
+    tot = sum(busy.values())
+    print(f"tick {1e-3 * (t1 - t0):.1f} us: {len(rows)} kernels, busy {tot:.1f} us, gaps {gaps:.1f} us "
+          f"({gaps / max(1, len(rows) - 1):.2f} us per boundary)")
+    for name in sorted(busy, key=busy.get, reverse=True):
+        print(f"  {name:48s} x{calls[name]:5d}  {busy[name]:9.1f} us  mean {busy[name] / calls[name]:7.2f}")
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "run":
+        run()
+    else:
+        analyze(sys.argv[2])
