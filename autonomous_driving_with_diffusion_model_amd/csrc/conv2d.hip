@@ -347,6 +347,10 @@ static int conv2d_launch(const ConvSpec& L, const float* base, const float* x, c
   return conv2d_launch_raw(L, x, base + L.o_w, base + L.o_scale, base + L.o_shift, res, y, N, H, W, relu, s);
 }
 
+static thread_local float* t_split_scratch = nullptr;
+static thread_local size_t t_split_floats = 0;
+void conv2d_set_split_scratch(float* p, size_t floats) { t_split_scratch = p; t_split_floats = p != nullptr ? floats : 0; }
+
 int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const float* scale, const float* shift,
                       const float* res, float* y, int N, int H, int W, int relu, hipStream_t s, const uint32_t* x_amax,
                       int x_amax_n) {
@@ -365,6 +369,8 @@ int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const f
   a.OH = conv_out(H, L.k, L.stride, L.pad); a.OW = conv_out(W, L.k, L.stride, L.pad);
   a.KH = L.k; a.KW = L.k; a.stride = L.stride; a.pad = L.pad; a.relu = relu;
   a.cin_pad = L.cin_pad; a.cc = L.cc;
+  a.x_u8 = nullptr;
+  a.ksplit = 1; a.cper = 0; a.part = t_split_scratch; a.part_stride = t_split_floats;   // part_stride: capacity until the launch fixes it
   if (conv2d_hs_eligible(L)) return conv2d_hs_launch(L, a, s);
   const int rows = (L.stride == 1 && L.k == 3 && g_conv_rows == 2) ? 2 : 1;   // 8-row tiles for the 3x3 stride-1 convs
   const int th = 4 * rows;
@@ -580,6 +586,10 @@ static int resnet_forward_impl(adx_resnet* r, const void* packed, void* workspac
   buf[1] = buf[0] + act;
   buf[2] = buf[1] + act;
 
+  struct ScratchScope {     // split-reduction scratch of the 3x3 convs of THIS call
+    void set(float* p, size_t n) { conv2d_set_split_scratch(p, n); }
+    ~ScratchScope() { conv2d_set_split_scratch(nullptr, 0); }
+  } scratch_scope;
   size_t ci = 0;
   int rc;
   {
@@ -590,6 +600,7 @@ static int resnet_forward_impl(adx_resnet* r, const void* packed, void* workspac
       fuse = (e != nullptr && e[0] == '0') ? 0 : 1;
     }
     if ((fuse || frames_u8 != nullptr) && conv2d_hs_eligible(c0)) {
+      scratch_scope.set(stem, (size_t)batch * 64 * h1 * w1);     // the unpooled stem map is never written on this path
       rc = conv2d_hs_stem_pool(c0, img, base + c0.o_w, base + c0.o_scale, base + c0.o_shift, buf[0], batch, h, w, s,
                                frames_u8, mean, stdv);
       if (rc != ADX_OK) return rc;

@@ -404,6 +404,8 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
     const int per = gridDim.x >> 3;
     if (bid < per * 8) bid = (bid & 7) * per + (bid >> 3);
   }
+  int kpart = 0;                       // split reduction (Conv2dArgs::ksplit): this workgroup's share of the chunks
+  if (a.ksplit > 1) { kpart = bid % a.ksplit; bid /= a.ksplit; }
   const int ct = bid % a.cout_tiles; bid /= a.cout_tiles;
   const int tx = bid % a.tiles_x; bid /= a.tiles_x;
   const int ty = bid % a.tiles_y; bid /= a.tiles_y;
@@ -413,13 +415,15 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
   const int cout0 = (ct * CT + slab) * kHsCout;
   const int l31 = lane & 31, khalf = lane >> 5;
   const size_t hw = (size_t)a.H * a.W;
-  const float* xin = a.x + (size_t)n * a.Cin * hw;
-  const int nchunks = a.cin_pad / kHsCC;
+  const int nchunks_all = a.cin_pad / kHsCC;
+  const int nchunks = a.ksplit > 1 ? a.cper : nchunks_all;       // chunks THIS workgroup reduces over
+  const int chunk0 = kpart * nchunks;
+  const float* xin = a.x + ((size_t)n * a.Cin + (size_t)chunk0 * kHsCC) * hw;
   const int nstages = nchunks * K;
-  const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.w) + (size_t)ct * CT * nchunks * NW;
+  const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.w) + ((size_t)ct * CT * nchunks_all + chunk0) * NW;
   constexpr uint32_t kOutside = 0xC0000000u;
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(xin), 0, (int)((size_t)a.Cin * hw * sizeof(float)), 0x00020000);
+      const_cast<float*>(xin), 0, (int)((size_t)(a.Cin - chunk0 * kHsCC) * hw * sizeof(float)), 0x00020000);
   const uint32_t plane_bytes = (uint32_t)(hw * sizeof(float));
   uint32_t goff[PIT];
   int pcell[PIT];
@@ -441,7 +445,7 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
     const int e = tid + NT * k;
     const int sl = e / 768, within = e - sl * 768;
     const bool ok = e < WST;
-    wsrc_off[k] = ok ? sl * nchunks * NW + within : 0;
+    wsrc_off[k] = ok ? sl * nchunks_all * NW + within : 0;
     wdst[k] = ok ? e : -1;
   }
   // BN scale / shift of this workgroup's channels: requested now, parked in LDS after the first stage's data (a wait
@@ -579,7 +583,8 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
   const uint32_t plane_ob = (uint32_t)(a.OH * a.OW) * (uint32_t)sizeof(float);
   const size_t img = (size_t)n * a.Cout * a.OH * a.OW;
   const int img_bytes = (int)(a.Cout * plane_ob);
-  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + img, 0, img_bytes, 0x00020000);
+  float* const ybase = a.ksplit > 1 ? a.part + (size_t)kpart * a.part_stride : a.y;
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(ybase + img, 0, img_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.res != nullptr ? a.res + img : a.y), 0, a.res != nullptr ? img_bytes : 0, 0x00020000);
   const float* sst = ss + slab * 64;
@@ -1080,6 +1085,27 @@ int conv2d_hs_launch_block_s2(const ConvSpec& c1, const ConvSpec& ds, const floa
   return conv2d_hs_launch(c1, a, s);
 }
 
+// second half of a split 3x3 conv: y = [relu](sum_p part[p] * scale[c] + shift[c] [+ res]), four elements per thread
+// (parts are added in index order: deterministic)
+__global__ void __launch_bounds__(256) conv2d_split_reduce_kernel(const float* __restrict__ part, size_t part_stride, int nparts,
+                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                  const float* __restrict__ res, float* __restrict__ y,
+                                                                  int cout, int plane4, size_t total4, int relu) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int c = (int)((i / plane4) % cout);
+  f32x4 v = reinterpret_cast<const f32x4*>(part)[i];
+  for (int p = 1; p < nparts; ++p) v += reinterpret_cast<const f32x4*>(part + (size_t)p * part_stride)[i];
+  const float sc = scale != nullptr ? scale[c] : 1.f, sh = shift != nullptr ? shift[c] : 0.f;
+  v = v * sc + sh;
+  if (res != nullptr) v += reinterpret_cast<const f32x4*>(res)[i];
+  if (relu) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaxf(v[k], 0.f);
+  }
+  reinterpret_cast<f32x4*>(y)[i] = v;
+}
+
 template <int MODE>
 static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
   constexpr int NT = MODE == 0 ? 256 : 512, TH = MODE == 1 ? 16 : 8, CT = MODE == 2 ? 2 : 1;
@@ -1095,6 +1121,31 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
   const size_t grid = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y * a.N;
   ADX_REQUIRE(grid < (1u << 31), "conv2d_hs: grid too large");
   ADX_REQUIRE((size_t)a.Cout * a.OH * a.OW * sizeof(float) < 0x7FFFFFFFu, "conv2d_hs: one image of the output exceeds the 32-bit byte offsets");
+  // Small batches (one camera frame per tick): a 512->512 layer on one 8x29 map is 8 workgroups, each walking 96 stages
+  // (83 us); with a scratch buffer the chunks are split over up to 16 workgroups per tile and a reduce launch finishes.
+  static const bool split_on = [] { const char* e = getenv("ADX_CONV_NO_KSPLIT"); return !(e != nullptr && e[0] == '1'); }();
+  const size_t out_floats = (size_t)a.N * a.Cout * a.OH * a.OW;
+  const size_t cap = a.part != nullptr ? a.part_stride : 0;      // conv2d_launch_raw parks the scratch capacity here
+  const int nchunks = a.cin_pad / kHsCC;
+  a.ksplit = 1; a.cper = nchunks; a.part_stride = 0;
+  if (MODE == 0 && split_on && cap > 0 && grid <= 64 && nchunks >= 8 && a.x_amax == nullptr && (a.OH * a.OW) % 4 == 0 &&
+      (reinterpret_cast<uintptr_t>(a.y) & 15) == 0 && (a.res == nullptr || (reinterpret_cast<uintptr_t>(a.res) & 15) == 0)) {
+    int S = 16;
+    while (S > 1 && (nchunks % S != 0 || (nchunks / S) % 2 != 0 || grid * S > 256 || out_floats * S > cap)) S >>= 1;
+    if (S > 1) {
+      Conv2dArgs c = a;
+      c.ksplit = S; c.cper = nchunks / S; c.part_stride = out_floats;
+      c.scale = nullptr; c.shift = nullptr; c.res = nullptr; c.relu = 0;
+      conv2d_hs3x3_kernel<MODE><<<dim3((unsigned)(grid * S)), dim3(NT), lds, s>>>(c);
+      ADX_LAUNCH_CHECK();
+      const size_t total4 = out_floats / 4;
+      conv2d_split_reduce_kernel<<<dim3((unsigned)ceil_div((long)total4, 256L)), dim3(256), 0, s>>>(
+          a.part, out_floats, S, a.scale, a.shift, a.res, a.y, a.Cout, a.OH * a.OW / 4, total4, a.relu);
+      ADX_LAUNCH_CHECK();
+      return ADX_OK;
+    }
+  }
+  a.part = nullptr;
   conv2d_hs3x3_kernel<MODE><<<dim3((unsigned)grid), dim3(NT), lds, s>>>(a);
   ADX_LAUNCH_CHECK();
   return ADX_OK;

@@ -39,6 +39,12 @@ struct Conv2dArgs {
   int cin_pad, cc;      // channels padded to the chunk size, chunk size (16, or 4 for the stem)
   int tiles_x, tiles_y, cout_tiles, ntiles;
   int PH, PW, PWp;      // staged patch rows, columns, padded row pitch
+  // conv2d_hs3x3 only: the input-channel chunks split over `ksplit` workgroups per tile (small batches: a 512->512 layer
+  // on one 8x29 map is 8 tiles); part kpart covers chunks [kpart * cper, (kpart + 1) * cper) and writes its raw sums to
+  // part + kpart * part_stride in the layout of y; conv2d_split_reduce_kernel adds them up and applies BN / residual / ReLU
+  int ksplit, cper;
+  float* part;
+  size_t part_stride;
 };
 
 
@@ -74,6 +80,9 @@ bool conv2d_hs_eligible(const ConvSpec& L);
 size_t conv2d_packed_floats(const ConvSpec& L);
 int conv2d_hs_pack(const ConvSpec& consumer, const float* w, void* packed, int dgrad, hipStream_t s);
 int conv2d_hs_launch(const ConvSpec& L, Conv2dArgs a, hipStream_t s);
+// scratch for split reductions of the launches issued by this thread until it is cleared (a region of the calling
+// executor's workspace, consumed in stream order)
+void conv2d_set_split_scratch(float* p, size_t floats);
 // stem conv + BN + ReLU + MaxPool2d(3, 2, 1) in one pass: writes only the pooled map [N][64][PH][PW]
 int conv2d_hs_stem_pool(const ConvSpec& L, const float* x, const float* w, const float* scale, const float* shift,
                         float* pooled, int N, int H, int W, hipStream_t s, const uint8_t* frames_u8 = nullptr,
