@@ -89,11 +89,20 @@ __device__ __forceinline__ void mm_fwd(float* out, int ldo, const float* in, int
 #pragma unroll
     for (int r = 0; r < RT; ++r) acc[r] = 0.f;
     const float* ip = in + tg * RT * ldi;
-#pragma unroll 4
-    for (int k = 0; k < K; ++k) {
-      const float w = wt[(size_t)k * N + n];
+    // four k per step: one 16-byte LDS read per row instead of four 4-byte ones (the loop was LDS-issue bound); the
+    // products are still added in ascending k (K % 4 == 0 and every tile is 16-byte aligned: E, FF multiples of 64)
+#pragma unroll 2
+    for (int k = 0; k < K; k += 4) {
+      const float w0 = wt[(size_t)k * N + n], w1 = wt[(size_t)(k + 1) * N + n], w2 = wt[(size_t)(k + 2) * N + n],
+                  w3 = wt[(size_t)(k + 3) * N + n];
 #pragma unroll
-      for (int r = 0; r < RT; ++r) acc[r] += ip[r * ldi + k] * w;
+      for (int r = 0; r < RT; ++r) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(ip + r * ldi + k);
+        acc[r] += x[0] * w0;
+        acc[r] += x[1] * w1;
+        acc[r] += x[2] * w2;
+        acc[r] += x[3] * w3;
+      }
     }
     const float b = bias != nullptr ? bias[n] : 0.f;
 #pragma unroll
@@ -165,11 +174,11 @@ __device__ __forceinline__ void colsum_acc(float* gb, int N, FA fa, int T, int t
 // later reused; Y: pre-norm sums / scratch; H1: norm1 output; F: feed-forward pre-activation;
 // XH1/XH2: normalised values for the LayerNorm backward; small per-row vectors at the end.
 struct Lds {
-  float* X; float* QKV; float* P; float* O; float* Y; float* H1; float* F; float* XH1; float* XH2; float* R1; float* R2;
+  float* X; float* QKV; float* P; float* O; float* Y; float* H1; float* F; float* XH1; float* XH2; float* R1; float* R2; float* R3;
   float* INb;   // NL + 1 saved [TP][E] tiles (layer inputs + gradient scratch)
   __device__ __forceinline__ float* IN(int i) const { return INb + i * TP * E; }
 };
-constexpr int kLdsFloats = TP * E * 6 + TP * 3 * E + NH * TP * TP + TP * FF + 2 * TP + (NL + 1) * TP * E;
+constexpr int kLdsFloats = TP * E * 6 + TP * 3 * E + NH * TP * TP + TP * FF + 3 * TP + (NL + 1) * TP * E;
 
 __device__ __forceinline__ Lds carve(float* s) {
   Lds l;
@@ -184,6 +193,7 @@ __device__ __forceinline__ Lds carve(float* s) {
   l.XH2 = s; s += TP * E;
   l.R1 = s; s += TP;
   l.R2 = s; s += TP;
+  l.R3 = s; s += TP;
   l.INb = s;
   return l;
 }
@@ -292,28 +302,45 @@ __device__ __forceinline__ void layer_forward(const Lds& l, const float* __restr
   __syncthreads();
   mm_fwd<false>(l.F, FF, l.H1, E, P + y.w1_t, P + y.b1, E, FF, tid);
   __syncthreads();
-  // Y = H1 + linear2(silu(F));  O is reused as scratch for silu(F) in 64-column slabs
+  // Y = H1 + linear2(silu(F))
   for (int idx = tid; idx < TP * E; idx += 256) l.Y[idx] = l.H1[idx];
   __syncthreads();
   {
-    // silu(F) @ W2^T, K = 256: accumulate directly, activation applied on the fly
-    for (int item = tid; item < E * (TP / RT); item += 256) {
-      const int n = item % E, tg = item / E;
-      float acc[RT];
+    // silu(F) @ W2^T, K = 256.  The activation (an exp and a division) is evaluated ONCE per element -- 64 columns of
+    // silu(F) * mask at a time into X (dead since Y = X + sa was formed; norm2 rewrites it below) -- not once per (element, output column) inside the product loop,
+    // which made this the longest phase of the layer.  Thread = (output column n, row group tg), accumulators live
+    // across the four slabs; the products are added in ascending k as before.
+    const int n = tid % E, tg = tid / E;           // E * (TP / RT) = 256 items = one per thread
+    float acc[RT];
 #pragma unroll
-      for (int r = 0; r < RT; ++r) acc[r] = 0.f;
-      const float* wt = P + y.w2_t;
-      for (int k = 0; k < FF; ++k) {
-        const float w = wt[(size_t)k * E + n];
-#pragma unroll
-        for (int r = 0; r < RT; ++r)
-          acc[r] += silu_f(l.F[(tg * RT + r) * FF + k]) * drop_mul(dr, k_in, (uint32_t)((tg * RT + r) * FF + k)) * w;
+    for (int r = 0; r < RT; ++r) acc[r] = 0.f;
+    const float* wt = P + y.w2_t;
+    for (int k0 = 0; k0 < FF; k0 += E) {
+      for (int idx = tid; idx < TP * E; idx += 256) {
+        const int t = idx >> 6, j = idx & 63;
+        l.X[idx] = silu_f(l.F[t * FF + k0 + j]) * drop_mul(dr, k_in, (uint32_t)(t * FF + k0 + j));
       }
-      const float b = P[y.b2 + n];
+      __syncthreads();
+      const float* ip = l.X + tg * RT * E;
+#pragma unroll 2
+      for (int k = 0; k < E; k += 4) {
+        const float w0 = wt[(size_t)(k0 + k) * E + n], w1 = wt[(size_t)(k0 + k + 1) * E + n],
+                    w2 = wt[(size_t)(k0 + k + 2) * E + n], w3 = wt[(size_t)(k0 + k + 3) * E + n];
 #pragma unroll
-      for (int r = 0; r < RT; ++r)
-        l.Y[(tg * RT + r) * E + n] += (acc[r] + b) * drop_mul(dr, k_d2, (uint32_t)((tg * RT + r) * E + n));
+        for (int r = 0; r < RT; ++r) {
+          const f32x4 x = *reinterpret_cast<const f32x4*>(ip + r * E + k);
+          acc[r] += x[0] * w0;
+          acc[r] += x[1] * w1;
+          acc[r] += x[2] * w2;
+          acc[r] += x[3] * w3;
+        }
+      }
+      __syncthreads();
     }
+    const float b = P[y.b2 + n];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+      l.Y[(tg * RT + r) * E + n] += (acc[r] + b) * drop_mul(dr, k_d2, (uint32_t)((tg * RT + r) * E + n));
   }
   __syncthreads();
   layer_norm_rows(l.X, l.Y, E, P + y.g2, P + y.be2, l.XH2, l.R2, T, tid);  // X becomes the layer output
@@ -477,9 +504,12 @@ struct TrajArgs {
 };
 
 // head: LayerNorm -> Linear(64, out_dim)
+// The normalised values and 1/std of the final norm go to their own places (the IN(NL) tile, which the backward pass
+// then turns into d(layer output) in place, and R3): the last layer's intermediates stay intact, so its backward needs
+// no recomputation.
 __device__ __forceinline__ void head_forward(const Lds& l, const float* __restrict__ P, const TPLayout& L, int T,
                                              int tid) {
-  layer_norm_rows(l.Y, l.X, E, P + L.gf, P + L.bef, l.XH2, l.R2, T, tid);
+  layer_norm_rows(l.Y, l.X, E, P + L.gf, P + L.bef, l.IN(NL), l.R3, T, tid);
   __syncthreads();
 }
 
@@ -501,22 +531,28 @@ __global__ void __launch_bounds__(256) trajpred_forward_kernel(const TrajArgs a)
   }
 }
 
-// shared by the backward and the fused guidance kernels: forward with the layer inputs kept, then
-// back-propagation of d(out) [T][out_dim] (given by `dout(t, j)`) down to d(action) [T][3] in l.O.
-template <typename DOut>
-__device__ __forceinline__ void backward_core(const Lds& l, const TrajArgs& a, int b, int tid, DOut dout) {
-  const float* P = a.P;
-  const TPLayout& L = a.L;
-  const int T = a.T, od = L.out_dim;
-  const Drop dr = make_drop(a.seed_lo, a.seed_hi, a.drop_thresh, a.drop_scale, b);
-  embed_rows(l.X, a.action + (int64_t)b * a.act_sb, a.act_st, a.te + (int64_t)b * E, P, L, T, tid);
+// forward with every layer's input kept (IN(li)); on return the LAST layer's intermediates and the head's normalised
+// output (l.Y), normalised values (IN(NL)) and 1/std (R3) are in LDS
+__device__ __forceinline__ void forward_keep(const Lds& l, const TrajArgs& a, int b, int tid, const Drop& dr) {
+  const int T = a.T;
+  embed_rows(l.X, a.action + (int64_t)b * a.act_sb, a.act_st, a.te + (int64_t)b * E, a.P, a.L, T, tid);
   __syncthreads();
   for (int li = 0; li < NL; ++li) {
     for (int idx = tid; idx < TP * E; idx += 256) l.IN(li)[idx] = l.X[idx];
     __syncthreads();
-    layer_forward(l, P, L.layer[li], T, tid, dr, li);
+    layer_forward(l, a.P, a.L.layer[li], T, tid, dr, li);
   }
-  head_forward(l, P, L, T, tid);   // XH2 / R2 now belong to the final norm
+  head_forward(l, a.P, a.L, T, tid);
+}
+
+// shared by the backward and the fused guidance kernels, after forward_keep(): back-propagation of d(out) [T][out_dim]
+// (given by `dout(t, j)`) down to d(action) [T][3] in l.O.  The last layer is back-propagated from the intermediates the
+// forward left; the layers below are recomputed from their saved inputs first.
+template <typename DOut>
+__device__ __forceinline__ void backward_core(const Lds& l, const TrajArgs& a, int b, int tid, const Drop& dr, DOut dout) {
+  const float* P = a.P;
+  const TPLayout& L = a.L;
+  const int T = a.T, od = L.out_dim;
   float* G = a.G;
   if (G != nullptr) {  // output_proj: out = Wop Ynorm + bop
     for (int idx = tid; idx < od * E; idx += 256) {
@@ -531,32 +567,35 @@ __device__ __forceinline__ void backward_core(const Lds& l, const TrajArgs& a, i
       atomicAdd(G + L.b_op + j, acc);
     }
   }
-  // d(normed) = dout @ Wop  -> H1
+  // d(normed) = dout @ Wop  -> X (the last layer's output: consumed by the head already)
   for (int idx = tid; idx < TP * E; idx += 256) {
     const int t = idx >> 6, i = idx & 63;
     float acc = 0.f;
     if (t < T)
       for (int j = 0; j < od; ++j) acc += dout(t, j) * P[L.w_op + j * E + i];
-    l.H1[idx] = acc;
+    l.X[idx] = acc;
   }
   __syncthreads();
-  float* D = l.IN(NL);
+  float* D = l.IN(NL);          // holds the final norm's normalised values; becomes d(last layer output) in place
   if (G != nullptr) {  // final LayerNorm affine
     for (int i = tid; i < E; i += 256) {
       float sg = 0.f, sb = 0.f;
-      for (int t = 0; t < T; ++t) { sg += l.H1[t * E + i] * l.XH2[t * E + i]; sb += l.H1[t * E + i]; }
+      for (int t = 0; t < T; ++t) { sg += l.X[t * E + i] * D[t * E + i]; sb += l.X[t * E + i]; }
       atomicAdd(G + L.gf + i, sg);
       atomicAdd(G + L.bef + i, sb);
     }
+    __syncthreads();
   }
-  layer_norm_bwd_rows(D, l.H1, l.XH2, l.R2, E, P + L.gf, T, tid);
+  layer_norm_bwd_rows(D, l.X, D, l.R3, E, P + L.gf, T, tid);    // each lane reads its own element before writing it
   for (int idx = tid + 0; idx < TP * E; idx += 256)
     if ((idx >> 6) >= T) D[idx] = 0.f;
   __syncthreads();
   for (int li = NL - 1; li >= 0; --li) {
-    for (int idx = tid; idx < TP * E; idx += 256) l.X[idx] = l.IN(li)[idx];
-    __syncthreads();
-    layer_forward(l, P, L.layer[li], T, tid, dr, li);     // recompute this layer's internals (same masks)
+    if (li != NL - 1) {
+      for (int idx = tid; idx < TP * E; idx += 256) l.X[idx] = l.IN(li)[idx];
+      __syncthreads();
+      layer_forward(l, P, L.layer[li], T, tid, dr, li);     // recompute this layer's internals (same masks)
+    }
     layer_backward(l, D, P, L.layer[li], T, tid, G, l.IN(li), dr, li);
     for (int idx = tid; idx < TP * E; idx += 256)
       if ((idx >> 6) >= T) D[idx] = 0.f;
@@ -594,7 +633,9 @@ __global__ void __launch_bounds__(256) trajpred_backward_kernel(const TrajArgs a
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* g = a.gout + (int64_t)b * a.gout_sb;
   const int64_t gst = a.gout_st;
-  backward_core(l, a, b, tid, [&](int t, int j) { return g[(int64_t)t * gst + j]; });
+  const Drop dr = make_drop(a.seed_lo, a.seed_hi, a.drop_thresh, a.drop_scale, b);
+  forward_keep(l, a, b, tid, dr);
+  backward_core(l, a, b, tid, dr, [&](int t, int j) { return g[(int64_t)t * gst + j]; });
   if (a.gact != nullptr)
     for (int idx = tid; idx < a.T * IN_DIM; idx += 256) {
       const int t = idx / IN_DIM, i = idx - t * IN_DIM;
@@ -615,12 +656,9 @@ __global__ void __launch_bounds__(256) guided_output_kernel(const TrajArgs a) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const int T = a.T, H = T + 1, od = a.L.out_dim;
   const float* act = a.action + (int64_t)b * a.act_sb;
-  // forward to get the state rows
-  embed_rows(l.X, act, a.act_st, a.te + (int64_t)b * E, a.P, a.L, T, tid);
-  __syncthreads();
+  // ONE forward (layer inputs kept) serves both the state rows and the gradient below
   const Drop dr_off{0u, 0u, 1.f};      // guidance runs the state head in eval mode
-  for (int li = 0; li < NL; ++li) layer_forward(l, a.P, a.L.layer[li], T, tid, dr_off, li);
-  head_forward(l, a.P, a.L, T, tid);
+  forward_keep(l, a, b, tid, dr_off);
   for (int idx = tid; idx < H * od; idx += 256) {
     const int h = idx / od, j = idx - h * od;
     float acc = 0.f;
@@ -657,7 +695,7 @@ __global__ void __launch_bounds__(256) guided_output_kernel(const TrajArgs a) {
   const float g0 = gxy[0], g1 = gxy[1];
   // gradient w.r.t. the action through the state path (row h* of x is state row h*-1; row 0 is the dummy zero)
   if (hs > 0) {
-    backward_core(l, a, b, tid, [&](int t, int j) { return (t == hs - 1 && j < 2) ? (j == 0 ? g0 : g1) : 0.f; });
+    backward_core(l, a, b, tid, dr_off, [&](int t, int j) { return (t == hs - 1 && j < 2) ? (j == 0 ? g0 : g1) : 0.f; });
   } else {
     for (int idx = tid; idx < TP * IN_DIM; idx += 256) l.O[idx] = 0.f;
     __syncthreads();

@@ -166,7 +166,9 @@ class GraphedSampler:
         torch.cuda.current_stream(dev).wait_stream(side)
         self.model._feat_cache = None          # the perception pass must be IN the graph (new frame every tick)
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        # thread-local capture mode: a process group's watchdog thread (multi-rank runs) may query events while this
+        # thread captures; in the default global mode that would invalidate the capture
+        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
             self._out = run()
         self.model._feat_cache = None          # the memo now points at the static frame buffer: drop it
         self._pointers = self._model_pointers()

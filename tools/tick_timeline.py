@@ -8,6 +8,7 @@ the total of the gaps between consecutive kernels (end of one to start of the ne
 import contextlib
 import csv
 import glob
+import os
 import sys
 from collections import defaultdict
 
@@ -26,6 +27,10 @@ def run():
     cfg.MODEL.HORIZON = 16
     cfg.TRAIN.USE_COND = cfg.GUIDANCE.USE_COND = "FREE_GUIDANCE"
     cfg.GUIDANCE.FREE_SCALE, cfg.EVAL.SAMPLE_STEPS = bench.FREE_SCALE, bench.N_INFER
+    if os.environ.get("MODE") == "classifier":      # configs/guidance/classifier_guidance.yaml
+        cfg.TRAIN.USE_COND = cfg.GUIDANCE.USE_COND = "CLASSIFIER_GUIDANCE"
+        cfg.GUIDANCE.LOSS_LIST = [["TargetGuidance", []]]
+        cfg.GUIDANCE.CLASSIFIER_SCALE, cfg.EVAL.SAMPLE_STEPS = 15.0, 2
     with contextlib.redirect_stdout(sys.stderr):
         model = build_model(cfg)
     P.load_procedural(model, 0)
