@@ -21,7 +21,7 @@ i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 class TConvDesc(C.Structure):
     _fields_ = [("kind", i32), ("taps", i32), ("stride", i32), ("pad", i32), ("c0", i32), ("c1", i32),
                 ("cout", i32), ("lin", i32), ("lout", i32), ("groups", i32), ("eps", f32), ("w_layout", i32),
-                ("w_flip", i32), ("exact", i32)]
+                ("w_flip", i32), ("exact", i32), ("lin_valid", i32), ("lout_valid", i32)]
 
 
 class TConvIO(C.Structure):

@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(64 * NW) tconv_kernel(const TConvArgs a) {
               const int col = 4 * qi + k;
               const int bl = col / a.lp, ip = col - bl * a.lp - a.pl;
               const int b = b0 + bl;
-              if (bl < a.bt && ip >= 0 && ip < a.lin && b < batch) v[k] = src[(int64_t)b * sb + (int64_t)ip * sl];
+              if (bl < a.bt && ip >= 0 && ip < a.lin_valid && b < batch) v[k] = src[(int64_t)b * sb + (int64_t)ip * sl];
             }
           }
         }
@@ -249,7 +249,12 @@ int tconv_check(const adx_tconv_desc* d) {
     ADX_REQUIRE(d->w_layout == 0 || d->w_layout == 1, "tconv: bad w_layout");
     ADX_REQUIRE((d->taps - 1 - d->pad + 1) / 2 >= 1, "tconv: transposed conv needs a left halo");
   }
-  ADX_REQUIRE(ilog2_exact(d->lout) >= 0 && d->lout <= 64, "tconv: lout must be a power of two <= 64, got %d", d->lout);
+  ADX_REQUIRE(ilog2_exact(d->lout) >= 0 && d->lout <= 64,
+              "tconv: lout must be a power of two <= 64, got %d (other lengths: round lin / lout up and give the real ones in "
+              "lin_valid / lout_valid)", d->lout);
+  ADX_REQUIRE(d->lin_valid >= 0 && d->lin_valid <= d->lin && d->lout_valid >= 0 && d->lout_valid <= d->lout,
+              "tconv: lin_valid %d / lout_valid %d outside [0, lin %d] / [0, lout %d]", d->lin_valid, d->lout_valid, d->lin,
+              d->lout);
   if (d->groups > 0) {
     ADX_REQUIRE(d->cout % d->groups == 0, "tconv: cout %d not divisible by groups %d", d->cout, d->groups);
     const int cg = d->cout / d->groups;
@@ -444,6 +449,8 @@ int tconv_forward(const adx_tconv_desc* d, const adx_tconv_io* io, hipStream_t s
   a.io = *io;
   a.kind = d->kind; a.taps = d->taps; a.stride = d->stride; a.pad = d->pad;
   a.c0 = d->c0; a.cin = t.cin; a.cout = d->cout; a.lin = d->lin; a.lout = d->lout;
+  a.lin_valid = d->lin_valid > 0 ? d->lin_valid : d->lin;
+  a.lout_valid = d->lout_valid > 0 ? d->lout_valid : d->lout;
   a.log2_lout = ilog2_exact(d->lout);
   a.groups = d->groups; a.cg = d->groups > 0 ? d->cout / d->groups : 1; a.eps = d->eps;
   a.ncb = t.ncb; a.nkb = t.nkb;
@@ -452,7 +459,7 @@ int tconv_forward(const adx_tconv_desc* d, const adx_tconv_io* io, hipStream_t s
   auto dense_src = [&](const float* p, int64_t sb, int64_t sc, int64_t sl) {
     return sl == 1 && sc == d->lin && sb % 4 == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
   };
-  a.dense = d->lin % 4 == 0 && t.pl % 4 == 0 && t.lp % 4 == 0 && dense_src(io->x0, io->x0_sb, io->x0_sc, io->x0_sl) &&
+  a.dense = a.lin_valid == d->lin && d->lin % 4 == 0 && t.pl % 4 == 0 && t.lp % 4 == 0 && dense_src(io->x0, io->x0_sb, io->x0_sc, io->x0_sl) &&
             (d->c1 == 0 || dense_src(io->x1, io->x1_sb, io->x1_sc, io->x1_sl));
   const int grid = ceil_div(io->batch, t.bt) * t.ntiles;
   const int key = t.mf * 16 + t.nf;

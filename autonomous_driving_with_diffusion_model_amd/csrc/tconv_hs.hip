@@ -724,6 +724,7 @@ bool tconv_hs_supported(const adx_tconv_desc* d) {
     return e != nullptr && e[0] == '1';
   }();
   if (force_exact || d->exact != 0) return false;
+  if ((d->lin_valid > 0 && d->lin_valid != d->lin) || (d->lout_valid > 0 && d->lout_valid != d->lout)) return false;
   if (d->lout > 32 || ilog2_exact_hs(d->lout) < 0 || ilog2_exact_hs(d->lin) < 0) return false;   // 32 rows per tile = whole samples
   if (32 % d->lout != 0) return false;
   if (d->groups > 0) {
@@ -891,6 +892,7 @@ static int hs_prepare(const adx_tconv_desc* d, const adx_tconv_io* io, HsTile* t
   a.io = *io;
   a.kind = d->kind; a.taps = d->taps; a.stride = d->stride; a.pad = d->pad;
   a.c0 = d->c0; a.cin = d->c0 + d->c1; a.cout = d->cout; a.lin = d->lin; a.lout = d->lout;
+  a.lin_valid = d->lin; a.lout_valid = d->lout;
   a.log2_lout = ilog2_exact_hs(d->lout);
   a.groups = d->groups; a.cg = d->groups > 0 ? d->cout / d->groups : 1; a.eps = d->eps;
   a.cin_pad = round_up(a.cin, 16);

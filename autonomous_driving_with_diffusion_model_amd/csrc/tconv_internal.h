@@ -28,6 +28,7 @@ struct TConvArgs {
   int ncb, nkb;
   int bt, ct, log2_ct, pl, lp, rs, ck, ntiles, cin_pad;
   int dense;  // both inputs are plain [B][C][L] tensors with lin % 4 == 0: 16-byte staging loads
+  int lin_valid, lout_valid;   // real lengths (<= lin, lout): adx_tconv_desc::lin_valid
 };
 
 // On entry P = smem holds NW partial tiles of TILE = bt * ct * lout floats each, laid out
@@ -64,7 +65,8 @@ __device__ __forceinline__ void tconv_epilogue(const TConvArgs& a, float* smem, 
     }
   }
   ADX_TSTAMP(5);
-  const int n = a.cg << a.log2_lout;  // elements per (sample, group)
+  const int n = a.cg << a.log2_lout;  // elements per (sample, group), padded positions included
+  const bool ragged = a.lout_valid != a.lout;      // uniform: a real length that is not a power of two
   float* red = smem + NW * tile_elems; // 2 x (tile_elems / 64) partial sums, behind the K-partials
   constexpr int NCH = tile_elems / 64;
   const bool gn = a.groups > 0;
@@ -78,7 +80,7 @@ __device__ __forceinline__ void tconv_epilogue(const TConvArgs& a, float* smem, 
     const int l = e & (a.lout - 1);
     const int c = n0 + ((e >> a.log2_lout) & (a.ct - 1));
     const int b = b0 + (e >> (a.log2_lout + a.log2_ct));
-    live[k] = e < tile_elems && b < batch && c < a.cout;
+    live[k] = e < tile_elems && b < batch && c < a.cout && l < a.lout_valid;
     gm[k] = 1.f; be[k] = 0.f; tb[k] = 0.f; rs_[k] = 0.f; yoff[k] = 0;
     if (live[k]) {
       if (gn) { gm[k] = a.io.gamma[c]; be[k] = a.io.beta[c]; }
@@ -91,11 +93,14 @@ __device__ __forceinline__ void tconv_epilogue(const TConvArgs& a, float* smem, 
   if (gn) {
     // two-pass mean / variance: wave shuffle, then the pair's n/64 wave partials through LDS
     const int cpp = n >> 6;  // 64-element chunks per pair (n is a multiple of 64: checked on the host)
-    const float inv_n = 1.0f / (float)n;
+    const float inv_n = 1.0f / (float)(a.cg * a.lout_valid);       // statistics over the real positions only
     float mean[EPT], rstd[EPT];
+    bool inr[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) inr[k] = !ragged || ((tid + NT * k) & (a.lout - 1)) < a.lout_valid;
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
-      const float s = wave_sum(v[k]);
+      const float s = wave_sum(inr[k] ? v[k] : 0.f);
       const int ch = wave + NW * k;
       if (lane == 0 && ch < NCH) red[ch] = s;
     }
@@ -108,7 +113,7 @@ __device__ __forceinline__ void tconv_epilogue(const TConvArgs& a, float* smem, 
       float s = 0.f;
       for (int i = 0; i < cpp; ++i) s += red[base + i];
       mean[k] = s * inv_n;
-      const float d = v[k] - mean[k];
+      const float d = inr[k] ? v[k] - mean[k] : 0.f;
       const float q = wave_sum(d * d);
       if (lane == 0 && wave + NW * k < NCH) red[NCH + wave + NW * k] = q;
     }

@@ -19,11 +19,16 @@
 
 namespace adx {
 
+static int pow2_ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
 static adx_tconv_desc conv_desc(int kind, int taps, int stride, int pad, int c0, int c1, int cout, int lin, int lout,
                                 int groups) {
+  // lin / lout are the real lengths; a horizon that is not a power of two (24 -> 24, 12, 6, 3) runs on the next power
+  // of two with the real lengths as masks (adx_tconv_desc::lin_valid)
   adx_tconv_desc d{};
   d.kind = kind; d.taps = taps; d.stride = stride; d.pad = pad;
-  d.c0 = c0; d.c1 = c1; d.cout = cout; d.lin = lin; d.lout = lout;
+  d.c0 = c0; d.c1 = c1; d.cout = cout; d.lin = pow2_ceil(lin); d.lout = pow2_ceil(lout);
+  if (d.lin != lin || d.lout != lout) { d.lin_valid = lin; d.lout_valid = lout; }
   d.groups = groups; d.eps = 1e-5f;
   return d;
 }
@@ -58,7 +63,7 @@ struct Builder {
   }
   ResBlock res_block(int c0, int c1, int cout, int len) {
     ResBlock B;
-    B.c0 = c0; B.c1 = c1; B.cout = cout; B.len = len;
+    B.c0 = c0; B.c1 = c1; B.cout = cout; B.len = pow2_ceil(len);     // pitch of the activation buffers
     B.a = conv_block(c0, c1, cout, len);
     B.b = conv_block(cout, 0, cout, len);
     B.p_tw = next_param++; B.p_tb = next_param++;

@@ -127,6 +127,8 @@ int adx_unet_forward_train(adx_unet* u, const void* packed, void* workspace, siz
   }
   ADX_REQUIRE(io->x && io->img_feature && io->t && io->out, "adx_unet_forward_train: null tensor");
   const int rows = io->rows, dim = u->cfg.dim, H = u->cfg.horizon, D = u->cfg.transition_dim;
+  ADX_REQUIRE((H & (H - 1)) == 0, "adx_unet_forward_train: the training kernels take horizons 16, 32, 64 (got %d); other "
+              "multiples of 8 are supported by the sampling forward only", H);
   ADX_REQUIRE(rows >= 1 && io->t_rows == rows && io->feat_rows == rows,
               "adx_unet_forward_train: time / image batch must equal the trajectory batch (%d)", rows);
   hipStream_t s = (hipStream_t)stream;

@@ -57,6 +57,11 @@ typedef struct adx_tconv_desc {
   /* 0 (default): split-fp16 MFMA where the geometry allows it (fp32-grade result, csrc/tconv_hs.hip);
    * 1: the exact-fp32 MFMA kernel (used for gradient-sized operands whose range fp16 cannot hold). */
   int32_t exact;
+  /* Lengths that are not powers of two (the reference accepts any horizon divisible by 8, modeling/temporal.py:59-75:
+   * 24 -> 24, 12, 6, 3): `lin` / `lout` are then the lengths rounded up to powers of two (the kernels' index arithmetic)
+   * and these the real ones; positions >= lin_valid read as zero, positions >= lout_valid are neither stored nor counted
+   * in the GroupNorm statistics.  0 = equal to lin / lout.  Forward only (the exact-fp32 kernel). */
+  int32_t lin_valid, lout_valid;
 } adx_tconv_desc;
 
 /* Size (bytes) of the packed weight image for a conv of this geometry. */
