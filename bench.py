@@ -68,12 +68,17 @@ def time_events(fn, reps, warm=2):
     return e0.elapsed_time(e1) / reps  # ms per call
 
 
+def pmc_traffic_file():
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    return files[-1] if files else None
+
+
 def pmc_traffic(key):
     """HBM bytes per launch from the newest committed rocprofv3 PMC passes (profiles/r*_pmc_traffic.json); rocprof cannot
     run inside this process, so the number is read back with its provenance."""
     try:
-        import glob
-        with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]) as f:
+        with open(pmc_traffic_file()) as f:
             for k, v in json.load(f)["kernels"].items():
                 if k.startswith(key):
                     return round(v["traffic"])
@@ -145,7 +150,7 @@ def conv2d_roofline(dev, reps=10):
             "avg_launch_ms_rocprof": rocprof_avg_ms("conv2d_hs3x3_kernel"),
             "fp32_equivalent_tflops": round(equiv, 1), "fp32_mfma_peak_tflops": PEAK_F32_TFLOPS,
             "traffic": pmc_traffic("conv2d_hs3x3_kernel"),
-            "traffic_note": "bytes/launch, 2 x FETCH_SIZE (gfx950 correction, calibrated: tools/micro/fetch_calib.hip) + WRITE_SIZE from profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc passes)",
+            "traffic_note": "bytes/launch, 2 x FETCH_SIZE (gfx950 correction, calibrated: tools/micro/fetch_calib.hip) + WRITE_SIZE from profiles/" + os.path.basename(pmc_traffic_file() or "(none)") + " (separate rocprofv3 --pmc passes)",
             "avg_launch_ms": round(avg_ms, 4), "launches_per_step": count,
             "algorithmic_gflop_per_launch": round(tot_fl / count / 1e9, 2),
             "mfma_gflop_per_launch": round(3 * tot_fl / count / 1e9, 2),

@@ -1,5 +1,6 @@
 # Round profile (run on the GPU box through gpurun): kernel stats of the whole bench, PMC traffic of the two roofline
-# kernels (separate --pmc passes, --kernel-trace only), the per-layer timeline of the temporal stack, the default bench.
+# kernels (separate --pmc passes, --kernel-trace only), the per-layer timeline of the temporal stack, the kernel make-up of
+# the two deployed ticks (B = 1: classifier-free and classifier guidance), the default bench.
 R=${R:-r02}
 rm -rf gpurun_out/${R}_stats gpurun_out/${R}_pmc_fetch gpurun_out/${R}_pmc_write gpurun_out/${R}_tconv_trace
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -8,6 +9,11 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${R}
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${R}_pmc_write -- python3 tools/pmc_kernels.py > gpurun_out/${R}_pmc_write.log 2>&1
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${R}_tconv_trace -- python3 tools/bench_tconv.py > gpurun_out/${R}_tconv_layers_hostclock.log 2>&1
 python tools/trace_chunks.py gpurun_out/${R}_tconv_trace > gpurun_out/${R}_tconv_layers.txt
+rm -rf gpurun_out/${R}_tick_free gpurun_out/${R}_tick_cls
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${R}_tick_free -- python3 tools/tick_timeline.py run > gpurun_out/${R}_tick_run.log 2>&1
+MODE=classifier rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${R}_tick_cls -- python3 tools/tick_timeline.py run >> gpurun_out/${R}_tick_run.log 2>&1
+python tools/tick_timeline.py analyze gpurun_out/${R}_tick_free > gpurun_out/${R}_tick_free_b1.txt
+python tools/tick_timeline.py analyze gpurun_out/${R}_tick_cls > gpurun_out/${R}_tick_classifier_b1.txt
 python bench.py > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.err
 ls gpurun_out/${R}_*/*/ | head -30
 tail -c 400 gpurun_out/${R}_bench_default.json
