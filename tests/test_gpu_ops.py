@@ -295,7 +295,10 @@ def test_image_front_end_folded_into_the_stem_is_bit_identical():
             got = m.forward_frames(frames)
         assert torch.equal(got, want), (shape, (got - want).abs().max().item())
     with torch.no_grad():
-        assert torch.equal(m.forward_frames(frames[0]), want[:1])     # a single [H, W, 3] frame
+        # a single [H, W, 3] frame; one frame and three take different reduction splits in the deep layers (small-grid
+        # launches split their input channels over workgroups), so the match is to summation order, not to the bit
+        close(m.forward_frames(frames[0]).cpu(), want[:1].cpu(), 2e-5, rtol=1e-6)
+        assert torch.equal(m.forward_frames(frames[:1]), m(ops.image_transform(frames[:1])))
     from autonomous_driving_with_diffusion_model_amd._lib import AdxError
     with pytest.raises(AdxError):
         m.forward_frames(frames.float())
