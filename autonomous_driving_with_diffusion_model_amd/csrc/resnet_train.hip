@@ -293,17 +293,73 @@ __global__ void __launch_bounds__(256) dilate2_kernel(const float* __restrict__ 
   *d = accumulate ? *d + src[i] : src[i];
 }
 
-// MaxPool2d(3, 2, 1) backward without atomics, two passes.  Pass 1 (one wave per output row): which of its 9 taps
-// is each window's first maximum (torch's tie rule) -> one byte per output.  Pass 2 (one wave per input row): an
-// input pixel lies in at most 2 x 2 windows; it receives dy of those whose code points back at it.
-__global__ void __launch_bounds__(256) maxpool_argcode_kernel(const float* __restrict__ x, uint8_t* __restrict__ code,
-                                                               int H, int W, int OH, int OW) {
+// MaxPool2d(3, 2, 1) backward without atomics.  The forward left one byte per pooled element: which of its window's 9 taps is
+// the first maximum (torch's tie rule).  maxpool_bwd_gather_kernel (one wave per input row): an input pixel lies in at most
+// 2 x 2 windows; it receives dy of those whose code points back at it.
+
+// Training forward of the stem's tail in ONE pass over the conv output: BatchNorm apply + ReLU + MaxPool2d(3, 2, 1) + the
+// first-maximum tap of every window (one byte, for the backward).  The 944 MB post-BN stem map (B = 64,
+// 3x256x900) is then never written nor re-read: bn_apply (read + write), maxpool (read) and a separate arg-max pass of the
+// backward (read) collapse into one read.  Same values as the separate passes: v = relu(fma(raw, scale, shift)) as bn_apply forms it,
+// the maximum with torch's NaN rule as maxpool_kernel, the code = the first tap that attains the maximum (torch's tie rule).
+__global__ void __launch_bounds__(256) bn_relu_pool_code_kernel(const float* __restrict__ raw, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, float* __restrict__ pooled,
+                                                                 uint8_t* __restrict__ code, int C, int H, int W, int OH, int OW) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int oy = blockIdx.y * 4 + wave;
   const int pl = blockIdx.x;
   if (oy >= OH) return;
-  const float* src = x + (size_t)pl * H * W;
-  uint8_t* dst = code + ((size_t)pl * OH + oy) * OW;
+  const float sc = scale[pl % C], sh = shift[pl % C];
+  const float* src = raw + (size_t)pl * H * W;
+  float* dst = pooled + ((size_t)pl * OH + oy) * OW;
+  uint8_t* cdst = code + ((size_t)pl * OH + oy) * OW;
+  if ((W & 1) == 0 && ((size_t)raw & 7) == 0) {
+    // even widths (every map of the 256x900 geometry): a lane loads the two columns 2 ox, 2 ox + 1 of its window as one
+    // 8-byte word and takes column 2 ox - 1 from its left neighbour (only lane 0 of a 64-column chunk loads it itself), like
+    // maxpool_kernel: every element of a row is read once per window row instead of 1.5 times in 4-byte pieces
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    auto act = [&](float r) { const float a = bn_eval(r, sc, sh); return a > 0.f ? a : 0.f; };
+    for (int ox0 = lane; ox0 - lane < OW; ox0 += 256) {     // wave-uniform trip count: the shuffles need every lane
+      float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, pm[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      int arg[4] = {-1, -1, -1, -1};
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int iy = oy * 2 - 1 + dy;
+        if (iy < 0 || iy >= H) continue;                 // wave-uniform
+        const float* row = src + (size_t)iy * W;
+        f32x2 v[4];
+        float left[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int ox = ox0 + 64 * q;
+          const bool in = 2 * ox + 1 < W;                // W even: both columns exist or neither
+          v[q] = in ? *reinterpret_cast<const f32x2*>(row + 2 * ox) : f32x2{-INFINITY, -INFINITY};
+          if (in) { v[q][0] = act(v[q][0]); v[q][1] = act(v[q][1]); }
+          left[q] = (lane == 0 && ox > 0 && 2 * ox - 1 < W) ? act(row[2 * ox - 1]) : -INFINITY;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int ox = ox0 + 64 * q;
+          const float nb = __shfl_up(v[q][1], 1, 64);
+          const float t3[3] = {lane == 0 ? left[q] : nb, v[q][0], v[q][1]};
+          const bool ok[3] = {ox > 0 && 2 * ox - 1 < W, 2 * ox < W, 2 * ox + 1 < W};
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const float x = t3[dx];
+            if (ok[dx] && (x > m[q] || arg[q] < 0)) { m[q] = x; arg[q] = dy * 3 + dx; }
+            if (ok[dx]) pm[q] = (x > pm[q] || x != x) ? x : pm[q];
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (ox0 + 64 * q < OW) {
+          dst[ox0 + 64 * q] = pm[q];
+          cdst[ox0 + 64 * q] = (uint8_t)arg[q];
+        }
+    }
+    return;
+  }
   for (int ox0 = lane; ox0 < OW; ox0 += 256) {
     float v[4][9];
 #pragma unroll
@@ -316,20 +372,29 @@ __global__ void __launch_bounds__(256) maxpool_argcode_kernel(const float* __res
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
           const int ix = (ox0 + 64 * q) * 2 - 1 + dx;
-          v[q][dy * 3 + dx] = (rok && ix >= 0 && ix < W) ? row[ix] : -INFINITY;
+          float a = -INFINITY;
+          if (rok && ix >= 0 && ix < W) {
+            a = bn_eval(row[ix], sc, sh);
+            a = a > 0.f ? a : 0.f;
+          }
+          v[q][dy * 3 + dx] = a;
         }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      float m = -INFINITY;
+      float m = -INFINITY, pm = -INFINITY;
       int arg = -1;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int iy = oy * 2 - 1 + t / 3, ix = (ox0 + 64 * q) * 2 - 1 + t % 3;
         const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
         if (in && (v[q][t] > m || arg < 0)) { m = v[q][t]; arg = t; }
+        pm = (v[q][t] > pm || v[q][t] != v[q][t]) ? v[q][t] : pm;
       }
-      if (ox0 + 64 * q < OW) dst[ox0 + 64 * q] = (uint8_t)arg;
+      if (ox0 + 64 * q < OW) {
+        dst[ox0 + 64 * q] = pm;
+        cdst[ox0 + 64 * q] = (uint8_t)arg;
+      }
     }
   }
 }
@@ -724,6 +789,7 @@ struct adx_resnet_tape {
   std::vector<Rec> recs;
   int batch = 0, h = 0, w = 0;
   float* pool_in = nullptr; float* pool_out = nullptr; int ph = 0, pw = 0, poh = 0, pow_ = 0;
+  uint8_t* pool_code = nullptr;   // first-maximum tap of every pooling window, written by the forward's fused stem tail
   float* final_map = nullptr; int fh = 0, fw_ = 0;
   size_t fwd_floats = 0;
 };
@@ -755,7 +821,7 @@ size_t adx_resnet_train_workspace_bytes(const adx_resnet* r, int32_t batch, int3
   conv(r->convs[ci++], h, w);
   const int h1 = conv_out_dim(h, 7, 2, 3), w1 = conv_out_dim(w, 7, 2, 3);
   int H = conv_out_dim(h1, 3, 2, 1), W = conv_out_dim(w1, 3, 2, 1);
-  f += al64((size_t)batch * 64 * H * W);
+  f += al64((size_t)batch * 64 * H * W) + al64(((size_t)batch * 64 * H * W + 3) / 4);    // pooled map + its arg-max codes
   big = std::max(big, (size_t)batch * 64 * h1 * w1);
   for (size_t b = 0; b < r->block_has_ds.size(); ++b) {
     const ConvSpec& c1 = r->convs[ci++];
@@ -795,7 +861,8 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
   float* scale = ws.take(512);
   float* shift = ws.take(512);
   int rc = ADX_OK;
-  auto conv_bn = [&](const ConvSpec& L, const float* x, int H, int W, const float* identity, int relu) -> float* {
+  auto conv_bn = [&](const ConvSpec& L, const float* x, int H, int W, const float* identity, int relu,
+                     bool apply = true) -> float* {
     adx_resnet_tape::Rec rec;
     rec.L = &L; rec.x = x; rec.H = H; rec.W = W; rec.relu = relu; rec.identity = identity;
     rec.OH = conv_out_dim(H, L.k, L.stride, L.pad); rec.OW = conv_out_dim(W, L.k, L.stride, L.pad);
@@ -811,7 +878,9 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
     bn_finalize_kernel<<<dim3(ceil_div(L.cout, 256)), dim3(256), 0, s>>>(
         sums, T[L.t_g], T[L.t_b], scale, shift, rec.mean, rec.rstd, update_running ? const_cast<float*>(T[L.t_m]) : nullptr,
         update_running ? const_cast<float*>(T[L.t_v]) : nullptr, L.cout, (double)batch * HW);
-    if (bn_planes_ok(HW, rec.raw, identity, rec.out)) {
+    if (!apply) {
+      // the caller consumes (raw, scale, shift) itself before the next conv_bn overwrites scale / shift (stream order)
+    } else if (bn_planes_ok(HW, rec.raw, identity, rec.out)) {
       const int planes = batch * L.cout;
       bn_apply_planes_kernel<<<dim3(std::min(ceil_div(planes, 4), 8192)), dim3(256), 0, s>>>(rec.raw, scale, shift, identity,
                                                                                             rec.out, L.cout, HW, planes, relu);
@@ -823,12 +892,20 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
     return rec.out;
   };
   size_t ci = 0;
-  float* stem = conv_bn(r->convs[ci++], img, h, w, nullptr, 1);
+  // stem: conv -> batch statistics -> [BN apply + ReLU + MaxPool + arg-max code] in one pass over the conv output; the
+  // post-BN stem map (rec.out of this record) is never formed -- nothing reads it: the backward re-derives the ReLU mask
+  // from the conv output (mask mode 2)
+  float* stem = conv_bn(r->convs[ci++], img, h, w, nullptr, 1, false);
   const int h1 = conv_out_dim(h, 7, 2, 3), w1 = conv_out_dim(w, 7, 2, 3);
   const int h2 = conv_out_dim(h1, 3, 2, 1), w2 = conv_out_dim(w1, 3, 2, 1);
   float* pooled = ws.take((size_t)batch * 64 * h2 * w2);
-  if (ws.ok && rc == ADX_OK) rc = maxpool_launch(stem, pooled, batch * 64, h1, w1, h2, w2, s);
+  uint8_t* pcode = reinterpret_cast<uint8_t*>(ws.take(((size_t)batch * 64 * h2 * w2 + 3) / 4));
+  if (ws.ok && rc == ADX_OK) {
+    bn_relu_pool_code_kernel<<<dim3(batch * 64, ceil_div(h2, 4)), dim3(256), 0, s>>>(tape->recs[0].raw, scale, shift, pooled, pcode,
+                                                                                 64, h1, w1, h2, w2);
+  }
   tape->pool_in = stem; tape->pool_out = pooled; tape->ph = h1; tape->pw = w1; tape->poh = h2; tape->pow_ = w2;
+  tape->pool_code = pcode;
   float* cur = pooled;
   int H = h2, W = w2;
   for (size_t b = 0; b < r->block_has_ds.size(); ++b) {
@@ -984,11 +1061,8 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
     for (auto p : gb) if (p != g_cur && p != gb[4]) { dstem = p; break; }
     const size_t nin = (size_t)batch * 64 * tape->ph * tape->pw;
     (void)nin;
-    // the byte codes live in the (still unused) dilation buffer
-    uint8_t* code = reinterpret_cast<uint8_t*>(gb[4]);
-    ADX_REQUIRE(dstem != gb[4] && g_cur != gb[4], "adx_resnet_backward: scratch buffer clash");
-    maxpool_argcode_kernel<<<dim3(batch * 64, ceil_div(tape->poh, 4)), dim3(256), 0, s>>>(tape->pool_in, code, tape->ph, tape->pw,
-                                                                                      tape->poh, tape->pow_);
+    const uint8_t* code = tape->pool_code;     // written by the forward's fused stem tail
+    ADX_REQUIRE(code != nullptr && dstem != gb[4] && g_cur != gb[4], "adx_resnet_backward: scratch buffer clash");
     maxpool_bwd_gather_kernel<<<dim3(batch * 64, ceil_div(tape->ph, 4)), dim3(256), 0, s>>>(code, g_cur, dstem, tape->ph, tape->pw,
                                                                                         tape->poh, tape->pow_);
     ADX_LAUNCH_CHECK();

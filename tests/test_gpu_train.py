@@ -227,8 +227,10 @@ def test_unet_gradients_vs_oracle_autograd(use_cond, H, B):
     assert all(named[k].grad is not None for k in keys)
 
 
-def test_perception_train_mode_vs_oracle_autograd():
-    """Batch-statistics BatchNorm forward, running-buffer update and every ResNet-34 parameter gradient.
+@pytest.mark.parametrize("hw", [(64, 96), (70, 102)])
+def test_perception_train_mode_vs_oracle_autograd(hw):
+    """Batch-statistics BatchNorm forward, running-buffer update and every ResNet-34 parameter gradient ((70, 102): odd map
+    widths, i.e. the generic paths of the pooling / BatchNorm passes).
 
     These gradients are not a smooth function of the arithmetic: with 18..72 samples per channel the deep
     batch-norms amplify fp32 rounding to ~1e-5 in the activations, and every ReLU unit whose pre-activation
@@ -243,7 +245,7 @@ def test_perception_train_mode_vs_oracle_autograd():
     m.train()
     sd = oracle_sd("NO_GUIDANCE")
     pkeys = [e.key for e in unet_entries("NO_GUIDANCE") if e.key.startswith("perception.") and not e.is_buffer]
-    img = P.synthetic_batch(3, 16, image_hw=(64, 96), seed=61)["imgs"]
+    img = P.synthetic_batch(3, 16, image_hw=hw, seed=61)["imgs"]
     w = P._uniform("perc.w", 61, (3, 64), -1.0, 1.0)
 
     def oracle_grads(dtype):
