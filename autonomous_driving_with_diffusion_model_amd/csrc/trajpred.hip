@@ -24,7 +24,8 @@ constexpr int NH = 4;        // heads
 constexpr int DH = 16;       // head dim
 constexpr int FF = 256;      // dim_feedforward
 constexpr int TP = 32;       // padded rows
-constexpr int RT = 8;        // rows per thread in the small GEMMs
+constexpr int NT = 1024;     // threads per workgroup (one workgroup per sample; LDS allows one per CU anyway: 4 waves per SIMD
+                             // hide the latencies of the ~60 dependent phases a single wave per SIMD exposed)
 constexpr int NL = 2;        // encoder layers
 constexpr int IN_DIM = 3;
 
@@ -80,10 +81,11 @@ __global__ void transpose_copy_kernel(const float* __restrict__ w, float* __rest
 // ---------------------------------------------------------------------------------------------
 // small GEMMs on an LDS-resident [TP][K] tile
 // out[t][n] = sum_k in[t][k] * wt[k][n] (+ bias[n]);  wt is K-major in global memory
-template <bool ACCUM>
+// RT = rows per thread: chosen per call so that N * (TP / RT) items fill the workgroup (N = 64: RT 2; 192, 256: RT 8)
+template <bool ACCUM, int RT>
 __device__ __forceinline__ void mm_fwd(float* out, int ldo, const float* in, int ldi, const float* __restrict__ wt,
                                        const float* __restrict__ bias, int K, int N, int tid) {
-  for (int item = tid; item < N * (TP / RT); item += 256) {
+  for (int item = tid; item < N * (TP / RT); item += NT) {
     const int n = item % N, tg = item / N;
     float acc[RT];
 #pragma unroll
@@ -118,7 +120,7 @@ __device__ __forceinline__ void layer_norm_rows(float* y, const float* x, int ld
                                                 int tid) {
   // one wave per row, 64 features = 64 lanes
   const int lane = tid & 63, wave = tid >> 6;
-  for (int t = wave; t < T; t += 4) {
+  for (int t = wave; t < T; t += NT / 64) {
     const float v = x[t * ld + lane];
     const float mean = wave_sum(v) * (1.0f / E);
     const float d = v - mean;
@@ -135,7 +137,7 @@ __device__ __forceinline__ void layer_norm_rows(float* y, const float* x, int ld
 __device__ __forceinline__ void layer_norm_bwd_rows(float* dx, const float* dy, const float* xhat, const float* rstd,
                                                     int ld, const float* __restrict__ g, int T, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
-  for (int t = wave; t < T; t += 4) {
+  for (int t = wave; t < T; t += NT / 64) {
     const float dxh = dy[t * ld + lane] * g[lane];
     const float xh = xhat[t * ld + lane];
     const float m1 = wave_sum(dxh) * (1.0f / E);
@@ -154,7 +156,7 @@ __device__ __forceinline__ float silu_grad(float x) {
 // One workgroup per sample adds into the shared gradient image with float atomics.
 template <typename FA>
 __device__ __forceinline__ void outer_acc(float* gW, int N, int K, FA fa, const float* Bm, int ldb, int T, int tid) {
-  for (int idx = tid; idx < N * K; idx += 256) {
+  for (int idx = tid; idx < N * K; idx += NT) {
     const int n = idx / K, k = idx - n * K;
     float acc = 0.f;
     for (int t = 0; t < T; ++t) acc += fa(t, n) * Bm[t * ldb + k];
@@ -163,7 +165,7 @@ __device__ __forceinline__ void outer_acc(float* gW, int N, int K, FA fa, const 
 }
 template <typename FA>
 __device__ __forceinline__ void colsum_acc(float* gb, int N, FA fa, int T, int tid) {
-  for (int n = tid; n < N; n += 256) {
+  for (int n = tid; n < N; n += NT) {
     float acc = 0.f;
     for (int t = 0; t < T; ++t) acc += fa(t, n);
     atomicAdd(gb + n, acc);
@@ -202,7 +204,7 @@ __device__ __forceinline__ Lds carve(float* s) {
 __device__ __forceinline__ void embed_rows(float* X, const float* __restrict__ act, int64_t act_stride,
                                            const float* __restrict__ te, const float* __restrict__ P,
                                            const TPLayout& L, int T, int tid) {
-  for (int idx = tid; idx < TP * E; idx += 256) {
+  for (int idx = tid; idx < TP * E; idx += NT) {
     const int t = idx >> 6, j = idx & 63;
     float v = 0.f;
     if (t < T) {
@@ -252,10 +254,10 @@ __device__ __forceinline__ void layer_forward(const Lds& l, const float* __restr
                                               int tid, const Drop& dr, int li) {
   const uint32_t k_att = drop_site(dr, 4 * li + 0), k_d1 = drop_site(dr, 4 * li + 1), k_in = drop_site(dr, 4 * li + 2),
                  k_d2 = drop_site(dr, 4 * li + 3);
-  mm_fwd<false>(l.QKV, 3 * E, l.X, E, P + y.w_in_t, P + y.b_in, E, 3 * E, tid);
+  mm_fwd<false, 8>(l.QKV, 3 * E, l.X, E, P + y.w_in_t, P + y.b_in, E, 3 * E, tid);
   __syncthreads();
   // scores + softmax: one thread per (head, query row)
-  for (int idx = tid; idx < NH * TP; idx += 256) {
+  for (int idx = tid; idx < NH * TP; idx += NT) {
     const int h = idx / TP, t = idx - h * TP;
     float* p = l.P + (h * TP + t) * TP;
     if (t < T) {
@@ -282,7 +284,7 @@ __device__ __forceinline__ void layer_forward(const Lds& l, const float* __restr
   }
   __syncthreads();
   // O = P @ V
-  for (int idx = tid; idx < TP * E; idx += 256) {
+  for (int idx = tid; idx < TP * E; idx += NT) {
     const int t = idx >> 6, c = idx & 63, h = c >> 4;
     float acc = 0.f;
     if (t < T) {
@@ -294,29 +296,31 @@ __device__ __forceinline__ void layer_forward(const Lds& l, const float* __restr
   }
   __syncthreads();
   // Y = X + dropout1(out_proj(O))   (H1 is free until the LayerNorm below writes it)
-  mm_fwd<false>(l.H1, E, l.O, E, P + y.w_out_t, P + y.b_out, E, E, tid);
+  mm_fwd<false, 2>(l.H1, E, l.O, E, P + y.w_out_t, P + y.b_out, E, E, tid);
   __syncthreads();
-  for (int idx = tid; idx < TP * E; idx += 256) l.Y[idx] = l.X[idx] + l.H1[idx] * drop_mul(dr, k_d1, (uint32_t)idx);
+  for (int idx = tid; idx < TP * E; idx += NT) l.Y[idx] = l.X[idx] + l.H1[idx] * drop_mul(dr, k_d1, (uint32_t)idx);
   __syncthreads();
   layer_norm_rows(l.H1, l.Y, E, P + y.g1, P + y.be1, l.XH1, l.R1, T, tid);
   __syncthreads();
-  mm_fwd<false>(l.F, FF, l.H1, E, P + y.w1_t, P + y.b1, E, FF, tid);
+  mm_fwd<false, 8>(l.F, FF, l.H1, E, P + y.w1_t, P + y.b1, E, FF, tid);
   __syncthreads();
   // Y = H1 + linear2(silu(F))
-  for (int idx = tid; idx < TP * E; idx += 256) l.Y[idx] = l.H1[idx];
+  for (int idx = tid; idx < TP * E; idx += NT) l.Y[idx] = l.H1[idx];
   __syncthreads();
   {
     // silu(F) @ W2^T, K = 256.  The activation (an exp and a division) is evaluated ONCE per element -- 64 columns of
     // silu(F) * mask at a time into X (dead since Y = X + sa was formed; norm2 rewrites it below) -- not once per (element, output column) inside the product loop,
     // which made this the longest phase of the layer.  Thread = (output column n, row group tg), accumulators live
     // across the four slabs; the products are added in ascending k as before.
-    const int n = tid % E, tg = tid / E;           // E * (TP / RT) = 256 items = one per thread
+    constexpr int RT = TP * E / NT;                // rows per thread: E * (TP / RT) items = one per thread
+    static_assert(RT >= 1 && TP % RT == 0 && E * (TP / RT) == NT, "one (column, row group) item per thread");
+    const int n = tid % E, tg = tid / E;
     float acc[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) acc[r] = 0.f;
     const float* wt = P + y.w2_t;
     for (int k0 = 0; k0 < FF; k0 += E) {
-      for (int idx = tid; idx < TP * E; idx += 256) {
+      for (int idx = tid; idx < TP * E; idx += NT) {
         const int t = idx >> 6, j = idx & 63;
         l.X[idx] = silu_f(l.F[t * FF + k0 + j]) * drop_mul(dr, k_in, (uint32_t)(t * FF + k0 + j));
       }
@@ -356,7 +360,7 @@ __device__ __forceinline__ void layer_backward(const Lds& l, float* D, const flo
   const uint32_t k_att = drop_site(dr, 4 * li + 0), k_d1 = drop_site(dr, 4 * li + 1), k_in = drop_site(dr, 4 * li + 2),
                  k_d2 = drop_site(dr, 4 * li + 3);
   if (G != nullptr) {  // norm2 affine
-    for (int i = tid; i < E; i += 256) {
+    for (int i = tid; i < E; i += NT) {
       float sg = 0.f, sb = 0.f;
       for (int t = 0; t < T; ++t) { sg += D[t * E + i] * l.XH2[t * E + i]; sb += D[t * E + i]; }
       atomicAdd(G + y.g2 + i, sg);
@@ -367,10 +371,10 @@ __device__ __forceinline__ void layer_backward(const Lds& l, float* D, const flo
   layer_norm_bwd_rows(l.Y, D, l.XH2, l.R2, E, P + y.g2, T, tid);   // Y = d(y2): the residual path's gradient ...
   __syncthreads();
   // ... and D (free until norm1's backward) = d(ff) = dropout2's mask on it
-  for (int idx = tid; idx < TP * E; idx += 256) D[idx] = l.Y[idx] * drop_mul(dr, k_d2, (uint32_t)idx);
+  for (int idx = tid; idx < TP * E; idx += NT) D[idx] = l.Y[idx] * drop_mul(dr, k_d2, (uint32_t)idx);
   __syncthreads();
   if (G != nullptr) {  // linear2: ff = W2 (mask * silu(F)) + b2, before F is overwritten
-    for (int idx = tid; idx < E * FF; idx += 256) {
+    for (int idx = tid; idx < E * FF; idx += NT) {
       const int j = idx / FF, n = idx - j * FF;
       float acc = 0.f;
       for (int t = 0; t < T; ++t)
@@ -378,9 +382,11 @@ __device__ __forceinline__ void layer_backward(const Lds& l, float* D, const flo
       atomicAdd(G + y.w2 + idx, acc);
     }
     colsum_acc(G + y.b2, E, [&](int t, int n) { return D[t * E + n]; }, T, tid);
+    __syncthreads();     // the loop below overwrites F, which the weight-gradient sums above still read
   }
   // ds = dff @ W2  ([T][256]); dF = ds * silu'(F), stored over F
-  for (int item = tid; item < FF * (TP / RT); item += 256) {
+  constexpr int RT = 8;          // FF * (TP / 8) = 1024 items
+  for (int item = tid; item < FF * (TP / RT); item += NT) {
     const int n = item % FF, tg = item / FF;
     float acc[RT];
 #pragma unroll
@@ -403,10 +409,10 @@ __device__ __forceinline__ void layer_backward(const Lds& l, float* D, const flo
     colsum_acc(G + y.b1, FF, [&](int t, int n) { return l.F[t * FF + n]; }, T, tid);
   }
   // dH1 = dy2 + dF @ W1   (W1 is [256][64]: K = 256 rows, N = 64 contiguous)
-  mm_fwd<true>(l.Y, E, l.F, FF, P + y.w1, nullptr, FF, E, tid);
+  mm_fwd<true, 2>(l.Y, E, l.F, FF, P + y.w1, nullptr, FF, E, tid);
   __syncthreads();
   if (G != nullptr) {  // norm1 affine
-    for (int i = tid; i < E; i += 256) {
+    for (int i = tid; i < E; i += NT) {
       float sg = 0.f, sb = 0.f;
       for (int t = 0; t < T; ++t) { sg += l.Y[t * E + i] * l.XH1[t * E + i]; sb += l.Y[t * E + i]; }
       atomicAdd(G + y.g1 + i, sg);
@@ -417,17 +423,17 @@ __device__ __forceinline__ void layer_backward(const Lds& l, float* D, const flo
   layer_norm_bwd_rows(D, l.Y, l.XH1, l.R1, E, P + y.g1, T, tid);
   __syncthreads();
   // d(sa) = dropout1's mask on d(y1), kept in XH2 (dead since norm2's backward); D stays the residual path's gradient
-  for (int idx = tid; idx < TP * E; idx += 256) l.XH2[idx] = D[idx] * drop_mul(dr, k_d1, (uint32_t)idx);
+  for (int idx = tid; idx < TP * E; idx += NT) l.XH2[idx] = D[idx] * drop_mul(dr, k_d1, (uint32_t)idx);
   __syncthreads();
   if (G != nullptr) {  // out_proj: sa = Wout O + bout
     outer_acc(G + y.w_out, E, E, [&](int t, int n) { return l.XH2[t * E + n]; }, l.O, E, T, tid);
     colsum_acc(G + y.b_out, E, [&](int t, int n) { return l.XH2[t * E + n]; }, T, tid);
   }
   // dO = dsa @ Wout  (Wout [64][64], row j = output feature)
-  mm_fwd<false>(l.Y, E, l.XH2, E, P + y.w_out, nullptr, E, E, tid);    // Y = dO
+  mm_fwd<false, 2>(l.Y, E, l.XH2, E, P + y.w_out, nullptr, E, E, tid);    // Y = dO
   __syncthreads();
   // dP[h][t][s] = sum_d dO[t][hd] V[s][hd];  dS = P * (dP - sum_s dP P), written into F (dead by now)
-  for (int idx = tid; idx < NH * TP; idx += 256) {
+  for (int idx = tid; idx < NH * TP; idx += NT) {
     const int h = idx / TP, t = idx - h * TP;
     if (t < T) {
       const float* p = l.P + (h * TP + t) * TP;
@@ -449,7 +455,7 @@ __device__ __forceinline__ void layer_backward(const Lds& l, float* D, const flo
   __syncthreads();
   // dV[s][c] = sum_t P[h][t][s] dO[t][c];  dQ[t][c] = sum_s dS[t][s] K[s][c] / 4;  dK[s][c] = sum_t dS[t][s] Q[t][c] / 4
   // written into O (dq), H1 (dk), XH1 (dv) -- all dead at this point
-  for (int idx = tid; idx < TP * E; idx += 256) {
+  for (int idx = tid; idx < TP * E; idx += NT) {
     const int t = idx >> 6, c = idx & 63, h = c >> 4;
     float dq = 0.f, dk = 0.f, dv = 0.f;
     if (t < T) {
@@ -474,9 +480,9 @@ __device__ __forceinline__ void layer_backward(const Lds& l, float* D, const flo
     colsum_acc(G + y.b_in + 2 * E, E, [&](int t, int n) { return l.XH1[t * E + n]; }, T, tid);
   }
   // dX = d(y1) + [dq dk dv] @ Win   (Win [192][64]); D already holds d(y1)
-  mm_fwd<true>(D, E, l.O, E, P + y.w_in, nullptr, E, E, tid);
-  mm_fwd<true>(D, E, l.H1, E, P + y.w_in + E * E, nullptr, E, E, tid);
-  mm_fwd<true>(D, E, l.XH1, E, P + y.w_in + 2 * E * E, nullptr, E, E, tid);
+  mm_fwd<true, 2>(D, E, l.O, E, P + y.w_in, nullptr, E, E, tid);
+  mm_fwd<true, 2>(D, E, l.H1, E, P + y.w_in + E * E, nullptr, E, E, tid);
+  mm_fwd<true, 2>(D, E, l.XH1, E, P + y.w_in + 2 * E * E, nullptr, E, E, tid);
   __syncthreads();
 }
 
@@ -513,7 +519,7 @@ __device__ __forceinline__ void head_forward(const Lds& l, const float* __restri
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(256) trajpred_forward_kernel(const TrajArgs a) {
+__global__ void __launch_bounds__(NT) trajpred_forward_kernel(const TrajArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const Lds l = carve(smem);
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -523,7 +529,7 @@ __global__ void __launch_bounds__(256) trajpred_forward_kernel(const TrajArgs a)
   for (int li = 0; li < NL; ++li) layer_forward(l, a.P, a.L.layer[li], a.T, tid, dr, li);
   head_forward(l, a.P, a.L, a.T, tid);
   const int od = a.L.out_dim;
-  for (int idx = tid; idx < a.T * od; idx += 256) {
+  for (int idx = tid; idx < a.T * od; idx += NT) {
     const int t = idx / od, j = idx - t * od;
     float acc = a.P[a.L.b_op + j];
     for (int i = 0; i < E; ++i) acc += l.Y[t * E + i] * a.P[a.L.w_op + j * E + i];
@@ -538,7 +544,7 @@ __device__ __forceinline__ void forward_keep(const Lds& l, const TrajArgs& a, in
   embed_rows(l.X, a.action + (int64_t)b * a.act_sb, a.act_st, a.te + (int64_t)b * E, a.P, a.L, T, tid);
   __syncthreads();
   for (int li = 0; li < NL; ++li) {
-    for (int idx = tid; idx < TP * E; idx += 256) l.IN(li)[idx] = l.X[idx];
+    for (int idx = tid; idx < TP * E; idx += NT) l.IN(li)[idx] = l.X[idx];
     __syncthreads();
     layer_forward(l, a.P, a.L.layer[li], T, tid, dr, li);
   }
@@ -555,20 +561,20 @@ __device__ __forceinline__ void backward_core(const Lds& l, const TrajArgs& a, i
   const int T = a.T, od = L.out_dim;
   float* G = a.G;
   if (G != nullptr) {  // output_proj: out = Wop Ynorm + bop
-    for (int idx = tid; idx < od * E; idx += 256) {
+    for (int idx = tid; idx < od * E; idx += NT) {
       const int j = idx / E, i = idx - j * E;
       float acc = 0.f;
       for (int t = 0; t < T; ++t) acc += dout(t, j) * l.Y[t * E + i];
       atomicAdd(G + L.w_op + idx, acc);
     }
-    for (int j = tid; j < od; j += 256) {
+    for (int j = tid; j < od; j += NT) {
       float acc = 0.f;
       for (int t = 0; t < T; ++t) acc += dout(t, j);
       atomicAdd(G + L.b_op + j, acc);
     }
   }
   // d(normed) = dout @ Wop  -> X (the last layer's output: consumed by the head already)
-  for (int idx = tid; idx < TP * E; idx += 256) {
+  for (int idx = tid; idx < TP * E; idx += NT) {
     const int t = idx >> 6, i = idx & 63;
     float acc = 0.f;
     if (t < T)
@@ -578,7 +584,7 @@ __device__ __forceinline__ void backward_core(const Lds& l, const TrajArgs& a, i
   __syncthreads();
   float* D = l.IN(NL);          // holds the final norm's normalised values; becomes d(last layer output) in place
   if (G != nullptr) {  // final LayerNorm affine
-    for (int i = tid; i < E; i += 256) {
+    for (int i = tid; i < E; i += NT) {
       float sg = 0.f, sb = 0.f;
       for (int t = 0; t < T; ++t) { sg += l.X[t * E + i] * D[t * E + i]; sb += l.X[t * E + i]; }
       atomicAdd(G + L.gf + i, sg);
@@ -587,29 +593,29 @@ __device__ __forceinline__ void backward_core(const Lds& l, const TrajArgs& a, i
     __syncthreads();
   }
   layer_norm_bwd_rows(D, l.X, D, l.R3, E, P + L.gf, T, tid);    // each lane reads its own element before writing it
-  for (int idx = tid + 0; idx < TP * E; idx += 256)
+  for (int idx = tid + 0; idx < TP * E; idx += NT)
     if ((idx >> 6) >= T) D[idx] = 0.f;
   __syncthreads();
   for (int li = NL - 1; li >= 0; --li) {
     if (li != NL - 1) {
-      for (int idx = tid; idx < TP * E; idx += 256) l.X[idx] = l.IN(li)[idx];
+      for (int idx = tid; idx < TP * E; idx += NT) l.X[idx] = l.IN(li)[idx];
       __syncthreads();
       layer_forward(l, P, L.layer[li], T, tid, dr, li);     // recompute this layer's internals (same masks)
     }
     layer_backward(l, D, P, L.layer[li], T, tid, G, l.IN(li), dr, li);
-    for (int idx = tid; idx < TP * E; idx += 256)
+    for (int idx = tid; idx < TP * E; idx += NT)
       if ((idx >> 6) >= T) D[idx] = 0.f;
     __syncthreads();
   }
   if (G != nullptr) {  // input_proj: x0 = Wip a + bip (+ pos + time_embed)
     const float* act = a.action + (int64_t)b * a.act_sb;
-    for (int idx = tid; idx < E * IN_DIM; idx += 256) {
+    for (int idx = tid; idx < E * IN_DIM; idx += NT) {
       const int j = idx / IN_DIM, i = idx - j * IN_DIM;
       float acc = 0.f;
       for (int t = 0; t < T; ++t) acc += D[t * E + j] * act[(int64_t)t * a.act_st + i];
       atomicAdd(G + L.w_ip + idx, acc);
     }
-    for (int j = tid; j < E; j += 256) {
+    for (int j = tid; j < E; j += NT) {
       float acc = 0.f;
       for (int t = 0; t < T; ++t) acc += D[t * E + j];
       atomicAdd(G + L.b_ip + j, acc);
@@ -617,7 +623,7 @@ __device__ __forceinline__ void backward_core(const Lds& l, const TrajArgs& a, i
     }
   }
   // d(action)[t][i] = sum_j D[t][j] Wip[j][i]
-  for (int idx = tid; idx < TP * IN_DIM; idx += 256) {
+  for (int idx = tid; idx < TP * IN_DIM; idx += NT) {
     const int t = idx / IN_DIM, i = idx - t * IN_DIM;
     float acc = 0.f;
     if (t < T)
@@ -627,7 +633,7 @@ __device__ __forceinline__ void backward_core(const Lds& l, const TrajArgs& a, i
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(256) trajpred_backward_kernel(const TrajArgs a) {
+__global__ void __launch_bounds__(NT) trajpred_backward_kernel(const TrajArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const Lds l = carve(smem);
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -637,7 +643,7 @@ __global__ void __launch_bounds__(256) trajpred_backward_kernel(const TrajArgs a
   forward_keep(l, a, b, tid, dr);
   backward_core(l, a, b, tid, dr, [&](int t, int j) { return g[(int64_t)t * gst + j]; });
   if (a.gact != nullptr)
-    for (int idx = tid; idx < a.T * IN_DIM; idx += 256) {
+    for (int idx = tid; idx < a.T * IN_DIM; idx += NT) {
       const int t = idx / IN_DIM, i = idx - t * IN_DIM;
       a.gact[(int64_t)b * a.gact_sb + (int64_t)t * a.gact_st + i] = l.O[idx];
     }
@@ -647,7 +653,7 @@ __global__ void __launch_bounds__(256) trajpred_backward_kernel(const TrajArgs a
 //   x = cat([0; state_pred(action[:-1])], action);  choose h* by TargetGuidance's rule;
 //   g_x = 2 (x[h*, :2] - target) at (h*, :2);  g_a = d(state)/d(action)^T g_x[1:, :4];
 //   x[:, :4] -= scale/15 * std * g_x[:, :4];  x[:, 4:] -= scale * std * g_a;  clip(-1, 1)
-__global__ void __launch_bounds__(256) guided_output_kernel(const TrajArgs a) {
+__global__ void __launch_bounds__(NT) guided_output_kernel(const TrajArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const Lds l = carve(smem);
   __shared__ float st[TP + 1][4];
@@ -659,7 +665,7 @@ __global__ void __launch_bounds__(256) guided_output_kernel(const TrajArgs a) {
   // ONE forward (layer inputs kept) serves both the state rows and the gradient below
   const Drop dr_off{0u, 0u, 1.f};      // guidance runs the state head in eval mode
   forward_keep(l, a, b, tid, dr_off);
-  for (int idx = tid; idx < H * od; idx += 256) {
+  for (int idx = tid; idx < H * od; idx += NT) {
     const int h = idx / od, j = idx - h * od;
     float acc = 0.f;
     if (h > 0) {
@@ -697,13 +703,13 @@ __global__ void __launch_bounds__(256) guided_output_kernel(const TrajArgs a) {
   if (hs > 0) {
     backward_core(l, a, b, tid, dr_off, [&](int t, int j) { return (t == hs - 1 && j < 2) ? (j == 0 ? g0 : g1) : 0.f; });
   } else {
-    for (int idx = tid; idx < TP * IN_DIM; idx += 256) l.O[idx] = 0.f;
+    for (int idx = tid; idx < TP * IN_DIM; idx += NT) l.O[idx] = 0.f;
     __syncthreads();
   }
   const int dims = od + IN_DIM;
   const float s_state = a.scale / 15.f * a.grad_scale, s_act = a.scale * a.grad_scale;
   float* xo = a.xg + (int64_t)b * H * dims;
-  for (int idx = tid; idx < H * dims; idx += 256) {
+  for (int idx = tid; idx < H * dims; idx += NT) {
     const int h = idx / dims, j = idx - h * dims;
     float v;
     if (j < od) {
@@ -828,7 +834,7 @@ int adx_trajpred_forward(adx_trajpred* t, const void* packed, const float* actio
   ADX_REQUIRE(action && time_embed && out, "adx_trajpred_forward: null tensor");
   a.action = action; a.act_sb = act_sb; a.act_st = act_st; a.te = time_embed;
   a.out = out; a.out_sb = (int64_t)T * t->L.out_dim; a.out_st = t->L.out_dim;
-  trajpred_forward_kernel<<<dim3(batch), dim3(256), kLdsFloats * sizeof(float), (hipStream_t)stream>>>(a);
+  trajpred_forward_kernel<<<dim3(batch), dim3(NT), kLdsFloats * sizeof(float), (hipStream_t)stream>>>(a);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
 }
@@ -846,7 +852,7 @@ int adx_trajpred_forward_train(adx_trajpred* t, const void* packed, const float*
   ADX_REQUIRE(action && time_embed && out, "adx_trajpred_forward_train: null tensor");
   a.action = action; a.act_sb = act_sb; a.act_st = act_st; a.te = time_embed;
   a.out = out; a.out_sb = (int64_t)T * t->L.out_dim; a.out_st = t->L.out_dim;
-  trajpred_forward_kernel<<<dim3(batch), dim3(256), kLdsFloats * sizeof(float), (hipStream_t)stream>>>(a);
+  trajpred_forward_kernel<<<dim3(batch), dim3(NT), kLdsFloats * sizeof(float), (hipStream_t)stream>>>(a);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
 }
@@ -861,7 +867,7 @@ int adx_trajpred_backward(adx_trajpred* t, const void* packed, const float* acti
   a.action = action; a.act_sb = act_sb; a.act_st = act_st; a.te = time_embed;
   a.gout = grad_out; a.gout_sb = (int64_t)T * t->L.out_dim; a.gout_st = t->L.out_dim;
   a.gact = grad_action; a.gact_sb = (int64_t)T * IN_DIM; a.gact_st = IN_DIM;
-  trajpred_backward_kernel<<<dim3(batch), dim3(256), kLdsFloats * sizeof(float), (hipStream_t)stream>>>(a);
+  trajpred_backward_kernel<<<dim3(batch), dim3(NT), kLdsFloats * sizeof(float), (hipStream_t)stream>>>(a);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
 }
@@ -883,7 +889,7 @@ int adx_trajpred_backward_params(adx_trajpred* t, const void* packed, const floa
   a.gout = grad_out; a.gout_sb = (int64_t)T * t->L.out_dim; a.gout_st = t->L.out_dim;
   a.gact = grad_action; a.gact_sb = (int64_t)T * IN_DIM; a.gact_st = IN_DIM;
   a.G = (float*)grad_image; a.dte = d_time_embed;
-  trajpred_backward_kernel<<<dim3(batch), dim3(256), kLdsFloats * sizeof(float), (hipStream_t)stream>>>(a);
+  trajpred_backward_kernel<<<dim3(batch), dim3(NT), kLdsFloats * sizeof(float), (hipStream_t)stream>>>(a);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
 }
@@ -914,7 +920,7 @@ int adx_guided_output(adx_trajpred* t, const void* packed, const float* action /
   ADX_REQUIRE(action && time_embed && target && x_guided, "adx_guided_output: null tensor");
   a.action = action; a.act_sb = (int64_t)(T + 1) * IN_DIM; a.act_st = IN_DIM; a.te = time_embed;
   a.target = target; a.xg = x_guided; a.grad_scale = model_std; a.scale = scale; a.loss = loss;
-  guided_output_kernel<<<dim3(batch), dim3(256), kLdsFloats * sizeof(float), (hipStream_t)stream>>>(a);
+  guided_output_kernel<<<dim3(batch), dim3(NT), kLdsFloats * sizeof(float), (hipStream_t)stream>>>(a);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
 }
