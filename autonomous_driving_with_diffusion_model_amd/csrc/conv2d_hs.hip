@@ -678,7 +678,14 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_stem_kernel(const Conv2dArgs
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, khalf = lane >> 5;
-  const int n = blockIdx.x / a.tiles_y, ty = blockIdx.x - n * a.tiles_y;
+  int bid = blockIdx.x, seg = 0;
+  if (a.stem_nseg > 1) { seg = bid % a.stem_nseg; bid /= a.stem_nseg; }
+  const int n = bid / a.tiles_y, ty = bid - n * a.tiles_y;
+  // this workgroup's tiles [tx_own, tx_end); with the pooling fused in, a segment that does not start at the left edge
+  // first computes the tile before it without storing anything: the pool's left neighbour column comes from there
+  const int tx_own = a.stem_nseg > 1 ? seg * a.stem_seg_tiles : 0;
+  const int tx_end = a.stem_nseg > 1 ? min(a.tiles_x, tx_own + a.stem_seg_tiles) : a.tiles_x;
+  const int tx_begin = POOL && tx_own > 0 ? tx_own - 1 : tx_own;
   const int oy0 = POOL ? ty * 8 - 1 : ty * 8, iy0 = oy0 * 2 - 3;          // first stem row of the band
   const size_t hw = (size_t)a.H * a.W;
   const float* xin = a.x + (size_t)n * 3 * hw;
@@ -778,17 +785,17 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_stem_kernel(const Conv2dArgs
   unsigned long long* tr = g_hs_trace + (size_t)(8192 + (blockIdx.x & 8191)) * 8;
   if (threadIdx.x == 0) tr[0] = __builtin_readcyclecounter();
 #endif
-  load_p(0);
-  store_p(0);
+  load_p(tx_begin);
+  store_p(PBUF == 2 ? tx_begin & 1 : 0);
   __syncthreads();
 #ifdef ADX_HS_TRACE
   if (threadIdx.x == 0) tr[1] = __builtin_readcyclecounter();
 #endif
-  for (int tx = 0; tx < a.tiles_x; ++tx) {
+  for (int tx = tx_begin; tx < tx_end; ++tx) {
 #ifdef ADX_HS_TRACE
     tr_t = (long long)__builtin_readcyclecounter();
 #endif
-    if (tx + 1 < a.tiles_x) load_p(tx + 1);
+    if (tx + 1 < tx_end) load_p(tx + 1);
     const int ox = tx * kTileW + l31;
     float vm[2][16];                 // POOL: running vertical maximum of this wave's pooled row
 #pragma unroll 1
@@ -892,7 +899,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_stem_kernel(const Conv2dArgs
     if (POOL) {
       // horizontal: pooled column 16 tx + i sits on lane 2 i; left neighbour of lane 0 = previous tile's lane 31
       const int pr = ty * 4 + wave, pq = tx * 16 + (l31 >> 1);
-      const bool st = pr < PHo && (l31 & 1) == 0 && pq < PWo;
+      const bool st = pr < PHo && (l31 & 1) == 0 && pq < PWo && tx >= tx_own;
       const uint32_t voff = st ? (uint32_t)(pr * PWo + pq) * 4u + (uint32_t)(4 * khalf) * plane_ob : kOutside;
 #pragma unroll
       for (int half = 0; half < 2; ++half)
@@ -913,7 +920,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_stem_kernel(const Conv2dArgs
 #ifdef ADX_HS_TRACE
     { const long long t = (long long)__builtin_readcyclecounter(); tr_e += t - tr_t; tr_t = t; }
 #endif
-    if (tx + 1 < a.tiles_x) {
+    if (tx + 1 < tx_end) {
       if (PBUF == 1) __syncthreads();        // every wave is done with the only patch copy
       store_p(PBUF == 2 ? (tx + 1) & 1 : 0);
     }
@@ -1046,7 +1053,16 @@ static int hs_stem_launch(Conv2dArgs a, hipStream_t s) {
   }
   a.tiles_x = ceil_div(a.OW, kTileW); a.cout_tiles = 1;
   a.tiles_y = POOL ? ceil_div((a.OH - 1) / 2 + 1, 4) : ceil_div(a.OH, 8);
-  conv2d_hs_stem_kernel<POOL, U8><<<dim3((unsigned)(a.tiles_y * a.N)), dim3(256), lds, s>>>(a);
+  // few images: split the bands' tile walks so that the grid covers the chip (one 256x900 frame: 16 bands of 15 tiles)
+  const int bands = a.tiles_y * a.N;
+  a.stem_seg_tiles = 0; a.stem_nseg = 1;
+  if (bands < 128 && a.tiles_x > 1) {
+    const int want = std::min(a.tiles_x, std::max(1, 256 / bands));
+    a.stem_seg_tiles = ceil_div(a.tiles_x, want);
+    a.stem_nseg = ceil_div(a.tiles_x, a.stem_seg_tiles);
+    if (a.stem_nseg <= 1) { a.stem_seg_tiles = 0; a.stem_nseg = 1; }
+  }
+  conv2d_hs_stem_kernel<POOL, U8><<<dim3((unsigned)(bands * a.stem_nseg)), dim3(256), lds, s>>>(a);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
 }

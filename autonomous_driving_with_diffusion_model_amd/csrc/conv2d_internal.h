@@ -45,6 +45,9 @@ struct Conv2dArgs {
   int ksplit, cper;
   float* part;
   size_t part_stride;
+  // stem kernels only: a band's 32-column tiles split into segments of stem_seg_tiles tiles, one workgroup each (few images:
+  // a band of one 256x900 frame is 15 tiles walked by ONE workgroup otherwise); 0 = the whole band
+  int stem_seg_tiles, stem_nseg;
 };
 
 
