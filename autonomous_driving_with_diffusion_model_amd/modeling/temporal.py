@@ -339,14 +339,17 @@ class TemporalMapUnet(nn.Module):
         rows = tc.rows
         if x.shape[0] != rows and x.shape[0] != 1:
             raise ValueError(f"x has {x.shape[0]} rows; the conditioning table was made for {rows} (or pass one row)")
-        if tc.weights_key != self._weights_key():
-            raise RuntimeError("the model's weights changed after time_conditioning() was computed")
-        self._ensure_packed(x.device)
+        if not 0 <= i < tc.time_bias.shape[0]:
+            raise IndexError(f"step {i} outside the conditioning table of {tc.time_bias.shape[0]} steps")
+        if i == 0:        # once per loop: fingerprinting 196 parameters is a visible part of an eagerly launched step
+            if tc.weights_key != self._weights_key():
+                raise RuntimeError("the model's weights changed after time_conditioning() was computed")
+            self._ensure_packed(x.device)
         classifier = self.use_cond == GuidanceType.CLASSIFIER_GUIDANCE
         out = torch.empty((rows, self.horizon, 3 if classifier else self.transition_dim), dtype=torch.float32, device=x.device)
         io = L.UnetIO()
         io.x, io.x_rows, io.rows, io.out = x.data_ptr(), x.shape[0], rows, out.data_ptr()
-        io.time_bias = tc.time_bias[i].data_ptr()
+        io.time_bias = tc.time_bias.data_ptr() + i * tc.step_bytes
         L.check(L.lib().adx_unet_forward(self._native(), self._packed.data_ptr(), self._workspace(rows, x.device).data_ptr(),
                                          C.byref(io), L.stream_ptr(x.device)), "adx_unet_forward")
         return self._finish(out, tc.time_embed[i] if classifier else None, return_action_and_time_only)
@@ -358,6 +361,7 @@ class TimeConditioning:
 
     def __init__(self, time_bias, time_embed, rows, weights_key):
         self.time_bias, self.time_embed, self.rows, self.weights_key = time_bias, time_embed, rows, weights_key
+        self.step_bytes = time_bias.stride(0) * time_bias.element_size()     # one step's [rows, width] slice
 
 
 def build_model(cfg) -> TemporalMapUnet:
