@@ -51,8 +51,12 @@ def test_host_side_validation_without_gpu(built):
     assert lib.adx_unet_packed_bytes(h) > 64_000_000         # 16 M UNet-side parameters
     assert lib.adx_unet_workspace_bytes(h, 64) > 0
     lib.adx_unet_destroy(h)
-    cfg.horizon = 24
-    assert lib.adx_unet_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    cfg.horizon = 24          # not a power of two: runs on 32 with the real lengths as masks (24 -> 12 -> 6 -> 3)
+    assert lib.adx_unet_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
+    lib.adx_unet_destroy(h)
+    for bad in (12, 8, 72):   # not divisible by 8; GroupNorm groups of 32 elements at the bottom; longer than 64
+        cfg.horizon = bad
+        assert lib.adx_unet_create(ctypes.byref(cfg), ctypes.byref(h)) == -1, bad
 
 
 def test_cpu_tensors_are_refused(built):
