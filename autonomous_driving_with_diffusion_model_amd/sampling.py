@@ -117,8 +117,12 @@ def evaluate_sample(model, noise_scheduler, image: torch.Tensor, init_trajs: tor
     trajs = init_trajs.clone()
     trajs[:, 0, :3] = 0
     noise_scheduler.set_timesteps(n_steps, device=image.device)
+    tc = None
+    if getattr(model, "cache_perception", False) and hasattr(model, "time_conditioning"):     # as in generate_traj
+        ts = noise_scheduler.timesteps
+        tc = model.time_conditioning(image, (ts.tensor if hasattr(ts, "tensor") else torch.as_tensor(ts)).to(image.device), rows=B)
     for i, t in enumerate(noise_scheduler.timesteps):
-        out = model(trajs, image, t.reshape(-1).repeat(B))
+        out = model(trajs, image, t.reshape(-1).repeat(B), time_cond=None if tc is None else (tc, i))
         kw = {}
         if step_noise is not None:
             kw["variance_noise"] = step_noise(i, tuple(trajs.shape)).to(image.device)
