@@ -30,6 +30,7 @@ struct GnBwdArgs {
   float* dgamma; float* dbeta; float* dbias;   // [C], accumulated atomically (caller zeroes)
   float* dtb; int64_t dtb_stride;              // [B][...] written (may be null)
   int B, C, L, log2_L, G, cg;
+  int Lv;                // real length (<= L): positions >= Lv do not exist (adx_tconv_desc::lout_valid)
 };
 
 // sum over aligned groups of `width` lanes (width = power of two <= 64); every lane gets its group's sum
@@ -47,14 +48,14 @@ __global__ void __launch_bounds__(256) gn_mish_bwd_kernel(const GnBwdArgs a) {
   const int b = pair / a.G, g = pair - b * a.G;
   const int n = a.cg << a.log2_L;
   const float mean = a.stats[(int64_t)pair * 2], rstd = a.stats[(int64_t)pair * 2 + 1];
-  const float inv_n = 1.0f / (float)n;
+  const float inv_n = 1.0f / (float)(a.cg * a.Lv);
   float dz[kGnEmax], xh[kGnEmax], gm[kGnEmax], dyv[kGnEmax];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int k = 0; k < kGnEmax; ++k) {
     const int e = lane + 64 * k;
     dz[k] = 0.f; xh[k] = 0.f; gm[k] = 0.f; dyv[k] = 0.f;
-    if (e < n) {
+    if (e < n && (e & (a.L - 1)) < a.Lv) {
       const int c = g * a.cg + (e >> a.log2_L), l = e & (a.L - 1);
       const float p = a.pre[((int64_t)b * a.C + c) * a.L + l];
       const float d = a.dy[(int64_t)b * a.dy_sb + (int64_t)c * a.dy_sc + (int64_t)l * a.dy_sl];
@@ -73,16 +74,16 @@ __global__ void __launch_bounds__(256) gn_mish_bwd_kernel(const GnBwdArgs a) {
   for (int k = 0; k < kGnEmax; ++k) {
     const int e = lane + 64 * k;
     if (64 * k >= n) break;              // wave-uniform
-    const bool ok = e < n;
     const int c = g * a.cg + (e >> a.log2_L), l = e & (a.L - 1);
+    const bool ok = e < n && l < a.Lv;
     const float dcv = ok ? rstd * (dz[k] * gm[k] - m1 - xh[k] * m2) : 0.f;
-    if (ok) a.dc[((int64_t)b * a.C + c) * a.L + l] = dcv;
+    if (e < n) a.dc[((int64_t)b * a.C + c) * a.L + l] = dcv;      // zero at positions that do not exist: the sums downstream stay unmasked
     // per-channel partial sums over the positions held by this chunk
     const float sg = seg_sum(ok ? dz[k] * xh[k] : 0.f, seg);
     const float sb = seg_sum(ok ? dz[k] : 0.f, seg);
     const float sc = seg_sum(dcv, seg);
     const float st = seg_sum(ok ? dyv[k] : 0.f, seg);
-    if (ok && (lane & (seg - 1)) == 0) {
+    if (e < n && (lane & (seg - 1)) == 0) {
       atomicAdd(a.dgamma + c, sg);
       atomicAdd(a.dbeta + c, sb);
       if (a.dbias != nullptr) atomicAdd(a.dbias + c, sc);
@@ -105,27 +106,28 @@ int gn_mish_backward(const GnBwdArgs& a, hipStream_t s) {
 
 int gn_mish_backward_raw(const float* dy, int64_t sb, int64_t sc, int64_t sl, const float* pre, const float* stats,
                          const float* gamma, const float* beta, float* dc, float* dgamma, float* dbeta, float* dbias,
-                         float* dtb, int64_t dtb_stride, int B, int C, int L, int groups, hipStream_t s) {
+                         float* dtb, int64_t dtb_stride, int B, int C, int L, int groups, hipStream_t s, int L_valid) {
   GnBwdArgs a;
   a.dy = dy; a.dy_sb = sb; a.dy_sc = sc; a.dy_sl = sl;
   a.pre = pre; a.stats = stats; a.gamma = gamma; a.beta = beta; a.dc = dc;
   a.dgamma = dgamma; a.dbeta = dbeta; a.dbias = dbias; a.dtb = dtb; a.dtb_stride = dtb_stride;
   a.B = B; a.C = C; a.L = L; a.G = groups; a.cg = C / groups;
+  a.Lv = L_valid > 0 ? L_valid : L;
   a.log2_L = 0;
   while ((1 << a.log2_L) < L) ++a.log2_L;
-  ADX_REQUIRE((1 << a.log2_L) == L, "gn_mish_backward: L must be a power of two");
+  ADX_REQUIRE((1 << a.log2_L) == L && a.Lv <= L, "gn_mish_backward: L must be a power of two (real length in L_valid)");
   return gn_mish_backward(a, s);
 }
 
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) bias_grad_kernel(const float* __restrict__ dc, int64_t sb, int64_t sc, int64_t sl,
-                                                         float* __restrict__ db, int B, int C, int L) {
+                                                         float* __restrict__ db, int B, int C, int L, int Lv) {
   // one workgroup per channel
   const int c = blockIdx.x, tid = threadIdx.x;
   float s = 0.f;
   for (int i = tid; i < B * L; i += 256) {
     const int b = i / L, l = i - b * L;
-    s += dc[(int64_t)b * sb + (int64_t)c * sc + (int64_t)l * sl];
+    if (l < Lv) s += dc[(int64_t)b * sb + (int64_t)c * sc + (int64_t)l * sl];
   }
   __shared__ float red[4];
   s = wave_sum(s);
@@ -134,23 +136,24 @@ __global__ void __launch_bounds__(256) bias_grad_kernel(const float* __restrict_
   if (tid == 0) db[c] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-int bias_grad(const float* dc, int64_t sb, int64_t sc, int64_t sl, float* db, int B, int C, int L, hipStream_t s) {
+int bias_grad(const float* dc, int64_t sb, int64_t sc, int64_t sl, float* db, int B, int C, int L, hipStream_t s, int L_valid) {
   ADX_REQUIRE(dc && db && B >= 1 && C >= 1 && L >= 1, "bias_grad: bad argument");
-  bias_grad_kernel<<<dim3(C), dim3(256), 0, s>>>(dc, sb, sc, sl, db, B, C, L);
+  bias_grad_kernel<<<dim3(C), dim3(256), 0, s>>>(dc, sb, sc, sl, db, B, C, L, L_valid > 0 ? L_valid : L);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
 }
 
 __global__ void __launch_bounds__(256) add_strided_kernel(float* __restrict__ dst, const float* __restrict__ src,
-                                                           int64_t sb, int64_t sc, int64_t sl, int B, int C, int L) {
+                                                           int64_t sb, int64_t sc, int64_t sl, int B, int C, int L, int Lv) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= B * C * L) return;
   const int l = idx % L, c = (idx / L) % C, b = idx / (L * C);
-  dst[idx] += src[(int64_t)b * sb + (int64_t)c * sc + (int64_t)l * sl];
+  if (l < Lv) dst[idx] += src[(int64_t)b * sb + (int64_t)c * sc + (int64_t)l * sl];
 }
 
-int add_strided(float* dst, const float* src, int64_t sb, int64_t sc, int64_t sl, int B, int C, int L, hipStream_t s) {
-  add_strided_kernel<<<dim3(ceil_div(B * C * L, 256)), dim3(256), 0, s>>>(dst, src, sb, sc, sl, B, C, L);
+// dst dense [B][C][L]; positions >= L_valid (0 = L) of src are not read (a strided view may not have them)
+int add_strided(float* dst, const float* src, int64_t sb, int64_t sc, int64_t sl, int B, int C, int L, hipStream_t s, int L_valid) {
+  add_strided_kernel<<<dim3(ceil_div(B * C * L, 256)), dim3(256), 0, s>>>(dst, src, sb, sc, sl, B, C, L, L_valid > 0 ? L_valid : L);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
 }
@@ -168,6 +171,7 @@ struct WgradArgs {
   const float* dc;        // [B][cout][lout] dense
   float* dw;              // kind 0: [cout][cin][taps]; kind 1 (conv-transpose weight): [cin][cout][taps] with roles swapped by the host
   int c0, cin, cout, lin, lout, log2_lout, taps, stride, pad;
+  int lin_valid, lout_valid;    // real lengths: x positions >= lin_valid read as zero, dc positions >= lout_valid likewise
   int batch, nb, nsplit, n_ci_tiles, n_co_tiles;
   int sbt, lp, pl, rs;    // samples per staged super-tile, per-sample pitch, left pad, LDS row stride
   int64_t dw_so, dw_si;   // strides of dw for (co, ci); tap stride is 1
@@ -207,7 +211,7 @@ __global__ void __launch_bounds__(256) tconv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int f = 0; f < NFO; ++f) {
         const int co = co0 + 16 * f + i16;
-        bv[j][f] = (mok && co < a.cout) ? a.dc[((int64_t)(bb + sl_) * a.cout + co) * a.lout + l] : 0.f;
+        bv[j][f] = (mok && co < a.cout && l < a.lout_valid) ? a.dc[((int64_t)(bb + sl_) * a.cout + co) * a.lout + l] : 0.f;
       }
     }
     if (bb > bs) __syncthreads();
@@ -218,7 +222,7 @@ __global__ void __launch_bounds__(256) tconv_wgrad_kernel(const WgradArgs a) {
       const int sl_ = col / a.lp, ip = col - sl_ * a.lp - a.pl;
       const int ci = ci0 + cl, b = bb + sl_;
       float v = 0.f;
-      if (sl_ < nsamp && ip >= 0 && ip < a.lin && ci < a.cin) {
+      if (sl_ < nsamp && ip >= 0 && ip < a.lin_valid && ci < a.cin) {
         v = ci < a.c0 ? a.x0[(int64_t)b * a.x0_sb + (int64_t)ci * a.x0_sc + (int64_t)ip * a.x0_sl]
                       : a.x1[(int64_t)b * a.x1_sb + (int64_t)(ci - a.c0) * a.x1_sc + (int64_t)ip * a.x1_sl];
       }
@@ -285,6 +289,8 @@ int tconv_wgrad(const adx_tconv_desc* d, const adx_tconv_io* io, const float* dc
   a.x1 = io->x1; a.x1_sb = io->x1_sb; a.x1_sc = io->x1_sc; a.x1_sl = io->x1_sl;
   a.dc = dc; a.dw = dw;
   a.c0 = d->c0; a.cin = d->c0 + d->c1; a.cout = d->cout; a.lin = d->lin; a.lout = d->lout;
+  a.lin_valid = d->lin_valid > 0 ? d->lin_valid : d->lin;
+  a.lout_valid = d->lout_valid > 0 ? d->lout_valid : d->lout;
   a.log2_lout = 0;
   while ((1 << a.log2_lout) < d->lout) ++a.log2_lout;
   a.taps = d->taps; a.stride = d->stride; a.pad = d->pad;
@@ -348,6 +354,7 @@ int adx_gn_mish_backward(const float* dy, int64_t dy_sb, int64_t dy_sc, int64_t 
   a.pre = pre; a.stats = stats; a.gamma = gamma; a.beta = beta; a.dc = dc;
   a.dgamma = dgamma; a.dbeta = dbeta; a.dbias = dbias; a.dtb = dtb; a.dtb_stride = dtb_stride;
   a.B = B; a.C = C; a.L = L; a.G = groups; a.cg = C / groups;
+  a.Lv = L;
   a.log2_L = 0;
   while ((1 << a.log2_L) < L) ++a.log2_L;
   ADX_REQUIRE((1 << a.log2_L) == L, "adx_gn_mish_backward: L must be a power of two");
@@ -359,7 +366,7 @@ int adx_tconv_wgrad(const adx_tconv_desc* d, const adx_tconv_io* io, const float
 }
 
 int adx_bias_grad(const float* dc, float* db, int32_t B, int32_t C, int32_t L, adx_stream stream) {
-  return bias_grad(dc, (int64_t)C * L, L, 1, db, B, C, L, (hipStream_t)stream);
+  return bias_grad(dc, (int64_t)C * L, L, 1, db, B, C, L, (hipStream_t)stream, 0);
 }
 
 }  // extern "C"

@@ -19,10 +19,10 @@ namespace adx {
 
 int gn_mish_backward_raw(const float* dy, int64_t sb, int64_t sc, int64_t sl, const float* pre, const float* stats,
                          const float* gamma, const float* beta, float* dc, float* dgamma, float* dbeta, float* dbias,
-                         float* dtb, int64_t dtb_stride, int B, int C, int L, int groups, hipStream_t s);
+                         float* dtb, int64_t dtb_stride, int B, int C, int L, int groups, hipStream_t s, int L_valid = 0);
 int tconv_wgrad(const adx_tconv_desc* d, const adx_tconv_io* io, const float* dc, float* dw, hipStream_t s, bool zero);
-int bias_grad(const float* dc, int64_t sb, int64_t sc, int64_t sl, float* db, int B, int C, int L, hipStream_t s);
-int add_strided(float* dst, const float* src, int64_t sb, int64_t sc, int64_t sl, int B, int C, int L, hipStream_t s);
+int bias_grad(const float* dc, int64_t sb, int64_t sc, int64_t sl, float* db, int B, int C, int L, hipStream_t s, int L_valid = 0);
+int add_strided(float* dst, const float* src, int64_t sb, int64_t sc, int64_t sl, int B, int C, int L, hipStream_t s, int L_valid = 0);
 int embed_backward(const adx_embed_weights* w, int dim, const int64_t* t, int t_rows, const float* cond,
                    const float* feat, int feat_rows, int rows, const float* time_embed, const float* d_mish_cond,
                    const float* d_time_embed_extra, float* d_feat, float* const* grads /* w1,b1,w3,b3,cw0,cb0,cw2,cb2 */,
@@ -127,8 +127,6 @@ int adx_unet_forward_train(adx_unet* u, const void* packed, void* workspace, siz
   }
   ADX_REQUIRE(io->x && io->img_feature && io->t && io->out, "adx_unet_forward_train: null tensor");
   const int rows = io->rows, dim = u->cfg.dim, H = u->cfg.horizon, D = u->cfg.transition_dim;
-  ADX_REQUIRE((H & (H - 1)) == 0, "adx_unet_forward_train: the training kernels take horizons 16, 32, 64 (got %d); other "
-              "multiples of 8 are supported by the sampling forward only", H);
   ADX_REQUIRE(rows >= 1 && io->t_rows == rows && io->feat_rows == rows,
               "adx_unet_forward_train: time / image batch must equal the trajectory batch (%d)", rows);
   hipStream_t s = (hipStream_t)stream;
@@ -287,6 +285,9 @@ int adx_unet_backward(adx_unet* u, const void* packed, void* workspace, size_t w
     const ConvLayer& L = *op.L;
     const adx_tconv_desc& d = L.d;
     const int cin = d.c0 + d.c1;
+    // real lengths (a horizon that is not a power of two runs on the next one: adx_tconv_desc::lin_valid); buffers keep the
+    // padded pitch, every kernel below skips the positions that do not exist
+    const int lov = d.lout_valid > 0 ? d.lout_valid : d.lout, liv = d.lin_valid > 0 ? d.lin_valid : d.lin;
     // ---- dy of this launch
     TAct dy;
     if (oi + 1 == tape->ops.size()) {
@@ -305,7 +306,7 @@ int adx_unet_backward(adx_unet* u, const void* packed, void* workspace, size_t w
         ADX_CHECK_HIP(hipMemsetAsync(rs.g, 0, sizeof(float) * (size_t)rows * op.res.c * op.res.len, s));
         rs.has = true;
       }
-      rc = add_strided(rs.g, dy.p, dy.sb, dy.sc, dy.sl, rows, op.res.c, op.res.len, s);
+      rc = add_strided(rs.g, dy.p, dy.sb, dy.sc, dy.sl, rows, op.res.c, op.res.len, s, lov);
       if (rc != ADX_OK) break;
     }
     // ---- through Mish / GroupNorm (and the time-bias add) down to the conv output
@@ -314,7 +315,7 @@ int adx_unet_backward(adx_unet* u, const void* packed, void* workspace, size_t w
       float* dg = grads[L.p_g]; float* dbe = grads[L.p_be]; float* dbi = grads[L.p_b];
       rc = gn_mish_backward_raw(dy.p, dy.sb, dy.sc, dy.sl, op.pre, op.stats, base + L.o_g, base + L.o_be, dc_buf, dg,
                                 dbe, dbi, op.tb_off >= 0 ? dtb + op.tb_off : nullptr, u->sum_c, rows, d.cout, d.lout,
-                                d.groups, s);
+                                d.groups, s, lov);
       if (rc != ADX_OK) break;
       dc = dc_buf;
     } else {
@@ -322,12 +323,12 @@ int adx_unet_backward(adx_unet* u, const void* packed, void* workspace, size_t w
         dc = dy.p;
       } else {  // the head writes [rows][H][D]: make the dense [rows][D][H] copy the GEMMs expect
         ADX_CHECK_HIP(hipMemsetAsync(dc_buf, 0, sizeof(float) * (size_t)rows * d.cout * d.lout, s));
-        rc = add_strided(dc_buf, dy.p, dy.sb, dy.sc, dy.sl, rows, d.cout, d.lout, s);
+        rc = add_strided(dc_buf, dy.p, dy.sb, dy.sc, dy.sl, rows, d.cout, d.lout, s, lov);
         if (rc != ADX_OK) break;
         dc = dc_buf;
       }
       if (L.p_b >= 0) {
-        rc = bias_grad(dc, (int64_t)d.cout * d.lout, d.lout, 1, grads[L.p_b], rows, d.cout, d.lout, s);
+        rc = bias_grad(dc, (int64_t)d.cout * d.lout, d.lout, 1, grads[L.p_b], rows, d.cout, d.lout, s, lov);
         if (rc != ADX_OK) break;
       }
     }
@@ -345,6 +346,7 @@ int adx_unet_backward(adx_unet* u, const void* packed, void* workspace, size_t w
         adx_tconv_desc m{};
         m.kind = 0; m.taps = d.taps; m.stride = d.stride; m.pad = d.pad;
         m.c0 = d.cout; m.c1 = 0; m.cout = cin; m.lin = d.lout; m.lout = d.lin; m.groups = 0; m.eps = d.eps;
+        m.lin_valid = d.lout_valid; m.lout_valid = d.lin_valid;
         wio.x0 = dc; wio.x0_sb = (int64_t)d.cout * d.lout; wio.x0_sc = d.lout; wio.x0_sl = 1;
         ADX_REQUIRE(op.x0.dense(), "adx_unet_backward: transposed conv input must be dense");
         rc = tconv_wgrad(&m, &wio, op.x0.p, grads[L.p_w], s, false);
@@ -355,6 +357,7 @@ int adx_unet_backward(adx_unet* u, const void* packed, void* workspace, size_t w
     if (!op.need_dx) continue;
     adx_tconv_desc g{};
     g.groups = 0; g.eps = d.eps; g.c0 = d.cout; g.c1 = 0; g.cout = cin; g.lin = d.lout; g.lout = d.lin; g.taps = d.taps;
+    g.lin_valid = d.lout_valid; g.lout_valid = d.lin_valid;
     g.exact = 1;   // gradients span many binades (1e-9 .. 1): keep them off the fp16 operand path
     if (d.kind == 0 && d.stride == 1) {
       g.kind = 0; g.stride = 1; g.pad = d.taps - 1 - d.pad; g.w_layout = 1; g.w_flip = 1;
@@ -388,7 +391,7 @@ int adx_unet_backward(adx_unet* u, const void* packed, void* workspace, size_t w
           ADX_CHECK_HIP(hipMemsetAsync(xs.g, 0, sizeof(float) * (size_t)rows * parts[k]->c * d.lin, s));
           xs.has = true;
         }
-        rc = add_strided(xs.g, cat_buf + (size_t)coff * d.lin, xsb, d.lin, 1, rows, parts[k]->c, d.lin, s);
+        rc = add_strided(xs.g, cat_buf + (size_t)coff * d.lin, xsb, d.lin, 1, rows, parts[k]->c, d.lin, s, liv);
         coff += parts[k]->c;
       }
     }

@@ -60,7 +60,8 @@ typedef struct adx_tconv_desc {
   /* Lengths that are not powers of two (the reference accepts any horizon divisible by 8, modeling/temporal.py:59-75:
    * 24 -> 24, 12, 6, 3): `lin` / `lout` are then the lengths rounded up to powers of two (the kernels' index arithmetic)
    * and these the real ones; positions >= lin_valid read as zero, positions >= lout_valid are neither stored nor counted
-   * in the GroupNorm statistics.  0 = equal to lin / lout.  Forward only (the exact-fp32 kernel). */
+   * in the GroupNorm statistics.  0 = equal to lin / lout.  Such descriptors run on the exact-fp32 kernel; adx_tconv_wgrad
+   * honours the same fields, and the training executor passes them to every backward kernel. */
   int32_t lin_valid, lout_valid;
 } adx_tconv_desc;
 

@@ -197,7 +197,11 @@ def test_traj_predict_dropout_matches_oracle_with_the_same_masks(B, T):
 
 
 @pytest.mark.parametrize("use_cond,H,B", [("NO_GUIDANCE", 16, 2), ("FREE_GUIDANCE", 32, 5),
-                                          ("CLASSIFIER_GUIDANCE", 16, 3)])
+                                          ("CLASSIFIER_GUIDANCE", 16, 3),
+                                          # horizons that are not powers of two (24 -> 24, 12, 6, 3): every backward kernel
+                                          # runs on the padded length and skips the positions that do not exist
+                                          ("NO_GUIDANCE", 24, 3), ("FREE_GUIDANCE", 40, 2), ("CLASSIFIER_GUIDANCE", 24, 2),
+                                          ("NO_GUIDANCE", 56, 2)])
 def test_unet_gradients_vs_oracle_autograd(use_cond, H, B):
     from test_gpu_model import make_model
     m, _ = make_model(use_cond, H)
