@@ -343,3 +343,34 @@ def test_training_step_at_a_ragged_horizon_vs_oracle_loss():
     want = OS.training_loss(oracle_sd("NO_GUIDANCE"), d["imgs"], d["trajs"], d["target"], d["t"], d["noise"], use_cond="NO_GUIDANCE")
     assert abs(loss.item() - want.item()) <= 2e-5 * max(1.0, abs(want.item())), (loss.item(), want.item())
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+
+
+@pytest.mark.parametrize("dim,mults,H", [(64, (1, 2, 4), 16), (128, (1, 2, 4, 8), 32), (64, (1, 2), 16)])
+def test_unet_other_widths_and_depths_vs_oracle(dim, mults, H):
+    """MODEL.DIM / MODEL.DIM_MULTS other than the default (64, (1, 2, 4, 8)): the executor builds its launch list from the
+    config (csrc/unet.hip: build), nothing is specialised for one width.  Unsupported shapes fail at construction with the
+    reason (GroupNorm groups that are not a power of two wide, or shorter than 64 elements)."""
+    from autonomous_driving_with_diffusion_model_amd.config import create_cfg
+    from autonomous_driving_with_diffusion_model_amd.modeling import build_model
+    g = torch.Generator().manual_seed(dim + H)
+    d = P.synthetic_batch(3, H, image_hw=(32, 32), seed=9)
+    feat = torch.randn(3, dim, generator=g)
+    for name in ("NO_GUIDANCE", "FREE_GUIDANCE"):
+        cfg = create_cfg()
+        cfg.MODEL.HORIZON, cfg.MODEL.DIM, cfg.MODEL.DIM_MULTS = H, dim, list(mults)
+        cfg.TRAIN.USE_COND = cfg.GUIDANCE.USE_COND = name
+        m = build_model(cfg)
+        with torch.no_grad():
+            for p in m.parameters():
+                p.copy_(torch.randn(p.shape, generator=g) * (0.5 / p[0].numel() ** 0.5 if p.dim() > 1 else 0.1))
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        m = m.to(DEV).eval()
+        m.perception.forward = lambda img: feat.to(DEV)   # test-only stub of the encoder output
+        cond = d["target"] if name == "FREE_GUIDANCE" else None
+        with torch.no_grad():
+            y = m(d["trajs"].to(DEV), d["imgs"].to(DEV), d["t"].to(DEV), cond=None if cond is None else cond.to(DEV)).cpu()
+        want = U.unet_forward(sd, d["trajs"], None, d["t"], cond, use_cond=name, dim=dim, dim_mults=mults, img_feature=feat)
+        close(y, want, 2e-5)
+    cfg.MODEL.DIM = 48
+    with pytest.raises(ValueError, match="power of two"):
+        build_model(cfg).to(DEV).eval()(d["trajs"].to(DEV), d["imgs"].to(DEV), d["t"].to(DEV))
