@@ -1111,7 +1111,14 @@ __global__ void __launch_bounds__(256) conv2d_split_reduce_kernel(const float* _
   if (i >= total4) return;
   const int c = (int)((i / plane4) % cout);
   f32x4 v = reinterpret_cast<const f32x4*>(part)[i];
-  for (int p = 1; p < nparts; ++p) v += reinterpret_cast<const f32x4*>(part + (size_t)p * part_stride)[i];
+  for (int p0 = 1; p0 < nparts; p0 += 8) {        // eight loads in flight, added in index order
+    f32x4 t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = reinterpret_cast<const f32x4*>(part + (size_t)(p0 + j < nparts ? p0 + j : 0) * part_stride)[i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (p0 + j < nparts) v += t[j];
+  }
   const float sc = scale != nullptr ? scale[c] : 1.f, sh = shift != nullptr ? shift[c] : 0.f;
   v = v * sc + sh;
   if (res != nullptr) v += reinterpret_cast<const f32x4*>(res)[i];

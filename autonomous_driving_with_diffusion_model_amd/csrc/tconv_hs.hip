@@ -209,7 +209,20 @@ __device__ __forceinline__ void hs_epilogue4(const TConvArgs& a, const float* P,
 #pragma unroll
     for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4*>(pp + w * ptile);   // fixed order: deterministic
   } else {
-    for (int w = 1; w < nparts; ++w) v += *reinterpret_cast<const f32x4*>(pp + (size_t)w * ptile);
+    // the partial tiles of a split reduction (global memory, written by workgroups on other XCDs a moment ago): all loads of a
+    // batch of 8 are issued before the first add, so the thread pays one memory round trip per batch, not one per tile; the
+    // adds keep the index order
+    for (int w0 = 1; w0 < nparts; w0 += 8) {
+      f32x4 t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int w = w0 + j < nparts ? w0 + j : 0;        // past the end: re-read tile 0 (valid), value unused
+        t[j] = *reinterpret_cast<const f32x4*>(pp + (size_t)w * ptile);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (w0 + j < nparts) v += t[j];
+    }
   }
   v += f32x4{biasA, biasA, two ? biasB : biasA, two ? biasB : biasA};
   if (a.io.pre != nullptr && live)          // dense [B][cout][lout]: the four elements are contiguous in both cases
