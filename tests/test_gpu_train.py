@@ -239,7 +239,7 @@ def test_perception_train_mode_vs_oracle_autograd(hw):
     These gradients are not a smooth function of the arithmetic: with 18..72 samples per channel the deep
     batch-norms amplify fp32 rounding to ~1e-5 in the activations, and every ReLU unit whose pre-activation
     lies that close to zero flips its mask.  torch's own fp32 CPU path differs from an fp64 evaluation of the
-    same graph by one flipped unit of the final map here (0.7 % of the gradient norm, tools/dbg_pgrad.py);
+    same graph by one flipped unit of the final map here (0.7 % of the gradient norm, tests/diagnostics/dbg_pgrad.py);
     which units flip depends on the summation order of each implementation.  The bar is therefore "as close
     to the fp64 oracle as the reference's fp32 arithmetic is" with room for a different set of flips (x3),
     per parameter tensor; the smooth part is pinned by the per-op gradient tests above."""
@@ -311,7 +311,7 @@ def test_training_step_vs_golden(golden, use_cond):
     #    layers) of zero takes a different mask in two fp32 implementations; ONE such element in a layer4 map of this
     #    fixture (2 x 3 pixels x batch 2 = 12 elements per channel) moves that layer's bias gradient by ~5e-3 of its norm
     #    and everything upstream of it by ~2e-3 (measured: tools/dbg_tape_cmp.py finds 10 flipped masks among 7.6 M taped
-    #    activations between the split-fp16 and the exact-fp32 forward; tools/dbg_block_grad.py shows the incoming gradient
+    #    activations between the split-fp16 and the exact-fp32 forward; tests/diagnostics/dbg_block_grad.py shows the incoming gradient
     #    itself is right to 3e-6).  torch's CPU fp32 backward shows the same effect against fp64 (e_ref up to 3e-2 on other
     #    seeds).  So the bar for perception tensors at this size is 3e-2; the tight per-tensor bar for the perception
     #    backward is in test_gpu_fullsize.py (16 x 8 x 29 elements per channel: a flip weighs 1e-4 there) and the kernels
