@@ -370,6 +370,7 @@ int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const f
   a.KH = L.k; a.KW = L.k; a.stride = L.stride; a.pad = L.pad; a.relu = relu;
   a.cin_pad = L.cin_pad; a.cc = L.cc;
   a.x_u8 = nullptr;
+  a.d2s_cin = 0; a.d2s_h = 0; a.d2s_w = 0; a.stem_seg_tiles = 0; a.stem_nseg = 1;
   a.ksplit = 1; a.cper = 0; a.part = t_split_scratch; a.part_stride = t_split_floats;   // part_stride: capacity until the launch fixes it
   if (conv2d_hs_eligible(L)) return conv2d_hs_launch(L, a, s);
   const int rows = (L.stride == 1 && L.k == 3 && g_conv_rows == 2) ? 2 : 1;   // 8-row tiles for the 3x3 stride-1 convs

@@ -292,20 +292,27 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
   // 32-bit VGPR); lanes outside the map carry the out-of-range offset (loads return 0, stores are dropped); without a
   // residual the descriptor is empty and every load returns 0.
   const int ox = ox0 + l31;
-  const uint32_t plane_ob = (uint32_t)(a.OH * a.OW) * (uint32_t)sizeof(float);
-  const size_t img = (size_t)n * a.Cout * a.OH * a.OW;
-  const int img_bytes = (int)(a.Cout * plane_ob);
+  // plain store: channel cout0 + c of an OH x OW map.  Depth-to-space store (Conv2dArgs::d2s_cin): this workgroup's 64
+  // channels belong to ONE parity class (d2s_cin is a multiple of 64), i.e. to channels ci0 .. ci0 + 63 of a d2s_h x d2s_w map
+  // at the pixels (2 oy + py, 2 ox + px)
+  const bool d2s = !DS && a.d2s_cin > 0;
+  const int cls = d2s ? cout0 / a.d2s_cin : 0, py = cls >> 1, px = cls & 1;
+  const int sH = d2s ? a.d2s_h : a.OH, sW = d2s ? a.d2s_w : a.OW, sC = d2s ? a.d2s_cin : a.Cout;
+  const uint32_t plane_ob = (uint32_t)(sH * sW) * (uint32_t)sizeof(float);
+  const size_t img = (size_t)n * sC * sH * sW;
+  const int img_bytes = (int)(sC * plane_ob);
   constexpr uint32_t kOut = 0xC0000000u;
   const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + img, 0, img_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(DS ? a.y_ds + img : a.y, 0, DS ? img_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.res != nullptr ? a.res + img : a.y), 0, a.res != nullptr ? img_bytes : 0, 0x00020000);
-  const uint32_t cbase_o = (uint32_t)cout0 * plane_ob;
+  const uint32_t cbase_o = (uint32_t)(d2s ? cout0 - cls * a.d2s_cin : cout0) * plane_ob;
   uint32_t voff[ROWS];
 #pragma unroll
   for (int rr = 0; rr < ROWS; ++rr) {
     const int oy = oy0 + wave * ROWS + rr;
-    voff[rr] = (oy < a.OH && ox < a.OW) ? (uint32_t)(oy * a.OW + ox) * 4u + (uint32_t)(4 * khalf) * plane_ob : kOut;
+    const int yy = d2s ? 2 * oy + py : oy, xx = d2s ? 2 * ox + px : ox;
+    voff[rr] = (oy < a.OH && ox < a.OW && yy < sH && xx < sW) ? (uint32_t)(yy * sW + xx) * 4u + (uint32_t)(4 * khalf) * plane_ob : kOut;
   }
   float rv[ROWS][2][16];
 #pragma unroll
@@ -1172,6 +1179,52 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
   conv2d_hs3x3_kernel<MODE><<<dim3((unsigned)grid), dim3(NT), lds, s>>>(a);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
+}
+
+// forward weight [cout][cin][3][3] -> weight [4 cin][cout][2][2] of the 2x2 conv that is the stride-2 data gradient:
+// class (py, px), window cell (r, c) of dy -> the forward tap (kh, kw) that links them, or none.  Row rule (columns alike):
+// an even input row 2j is reached from output row j through kh = 1 only (window row 0); an odd row 2j + 1 from output row j
+// through kh = 2 (window row 0) and from output row j + 1 through kh = 0 (window row 1).
+__global__ void dgrad_s2_weights_kernel(const float* __restrict__ w, float* __restrict__ out, int cin, int cout) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;     // over [4][cin][cout][2][2]
+  if (idx >= (size_t)16 * cin * cout) return;
+  const int c = idx & 1, r = (idx >> 1) & 1;
+  size_t rest = idx >> 2;
+  const int co = rest % cout; rest /= cout;
+  const int ci = rest % cin;
+  const int cls = (int)(rest / cin), py = cls >> 1, px = cls & 1;
+  const int kh = py == 0 ? (r == 0 ? 1 : -1) : (r == 0 ? 2 : 0);
+  const int kw = px == 0 ? (c == 0 ? 1 : -1) : (c == 0 ? 2 : 0);
+  out[idx] = (kh >= 0 && kw >= 0) ? w[(((size_t)co * cin + ci) * 3 + kh) * 3 + kw] : 0.f;
+}
+
+bool conv2d_hs_dgrad_s2_eligible(int cin, int cout) {
+  static const bool off = [] { const char* e = getenv("ADX_S2_DGRAD_DILATE"); return e != nullptr && e[0] == '1'; }();   // A/B: the zero-dilated path
+  ConvSpec probe{};
+  probe.cin = cout; probe.cin_pad = cout; probe.cout = 4 * cin; probe.k = 3; probe.stride = 1; probe.dgrad = 1;
+  return !off && cin % kHsCout == 0 && cout % kHsCC == 0 && conv2d_hs_eligible(probe);
+}
+
+int conv2d_hs_dgrad_s2(const float* w, const float* dy, float* dx, int accumulate, int N, int cin, int cout, int H, int W,
+                       float* wbuild, float* wimg, const uint32_t* dy_amax, int dy_amax_n, hipStream_t s) {
+  ADX_REQUIRE(w && dy && dx && wbuild && wimg, "conv2d_hs_dgrad_s2: null pointer");
+  ADX_REQUIRE(conv2d_hs_dgrad_s2_eligible(cin, cout), "conv2d_hs_dgrad_s2: cin %d / cout %d outside the kernel's rules", cin, cout);
+  const size_t nw = (size_t)16 * cin * cout;
+  dgrad_s2_weights_kernel<<<dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s>>>(w, wbuild, cin, cout);
+  ADX_LAUNCH_CHECK();
+  ConvSpec g{};
+  g.cin = cout; g.cin_pad = cout; g.cout = 4 * cin; g.k = 2; g.stride = 1; g.pad = 0; g.cc = kHsCC;
+  int rc = conv2d_hs_pack(g, wbuild, wimg, 0, s);
+  if (rc != ADX_OK) return rc;
+  Conv2dArgs a{};
+  a.x = dy; a.w = wimg; a.res = accumulate ? dx : nullptr; a.y = dx; a.x_amax = dy_amax; a.x_amax_n = dy_amax_n;
+  a.N = N; a.Cin = cout; a.H = conv_out_dim(H, 3, 2, 1); a.W = conv_out_dim(W, 3, 2, 1); a.Cout = 4 * cin;
+  a.OH = a.H; a.OW = a.W;                  // one 2x2 window per low-resolution pixel; the window's far row / column may lie
+  a.KH = 2; a.KW = 2; a.stride = 1; a.pad = 0; a.relu = 0;     // outside dy: zeros, like any padding
+  a.cin_pad = cout; a.cc = kHsCC;
+  a.d2s_cin = cin; a.d2s_h = H; a.d2s_w = W;
+  ADX_REQUIRE((size_t)cin * H * W * sizeof(float) < 0x7FFFFFFFu, "conv2d_hs_dgrad_s2: one image of dx exceeds the 32-bit byte offsets");
+  return hs_launch_t<1, 2, 2, 2, false>(a, s);
 }
 
 int conv2d_hs_launch(const ConvSpec& L, Conv2dArgs a, hipStream_t s) {

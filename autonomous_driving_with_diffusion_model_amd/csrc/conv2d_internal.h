@@ -48,6 +48,11 @@ struct Conv2dArgs {
   // stem kernels only: a band's 32-column tiles split into segments of stem_seg_tiles tiles, one workgroup each (few images:
   // a band of one 256x900 frame is 15 tiles walked by ONE workgroup otherwise); 0 = the whole band
   int stem_seg_tiles, stem_nseg;
+  // generic split kernel only: depth-to-space store.  The conv's output channels are four groups of d2s_cin channels, one per
+  // parity class (py, px) of a map of d2s_h x d2s_w pixels; channel g * d2s_cin + ci at (oy, ox) is stored to (and its residual
+  // read from) channel ci at (2 oy + py, 2 ox + px), g = 2 py + px.  0 = plain NCHW store.  This is how the data gradient of a
+  // stride-2 3x3 conv runs as ONE stride-1 2x2 conv on the low-resolution gradient (conv2d_hs_dgrad_s2).
+  int d2s_cin, d2s_h, d2s_w;
 };
 
 
@@ -83,6 +88,15 @@ bool conv2d_hs_eligible(const ConvSpec& L);
 size_t conv2d_packed_floats(const ConvSpec& L);
 int conv2d_hs_pack(const ConvSpec& consumer, const float* w, void* packed, int dgrad, hipStream_t s);
 int conv2d_hs_launch(const ConvSpec& L, Conv2dArgs a, hipStream_t s);
+// Data gradient of a 3x3 stride-2 pad-1 conv (forward weight w [cout][cin][3][3], forward input h x w, output oh x ow):
+// dx [n][cin][h][w] (+= when accumulate) from dy [n][cout][oh][ow].  An input pixel of parity class (py, px) receives from
+// 1 / 2 / 2 / 4 of the nine taps, and all of them lie in the 2x2 window [oy, oy+1] x [ox, ox+1] of dy with oy = iy >> 1,
+// ox = ix >> 1: one stride-1 2x2 conv with 4 cin output channels and a depth-to-space store -- 16 tap-products per four
+// pixels where convolving a zero-dilated gradient with the flipped 3x3 kernel spends 36.  wbuild (16 cout cin floats) and
+// wimg (16 cout cin floats) are scratch.  Returns ADX_ERR_INVALID when the shape is outside the kernel's rules.
+bool conv2d_hs_dgrad_s2_eligible(int cin, int cout);
+int conv2d_hs_dgrad_s2(const float* w, const float* dy, float* dx, int accumulate, int N, int cin, int cout, int H, int W,
+                       float* wbuild, float* wimg, const uint32_t* dy_amax, int dy_amax_n, hipStream_t s);
 // scratch for split reductions of the launches issued by this thread until it is cleared (a region of the calling
 // executor's workspace, consumed in stream order)
 void conv2d_set_split_scratch(float* p, size_t floats);

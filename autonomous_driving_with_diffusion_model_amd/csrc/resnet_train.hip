@@ -832,7 +832,7 @@ size_t adx_resnet_train_workspace_bytes(const adx_resnet* r, int32_t batch, int3
     conv(c2, OH, OW);
     H = OH; W = OW;
   }
-  f += al64(r->convs.size() * 2 * 512 * 2) + al64(kAmaxPartials) + al64((size_t)512 * 256 * 9) + 5 * al64(big) + al64(wmax);   // backward: sums, amax, 3x3 image of a 1x1 gradient, 5 gradient buffers, dgrad weights
+  f += al64(r->convs.size() * 2 * 512 * 2) + al64(kAmaxPartials) + al64((size_t)512 * 256 * 9) + 5 * al64(big) + 2 * al64(wmax);   // backward: sums, amax, 3x3 image of a 1x1 gradient, 5 gradient buffers, dgrad weights
   return (f + 1024) * sizeof(float);
 }
 
@@ -956,6 +956,7 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
   float* gb[5];
   for (auto& p : gb) p = ws.take(big);
   float* wimg = ws.take(wmax);
+  float* wbuild = ws.take(wmax);     // the stride-2 data gradient's 2x2 weights before packing (16 cin cout <= 9 x 512 x 512)
   ADX_REQUIRE(ws.ok, "adx_resnet_backward: workspace of %zu bytes too small", workspace_bytes);
   int rc = ADX_OK;
 
@@ -1004,6 +1005,11 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
     if (rc2 != ADX_OK) return rc2;
     if (L.stride == 1) {
       return conv2d_launch_raw(g, draw, wimg, nullptr, nullptr, dx_has ? dx : nullptr, dx, batch, rec.OH, rec.OW, 0, s, amax, n_amax);
+    }
+    if (L.k == 3 && conv2d_hs_dgrad_s2_eligible(L.cin, L.cout) && (size_t)16 * L.cin * L.cout <= wmax) {
+      // one stride-1 2x2 conv on the low-resolution gradient with a depth-to-space store (conv2d_hs_dgrad_s2): 16 tap-products
+      // per four input pixels instead of the 36 of the zero-dilated form below, and no dilated tensor
+      return conv2d_hs_dgrad_s2(T[L.t_w], draw, dx, dx_has ? 1 : 0, batch, L.cin, L.cout, rec.H, rec.W, wbuild, wimg, amax, n_amax, s);
     }
     if (L.k == 3) {
       // zero-dilate draw to the input resolution, then an ordinary 3x3 stride-1 conv with the flipped weights
