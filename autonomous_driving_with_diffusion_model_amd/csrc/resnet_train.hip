@@ -1050,9 +1050,10 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
     if (rc != ADX_OK) break;
     float* dx = g_cur;                                                   // d(block out) is dead now: reuse for d(block in)
     if (ds) {
-      rc = conv_bn_bwd(*dsr, dz2, nullptr, draw, dx, false, true);       // identity path through the downsample conv
+      rc = conv_bn_bwd(c1, do1, nullptr, draw, dx, false, true);         // main path: writes every pixel of d(block in)
       if (rc != ADX_OK) break;
-      rc = conv_bn_bwd(c1, do1, nullptr, draw, dx, true, true);          // main path accumulates
+      rc = conv_bn_bwd(*dsr, dz2, nullptr, draw, dx, true, true);        // identity path through the downsample conv adds to
+                                                                         // the even pixels (no clearing pass over dx)
     } else {
       // identity gradient is dz2 itself: main path = conv(...) + res(dz2)
       rc = conv_bn_bwd(c1, do1, nullptr, draw, dz2, true, true);
