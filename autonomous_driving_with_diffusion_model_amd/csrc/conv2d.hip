@@ -353,7 +353,8 @@ void conv2d_set_split_scratch(float* p, size_t floats) { t_split_scratch = p; t_
 
 int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const float* scale, const float* shift,
                       const float* res, float* y, int N, int H, int W, int relu, hipStream_t s, const uint32_t* x_amax,
-                      int x_amax_n) {
+                      int x_amax_n, float* stats_part, size_t stats_floats, int* stats_p) {
+  if (stats_p != nullptr) *stats_p = 0;
   static bool env_read = false;
   if (!env_read) {
     const char* e = getenv("ADX_CONV_ROWS");
@@ -372,7 +373,16 @@ int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const f
   a.x_u8 = nullptr;
   a.d2s_cin = 0; a.d2s_h = 0; a.d2s_w = 0; a.stem_seg_tiles = 0; a.stem_nseg = 1;
   a.ksplit = 1; a.cper = 0; a.part = t_split_scratch; a.part_stride = t_split_floats;   // part_stride: capacity until the launch fixes it
-  if (conv2d_hs_eligible(L)) return conv2d_hs_launch(L, a, s);
+  a.stats_part = nullptr; a.stats_p = 0;
+  if (conv2d_hs_eligible(L)) {
+    if (stats_part != nullptr && stats_p != nullptr && conv2d_hs_stats_tiles(L, a) > 0 &&
+        (size_t)conv2d_hs_stats_tiles(L, a) * L.cout * 2 <= stats_floats) {
+      a.stats_part = stats_part;
+      a.stats_p = conv2d_hs_stats_tiles(L, a);
+      *stats_p = a.stats_p;
+    }
+    return conv2d_hs_launch(L, a, s);
+  }
   const int rows = (L.stride == 1 && L.k == 3 && g_conv_rows == 2) ? 2 : 1;   // 8-row tiles for the 3x3 stride-1 convs
   const int th = 4 * rows;
   a.tiles_x = ceil_div(a.OW, kTileW); a.tiles_y = ceil_div(a.OH, th); a.cout_tiles = L.cout / kCoutT;

@@ -52,6 +52,11 @@ __device__ __forceinline__ void split8(const float* v, float xs, u32x4& hi, u32x
   lo = __builtin_bit_cast(u32x4, l);
 }
 
+template <int CTRL>
+__device__ __forceinline__ float hs_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
 // STRIDE/K: the convolution; ROWS: output rows per wave (tile = 4*ROWS rows x 32 columns x 64 channels);
 // PBUF: LDS copies of the patch (2: one barrier per stage; 1: an extra barrier per chunk, for the large stride-2
 // patches); DS: also evaluate the BasicBlock's 1x1 stride-2 downsample conv (modeling/resnet.py:223-232) on the
@@ -384,7 +389,7 @@ __device__ __forceinline__ void hs_trace_id() {
 #define HS_TRACE(slot)
 #endif
 
-template <int MODE>
+template <int MODE, bool STATS = false>
 __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(const Conv2dArgs a) {
   constexpr int NT = MODE == 0 ? 256 : 512;            // threads
   constexpr int TH = MODE == 1 ? 16 : 8;               // output rows per workgroup
@@ -616,6 +621,44 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   HS_TRACE(6);
 #endif
+  if (STATS) {
+    // Training forward: this workgroup's per-channel sum and sum of squares of the conv output (pixels outside the map
+    // excluded), so that the BatchNorm statistics need no pass over the output tensor.  Per (half, r) register: the two rows
+    // of the lane, then the 16 lanes of a DPP row; lanes 0 / 16 / 32 / 48 park their row's totals in LDS (the patch is dead:
+    // every wave passed the main loop's last barrier), 64 CT x 2 threads add the 2 x NW/CT rows up in a fixed order.
+    float* red = reinterpret_cast<float*>(smem_raw);          // [wave][lane >> 4][32][2]
+    const bool val0 = voff[0] != kOutside, val1 = voff[1] != kOutside;
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v0 = val0 ? (accm[0][half][r] + accl[0][half][r] * (1.f / kLoScale)) * xs_inv : 0.f;
+        const float v1 = val1 ? (accm[1][half][r] + accl[1][half][r] * (1.f / kLoScale)) * xs_inv : 0.f;
+        float sm = v0 + v1, sq = v0 * v0 + v1 * v1;
+        sm += hs_dpp<0xB1>(sm);  sq += hs_dpp<0xB1>(sq);      // quad_perm [1,0,3,2]
+        sm += hs_dpp<0x4E>(sm);  sq += hs_dpp<0x4E>(sq);      // quad_perm [2,3,0,1]
+        sm += hs_dpp<0x141>(sm); sq += hs_dpp<0x141>(sq);     // row_half_mirror
+        sm += hs_dpp<0x140>(sm); sq += hs_dpp<0x140>(sq);     // row_mirror: every lane of a row of 16 holds the row's total
+        if ((lane & 15) == 0) {
+          float* d = red + (((wave * 4 + (lane >> 4)) * 32) + half * 16 + r) * 2;
+          d[0] = sm;
+          d[1] = sq;
+        }
+      }
+    __syncthreads();
+    if (tid < 2 * 64 * CT) {
+      const int which = tid & 1, chs = tid >> 1, sl = chs >> 6, ch = chs & 63;     // channel ch of slab sl
+      const int c5 = ch & 31, kh2 = (c5 >> 2) & 1, r = (c5 & 3) + 4 * (c5 >> 3), idx32 = (ch >> 5) * 16 + r;
+      constexpr int WPS = (NT / 64) / CT;                   // waves per slab
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < WPS; ++w)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) t += red[((((MODE == 2 ? sl * WPS + w : w) * 4 + kh2 * 2 + j) * 32) + idx32) * 2 + which];
+      const int p = (n * a.tiles_y + ty) * a.tiles_x + tx;
+      a.stats_part[((size_t)((ct * CT + sl) * kHsCout + ch) * 2 + which) * a.stats_p + p] = t;
+    }
+  }
   auto finish = [&](auto relu) {       // two copies of the store loop: the ReLU is one v_max, not a compare + select
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr)
@@ -1143,7 +1186,9 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
   static_assert(lds <= (MODE == 0 ? 80 : 160) * 1024, "LDS budget");
   static bool attr = false;
   if (!attr) {
-    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE>),
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = true;
   }
@@ -1158,6 +1203,14 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
   const size_t cap = a.part != nullptr ? a.part_stride : 0;      // conv2d_launch_raw parks the scratch capacity here
   const int nchunks = a.cin_pad / kHsCC;
   a.ksplit = 1; a.cper = nchunks; a.part_stride = 0;
+  if (a.stats_part != nullptr) {          // training forward: statistics in the epilogue (one workgroup per tile: no split)
+    ADX_REQUIRE(a.stats_p == a.N * a.tiles_y * a.tiles_x, "conv2d_hs: statistics buffer laid out for %d tiles, launch has %d",
+                a.stats_p, a.N * a.tiles_y * a.tiles_x);
+    a.part = nullptr;
+    conv2d_hs3x3_kernel<MODE, true><<<dim3((unsigned)grid), dim3(NT), lds, s>>>(a);
+    ADX_LAUNCH_CHECK();
+    return ADX_OK;
+  }
   if (MODE == 0 && split_on && cap > 0 && grid <= 64 && nchunks >= 8 && a.x_amax == nullptr && (a.OH * a.OW) % 4 == 0 &&
       (reinterpret_cast<uintptr_t>(a.y) & 15) == 0 && (a.res == nullptr || (reinterpret_cast<uintptr_t>(a.res) & 15) == 0)) {
     int S = 16;
@@ -1179,6 +1232,37 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
   conv2d_hs3x3_kernel<MODE><<<dim3((unsigned)grid), dim3(NT), lds, s>>>(a);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
+}
+
+// tile mode of the pipelined 3x3 stride-1 kernel for this launch, -1 when another kernel serves it
+static int hs3x3_mode(const ConvSpec& L, const Conv2dArgs& a) {
+  if (!(L.k == 3 && L.stride == 1 && a.w_ds == nullptr)) return -1;
+  static int pipe = -1;
+  if (pipe < 0) {
+    const char* e = getenv("ADX_HS_PIPE");      // ADX_HS_PIPE=0: the one-stage-ahead kernel for every 3x3 conv
+    pipe = (e != nullptr && e[0] == '0') ? 0 : 1;
+  }
+  if (!(pipe && (L.cin_pad / kHsCC) % 2 == 0 && L.pad == 1)) return -1;
+  static int mode_env = -2;       // ADX_HS_MODE=0|1|2 pins the tile mode (default: by shape)
+  if (mode_env == -2) {
+    const char* e = getenv("ADX_HS_MODE");
+    mode_env = e != nullptr ? atoi(e) : -1;
+  }
+  // The three tiles time within 3 % of each other on every ResNet-34 shape (the MFMA rate the chip sustains on
+  // random data paces all of them): short K loops take the small tile (better tail balance), long ones the
+  // 8-wave tiles that move fewer operand bytes per MFMA.
+  int mode = a.Cin < 256 ? 0 : (a.OH > 8 ? 1 : (a.Cout % 128 == 0 ? 2 : 0));
+  // small batches (the deployed case: one camera frame per tick): the 8-wave tiles leave most of the chip idle (512->512
+  // @8x29 at B = 1: four workgroups); the 4-wave tile doubles the workgroup count
+  if ((long)a.N * ceil_div(a.OH, 8) * ceil_div(a.OW, kTileW) * (a.Cout / kHsCout) <= 256) mode = 0;
+  if (mode_env >= 0 && !(mode_env == 2 && a.Cout % 128 != 0)) mode = mode_env;
+  return mode;
+}
+
+int conv2d_hs_stats_tiles(const ConvSpec& L, const Conv2dArgs& a) {
+  const int mode = hs3x3_mode(L, a);
+  if (mode < 0) return 0;
+  return a.N * ceil_div(a.OH, mode == 1 ? 16 : 8) * ceil_div(a.OW, kTileW);
 }
 
 // forward weight [cout][cin][3][3] -> weight [4 cin][cout][2][2] of the 2x2 conv that is the stride-2 data gradient:
@@ -1235,27 +1319,9 @@ int conv2d_hs_launch(const ConvSpec& L, Conv2dArgs a, hipStream_t s) {
     return hs_stem_launch<false>(a, s);
   }
   if (L.k == 3 && L.stride == 1 && !ds) {
-    static int pipe = -1;
-    if (pipe < 0) {
-      const char* e = getenv("ADX_HS_PIPE");      // ADX_HS_PIPE=0: the one-stage-ahead kernel for every 3x3 conv
-      pipe = (e != nullptr && e[0] == '0') ? 0 : 1;
-    }
-    if (pipe && (L.cin_pad / kHsCC) % 2 == 0 && L.pad == 1) {
-      static int mode_env = -2;       // ADX_HS_MODE=0|1|2 pins the tile mode (default: by shape)
-      if (mode_env == -2) {
-        const char* e = getenv("ADX_HS_MODE");
-        mode_env = e != nullptr ? atoi(e) : -1;
-      }
-      // The three tiles time within 3 % of each other on every ResNet-34 shape (the MFMA rate the chip sustains on
-      // random data paces all of them): short K loops take the small tile (better tail balance), long ones the
-      // 8-wave tiles that move fewer operand bytes per MFMA.
-      int mode = a.Cin < 256 ? 0 : (a.OH > 8 ? 1 : (a.Cout % 128 == 0 ? 2 : 0));
-      // small batches (the deployed case: one camera frame per tick): the 8-wave tiles leave most of the chip idle (512->512
-      // @8x29 at B = 1: four workgroups); the 4-wave tile doubles the workgroup count
-      if ((long)a.N * ceil_div(a.OH, 8) * ceil_div(a.OW, kTileW) * (a.Cout / kHsCout) <= 256) mode = 0;
-      if (mode_env >= 0 && !(mode_env == 2 && a.Cout % 128 != 0)) mode = mode_env;
-      return mode == 1 ? hs3x3_launch<1>(a, s) : (mode == 2 ? hs3x3_launch<2>(a, s) : hs3x3_launch<0>(a, s));
-    }
+    const int mode = hs3x3_mode(L, a);
+    if (mode >= 0) return mode == 1 ? hs3x3_launch<1>(a, s) : (mode == 2 ? hs3x3_launch<2>(a, s) : hs3x3_launch<0>(a, s));
+    ADX_REQUIRE(a.stats_part == nullptr, "conv2d_hs: statistics requested from a launch the pipelined kernel does not serve");
     return hs_launch_t<1, 3, 2, 2, false>(a, s);
   }
   if (L.k == 3 && L.stride == 2 && L.pad == 1) return ds ? hs_launch_t<2, 3, 1, 1, true>(a, s) : hs_launch_t<2, 3, 1, 1, false>(a, s);

@@ -53,6 +53,10 @@ struct Conv2dArgs {
   // read from) channel ci at (2 oy + py, 2 ox + px), g = 2 py + px.  0 = plain NCHW store.  This is how the data gradient of a
   // stride-2 3x3 conv runs as ONE stride-1 2x2 conv on the low-resolution gradient (conv2d_hs_dgrad_s2).
   int d2s_cin, d2s_h, d2s_w;
+  // conv2d_hs3x3 only (training forward): per-workgroup sums of the output and of its squares, [Cout][2][stats_p] floats
+  // (p = (image, row tile, column tile)), pixels outside the map excluded; bn statistics then need no pass over the output
+  float* stats_part;
+  int stats_p;
 };
 
 
@@ -74,7 +78,11 @@ namespace adx {
 // into fp16's normal range by an exact power of two (data gradients are far below 2^-14)
 int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const float* scale, const float* shift,
                       const float* res, float* y, int N, int H, int W, int relu, hipStream_t s,
-                      const uint32_t* x_amax = nullptr, int x_amax_n = 0);
+                      const uint32_t* x_amax = nullptr, int x_amax_n = 0, float* stats_part = nullptr, size_t stats_floats = 0,
+                      int* stats_p = nullptr);
+// stats_part (optional, stats_floats floats): where the launch may leave per-workgroup partial sums of its output and of its
+// squares ([Cout][2][P] floats); *stats_p = P when it did (the pipelined 3x3 stride-1 kernel does), 0 when the caller has to
+// compute the statistics from the output itself
 // [Cout][Cin][k][k] -> [tap][cin_pad][Cout]; dgrad = 1 packs the data-gradient view instead:
 // [tap'][cout_pad as K][Cin as N] with the taps flipped (conv of dy with this image gives dx)
 int conv2d_pack_raw(const float* w, float* packed, int cout, int cin, int k, int cin_pad, int dgrad, hipStream_t s);
@@ -88,6 +96,9 @@ bool conv2d_hs_eligible(const ConvSpec& L);
 size_t conv2d_packed_floats(const ConvSpec& L);
 int conv2d_hs_pack(const ConvSpec& consumer, const float* w, void* packed, int dgrad, hipStream_t s);
 int conv2d_hs_launch(const ConvSpec& L, Conv2dArgs a, hipStream_t s);
+// partial-sum slots (workgroups per 64-channel slab) the pipelined 3x3 stride-1 kernel would fill for this launch, 0 if another
+// kernel serves it
+int conv2d_hs_stats_tiles(const ConvSpec& L, const Conv2dArgs& a);
 // Data gradient of a 3x3 stride-2 pad-1 conv (forward weight w [cout][cin][3][3], forward input h x w, output oh x ow):
 // dx [n][cin][h][w] (+= when accumulate) from dy [n][cout][oh][ow].  An input pixel of parity class (py, px) receives from
 // 1 / 2 / 2 / 4 of the nine taps, and all of them lie in the 2x2 window [oy, oy+1] x [ox, ox+1] of dy with oy = iy >> 1,

@@ -88,6 +88,20 @@ __global__ void __launch_bounds__(256) channel_sums_kernel(const float* __restri
   }
 }
 
+// The pipelined 3x3 conv leaves per-workgroup partial sums of its output and of its squares ([C][2][P] floats, conv2d_hs.hip:
+// STATS); this adds the P partials of every (channel, moment) in fp64 -- one workgroup each, fixed order -- into the same
+// sums[c][2] slots channel_sums_kernel<0> would have filled from a pass over the whole output tensor.
+__global__ void __launch_bounds__(256) stats_reduce_kernel(const float* __restrict__ part, double* __restrict__ sums, int P) {
+  const float* src = part + (size_t)blockIdx.x * P;      // blockIdx.x = 2 c + moment
+  double s = 0.0;
+  for (int i = threadIdx.x; i < P; i += 256) s += (double)src[i];
+  __shared__ double red[4];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) sums[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // batch statistics -> scale/shift for the apply pass, saved mean/rstd, running-buffer update
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift,
@@ -164,6 +178,7 @@ __global__ void __launch_bounds__(256) bn_apply_planes_kernel(const float* __res
   }
 }
 
+constexpr size_t kStatsPartFloats = (size_t)1 << 20;   // per-workgroup partial sums of one conv launch ([C][2][tiles])
 constexpr size_t kAmaxPartials = 4096;   // workgroups of bn_bwd_apply_kernel = partial maxima handed to the dgrad conv
 
 // draw = gamma*rstd * (dz - m1 - xhat*m2); also d gamma / d beta (one thread per channel does that part)
@@ -807,7 +822,7 @@ void adx_resnet_tape_destroy(adx_resnet_tape* t) { delete t; }
 
 size_t adx_resnet_train_workspace_bytes(const adx_resnet* r, int32_t batch, int32_t h, int32_t w) {
   if (!r || batch < 1 || h < 32 || w < 32) return 0;
-  size_t f = al64(r->convs.size() * 2 * 512 * 2) + 2 * al64(512);   // forward: per-conv sums, scale, shift
+  size_t f = al64(r->convs.size() * 2 * 512 * 2) + 2 * al64(512) + al64(kStatsPartFloats);   // forward: per-conv sums, scale, shift, conv-epilogue partial sums
   size_t big = 0, wmax = 0;
   auto conv = [&](const ConvSpec& L, int H, int W) {
     const int OH = conv_out_dim(H, L.k, L.stride, L.pad), OW = conv_out_dim(W, L.k, L.stride, L.pad);
@@ -860,6 +875,7 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
   if (ws.ok) ADX_CHECK_HIP(hipMemsetAsync(sums_all, 0, sizeof(double) * n_convs * 2 * 512, s));
   float* scale = ws.take(512);
   float* shift = ws.take(512);
+  float* stats_part = ws.take(kStatsPartFloats);
   int rc = ADX_OK;
   auto conv_bn = [&](const ConvSpec& L, const float* x, int H, int W, const float* identity, int relu,
                      bool apply = true) -> float* {
@@ -869,12 +885,18 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
     const size_t n = (size_t)batch * L.cout * rec.OH * rec.OW;
     rec.raw = ws.take(n); rec.out = ws.take(n); rec.mean = ws.take(L.cout); rec.rstd = ws.take(L.cout);
     if (!ws.ok || rc != ADX_OK) { tape->recs.push_back(rec); return rec.out; }
-    rc = conv2d_launch_raw(L, x, base + L.o_w, nullptr, nullptr, nullptr, rec.raw, batch, H, W, 0, s);
+    int stats_p = 0;     // > 0: the conv's own epilogue left per-workgroup partial sums (the 3x3 stride-1 layers)
+    rc = conv2d_launch_raw(L, x, base + L.o_w, nullptr, nullptr, nullptr, rec.raw, batch, H, W, 0, s, nullptr, 0, stats_part,
+                           kStatsPartFloats, &stats_p);
     if (rc != ADX_OK) { tape->recs.push_back(rec); return rec.out; }
     const int HW = rec.OH * rec.OW;
     double* sums = sums_all + (size_t)(&L - r->convs.data()) * 2 * 512;
-    channel_sums_kernel<0><<<dim3(batch * L.cout), dim3(256), 0, s>>>(rec.raw, nullptr, nullptr, nullptr, nullptr, sums,
-                                                                      L.cout, HW, 0, nullptr, nullptr);
+    if (stats_p > 0) {
+      stats_reduce_kernel<<<dim3(2 * L.cout), dim3(256), 0, s>>>(stats_part, sums, stats_p);
+    } else {
+      channel_sums_kernel<0><<<dim3(batch * L.cout), dim3(256), 0, s>>>(rec.raw, nullptr, nullptr, nullptr, nullptr, sums,
+                                                                        L.cout, HW, 0, nullptr, nullptr);
+    }
     bn_finalize_kernel<<<dim3(ceil_div(L.cout, 256)), dim3(256), 0, s>>>(
         sums, T[L.t_g], T[L.t_b], scale, shift, rec.mean, rec.rstd, update_running ? const_cast<float*>(T[L.t_m]) : nullptr,
         update_running ? const_cast<float*>(T[L.t_v]) : nullptr, L.cout, (double)batch * HW);
