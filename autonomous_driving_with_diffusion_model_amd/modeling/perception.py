@@ -79,6 +79,7 @@ class PerceptionResNet34(nn.Module):
         super().__init__()
         self.out_dim = out_dim
         self._entries = resnet34_entries("", out_dim)
+        self._tensor_list = None
         populate(self, self._entries)
         self._handle = None
         self._packed = None
@@ -101,9 +102,22 @@ class PerceptionResNet34(nn.Module):
             pass
 
     def _tensors(self):
-        sd = dict(self.named_parameters())
-        sd.update(dict(self.named_buffers()))
-        return [sd[e.key] for e in self._entries if e.dtype == "f32"]
+        # the tensor OBJECTS are looked up once (walking the module tree twice per call was a visible part of an eagerly
+        # launched B = 1 step); nn.Module keeps them across .to() / load_state_dict() / optimizer steps, and everything that
+        # could replace them (_apply, load_state_dict, invalidate) drops the list
+        if self._tensor_list is None:
+            sd = dict(self.named_parameters())
+            sd.update(dict(self.named_buffers()))
+            self._tensor_list = [sd[e.key] for e in self._entries if e.dtype == "f32"]
+        return self._tensor_list
+
+    def _apply(self, fn, *a, **k):
+        self._tensor_list = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._tensor_list = None
+        return super().load_state_dict(*a, **k)
 
     def weights_key(self):
         ts = self._tensors()
@@ -111,6 +125,7 @@ class PerceptionResNet34(nn.Module):
 
     def invalidate(self):
         self._pack_key = None
+        self._tensor_list = None
 
     def _ensure_packed(self):
         key = self.weights_key()

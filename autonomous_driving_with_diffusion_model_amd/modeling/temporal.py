@@ -120,6 +120,7 @@ class TemporalMapUnet(nn.Module):
                                           hidden_dim=64, num_layers=2)
         self._unet_keys = [e.key for e in unet_side]
         self.magic_num = 23.315
+        self._unet_param_list = None
         self.cache_perception = True
         self._handle = None
         self._packed = None
@@ -151,8 +152,12 @@ class TemporalMapUnet(nn.Module):
             pass
 
     def _unet_params(self):
-        named = dict(self.named_parameters())
-        return [named[k] for k in self._unet_keys]
+        # looked up once: walking the module tree on every forward was a visible part of an eagerly launched B = 1 step;
+        # refresh_weights() -- called by everything that could replace a Parameter object -- drops the list
+        if self._unet_param_list is None:
+            named = dict(self.named_parameters())
+            self._unet_param_list = [named[k] for k in self._unet_keys]
+        return self._unet_param_list
 
     def _weights_key(self):
         ps = self._unet_params()
@@ -161,6 +166,7 @@ class TemporalMapUnet(nn.Module):
     def refresh_weights(self):
         """Force a re-pack of the HIP weight images (needed only after out-of-band `.data` writes)."""
         self._pack_key = None
+        self._unet_param_list = None
         self.perception.invalidate()
         self._feat_cache = None
         if hasattr(self, "state_pred"):

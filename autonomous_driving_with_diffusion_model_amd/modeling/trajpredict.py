@@ -131,10 +131,25 @@ class TrajPredict(nn.Module):
 
     def invalidate(self):
         self._pack_key = None
+        self._param_list = None
+
+    def _params(self):
+        # looked up once (see TemporalMapUnet._unet_params); invalidate() / _apply / load_state_dict drop the list
+        if getattr(self, "_param_list", None) is None:
+            named = dict(self.named_parameters())
+            self._param_list = [named[e.key] for e in self._entries]
+        return self._param_list
+
+    def _apply(self, fn, *a, **k):
+        self._param_list = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._param_list = None
+        return super().load_state_dict(*a, **k)
 
     def _ensure_packed(self, device):
-        named = dict(self.named_parameters())
-        ps = [named[e.key] for e in self._entries]
+        ps = self._params()
         key = (ps[0].data_ptr(), sum(p._version for p in ps))
         h = self._native()
         if key != self._pack_key or self._packed is None or self._packed.device != device:
