@@ -17,5 +17,5 @@ for d in sorted(glob.glob("gpurun_out/pmc[AB]_*")):
     res[d.split("/")[-1]] = {k: round(sum(v[1:]) / max(1, len(v) - 1)) for k, v in acc.items()}
     print(d, res[d.split("/")[-1]])
 import json
-json.dump({"source": "bash tools/pmc_sq.sh: rocprofv3 --kernel-trace --pmc <8 counters> -- python3 tools/pmc_one.py <cin> <h> <w> (B = 64, one 3x3 stride-1 conv with BN + residual + ReLU, per launch, averaged over 4 launches); pmcA / pmcB = the two counter sets", "kernel": "conv2d_hs3x3_kernel", "counters": res}, open("gpurun_out/r01_sq_counters.json", "w"), indent=1)
+json.dump({"source": "bash tools/pmc_sq.sh: rocprofv3 --kernel-trace --pmc <8 counters> -- python3 tools/pmc_one.py <cin> <h> <w> (B = 64, one 3x3 stride-1 conv with BN + residual + ReLU, per launch, averaged over 4 launches); pmcA / pmcB = the two counter sets", "kernel": "conv2d_hs3x3_kernel", "counters": res}, open("gpurun_out/" + __import__("os").environ.get("R", "r02") + "_sq_counters.json", "w"), indent=1)
 PY
