@@ -76,6 +76,7 @@ _SIGS = {
     "adx_unet_workspace_bytes": (C.c_size_t, [vp, i32]),
     "adx_unet_forward": (i32, [vp, vp, vp, C.POINTER(UnetIO), vp]),
     "adx_unet_time_bias_width": (i32, [vp]),
+    "adx_unet_time_conditioning_workspace_bytes": (C.c_size_t, [vp, i32]),
     "adx_unet_time_conditioning": (i32, [vp, vp, vp, C.POINTER(UnetIO), vp, vp, vp]),
     "adx_unet_tape_create": (i32, [C.POINTER(vp)]),
     "adx_unet_tape_destroy": (None, [vp]),
@@ -116,6 +117,7 @@ _SIGS = {
     "adx_guided_output": (i32, [vp, vp, vp, vp, vp, f32, f32, vp, vp, i32, i32, vp]),
     "adx_optim_chunk": (i32, []),
     "adx_adamw_ema_step": (i32, [vp, vp, vp, i32, f32, f32, f32, f32, f32, i32, f32, i32, i32, vp]),
+    "adx_adamw_ema_step_scaled": (i32, [vp, vp, vp, i32, f32, f32, f32, f32, f32, i32, f32, i32, i32, f32, vp]),
     "adx_image_normalize": (i32, [vp, vp, i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), vp]),
     "adx_image_augment": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp]),
     "adx_ddim_step": (i32, [C.POINTER(StepCoef), vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
@@ -191,6 +193,28 @@ def require_gpu_f32(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Te
     if t.dtype != dtype:
         raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
     return t if t.is_contiguous() else t.contiguous()
+
+
+def write_stamp(t: torch.Tensor) -> int:
+    """A number that moves when `t` is written in place: autograd's version counter.  Inference tensors -- everything
+    created under `torch.inference_mode()`, which is how the reference's `train.evaluate` runs (train.py:53) -- carry no
+    counter (`._version` raises on them); they answer 0, so a memo keyed on (identity, stamp) then rests on identity alone:
+    an in-place write to an inference tensor between two forwards is NOT seen (none of the reference's callers does one;
+    `model.cache_perception = False` or `model.refresh_weights()` covers a caller that does)."""
+    return 0 if t.is_inference() else t._version
+
+
+def grad_buffer(p: torch.Tensor) -> torch.Tensor:
+    """Where a backward node writes d(loss)/d(p).  Under `parallel.GradientAverager` every parameter owns a view into a
+    flat communication bucket (`p._adx_grad_view`); when the parameter has no gradient yet, a fresh alias of that view is
+    handed out -- autograd adopts a gradient tensor nobody else holds as `.grad` without copying, so the gradient is born
+    inside the bucket the collective runs on.  With a gradient already present (accumulation over several backwards)
+    autograd ADDS what the node returns to `.grad`, which may be this very storage: then, and without an averager, the
+    node gets a buffer of its own."""
+    v = getattr(p, "_adx_grad_view", None)
+    if v is not None and p.grad is None and v.device == p.device and v.shape == p.shape:
+        return v.detach()
+    return torch.empty_like(p)
 
 
 def ptr_array(tensors: Sequence[torch.Tensor]):

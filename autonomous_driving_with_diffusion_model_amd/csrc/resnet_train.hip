@@ -824,16 +824,16 @@ size_t adx_resnet_train_workspace_bytes(const adx_resnet* r, int32_t batch, int3
   if (!r || batch < 1 || h < 32 || w < 32) return 0;
   size_t f = al64(r->convs.size() * 2 * 512 * 2) + 2 * al64(512) + al64(kStatsPartFloats);   // forward: per-conv sums, scale, shift, conv-epilogue partial sums
   size_t big = 0, wmax = 0;
-  auto conv = [&](const ConvSpec& L, int H, int W) {
+  auto conv = [&](const ConvSpec& L, int H, int W, bool apply = true) {
     const int OH = conv_out_dim(H, L.k, L.stride, L.pad), OW = conv_out_dim(W, L.k, L.stride, L.pad);
     const size_t n = (size_t)batch * L.cout * OH * OW;
-    f += 2 * al64(n) + 2 * al64(L.cout);
+    f += (apply ? 2 : 1) * al64(n) + 2 * al64(L.cout);      // conv output (+ post-BN map) + saved mean / rstd
     big = std::max(big, n);
     big = std::max(big, (size_t)batch * L.cin * H * W);
     wmax = std::max(wmax, (size_t)L.k * L.k * L.cout * L.cin);
   };
   size_t ci = 0;
-  conv(r->convs[ci++], h, w);
+  conv(r->convs[ci++], h, w, false);        // the stem's post-BN map is never formed (fused BN + ReLU + pool pass)
   const int h1 = conv_out_dim(h, 7, 2, 3), w1 = conv_out_dim(w, 7, 2, 3);
   int H = conv_out_dim(h1, 3, 2, 1), W = conv_out_dim(w1, 3, 2, 1);
   f += al64((size_t)batch * 64 * H * W) + al64(((size_t)batch * 64 * H * W + 3) / 4);    // pooled map + its arg-max codes
@@ -883,7 +883,8 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
     rec.L = &L; rec.x = x; rec.H = H; rec.W = W; rec.relu = relu; rec.identity = identity;
     rec.OH = conv_out_dim(H, L.k, L.stride, L.pad); rec.OW = conv_out_dim(W, L.k, L.stride, L.pad);
     const size_t n = (size_t)batch * L.cout * rec.OH * rec.OW;
-    rec.raw = ws.take(n); rec.out = ws.take(n); rec.mean = ws.take(L.cout); rec.rstd = ws.take(L.cout);
+    // apply == false (the stem): the post-BN map is never formed, so it gets no storage either (0.94 GB at B = 64)
+    rec.raw = ws.take(n); rec.out = apply ? ws.take(n) : nullptr; rec.mean = ws.take(L.cout); rec.rstd = ws.take(L.cout);
     if (!ws.ok || rc != ADX_OK) { tape->recs.push_back(rec); return rec.out; }
     int stats_p = 0;     // > 0: the conv's own epilogue left per-workgroup partial sums (the 3x3 stride-1 layers)
     rc = conv2d_launch_raw(L, x, base + L.o_w, nullptr, nullptr, nullptr, rec.raw, batch, H, W, 0, s, nullptr, 0, stats_part,
@@ -1055,10 +1056,7 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
 
   // BasicBlocks in reverse.  recs: [stem, (c1, [ds], c2) per block] in forward launch order
   size_t ri = tape->recs.size();
-  static const int dbg_stop = [] { const char* e = getenv("ADX_DBG_STOP_BLOCKS"); return e ? atoi(e) : -1; }();   // diagnostic: return after N blocks
-  int blocks_done = 0;
   for (size_t b = r->block_has_ds.size(); b-- > 0 && rc == ADX_OK;) {
-    if (dbg_stop >= 0 && blocks_done++ == dbg_stop) return ADX_OK;
     const bool ds = r->block_has_ds[b] != 0;
     const adx_resnet_tape::Rec& c2 = tape->recs[--ri];
     const adx_resnet_tape::Rec* dsr = ds ? &tape->recs[--ri] : nullptr;

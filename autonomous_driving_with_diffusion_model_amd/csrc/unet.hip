@@ -275,14 +275,6 @@ int adx_unet_create(const adx_unet_config* cfg, adx_unet** out) {
 }
 
 void adx_unet_destroy(adx_unet* u) {
-  if (u == nullptr) return;
-  if (u->side_state == 1) {
-    for (int i = 0; i < 16; ++i) {
-      (void)hipEventDestroy(u->ev_fork[i]);
-      (void)hipEventDestroy(u->ev_join[i]);
-    }
-    (void)hipStreamDestroy(u->side);
-  }
   delete u;
 }
 
@@ -407,56 +399,24 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
   // the last conv of the block, after h and the 1x1-residual buffers of that block were taken).
   int nb = 0;
   auto next_buf = [&]() { float* p = bufs[nb]; nb = (nb + 1) % kRing; return p; };
-  if (u->side_state == 0) {
-    // Measured (round 2, B = 64 and B = 1): the fork/join costs more than the overlap gains -- 1664 -> 1244 steps/s
-    // eager, 1603 -> 1423 as a graph (cross-queue dependencies are several microseconds each) -- so the side stream is
-    // opt-in (ADX_UNET_SIDE=1) and the default issues R(x) in stream order.
-    const char* e = getenv("ADX_UNET_SIDE");
-    u->side_state = -1;
-    if (e != nullptr && e[0] == '1' && hipStreamCreateWithFlags(&u->side, hipStreamNonBlocking) == hipSuccess) {
-      bool ok = true;
-      for (int i = 0; i < 16 && ok; ++i)
-        ok = hipEventCreateWithFlags(&u->ev_fork[i], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&u->ev_join[i], hipEventDisableTiming) == hipSuccess;
-      if (ok) u->side_state = 1;
-    }
-    (void)hipGetLastError();
-  }
-  int n_fork = 0;
+  // R(x) of a block beside its first conv on a side stream was measured and removed (round 2: fork/join edges cost more
+  // than the overlap gains, 1664 -> 1244 steps/s eager, 1603 -> 1423 as a graph): everything is issued in stream order.
   auto run_block = [&](const ResBlock& B, const Act& x0, const Act* x1, float* dst) -> int {
     float* h = next_buf();
     Act res = x0;  // identity residual (cin == cout, never a concat)
-    int r = ADX_OK, fork = -1;
-    if (B.has_r && u->side_state != 1) {
+    if (B.has_r) {
       // R(x) and block[0] read the same input and nothing of each other: ONE launch where both run on the short-K
       // kernel (tconv_hs_forward_pair), two otherwise
       float* rb = next_buf();
       const adx_tconv_io io_a = make_io(B.a, base, x0, x1, tb + B.tb_off, u->sum_c, nullptr, h, (int64_t)B.cout * B.len, B.len, 1, rows);
       const adx_tconv_io io_r = make_io(B.r, base, x0, x1, nullptr, 0, nullptr, rb, (int64_t)B.cout * B.len, B.len, 1, rows);
-      r = tconv_hs_forward_pair(&B.a.d, &io_a, &B.r.d, &io_r, s);
+      const int r = tconv_hs_forward_pair(&B.a.d, &io_a, &B.r.d, &io_r, s);
       if (r != ADX_OK) return r;
       res = dense(rb, B.cout, B.len);
-      const Act hin2 = dense(h, B.cout, B.len);
-      return run_conv(B.b, base, hin2, nullptr, nullptr, 0, &res, dst, (int64_t)B.cout * B.len, B.len, 1, rows, s);
-    }
-    if (B.has_r) {
-      // opt-in side stream (ADX_UNET_SIDE=1): R(x) beside block[0], fork after the producer of x0, join before block[1]
-      float* rb = next_buf();
-      hipStream_t rs = s;
-      if (u->side_state == 1 && n_fork < 16) {
-        fork = n_fork++;
-        ADX_CHECK_HIP(hipEventRecord(u->ev_fork[fork], s));
-        ADX_CHECK_HIP(hipStreamWaitEvent(u->side, u->ev_fork[fork], 0));
-        rs = u->side;
-      }
-      r = run_conv(B.r, base, x0, x1, nullptr, 0, nullptr, rb, (int64_t)B.cout * B.len, B.len, 1, rows, rs);
-      if (fork >= 0) ADX_CHECK_HIP(hipEventRecord(u->ev_join[fork], u->side));
+    } else {
+      const int r = run_conv(B.a, base, x0, x1, tb + B.tb_off, u->sum_c, nullptr, h, (int64_t)B.cout * B.len, B.len, 1, rows, s);
       if (r != ADX_OK) return r;
-      res = dense(rb, B.cout, B.len);
     }
-    r = run_conv(B.a, base, x0, x1, tb + B.tb_off, u->sum_c, nullptr, h, (int64_t)B.cout * B.len, B.len, 1, rows, s);
-    if (r != ADX_OK) return r;
-    if (fork >= 0) ADX_CHECK_HIP(hipStreamWaitEvent(s, u->ev_join[fork], 0));
     const Act hin = dense(h, B.cout, B.len);
     return run_conv(B.b, base, hin, nullptr, nullptr, 0, &res, dst, (int64_t)B.cout * B.len, B.len, 1, rows, s);
   };
@@ -525,6 +485,12 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
 
 int32_t adx_unet_time_bias_width(const adx_unet* u) { return u ? u->sum_c : 0; }
 
+size_t adx_unet_time_conditioning_workspace_bytes(const adx_unet* u, int32_t rows) {
+  if (!u || rows < 1) return 0;
+  const int dim = u->cfg.dim;        // time_embed + Mish(cond) rows only: no activation ring
+  return (align64((size_t)rows * dim) + align64((size_t)rows * 2 * dim)) * sizeof(float);
+}
+
 int adx_unet_time_conditioning(adx_unet* u, const void* packed, void* workspace, const adx_unet_io* io, float* time_embed,
                                float* time_bias, adx_stream stream) {
   ADX_REQUIRE(u && packed && workspace && io && time_bias, "adx_unet_time_conditioning: null argument");
@@ -537,7 +503,7 @@ int adx_unet_time_conditioning(adx_unet* u, const void* packed, void* workspace,
   int rc = check_conditioning_io(u, io, "adx_unet_time_conditioning");
   if (rc != ADX_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
-  float* ws = (float*)workspace;                    // same front layout as adx_unet_forward: te, mc
+  float* ws = (float*)workspace;                    // te, mc (adx_unet_time_conditioning_workspace_bytes)
   float* te = ws;
   float* mc = ws + align64((size_t)rows * dim);
   rc = time_conditioning(u, (const float*)packed, io, rows, te, mc, time_bias, s);

@@ -36,11 +36,5 @@ struct adx_unet {
   size_t o_tlin_raw = 0, o_tlin_b = 0;  // concatenated [sum_c][2 dim] block-Linear weight (staging) and bias
   size_t packed_floats = 0;
   bool packed_once = false;
-  // Side stream for the 1x1 residual convolutions: R(x) of a residual block depends only on the block's input, so it
-  // runs beside the block's first Conv1dBlock instead of between the two (fork / join with events; under stream
-  // capture the same calls become graph edges).  Created on the first forward, on the device that is current then.
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork[16] = {}, ev_join[16] = {};
-  int side_state = 0;   // 0: not decided yet, 1: ready, -1: off (the default; ADX_UNET_SIDE=1 turns it on)
 };
 

@@ -59,7 +59,7 @@ class _PerceptionTrainFn(torch.autograd.Function):
             if e.is_buffer:
                 slots.append(None)
             else:
-                grads[e.key] = torch.empty_like(named[e.key])
+                grads[e.key] = L.grad_buffer(named[e.key])      # born in its communication bucket under DataParallel
                 slots.append(grads[e.key])
         garr = (L.vp * len(slots))()
         for i, t in enumerate(slots):
@@ -121,7 +121,7 @@ class PerceptionResNet34(nn.Module):
 
     def weights_key(self):
         ts = self._tensors()
-        return (ts[0].data_ptr(), sum(t._version for t in ts), self.training)
+        return (ts[0].data_ptr(), sum(L.write_stamp(t) for t in ts), self.training)
 
     def invalidate(self):
         self._pack_key = None

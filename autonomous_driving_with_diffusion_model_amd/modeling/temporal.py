@@ -78,7 +78,7 @@ class _UnetTrainFn(torch.autograd.Function):
         g = L.require_gpu_f32(grad_out, "grad_out")
         rows = g.shape[0]
         gte = None if grad_te is None else L.require_gpu_f32(grad_te, "grad_time_embed")
-        grads = [torch.empty_like(p) for p in params]
+        grads = [L.grad_buffer(p) for p in params]     # born in their communication buckets under DataParallel
         d_feat = torch.empty((rows, module.dim), dtype=torch.float32, device=g.device)
         pa = L.ptr_array([p.detach() for p in params])
         ga = L.ptr_array(grads)
@@ -128,7 +128,7 @@ class TemporalMapUnet(nn.Module):
         self._ws = None
         self._ws_rows = 0
         self._freqs = None
-        self._feat_cache = None  # (weakref(img), img._version, weights_key, feature)
+        self._feat_cache = None  # (weakref(img), L.write_stamp(img), weights_key, feature)
 
     # -- native object management --------------------------------------------------------------
     def _native(self):
@@ -161,7 +161,7 @@ class TemporalMapUnet(nn.Module):
 
     def _weights_key(self):
         ps = self._unet_params()
-        return (ps[0].data_ptr(), sum(p._version for p in ps))
+        return (ps[0].data_ptr(), sum(L.write_stamp(p) for p in ps))
 
     def refresh_weights(self):
         """Force a re-pack of the HIP weight images (needed only after out-of-band `.data` writes)."""
@@ -209,13 +209,15 @@ class TemporalMapUnet(nn.Module):
 
     # -- perception with per-image memoisation -------------------------------------------------
     def image_feature(self, img: torch.Tensor) -> torch.Tensor:
-        use_cache = self.cache_perception and not self.training and not torch.is_grad_enabled()
+        # eval mode: the forward is a plain native call in every grad mode (no_grad, inference_mode -- train.py:53 -- or grad
+        # enabled, as interact.py:147-155 calls it), its result depends on (image, weights) only
+        use_cache = self.cache_perception and not self.training
         if use_cache and self._feat_cache is not None:
-            ref, ver, wkey, feat = self._feat_cache
-            if ref() is img and ver == img._version and wkey == self.perception.weights_key():
+            ref, stamp, wkey, feat = self._feat_cache
+            if ref() is img and stamp == L.write_stamp(img) and wkey == self.perception.weights_key():
                 return feat
         feat = self.perception(img)
-        self._feat_cache = (weakref.ref(img), img._version, self.perception.weights_key(), feat) if use_cache else None
+        self._feat_cache = (weakref.ref(img), L.write_stamp(img), self.perception.weights_key(), feat) if use_cache else None
         return feat
 
     # -- training path -----------------------------------------------------------------------------
@@ -281,7 +283,9 @@ class TemporalMapUnet(nn.Module):
         io = L.UnetIO()
         io.img_feature, io.feat_rows = feat_full.data_ptr(), total
         io.t, io.t_rows, io.cond, io.rows = t_full.data_ptr(), total, L.ptr(cond_full), total
-        L.check(L.lib().adx_unet_time_conditioning(h, self._packed.data_ptr(), self._workspace(total, dev).data_ptr(),
+        # a scratch of its own (3 * dim floats per table row), not the forward's activation workspace grown to n * rows rows
+        ws = torch.empty(L.lib().adx_unet_time_conditioning_workspace_bytes(h, total), dtype=torch.uint8, device=dev)
+        L.check(L.lib().adx_unet_time_conditioning(h, self._packed.data_ptr(), ws.data_ptr(),
                                                    C.byref(io), te.data_ptr(), tb.data_ptr(), L.stream_ptr(dev)),
                 "adx_unet_time_conditioning")
         return TimeConditioning(tb, te, rows, self._weights_key())

@@ -55,7 +55,7 @@ class _TrajPredictTrainFn(torch.autograd.Function):
                                                      L.stream_ptr(g.device)),
                 "adx_trajpred_backward_params")
         offs = module._param_offsets()
-        grads = [image[o:o + p.numel()].view_as(p).clone() for o, p in zip(offs, params)]
+        grads = [L.grad_buffer(p).copy_(image[o:o + p.numel()].view_as(p)) for o, p in zip(offs, params)]
         return (ga, dte, None, *grads)
 
 
@@ -150,7 +150,7 @@ class TrajPredict(nn.Module):
 
     def _ensure_packed(self, device):
         ps = self._params()
-        key = (ps[0].data_ptr(), sum(p._version for p in ps))
+        key = (ps[0].data_ptr(), sum(L.write_stamp(p) for p in ps))
         h = self._native()
         if key != self._pack_key or self._packed is None or self._packed.device != device:
             ts = [L.require_gpu_f32(p.detach(), "state_pred parameter") for p in ps]

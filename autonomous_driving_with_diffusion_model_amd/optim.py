@@ -39,6 +39,7 @@ class FusedAdamWEMA:
         self.ema_kw = dict(update_after_step=ema_update_after_step, inv_gamma=ema_inv_gamma, power=ema_power,
                            max_decay=ema_max_decay, use_ema_warmup=True)
         self.step_count = 0
+        self.grad_scale = 1.0           # parallel.DataParallel(optimizer=self) sets 1 / world: the buckets carry the sum
         self.exp_avg = [torch.zeros_like(p) for p in self.params]
         self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
         self.shadow_params = [p.detach().clone() for p in self.params] if use_ema else [None] * len(self.params)
@@ -108,10 +109,11 @@ class FusedAdamWEMA:
             self._table_key = key
         self._keep_grads = grads                           # contiguous copies (if any) must outlive the launch
         decay = ema_decay(self.step_count, **self.ema_kw) if self.use_ema else 0.0
-        L.check(L.lib().adx_adamw_ema_step(self._table_dev.data_ptr(), self._block_tensor.data_ptr(),
-                                           self._block_chunk.data_ptr(), self._n_blocks, lr, self.betas[0], self.betas[1],
-                                           self.eps, self.weight_decay, self.step_count, decay, int(self.use_ema),
-                                           int(self.sanitize), L.stream_ptr(self.params[0].device)), "adx_adamw_ema_step")
+        L.check(L.lib().adx_adamw_ema_step_scaled(self._table_dev.data_ptr(), self._block_tensor.data_ptr(),
+                                                  self._block_chunk.data_ptr(), self._n_blocks, lr, self.betas[0],
+                                                  self.betas[1], self.eps, self.weight_decay, self.step_count, decay,
+                                                  int(self.use_ema), int(self.sanitize), float(self.grad_scale),
+                                                  L.stream_ptr(self.params[0].device)), "adx_adamw_ema_step")
         # the kernel wrote through raw pointers: move the version counters so the model re-packs its weights
         bump = getattr(torch.autograd.graph, "increment_version", None)
         for p in self.params:

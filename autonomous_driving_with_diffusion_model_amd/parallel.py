@@ -42,18 +42,63 @@ def make_buckets(sizes: Sequence[int], bucket_elems: int) -> List[List[int]]:
 
 
 class GradientAverager:
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 64.0, group=None):
+    """Bucketed gradient mean over the ranks, reduced IN PLACE.
+
+    Every bucket is one flat tensor and every parameter owns a view into it (`param._adx_grad_view`).  This package's
+    backward nodes (temporal stack, perception, TrajPredict) write a parameter's gradient straight into that view when
+    the parameter has no gradient yet (`_lib.grad_buffer`), autograd adopts the view as `.grad` without copying, and the
+    collective then runs on the bucket itself: no copy-in, no copy-out (2 x 149 MB of HBM traffic per step before).  A
+    gradient that lives elsewhere (a foreign module's, or one accumulated over several backwards) is copied in and out
+    as before -- the result is the same, only slower.
+
+    primitive  "all_reduce" (one collective per bucket) or "reduce_scatter" (reduce_scatter_tensor into this rank's
+               slice of the bucket + all_gather_into_tensor back, both in place: the explicit two-phase form SURVEY 8e
+               prefers on a fully connected xGMI node; buckets are padded to a multiple of the world size).
+    mean       True: `.grad` holds the mean after `synchronize()` (ReduceOp.AVG: no separate division pass).
+               False: `.grad` holds the SUM and `grad_scale` = 1 / world is left to the consumer --
+               `FusedAdamWEMA(grad_scale=...)` folds it into its single pass over the gradients."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 64.0, group=None,
+                 primitive: str = "all_reduce", mean: bool = True):
+        if primitive not in ("all_reduce", "reduce_scatter"):
+            raise ValueError(f"primitive must be 'all_reduce' or 'reduce_scatter', got {primitive!r}")
         self.params = [p for p in params if p.requires_grad]
-        self.group = group
+        self.group, self.primitive, self.mean = group, primitive, mean
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.grad_scale = 1.0 if mean else 1.0 / self.world
         self.buckets = make_buckets([p.numel() for p in self.params], int(bucket_mb * 1024 * 1024 / 4))
         self._flat: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
+        self._views: List[list] = [[] for _ in self.buckets]
         self._hooks: list = []
         self._pending: list = []
         self._ready: List[int] = []
+        self.copied_in = 0            # gradients of the last reduction that did not live in their bucket (diagnostic)
+        if self.world > 1:
+            for bi in range(len(self.buckets)):
+                self._ensure_bucket(bi)
+
+    def _ensure_bucket(self, bi: int) -> torch.Tensor:
+        idxs = self.buckets[bi]
+        p0 = self.params[idxs[0]]
+        flat = self._flat[bi]
+        if flat is not None and flat.device == p0.device:
+            return flat
+        n = sum(self.params[i].numel() for i in idxs)
+        padded = (n + self.world - 1) // self.world * self.world       # reduce_scatter needs equal slices
+        flat = self._flat[bi] = torch.zeros(padded, dtype=p0.dtype, device=p0.device)
+        views, off = [], 0
+        for i in idxs:
+            p = self.params[i]
+            v = flat[off:off + p.numel()].view(p.shape)
+            p._adx_grad_view = v          # the backward nodes write here (see _lib.grad_buffer)
+            views.append(v)
+            off += p.numel()
+        self._views[bi] = views
+        return flat
 
     def attach(self) -> "GradientAverager":
-        """Overlap mode: a bucket's all-reduce is launched from autograd hooks the moment its last gradient has been
+        """Overlap mode: a bucket's collective is launched from autograd hooks the moment its last gradient has been
         accumulated, i.e. DURING backward (the temporal stack's gradients are complete before the perception backward
         -- two thirds of the step -- has even been queued).  Call `synchronize()` after `loss.backward()`."""
         if self._hooks:
@@ -87,7 +132,7 @@ class GradientAverager:
 
     @torch.no_grad()
     def synchronize(self) -> None:
-        """Overlap mode: wait for the collectives the hooks launched and write the means back."""
+        """Overlap mode: wait for the collectives the hooks launched (and write back what had to be copied in)."""
         if self.world == 1:
             return
         if any(self._ready):
@@ -98,22 +143,29 @@ class GradientAverager:
     @torch.no_grad()
     def _launch(self, bi: int):
         idxs = self.buckets[bi]
-        grads = [self.params[i].grad for i in idxs]
-        if any(g is None for g in grads):
-            raise RuntimeError("a parameter has no gradient (every rank must produce every gradient)")
-        n = sum(g.numel() for g in grads)
-        flat = self._flat[bi]
-        if flat is None or flat.numel() != n or flat.device != grads[0].device:
-            flat = self._flat[bi] = torch.empty(n, dtype=grads[0].dtype, device=grads[0].device)
-        off = 0
-        for g in grads:
-            flat[off:off + g.numel()].copy_(g.reshape(-1))
-            off += g.numel()
-        return (dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), bi)
+        flat = self._ensure_bucket(bi)
+        copied = []
+        for i, v in zip(idxs, self._views[bi]):
+            g = self.params[i].grad
+            if g is None:
+                raise RuntimeError("a parameter has no gradient (every rank must produce every gradient)")
+            if g.data_ptr() != v.data_ptr() or g.device != v.device:      # not born in the bucket: bring it in
+                v.copy_(g)
+                copied.append(i)
+        op = dist.ReduceOp.AVG if self.mean else dist.ReduceOp.SUM
+        if self.primitive == "reduce_scatter":
+            shard = flat.view(self.world, -1)[self.rank]
+            w1 = dist.reduce_scatter_tensor(shard, flat, op=op, group=self.group, async_op=True)
+            if dist.get_backend(self.group) != "nccl":
+                w1.wait()     # RCCL runs a group's collectives in issue order on its own stream; gloo's worker threads do not
+            works = [w1, dist.all_gather_into_tensor(flat, shard, group=self.group, async_op=True)]
+        else:
+            works = [dist.all_reduce(flat, op=op, group=self.group, async_op=True)]
+        return (works, bi, copied)
 
     @torch.no_grad()
     def average(self, async_op: bool = False):
-        """All-reduce (mean) every gradient after backward.  Returns the list of work handles when async_op."""
+        """Reduce every bucket after backward (no hooks).  Returns the list of pending reductions when async_op."""
         if self.world == 1:
             return []
         works = [self._launch(bi) for bi in range(len(self.buckets))]
@@ -124,15 +176,14 @@ class GradientAverager:
 
     @torch.no_grad()
     def finish(self, works) -> None:
-        for work, bi in works:
-            work.wait()
-            flat = self._flat[bi]
-            flat.div_(self.world)
-            off = 0
-            for i in self.buckets[bi]:
-                g = self.params[i].grad
-                g.copy_(flat[off:off + g.numel()].view_as(g))
-                off += g.numel()
+        self.copied_in = 0
+        for handles, bi, copied in works:
+            for h in handles:
+                h.wait()
+            self.copied_in += len(copied)
+            where = dict(zip(self.buckets[bi], self._views[bi]))
+            for i in copied:
+                self.params[i].grad.copy_(where[i])
 
 
 class BufferBroadcaster:
@@ -173,8 +224,9 @@ class BufferBroadcaster:
                 for b in bufs:
                     b.copy_(flat[off:off + b.numel()].view_as(b))
                     off += b.numel()
-        if n and dist.get_rank(self.group) != self.src and hasattr(self.module, "refresh_weights"):
-            self.module.refresh_weights()       # eval-mode weight images fold the running statistics
+        # No refresh_weights() here: the copy_ above moves the buffers' version counters, which is what the eval-mode weight
+        # images are keyed on (PerceptionResNet34.weights_key), so they are rebuilt at the next eval forward -- and ranks
+        # > 0 do no host work per step that rank 0 does not (every collective waits for the slowest rank).
         return n
 
 
@@ -186,12 +238,19 @@ class DataParallel(torch.nn.Module):
     is one explicit call so that the collective's wait sits where the trainer wants it), then the optimizer step.
     `.module` is the wrapped model, like DDP's attribute that `accelerator.unwrap_model` reads."""
 
-    def __init__(self, module: torch.nn.Module, bucket_mb: float = 64.0, broadcast_buffers: bool = True, group=None):
+    def __init__(self, module: torch.nn.Module, bucket_mb: float = 64.0, broadcast_buffers: bool = True, group=None,
+                 primitive: str = "all_reduce", optimizer=None):
+        """optimizer: a `FusedAdamWEMA` over the same parameters.  The buckets then carry the SUM and the 1 / world goes
+        into the optimizer's single pass over the gradients (`optimizer.grad_scale`); `.grad` between `synchronize()` and
+        `optimizer.step()` is the sum, not the mean.  Without it `.grad` holds the mean, as under DDP."""
         super().__init__()
         self.module = module
         broadcast_parameters(module, src=0, group=group)
         self.buffers_sync = BufferBroadcaster(module, src=0, group=group) if broadcast_buffers else None
-        self.averager = GradientAverager(module.parameters(), bucket_mb=bucket_mb, group=group).attach()
+        self.averager = GradientAverager(module.parameters(), bucket_mb=bucket_mb, group=group, primitive=primitive,
+                                         mean=optimizer is None).attach()
+        if optimizer is not None:
+            optimizer.grad_scale = self.averager.grad_scale
 
     def forward(self, *args, **kwargs):
         if self.buffers_sync is not None and self.module.training and torch.is_grad_enabled():

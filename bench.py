@@ -111,9 +111,8 @@ def conv2d_roofline(dev, reps=10):
 
     The kernel produces an fp32-grade result on the fp16 matrix cores: every operand is split into an fp16 hi and a
     scaled fp16 lo part and each algorithmic multiply-add is issued as three v_mfma_f32_32x32x16_f16 products
-    (csrc/conv2d_hs.hip), so the roofline is the dense fp16 MFMA peak and `achieved` counts the MFMA work actually
-    issued = 3 x the convolution's 2*M*N*K.  `fp32_equivalent_tflops` is the same time against the algorithmic
-    flops, to be read against the 157.3 TFLOP/s fp32 MFMA peak that an exact-fp32 kernel is bounded by."""
+    (csrc/conv2d_hs.hip), so the roofline is the dense fp16 MFMA peak.  `achieved` / `frac` count the ALGORITHMIC work
+    (the convolution's 2*M*N*K); `achieved_issued` / `frac_issued` the MFMA work actually issued = 3 x that."""
     from autonomous_driving_with_diffusion_model_amd import ops
     shapes = {}
     for c in resnet_conv_table(*IMG):
@@ -131,7 +130,7 @@ def conv2d_roofline(dev, reps=10):
         fl = conv_flops(B, cin, cout, k, s, p, h, w)
         byts = 4.0 * (x.numel() + y.numel() + wt.numel())
         per_shape.append({"shape": f"{cin}->{cout} k{k} @{h}x{w}", "count": cnt, "ms": round(ms, 4),
-                          "mfma_tflops": round(3 * fl / ms / 1e9, 1), "fp32_equivalent_tflops": round(fl / ms / 1e9, 1)})
+                          "algorithmic_tflops": round(fl / ms / 1e9, 1), "issued_mfma_tflops": round(3 * fl / ms / 1e9, 1)})
         tot_ms += ms * cnt
         tot_fl += fl * cnt
         tot_bytes += byts * cnt
@@ -142,13 +141,14 @@ def conv2d_roofline(dev, reps=10):
     achieved = 3.0 * equiv                     # fp16 MFMA TFLOP/s issued
     return {"kernel": "conv2d_hs3x3_kernel<0|1|2> (ResNet-34 3x3 stride-1 convs, B=64, 3x256x900; fp32-grade result "
                       "from fp16 hi/lo split operands, 3 MFMA products per multiply-add)",
-            "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F16_TFLOPS, 4),
-            "frac_algorithmic": round(equiv / PEAK_F16_TFLOPS, 4),
-            "achieved_note": "fp16 MFMA flops issued = 3 x algorithmic conv flops, / HIP-event launch time; "
-                             "frac_algorithmic = algorithmic conv flops / the same time / the same fp16 peak",
+            "bound": "mfma", "achieved": round(equiv, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(equiv / PEAK_F16_TFLOPS, 4),
+            "achieved_issued": round(achieved, 1), "frac_issued": round(achieved / PEAK_F16_TFLOPS, 4),
+            "achieved_note": "achieved / frac (the contract figures, SURVEY 8d) = ALGORITHMIC conv flops (2*M*N*K) per launch / "
+                             "HIP-event launch time, against the dense fp16 MFMA peak; achieved_issued / frac_issued = the fp16 "
+                             "MFMA flops the kernel actually issues (3 x algorithmic: hi*hi + hi*lo + lo*hi) / the same time",
             "avg_launch_ms_rocprof": rocprof_avg_ms("conv2d_hs3x3_kernel"),
-            "fp32_equivalent_tflops": round(equiv, 1), "fp32_mfma_peak_tflops": PEAK_F32_TFLOPS,
+            "fp32_mfma_peak_tflops": PEAK_F32_TFLOPS, "frac_of_fp32_mfma_peak": round(equiv / PEAK_F32_TFLOPS, 3),
             "traffic": pmc_traffic("conv2d_hs3x3_kernel"),
             "traffic_note": "bytes/launch, 2 x FETCH_SIZE (gfx950 correction, calibrated: tools/micro/fetch_calib.hip) + WRITE_SIZE from profiles/" + os.path.basename(pmc_traffic_file() or "(none)") + " (separate rocprofv3 --pmc passes)",
             "avg_launch_ms": round(avg_ms, 4), "launches_per_step": count,
@@ -184,10 +184,10 @@ def tconv_roofline(model, dev, reps=20):
     del fn
     return {"kernel": "tconv_hs_kernel<2,8,4> (Conv1d 512->512 k5 + GroupNorm + Mish, 128x4 positions; fp32-grade result "
                       "from fp16 hi/lo split operands, 3 MFMA products per multiply-add)",
-            "bound": "mfma", "achieved": round(3 * fl / ms / 1e9, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(3 * fl / ms / 1e9 / PEAK_F16_TFLOPS, 4),
-            "frac_algorithmic": round(fl / ms / 1e9 / PEAK_F16_TFLOPS, 4),
-            "fp32_equivalent_tflops": round(fl / ms / 1e9, 2), "fp32_mfma_peak_tflops": PEAK_F32_TFLOPS,
+            "bound": "mfma", "achieved": round(fl / ms / 1e9, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(fl / ms / 1e9 / PEAK_F16_TFLOPS, 4),
+            "achieved_issued": round(3 * fl / ms / 1e9, 2), "frac_issued": round(3 * fl / ms / 1e9 / PEAK_F16_TFLOPS, 4),
+            "fp32_mfma_peak_tflops": PEAK_F32_TFLOPS,
             "traffic": pmc_traffic("tconv_hs_kernel<2"), "avg_launch_ms": round(ms, 4),
             "avg_launch_ms_rocprof": rocprof_avg_ms("tconv_hs_kernel<2"),
             "algorithmic_gflop_per_launch": round(fl / 1e9, 3), "algorithmic_mb_per_launch": round(byts / 1e6, 2),
@@ -283,10 +283,10 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(steps=3):
+def cpu_baseline(steps=5):
     """The oracle (CPU restatement of the reference, kind 'port') on the host cores of this box,
     same workload: one reference-faithful denoising step = ResNet-34 on 64 images + UNet on the
-    2x64 CFG batch + DDIM step.  Bounded sample: 1 warm-up + `steps` timed steps."""
+    2x64 CFG batch + DDIM step.  Bounded sample: 1 warm-up + `steps` timed steps; `value` is 1 / the MEDIAN step."""
     from autonomous_driving_with_diffusion_model_amd.modeling.spec import unet_entries
     from autonomous_driving_with_diffusion_model_amd.utils import procedural as P
     from oracle import unet as U
@@ -317,11 +317,11 @@ def cpu_baseline(steps=3):
                            use_cond="FREE_GUIDANCE", img_feature=feat)
         unet_s = (time.perf_counter() - t0) / 3
     timed = times[1:]
-    per = sum(timed) / len(timed)
+    per = sorted(timed)[len(timed) // 2]          # median: single steps wander by +-10 % on a shared host
     return {"value": round(1.0 / per, 4), "unit": "denoising-steps/sec", "cores": cores, "cpu": cpu_model_name(),
             "kind": "port", "per_step_s": [round(x, 3) for x in timed],
             "sample": f"{len(timed)} reference-faithful steps (ResNet-34 on 64x3x256x900 + UNet 2x64xH32 + DDIM step) "
-                      f"after 1 warm-up, torch-CPU fp32, {cores} threads",
+                      f"after 1 warm-up, torch-CPU fp32, {cores} threads; value = 1 / median step",
             "s_per_step": round(per, 3), "unet_only_steps_per_sec": round(1.0 / unet_s, 3)}
 
 
@@ -384,13 +384,35 @@ def train_leg(dev, world, steps=5, warm=3):
             "steps": steps, "approx_tflops_per_gpu": round(flops * steps / dt / 1e12, 1), "final_loss": round(float(loss.detach()), 5)}
 
 
+def visible_gpu_count() -> int:
+    """GPUs this process would see, counted WITHOUT touching the HIP runtime (a torch.cuda.device_count() that falls back to
+    hipGetDeviceCount initialises it, and a process that has done so must not start other GPU programs on this pool): the
+    visibility variables if set, else the KFD topology (nodes with SIMDs are GPUs; CPU nodes report simd_count 0)."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    import glob
+    n = 0
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            with open(path) as f:
+                for line in f:
+                    k, _, val = line.partition(" ")
+                    if k == "simd_count" and int(val) > 0:
+                        n += 1
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def launch_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher around it: start N copies of this script, one per GPU, with the
     rendezvous variables torchrun would set.  The parent never touches a GPU (no HIP call before or after the spawn);
     the first child that fails takes the others down and its exit code becomes the parent's."""
     import socket
     import subprocess
-    have = torch.cuda.device_count()          # counts devices without initialising HIP on this image
+    have = visible_gpu_count()                # no torch.cuda / HIP call in the parent: it forks the ranks
     if have < n and "--launch-check" not in sys.argv and os.environ.get("ADX_BENCH_SAME_DEVICE") != "1":
         print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
         return 2
@@ -577,7 +599,13 @@ def main():
             "metric": "denoising-steps/sec", "value": round(world * args.steps / dt, 3), "unit": "denoising-steps/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "dtype_note": "fp32 inputs, outputs and accumulation; the 2-D convolutions multiply fp16 hi/lo split operands (3 MFMAs per product, error below fp32 accumulation's own: DESIGN.md section 3)", "data": "synthetic",
+            "dtype_note": "fp32 inputs, outputs and accumulation; the 2-D convolutions multiply fp16 hi/lo split operands (3 MFMAs per product, error below fp32 accumulation's own: DESIGN.md section 3)",
+            "parity_note": "north_star: fp32 trajectory outputs within 1e-4.  Measured at this workload against the CPU oracle "
+                           "(tests/test_gpu_fullsize.py, B = 64, 50 steps): 1.6e-5 on the normalised trajectory, i.e. 2.0e-5 on "
+                           "channels 2-6 as returned and 3.8e-4 on the RETURNED x, y, which the callers multiply by magic_num = "
+                           "23.315 after the clamp (interact.py:167); the tests bound channels 0-1 by 23.315e-4 and the rest by "
+                           "1e-4 (tests/helpers.py:close_traj).  Read strictly on the returned x, y the 1e-4 is not met",
+            "data": "synthetic",
             "config": {"workload": "configs/guidance/free_guidance.yaml: 50-step DDIM sampling, classifier-free "
                                    "guidance scale 7.5, 64 scenes per GPU (UNet batch 128), horizon 32, image 3x256x900, "
                                    "reference-faithful (ResNet-34 perception re-run every step)",

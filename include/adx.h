@@ -156,10 +156,12 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
  * time_mlp Linear of all 16 residual blocks (modeling/temporal.py:206-216, modeling/helpers.py:121-123) -- for `rows`
  * rows at once, e.g. all 50 timesteps of a sampling loop x the rows of one step: inside the loop
  * (interact.py:128-166) these are the same launches every tick, and none of them depends on the trajectory.  Uses
- * io->t, t_rows, cond, img_feature, feat_rows, rows (workspace sized by adx_unet_workspace_bytes(u, rows)).  Writes
+ * io->t, t_rows, cond, img_feature, feat_rows, rows (workspace sized by adx_unet_time_conditioning_workspace_bytes(u,
+ * rows): two small per-row vectors, not a forward's activation ring).  Writes
  * time_bias [rows][adx_unet_time_bias_width(u)] and, if not NULL, time_embed [rows][dim].  Row-wise identical to what
  * adx_unet_forward computes internally. */
 int32_t adx_unet_time_bias_width(const adx_unet* u);
+size_t adx_unet_time_conditioning_workspace_bytes(const adx_unet* u, int32_t rows);
 int adx_unet_time_conditioning(adx_unet* u, const void* packed, void* workspace, const adx_unet_io* io, float* time_embed,
                                float* time_bias, adx_stream s);
 
@@ -296,6 +298,11 @@ int adx_optim_chunk(void);
 int adx_adamw_ema_step(const void* table, const int32_t* block_tensor, const int32_t* block_chunk, int32_t n_blocks,
                        float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
                        float ema_decay, int32_t use_ema, int32_t sanitize, adx_stream s);
+/* the same with every gradient multiplied by grad_scale as it is read (data-parallel training: 1 / world_size when the
+ * all-reduce left the SUM over the ranks in .grad; the reference's DDP divides inside its own reduction, train.py:176-178) */
+int adx_adamw_ema_step_scaled(const void* table, const int32_t* block_tensor, const int32_t* block_chunk, int32_t n_blocks,
+                       float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                       float ema_decay, int32_t use_ema, int32_t sanitize, float grad_scale, adx_stream s);
 
 /* ------------------------------------------------------------------------------------
  * Scheduler step math.  The integer schedule and the fp32 scalar coefficients are computed

@@ -1,0 +1,37 @@
+"""First-step loss of bench.py's training leg (BASELINE configs[1]: NO_GUIDANCE, B = 64, H = 32, 3x256x900, procedural
+weights seed 0, synthetic batch seed 7 = rank 0's), computed by the CPU oracle's train-mode FORWARD (batch-statistics
+BatchNorm).  bench.py asserts its own first step against this figure; tests/test_gpu_fullsize.py recomputes it on the
+GPU box's host.  Usage: python tests/golden/make_bench_loss.py  ->  tests/golden/bench_train_loss.json"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from autonomous_driving_with_diffusion_model_amd.modeling.spec import unet_entries  # noqa: E402
+from autonomous_driving_with_diffusion_model_amd.utils import procedural as P  # noqa: E402
+from oracle import sampling as OS  # noqa: E402
+
+
+def bench_train_loss(batch=64, horizon=32, image_hw=(256, 900), seed=7, dtype=torch.float32):
+    sd = P.procedural_state_dict(((e.key, e.shape) for e in unet_entries("NO_GUIDANCE")), 0)
+    d = P.synthetic_batch(batch, horizon, image_hw=image_hw, seed=seed)
+    cast = lambda t: t.to(dtype) if t.is_floating_point() else t  # noqa: E731
+    sd = {k: cast(v) for k, v in sd.items()}
+    with torch.no_grad():
+        return OS.training_loss(sd, cast(d["imgs"]), cast(d["trajs"]), cast(d["target"]), d["t"], cast(d["noise"]),
+                                use_cond="NO_GUIDANCE").item()
+
+
+if __name__ == "__main__":
+    t0 = time.time()
+    l32 = bench_train_loss(dtype=torch.float32)
+    l64 = bench_train_loss(dtype=torch.float64)
+    out = {"loss_fp32": l32, "loss_fp64": l64, "batch": 64, "horizon": 32, "image_hw": [256, 900], "weights_seed": 0,
+           "batch_seed": 7, "use_cond": "NO_GUIDANCE", "made_by": "tests/golden/make_bench_loss.py (CPU oracle, train-mode forward)"}
+    with open(os.path.join(HERE, "bench_train_loss.json"), "w") as f:
+        json.dump(out, f)
+    print(out, f"{time.time() - t0:.0f} s")

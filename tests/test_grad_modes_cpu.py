@@ -1,0 +1,78 @@
+"""Host logic that must work in every grad mode the reference's callers use, checked without a GPU.
+
+`train.evaluate` runs under `torch.inference_mode()` (train.py:53): its tensors carry no version counter, so every memo
+keyed on `._version` must go through `_lib.write_stamp`.  The native calls are stubbed out; what runs here is the Python
+around them."""
+import torch
+
+from autonomous_driving_with_diffusion_model_amd import _lib as L
+from autonomous_driving_with_diffusion_model_amd.config import create_cfg
+from autonomous_driving_with_diffusion_model_amd.modeling import build_model
+
+
+def test_write_stamp():
+    a = torch.zeros(3)
+    s0 = L.write_stamp(a)
+    a.add_(1)
+    assert L.write_stamp(a) == s0 + 1
+    with torch.inference_mode():
+        b = torch.zeros(3)
+        assert b.is_inference() and L.write_stamp(b) == 0
+        b.add_(1)
+        assert L.write_stamp(b) == 0
+
+
+def _stubbed_model():
+    m = build_model(create_cfg()).eval()
+    calls = []
+
+    def encoder(img):
+        calls.append(img)
+        return img.float().mean(dim=(1, 2, 3))[:, None].repeat(1, m.dim)
+    m.perception.forward = encoder
+    return m, calls
+
+
+def test_image_feature_memo_in_every_grad_mode():
+    for ctx in (torch.no_grad, torch.inference_mode, torch.enable_grad):
+        m, calls = _stubbed_model()
+        with ctx():
+            img = torch.randn(2, 3, 8, 8)
+            f0 = m.image_feature(img)
+            assert m.image_feature(img) is f0 and len(calls) == 1          # same object: memo hit
+            img2 = img.clone()
+            f1 = m.image_feature(img2)
+            assert len(calls) == 2 and torch.equal(f0, f1)                 # another object: encoder runs
+            if not img2.is_inference():
+                img2.mul_(2)                                               # in-place write: the version counter sees it
+                m.image_feature(img2)
+                assert len(calls) == 3
+        m.cache_perception = False
+        with ctx():
+            m.image_feature(img2)
+            m.image_feature(img2)
+        assert len(calls) >= 4
+
+
+def test_memo_is_dropped_in_train_mode_and_after_weight_changes():
+    m, calls = _stubbed_model()
+    img = torch.randn(1, 3, 8, 8)
+    with torch.no_grad():
+        m.image_feature(img)
+        m.image_feature(img)
+        assert len(calls) == 1
+        next(m.perception.parameters()).add_(1.0)                          # optimizer-style update
+        m.image_feature(img)
+        assert len(calls) == 2
+        m.train()
+        m.image_feature(img)
+        m.image_feature(img)
+        assert len(calls) == 4
+
+
+def test_weight_keys_work_on_inference_parameters():
+    """A model moved / loaded inside inference_mode holds inference tensors as parameters."""
+    with torch.inference_mode():
+        m, _ = _stubbed_model()
+        m = m.to(torch.float32)
+        assert isinstance(m._weights_key(), tuple) and isinstance(m.perception.weights_key(), tuple)

@@ -90,6 +90,82 @@ def test_gradient_averaging_and_broadcast_world2():
     assert res[0][3] > 1
 
 
+class _BucketBornGrad(torch.autograd.Function):
+    """A backward node written like this package's (modeling/temporal.py:_UnetTrainFn.backward): the parameter gradient
+    is written into the buffer `_lib.grad_buffer` hands out and returned."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        from autonomous_driving_with_diffusion_model_amd import _lib as L
+        x, w = ctx.saved_tensors
+        gw = L.grad_buffer(w)
+        torch.mm(g.t(), x, out=gw)
+        return g @ w, gw
+
+
+def _inplace_worker(rank, world, port, out, primitive):
+    """In-place buckets: gradients born inside the flat bucket are reduced without copies (copied_in == 0); a foreign
+    gradient (plain torch module) in the same averager is copied in and out; mean=False leaves the sum + grad_scale."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    w = torch.nn.Parameter(torch.randn(5, 7))            # 35 elements: not a multiple of the world size (padding)
+    lin = torch.nn.Linear(5, 3)
+    x = torch.randn(4, 7) * (rank + 1)
+    ok = True
+    for mean in (True, False):
+        avg = GradientAverager([w, *lin.parameters()], bucket_mb=1e-3, primitive=primitive, mean=mean).attach()
+        for step in range(2):
+            w.grad = None
+            lin.zero_grad(set_to_none=True)
+            lin(_BucketBornGrad.apply(x, w)).square().sum().backward()
+            born_in_bucket = w.grad.data_ptr() == w._adx_grad_view.data_ptr()
+            # reference values: the same loss with plain autograd, gathered over the ranks
+            w2 = w.detach().clone().requires_grad_()
+            l2 = torch.nn.Linear(5, 3)
+            l2.load_state_dict(lin.state_dict())
+            l2(x @ w2.t()).square().sum().backward()
+            avg.synchronize()
+            for got, loc in ((w.grad, w2.grad), (lin.weight.grad, l2.weight.grad), (lin.bias.grad, l2.bias.grad)):
+                parts = [torch.zeros_like(loc) for _ in range(world)]
+                dist.all_gather(parts, loc)
+                want = sum(parts) / world
+                ok = ok and torch.allclose(got * avg.grad_scale, want, atol=1e-5, rtol=1e-5)
+            ok = ok and born_in_bucket and avg.copied_in == 2            # the Linear's two gradients only
+            ok = ok and (avg.grad_scale == (1.0 if mean else 1.0 / world))
+        # accumulation over two backwards without clearing: the node must NOT write into the live .grad's storage
+        w.grad = None
+        lin.zero_grad(set_to_none=True)
+        avg.detach()
+        for _ in range(2):
+            lin(_BucketBornGrad.apply(x, w)).square().sum().backward()
+        w2 = w.detach().clone().requires_grad_()
+        (2 * lin(x @ w2.t()).square().sum()).backward()
+        ok = ok and torch.allclose(w.grad, w2.grad, atol=1e-4, rtol=1e-5)
+    out.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_inplace_buckets_reduce_scatter_and_deferred_scale_world2():
+    ctx = mp.get_context("spawn")
+    for primitive in ("all_reduce", "reduce_scatter"):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_inplace_worker, args=(r, 2, port, q, primitive)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=120) for _ in procs)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert all(r[1] for r in res), (primitive, res)
+
+
 def _dp_worker(rank, world, port, out):
     """The reference's DDP semantics on a small conv + BatchNorm net: per-forward buffer broadcast from rank 0
     (statistics are NOT averaged), hook-driven gradient means, and the LR schedule that ticks `world` times per
