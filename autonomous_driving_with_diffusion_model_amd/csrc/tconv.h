@@ -26,6 +26,14 @@ size_t tconv_packed_floats(const adx_tconv_desc* d);
 int tconv_pack(const adx_tconv_desc* d, const float* w, float* packed, hipStream_t s);
 int tconv_forward(const adx_tconv_desc* d, const adx_tconv_io* io, hipStream_t s);
 
+// tile rules of the exact-fp32 MFMA kernel (power-of-two group widths, groups of a multiple of 64 elements)
+bool tconv_exact_supported(const adx_tconv_desc* d);
+// any-shape fallback (tconv_generic.hip): plain fp32 FMAs, one workgroup per (sample, GroupNorm group)
+bool tconv_generic_supported(const adx_tconv_desc* d);
+size_t tconv_generic_packed_floats(const adx_tconv_desc* d);
+int tconv_generic_pack(const adx_tconv_desc* d, const float* w, float* packed, hipStream_t s);
+int tconv_generic_forward(const adx_tconv_desc* d, const adx_tconv_io* io, hipStream_t s);
+
 // split-fp16 MFMA implementation (tconv_hs.hip); tconv_pack / tconv_forward route to it when the geometry is
 // supported and the descriptor does not ask for the exact-fp32 kernel
 bool tconv_hs_supported(const adx_tconv_desc* d);

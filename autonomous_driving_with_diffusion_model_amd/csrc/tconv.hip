@@ -20,6 +20,7 @@
 //   3. the 4 partial tiles are summed through LDS in the [sample][channel][pos] order of
 //      the output tensor, one wave per (sample, group) computes two-pass mean/variance with
 //      wavefront shuffles, applies affine + Mish + time bias + residual and stores coalesced.
+#include <algorithm>
 #include <array>
 #include <map>
 #include <mutex>
@@ -255,15 +256,21 @@ int tconv_check(const adx_tconv_desc* d) {
   ADX_REQUIRE(d->lin_valid >= 0 && d->lin_valid <= d->lin && d->lout_valid >= 0 && d->lout_valid <= d->lout,
               "tconv: lin_valid %d / lout_valid %d outside [0, lin %d] / [0, lout %d]", d->lin_valid, d->lout_valid, d->lin,
               d->lout);
-  if (d->groups > 0) {
-    ADX_REQUIRE(d->cout % d->groups == 0, "tconv: cout %d not divisible by groups %d", d->cout, d->groups);
-    const int cg = d->cout / d->groups;
-    ADX_REQUIRE(ilog2_exact(cg) >= 0 && cg <= 128, "tconv: group width %d must be a power of two <= 128", cg);
-    ADX_REQUIRE(d->cout % 16 == 0, "tconv: GroupNorm convs need cout %% 16 == 0");
-    ADX_REQUIRE((cg * d->lout) % 64 == 0, "tconv: GroupNorm group of %d x %d elements must be a multiple of 64", cg,
-                d->lout);
-  }
+  if (d->groups > 0) ADX_REQUIRE(d->cout % d->groups == 0, "tconv: cout %d not divisible by groups %d", d->cout, d->groups);
+  ADX_REQUIRE(tconv_hs_supported(d) || tconv_exact_supported(d) || tconv_generic_supported(d),
+              "tconv: no kernel covers this layer (the general-shape kernel needs a sample's %d x %d input in 128 KB of LDS)",
+              d->c0 + d->c1, d->lin);
   return ADX_OK;
+}
+
+// the tile rules of the exact-fp32 MFMA kernel below (layers outside them run on tconv_generic.hip)
+bool tconv_exact_supported(const adx_tconv_desc* d) {
+  if (d->groups > 0) {
+    if (d->cout % d->groups != 0) return false;
+    const int cg = d->cout / d->groups;
+    if (ilog2_exact(cg) < 0 || cg > 128 || d->cout % 16 != 0 || (cg * d->lout) % 64 != 0) return false;
+  }
+  return true;
 }
 
 // LDS pitch search: the A fragment of one MFMA is read by lanes (r = row 0..15, kk = 0..3) at
@@ -310,6 +317,7 @@ int tconv_tile(const adx_tconv_desc* d, int batch, TConvTile* t) {
   int rc = tconv_check(d);
   if (rc != ADX_OK) return rc;
   ADX_REQUIRE(batch >= 1, "tconv: batch must be >= 1");
+  ADX_REQUIRE(tconv_exact_supported(d), "tconv: the exact-fp32 MFMA kernel does not tile this layer");
   t->cin = d->c0 + d->c1;
   t->cin_pad = round_up(t->cin, 16);
   t->ncb = t->cin_pad / 16;
@@ -397,7 +405,8 @@ size_t tconv_packed_floats(const adx_tconv_desc* d) {
   const int cin_pad = round_up(d->c0 + d->c1, 16);
   const size_t exact = (size_t)(round_up(d->cout, 16) / 16) * d->taps * (cin_pad / 16) * 256;
   const size_t hs = tconv_hs_packed_floats(d);     // both images fit: the `exact` flag may flip between pack calls
-  return exact > hs ? exact : hs;
+  const size_t gen = tconv_generic_packed_floats(d);
+  return std::max(std::max(exact, hs), gen);
 }
 
 int tconv_pack(const adx_tconv_desc* d, const float* w, float* packed, hipStream_t s) {
@@ -405,6 +414,7 @@ int tconv_pack(const adx_tconv_desc* d, const float* w, float* packed, hipStream
   if (rc != ADX_OK) return rc;
   ADX_REQUIRE(w != nullptr && packed != nullptr, "tconv_pack: null pointer");
   if (tconv_hs_supported(d)) return tconv_hs_pack(d, w, packed, s);
+  if (!tconv_exact_supported(d)) return tconv_generic_pack(d, w, packed, s);
   const int cin = d->c0 + d->c1;
   const int ncb = round_up(cin, 16) / 16;
   const size_t total = tconv_packed_floats(d);
@@ -438,13 +448,17 @@ static int launch(const TConvArgs& a, int grid, size_t lds, int nw, hipStream_t 
 
 int tconv_forward(const adx_tconv_desc* d, const adx_tconv_io* io, hipStream_t s) {
   ADX_REQUIRE(io != nullptr, "tconv_forward: null io");
-  TConvTile t;
-  int rc = tconv_tile(d, io->batch, &t);
+  int rc = tconv_check(d);
   if (rc != ADX_OK) return rc;
+  ADX_REQUIRE(io->batch >= 1, "tconv: batch must be >= 1");
   ADX_REQUIRE(io->x0 != nullptr && io->packed_w != nullptr && io->y != nullptr, "tconv_forward: null tensor");
   ADX_REQUIRE(d->c1 == 0 || io->x1 != nullptr, "tconv_forward: c1 > 0 but x1 is null");
   ADX_REQUIRE(d->groups == 0 || (io->gamma != nullptr && io->beta != nullptr), "tconv_forward: GroupNorm affine missing");
   if (tconv_hs_supported(d)) return tconv_hs_forward(d, io, s);   // split-fp16 MFMA path (tconv_hs.hip)
+  if (!tconv_exact_supported(d)) return tconv_generic_forward(d, io, s);   // any other shape (tconv_generic.hip)
+  TConvTile t;
+  rc = tconv_tile(d, io->batch, &t);
+  if (rc != ADX_OK) return rc;
   TConvArgs a;
   a.io = *io;
   a.kind = d->kind; a.taps = d->taps; a.stride = d->stride; a.pad = d->pad;

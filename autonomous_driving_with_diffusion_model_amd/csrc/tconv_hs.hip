@@ -743,6 +743,7 @@ bool tconv_hs_supported(const adx_tconv_desc* d) {
   if (d->groups > 0) {
     const int cg = d->cout / d->groups;
     if (cg > 64 || ilog2_exact_hs(cg) < 0) return false;
+    if ((cg * d->lout) % 64 != 0 || d->cout % 16 != 0) return false;     // both epilogues reduce a (sample, group) in whole waves
   }
   return true;
 }

@@ -144,19 +144,19 @@ static int build(adx_unet* u) {
     u->o_c2w = B.take((size_t)c.dim * c.dim); u->o_c2b = B.take(c.dim);
   }
   u->packed_floats = B.off;
-  // validate every layer's geometry now so that forward() cannot fail on shape grounds
-  TConvTile t;
+  // validate every layer's geometry now so that forward() cannot fail on shape grounds (any layer one of the three
+  // temporal kernels covers: tconv_check)
   for (auto& b : u->blocks) {
-    int rc = tconv_tile(&b.a.d, 1, &t);
-    if (rc == ADX_OK) rc = tconv_tile(&b.b.d, 1, &t);
-    if (rc == ADX_OK && b.has_r) rc = tconv_tile(&b.r.d, 1, &t);
+    int rc = tconv_check(&b.a.d);
+    if (rc == ADX_OK) rc = tconv_check(&b.b.d);
+    if (rc == ADX_OK && b.has_r) rc = tconv_check(&b.r.d);
     if (rc != ADX_OK) return rc;
   }
-  for (auto& l : u->downs) { int rc = tconv_tile(&l.d, 1, &t); if (rc != ADX_OK) return rc; }
-  for (auto& l : u->ups) { int rc = tconv_tile(&l.d, 1, &t); if (rc != ADX_OK) return rc; }
-  int rc = tconv_tile(&u->head0.d, 1, &t);
-  if (rc == ADX_OK) rc = tconv_tile(&u->head1.d, 1, &t);
-  if (rc == ADX_OK) rc = tconv_tile(&u->tlin.d, 1, &t);
+  for (auto& l : u->downs) { int rc = tconv_check(&l.d); if (rc != ADX_OK) return rc; }
+  for (auto& l : u->ups) { int rc = tconv_check(&l.d); if (rc != ADX_OK) return rc; }
+  int rc = tconv_check(&u->head0.d);
+  if (rc == ADX_OK) rc = tconv_check(&u->head1.d);
+  if (rc == ADX_OK) rc = tconv_check(&u->tlin.d);
   return rc;
 }
 

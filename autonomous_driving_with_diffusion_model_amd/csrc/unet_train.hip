@@ -126,6 +126,18 @@ int adx_unet_forward_train(adx_unet* u, const void* packed, void* workspace, siz
     return ADX_ERR_STATE;
   }
   ADX_REQUIRE(io->x && io->img_feature && io->t && io->out, "adx_unet_forward_train: null tensor");
+  {
+    // the backward kernels (tbwd.hip) tile like the MFMA forward kernels: a model with layers only the general-shape
+    // kernel covers (GroupNorm widths that are not powers of two, groups of fewer than 64 elements) samples but does not train
+    auto trainable = [](const adx_tconv_desc& d) { return tconv_exact_supported(&d); };
+    bool ok = trainable(u->head0.d) && trainable(u->head1.d);
+    for (auto& b : u->blocks) ok = ok && trainable(b.a.d) && trainable(b.b.d) && (!b.has_r || trainable(b.r.d));
+    for (auto& l : u->downs) ok = ok && trainable(l.d);
+    for (auto& l : u->ups) ok = ok && trainable(l.d);
+    ADX_REQUIRE(ok, "adx_unet_forward_train: this configuration has GroupNorm groups that are not a power of two wide or hold "
+                    "fewer than 64 elements; such layers run in sampling only (csrc/tconv_generic.hip), training needs "
+                    "MODEL.DIM in {32, 64, 128, ...} and a horizon of at least 16");
+  }
   const int rows = io->rows, dim = u->cfg.dim, H = u->cfg.horizon, D = u->cfg.transition_dim;
   ADX_REQUIRE(rows >= 1 && io->t_rows == rows && io->feat_rows == rows,
               "adx_unet_forward_train: time / image batch must equal the trajectory batch (%d)", rows);

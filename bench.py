@@ -56,6 +56,18 @@ def conv_flops(n, cin, cout, k, s, p, h, w):
     return 2.0 * n * cout * oh * ow * cin * k * k
 
 
+def max_over_ranks(dt, world, dev):
+    """(max over ranks, every rank's own time): the contract's time is the slowest rank's; the per-rank list makes a scaling
+    run diagnosable (one slow GPU / one slow link shows up as one outlier instead of as a mystery in the maximum)."""
+    if world == 1:
+        return dt, [dt]
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    parts = [torch.zeros_like(t) for _ in range(world)]
+    torch.distributed.all_gather(parts, t)
+    per = [p.item() for p in parts]
+    return max(per), per
+
+
 def time_events(fn, reps, warm=2):
     for _ in range(warm):
         fn()
@@ -345,7 +357,7 @@ def train_leg(dev, world, steps=5, warm=3):
     opt = FusedAdamWEMA(model.parameters(), lr=1e-4, warmup_steps=1000, lr_ticks_per_step=world)
     # rank 0's weights and buffers to everyone, per-forward BatchNorm-buffer broadcast, bucketed all-reduce from hooks
     # during backward (the reference's DistributedDataParallel semantics, train.py:176-178)
-    dp = DataParallel(model) if world > 1 else None
+    dp = DataParallel(model, optimizer=opt) if world > 1 else None       # buckets carry the sum, 1 / world folded into opt.step
     fwd = dp if dp is not None else model
     sch = S.DDPMScheduler(**SCHED_KW)
     d = {k: v.to(dev) for k, v in P.synthetic_batch(B, H, image_hw=IMG, seed=7 + int(os.environ.get("RANK", "0"))).items()}
@@ -361,7 +373,19 @@ def train_leg(dev, world, steps=5, warm=3):
         opt.zero_grad()
         return loss
 
-    for _ in range(warm):
+    # the first step's loss is a known number: the CPU oracle's train-mode forward on the same inputs (rank 0's batch, seed 7;
+    # tests/golden/make_bench_loss.py wrote it, tests/test_gpu_fullsize.py recomputes it on the box) -- a training leg that
+    # computes something else must not report a time
+    first = float(step().detach())
+    expected = None
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "bench_train_loss.json")) as f:
+            expected = json.load(f)["loss_fp32"]
+    except (OSError, KeyError, ValueError):
+        pass
+    if int(os.environ.get("RANK", "0")) == 0 and expected is not None and not abs(first - expected) <= 2e-5 * max(1.0, abs(expected)):
+        raise RuntimeError(f"training leg: first-step loss {first!r} differs from the oracle's {expected!r}")
+    for _ in range(warm - 1):
         step()
     if world > 1:
         torch.distributed.barrier()
@@ -372,16 +396,16 @@ def train_leg(dev, world, steps=5, warm=3):
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = tt.item()
+    dt, per_rank = max_over_ranks(time.perf_counter() - t0, world, dev)
     flops = 3 * (64 * 34.02e9) + 3 * 10.03e9      # ~3x forward
     return {"workload": "configs/default.yaml train step, NO_GUIDANCE, batch 64 per GPU, horizon 32, image 3x256x900, "
                         "fwd + bwd + fused AdamW/EMA" + (" + RCCL gradient all-reduce" if world > 1 else ""),
             "value": round(world * steps / dt, 3), "unit": "train-steps/sec", "ms_per_step": round(1e3 * dt / steps, 2),
-            "steps": steps, "approx_tflops_per_gpu": round(flops * steps / dt / 1e12, 1), "final_loss": round(float(loss.detach()), 5)}
+            "steps": steps, "approx_tflops_per_gpu": round(flops * steps / dt / 1e12, 1), "first_step_loss": round(first, 7),
+            "first_step_loss_oracle": expected, "final_loss": round(float(loss.detach()), 5),
+            **({"per_rank_ms_per_step": [round(1e3 * t / steps, 2) for t in per_rank],
+                "gradient_buckets": {"primitive": dp.averager.primitive, "n": len(dp.averager.buckets),
+                                     "copied_in_last_step": dp.averager.copied_in}} if world > 1 else {})}
 
 
 def visible_gpu_count() -> int:
@@ -549,17 +573,12 @@ def main():
         t0 = time.perf_counter()
         run(n_steps)
         barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-            dt = tt.item()
-        return dt
+        return max_over_ranks(time.perf_counter() - t0, world, dev)
 
     model.cache_perception = False          # reference-faithful: perception re-run every step
-    dt = timed(args.steps, args.warmup)
+    dt, per_rank = timed(args.steps, args.warmup)
     model.cache_perception = True           # product default: one perception pass per scene
-    dt_h = timed(max(args.steps, N_INFER), args.warmup)
+    dt_h, per_rank_h = timed(max(args.steps, N_INFER), args.warmup)
     steps_h = max(args.steps, N_INFER)
 
     # the same hoisted loop as ONE HIP graph per 50-step tick (sampling.GraphedSampler: perception pass, 50 x (UNet +
@@ -575,11 +594,7 @@ def main():
         for _ in range(ticks):
             gs(d["imgs"], d["target"], d["init_trajs"])
         barrier()
-        dt_g = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt_g], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt_g = tt.item()
+        dt_g, per_rank_g = max_over_ranks(time.perf_counter() - t0, world, dev)
     steps_g = ticks * N_INFER
     del gs
 
@@ -620,6 +635,10 @@ def main():
                               "included) replayed as one HIP graph; bit-identical to the eager loop",
                               "trajectories_per_sec": round(world * B * ticks / dt_g, 2)},
         }
+        if world > 1:
+            res["per_rank_ms_per_step"] = [round(1e3 * t / args.steps, 3) for t in per_rank]
+            res["hoisted"]["per_rank_ms_per_step"] = [round(1e3 * t / steps_h, 4) for t in per_rank_h]
+            res["hoisted_graph"]["per_rank_ms_per_step"] = [round(1e3 * t / steps_g, 4) for t in per_rank_g]
         if train is not None:
             res["train"] = train
         if not args.no_roofline:

@@ -54,7 +54,14 @@ def test_host_side_validation_without_gpu(built):
     cfg.horizon = 24          # not a power of two: runs on 32 with the real lengths as masks (24 -> 12 -> 6 -> 3)
     assert lib.adx_unet_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
     lib.adx_unet_destroy(h)
-    for bad in (12, 8, 72):   # not divisible by 8; GroupNorm groups of 32 elements at the bottom; longer than 64
+    cfg.horizon = 8           # GroupNorm groups of 32 elements at the bottom of the up path: the general-shape kernel's
+    assert lib.adx_unet_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
+    lib.adx_unet_destroy(h)
+    cfg.horizon, cfg.dim = 32, 48     # GroupNorm(8, 48): groups of 6 channels (modeling/helpers.py:105-107 takes any C % 8 == 0)
+    assert lib.adx_unet_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
+    lib.adx_unet_destroy(h)
+    cfg.dim = 64
+    for bad in (12, 72):      # not divisible by 8 (the reference's own down / up path breaks); longer than 64
         cfg.horizon = bad
         assert lib.adx_unet_create(ctypes.byref(cfg), ctypes.byref(h)) == -1, bad
 

@@ -345,11 +345,14 @@ def test_training_step_at_a_ragged_horizon_vs_oracle_loss():
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
 
 
-@pytest.mark.parametrize("dim,mults,H", [(64, (1, 2, 4), 16), (128, (1, 2, 4, 8), 32), (64, (1, 2), 16)])
+@pytest.mark.parametrize("dim,mults,H", [(64, (1, 2, 4), 16), (128, (1, 2, 4, 8), 32), (64, (1, 2), 16),
+                                         (48, (1, 2, 4, 8), 32), (96, (1, 2, 4), 16), (64, (1, 2, 4, 8), 8), (48, (1, 2, 4, 8), 24)])
 def test_unet_other_widths_and_depths_vs_oracle(dim, mults, H):
-    """MODEL.DIM / MODEL.DIM_MULTS other than the default (64, (1, 2, 4, 8)): the executor builds its launch list from the
-    config (csrc/unet.hip: build), nothing is specialised for one width.  Unsupported shapes fail at construction with the
-    reason (GroupNorm groups that are not a power of two wide, or shorter than 64 elements)."""
+    """MODEL.DIM / MODEL.DIM_MULTS / MODEL.HORIZON other than the default (64, (1, 2, 4, 8), 16): the executor builds its
+    launch list from the config (csrc/unet.hip: build), nothing is specialised for one width.  The reference takes any
+    DIM divisible by 8 (GroupNorm(8, C), modeling/helpers.py:105-107) and any horizon divisible by 2^(levels - 1): layers
+    whose GroupNorm groups are not a power of two wide (DIM = 48: 6, 12, 24, 48 channels; 96: 12, 24, 48) or hold fewer than
+    64 elements (H = 8: 32 at the bottom of the up path) run on the general-shape kernel (csrc/tconv_generic.hip)."""
     from autonomous_driving_with_diffusion_model_amd.config import create_cfg
     from autonomous_driving_with_diffusion_model_amd.modeling import build_model
     g = torch.Generator().manual_seed(dim + H)
@@ -371,6 +374,9 @@ def test_unet_other_widths_and_depths_vs_oracle(dim, mults, H):
             y = m(d["trajs"].to(DEV), d["imgs"].to(DEV), d["t"].to(DEV), cond=None if cond is None else cond.to(DEV)).cpu()
         want = U.unet_forward(sd, d["trajs"], None, d["t"], cond, use_cond=name, dim=dim, dim_mults=mults, img_feature=feat)
         close(y, want, 2e-5)
-    cfg.MODEL.DIM = 48
-    with pytest.raises(ValueError, match="power of two"):
-        build_model(cfg).to(DEV).eval()(d["trajs"].to(DEV), d["imgs"].to(DEV), d["t"].to(DEV))
+    if dim % 32 != 0 or H < 16:
+        # such a model samples but does not train (the backward kernels tile like the MFMA forward kernels): said, not crashed
+        m.train()
+        m.perception.forward = lambda img: feat.to(DEV).requires_grad_()
+        with pytest.raises(ValueError, match="sampling only"):
+            m(d["trajs"].to(DEV), d["imgs"].to(DEV), d["t"].to(DEV), cond=None if cond is None else cond.to(DEV))
