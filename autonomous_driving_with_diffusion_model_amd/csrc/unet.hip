@@ -75,6 +75,94 @@ struct Builder {
   }
 };
 
+// ---- chains (tconv_chain.hip): which runs of layers go into one launch ---------------------------------------------------
+constexpr int kChainMaxChannels = 128;     // all channels of a layer in one workgroup: every workgroup streams every weight
+
+static bool chains_enabled() {
+  static const bool on = [] { const char* e = getenv("ADX_UNET_NO_CHAIN"); return !(e != nullptr && e[0] == '1'); }();
+  return on;
+}
+
+static ChainStage& chain_add(ChainArgs& a, const ConvLayer& L, int src, int dst, int f_dst, int out, int tb_col) {
+  ChainStage& st = a.st[a.n_stages++];
+  memset(&st, 0, sizeof(st));
+  chain_fill_stage(&st, &L.d);
+  st.src = src; st.dst = dst; st.f_dst = f_dst; st.out = out; st.tb_col = tb_col;
+  st.w_off = (int)L.o_cw;
+  st.b_off = L.p_b >= 0 ? (int)L.o_b : -1;
+  st.g_off = L.p_g >= 0 ? (int)L.o_g : -1;
+  st.be_off = L.p_be >= 0 ? (int)L.o_be : -1;
+  st.r_src = -1;
+  return st;
+}
+
+// LDS layout of a chain for `bt` samples per workgroup; returns the bytes, fills cell_off / f_off / xch_off
+static size_t chain_layout(ChainArgs& a, int bt) {
+  size_t cell16[kChainMaxCells] = {0, 0, 0, 0}, f[2] = {0, 0}, xch = 0;
+  auto need = [&](int buf, size_t rows, int pitch) { if (buf >= 0) cell16[buf] = std::max(cell16[buf], (rows + 1) * (size_t)pitch); };
+  need(a.st[0].src, (size_t)bt * a.in_len, 2 * (a.in_cpad / 8) + 1);
+  for (int i = 0; i < a.n_stages; ++i) {
+    const ChainStage& st = a.st[i];
+    need(st.src, (size_t)bt * st.lin, st.src_pitch);
+    need(st.dst, (size_t)bt * st.lout, st.dst_pitch);
+    if (st.r_src >= 0) need(st.r_src, (size_t)bt * st.lout, st.r_pitch);
+    const size_t rows_pad = (size_t)round_up(bt * st.lout, 16);
+    f[st.f_dst] = std::max(f[st.f_dst], rows_pad * (size_t)(st.cout_pad + 4));
+    xch = std::max(xch, (rows_pad / 16) * (size_t)st.n_ct * 8);
+  }
+  size_t off = 0;     // floats
+  for (int k = 0; k < kChainMaxCells; ++k) { a.cell_off[k] = (int)off; off += cell16[k] * 4; }
+  for (int k = 0; k < 2; ++k) { a.f_off[k] = (int)off; off += (f[k] + 3) / 4 * 4; }
+  a.xch_off = (int)off;
+  off += xch;
+  return off * sizeof(float);
+}
+
+// b0 / b1: the level's two residual blocks; tail: its down / up conv (may be null); h0 / h1: final_conv behind the last up level
+static void plan_chain(ChainPlan* cp, const ResBlock& b0, const ResBlock& b1, const ConvLayer* tail, const ConvLayer* h0,
+                       const ConvLayer* h1, bool up_level) {
+  cp->valid = false;
+  if (!chains_enabled() || !b0.has_r || b1.has_r) return;      // block 0 changes the channel count (R = 1x1 conv), block 1 keeps it
+  if (b0.cout > kChainMaxChannels || b1.cout != b0.cout) return;
+  const ConvLayer* all[] = {&b0.a, &b0.b, &b0.r, &b1.a, &b1.b, tail, h0, h1};
+  for (const ConvLayer* L : all)
+    if (L != nullptr && !chain_layer_ok(&L->d)) return;
+  ChainArgs& a = cp->tmpl;
+  memset(&a, 0, sizeof(a));
+  a.in_c0 = b0.c0; a.in_c1 = b0.c1; a.in_cpad = round_up(b0.c0 + b0.c1, 16); a.in_len = b0.a.d.lin;
+  cp->len = b0.a.d.lin;
+  // cell buffers: 0 = block input (and, later, block 1's output), 1 = a block's inner activation, 2 = block 0's output
+  chain_add(a, b0.a, 0, 1, 0, -1, b0.tb_off);
+  ChainStage& s1 = chain_add(a, b0.b, 1, 2, 1, -1, -1);
+  {
+    ChainStage r;
+    chain_fill_stage(&r, &b0.r.d);
+    s1.r_src = 0; s1.r_log2_ncell = r.log2_ncell; s1.r_nsteps = r.nsteps; s1.r_pitch = r.src_pitch;
+    s1.r_w_off = (int)b0.r.o_cw; s1.r_b_off = b0.r.p_b >= 0 ? (int)b0.r.o_b : -1;
+  }
+  chain_add(a, b1.a, 2, 1, 0, -1, b1.tb_off);
+  ChainStage& s3 = chain_add(a, b1.b, 1, tail != nullptr ? 0 : -1, 1, up_level ? -1 : 0, -1);
+  s3.res_identity = 1;
+  cp->with_head = false;
+  if (tail != nullptr) {
+    const bool head = up_level && h0 != nullptr && h1 != nullptr;
+    chain_add(a, *tail, 0, head ? 1 : -1, 0, head ? -1 : (up_level ? 0 : 1), -1);
+    if (head) {
+      chain_add(a, *h0, 1, 2, 1, -1, -1);
+      chain_add(a, *h1, 2, -1, 0, 0, -1);
+      cp->with_head = true;
+    }
+  } else if (up_level) {
+    s3.out = 0;
+  }
+  // must fit with the smallest row tile; the launch picks the largest `bt` that fits
+  const int bt_min = std::max(1, 16 / cp->len);
+  int max_rows = 0;
+  for (int i = 0; i < a.n_stages; ++i) max_rows = std::max(max_rows, bt_min * a.st[i].lout);
+  if (max_rows > 64 || chain_layout(a, bt_min) > kChainMaxLds) return;
+  cp->valid = true;
+}
+
 static int build(adx_unet* u) {
   const adx_unet_config& c = u->cfg;
   ADX_REQUIRE(c.n_mults >= 1 && c.n_mults <= 8, "unet: n_mults %d out of range", c.n_mults);
@@ -143,6 +231,32 @@ static int build(adx_unet* u) {
     u->o_c0w = B.take(2 * c.dim); u->o_c0b = B.take(c.dim);
     u->o_c2w = B.take((size_t)c.dim * c.dim); u->o_c2b = B.take(c.dim);
   }
+  // chains: one per level where one workgroup can hold every channel (plan_chain decides); their layers get a second
+  // weight image in the chain kernel's layout
+  u->down_chains.assign(n, ChainPlan{});
+  u->up_chains.assign(n > 1 ? n - 1 : 0, ChainPlan{});
+  auto give_images = [&](std::initializer_list<ConvLayer*> ls) {
+    for (ConvLayer* L : ls)
+      if (L != nullptr && !L->chained) { L->chained = true; L->o_cw = B.take(chain_packed_floats(&L->d)); }
+  };
+  for (int i = 0; i < n; ++i) {
+    ResBlock& b0 = u->blocks[2 * i];
+    ResBlock& b1 = u->blocks[2 * i + 1];
+    ConvLayer* dn = i < n - 1 ? &u->downs[i] : nullptr;
+    plan_chain(&u->down_chains[i], b0, b1, dn, nullptr, nullptr, false);             // first pass: does the level qualify?
+    if (!u->down_chains[i].valid) continue;
+    give_images({&b0.a, &b0.b, &b0.r, &b1.a, &b1.b, dn});
+    plan_chain(&u->down_chains[i], b0, b1, dn, nullptr, nullptr, false);             // second pass: with the images' offsets
+  }
+  for (int i = 0; i < n - 1; ++i) {
+    ResBlock& b0 = u->blocks[2 * n + 2 + 2 * i];
+    ResBlock& b1 = u->blocks[2 * n + 2 + 2 * i + 1];
+    const bool last = i == n - 2;
+    plan_chain(&u->up_chains[i], b0, b1, &u->ups[i], last ? &u->head0 : nullptr, last ? &u->head1 : nullptr, true);
+    if (!u->up_chains[i].valid) continue;
+    give_images({&b0.a, &b0.b, &b0.r, &b1.a, &b1.b, &u->ups[i], last ? &u->head0 : nullptr, last ? &u->head1 : nullptr});
+    plan_chain(&u->up_chains[i], b0, b1, &u->ups[i], last ? &u->head0 : nullptr, last ? &u->head1 : nullptr, true);
+  }
   u->packed_floats = B.off;
   // validate every layer's geometry now so that forward() cannot fail on shape grounds (any layer one of the three
   // temporal kernels covers: tconv_check)
@@ -168,6 +282,7 @@ static int copy_f(float* dst, const float* src, size_t n, hipStream_t) {
 
 static int pack_layer(const ConvLayer& L, const float* const* P, float* base, hipStream_t s) {
   int rc = tconv_pack(&L.d, P[L.p_w], base + L.o_w, s);
+  if (rc == ADX_OK && L.chained) rc = chain_pack(&L.d, P[L.p_w], base + L.o_cw, s);
   if (rc == ADX_OK && L.p_b >= 0) rc = copy_f(base + L.o_b, P[L.p_b], L.d.cout, s);
   if (rc == ADX_OK && L.p_g >= 0) rc = copy_f(base + L.o_g, P[L.p_g], L.d.cout, s);
   if (rc == ADX_OK && L.p_be >= 0) rc = copy_f(base + L.o_be, P[L.p_be], L.d.cout, s);
@@ -421,11 +536,52 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
     return run_conv(B.b, base, hin, nullptr, nullptr, 0, &res, dst, (int64_t)B.cout * B.len, B.len, 1, rows, s);
   };
 
+  // one launch for a whole level (tconv_chain.hip) where the plan allows it
+  static const int chain_rows = [] { const char* e = getenv("ADX_CHAIN_ROWS"); return e ? atoi(e) : 0; }();   // 16 / 32: A/B
+  auto run_chain = [&](const ChainPlan& cp, const Act& in0, const Act* in1, const Act& o0, const Act* o1) -> int {
+    ChainArgs a = cp.tmpl;
+    // rows per workgroup: 32 where that still gives the chip a hundred workgroups, else 16 (more, smaller workgroups)
+    int target = chain_rows > 0 ? chain_rows : (((int64_t)rows * cp.len >= 32 * 96) ? 32 : 16);
+    int bt = std::max(1, target / cp.len);
+    size_t lds = chain_layout(a, bt);
+    int max_rows = 0;
+    for (int k = 0; k < a.n_stages; ++k) max_rows = std::max(max_rows, bt * a.st[k].lout);
+    if (lds > kChainMaxLds || max_rows > 64) {
+      bt = std::max(1, 16 / cp.len);
+      lds = chain_layout(a, bt);
+    }
+    a.packed = base; a.tb = tb; a.tb_stride = u->sum_c;
+    a.in0 = in0.p; a.in0_sb = in0.sb; a.in0_sc = in0.sc; a.in0_sl = in0.sl;
+    if (in1 != nullptr) { a.in1 = in1->p; a.in1_sb = in1->sb; a.in1_sc = in1->sc; a.in1_sl = in1->sl; }
+    auto dense4 = [](const Act& t) {
+      return t.sl == 1 && t.sc % 4 == 0 && t.sb % 4 == 0 && (reinterpret_cast<uintptr_t>(t.p) & 15) == 0;
+    };
+    a.in_vec = cp.len % 4 == 0 && dense4(in0) && (in1 == nullptr || dense4(*in1));
+    a.out[0] = ChainOut{const_cast<float*>(o0.p), o0.sb, o0.sc, o0.sl, dense4(o0) ? 1 : 0};
+    if (o1 != nullptr) a.out[1] = ChainOut{const_cast<float*>(o1->p), o1->sb, o1->sc, o1->sl, dense4(*o1) ? 1 : 0};
+    a.batch = rows; a.bt = bt;
+    return chain_launch(a, ceil_div(rows, bt), lds, s);
+  };
+
   size_t bi = 0;
   const int n = u->n_levels;
   for (int i = 0; i < n; ++i) {
     const ResBlock& B0 = u->blocks[bi++];
     const ResBlock& B1 = u->blocks[bi++];
+    if (u->down_chains[i].valid) {
+      const Act skip = dense(skips[i], B1.cout, B1.len);
+      if (i < n - 1) {
+        const ConvLayer& dn = u->downs[i];
+        const Act y = dense(next_buf(), dn.d.cout, dn.d.lout);
+        rc = run_chain(u->down_chains[i], cur, nullptr, skip, &y);
+        cur = y;
+      } else {
+        rc = run_chain(u->down_chains[i], cur, nullptr, skip, nullptr);
+        cur = skip;
+      }
+      if (rc != ADX_OK) return rc;
+      continue;
+    }
     float* y0 = next_buf();
     rc = run_block(B0, cur, nullptr, y0);
     if (rc != ADX_OK) return rc;
@@ -448,11 +604,27 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
     if (rc != ADX_OK) return rc;
     cur = dense(y, B.cout, B.len);
   }
+  bool head_done = false;
   for (int i = 0; i < n - 1; ++i) {
     const ResBlock& B0 = u->blocks[bi++];
     const ResBlock& B1 = u->blocks[bi++];
     // h.pop(): the deepest skip first; h[0] is pushed but never popped (temporal.py:226-227)
     const Act skip = dense(skips[n - 1 - i], B0.c1, B0.len);
+    if (u->up_chains[i].valid) {
+      const ChainPlan& cp = u->up_chains[i];
+      if (cp.with_head) {      // ... Upsample1d, final_conv: the chain writes the model output itself
+        const Act o{io->out, (int64_t)H * u->out_ch, 1, (int64_t)u->out_ch};
+        rc = run_chain(cp, cur, &skip, o, nullptr);
+        head_done = true;
+      } else {
+        const ConvLayer& up = u->ups[i];
+        const Act y = dense(next_buf(), up.d.cout, up.d.lout);
+        rc = run_chain(cp, cur, &skip, y, nullptr);
+        cur = y;
+      }
+      if (rc != ADX_OK) return rc;
+      continue;
+    }
     float* y0 = next_buf();
     rc = run_block(B0, cur, &skip, y0);
     if (rc != ADX_OK) return rc;
@@ -467,7 +639,7 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
     if (rc != ADX_OK) return rc;
     cur = dense(y2, up.d.cout, up.d.lout);
   }
-  {  // final_conv / act_conv: Conv1dBlock + 1x1, written back as [rows][H][out_ch] (temporal.py:233-235,243-244)
+  if (!head_done) {  // final_conv / act_conv: Conv1dBlock + 1x1, written back as [rows][H][out_ch] (temporal.py:233-235,243-244)
     float* y = next_buf();
     const ConvLayer& h0 = u->head0;
     rc = run_conv(h0, base, cur, nullptr, nullptr, 0, nullptr, y, (int64_t)h0.d.cout * h0.d.lout, h0.d.lout, 1, rows, s);

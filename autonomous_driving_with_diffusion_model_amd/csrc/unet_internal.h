@@ -3,6 +3,7 @@
 #include <vector>
 
 #include "tconv.h"
+#include "tconv_chain.h"
 
 namespace adx {
 
@@ -13,6 +14,18 @@ struct ConvLayer {
   adx_tconv_desc d{};
   int p_w = -1, p_b = -1, p_g = -1, p_be = -1;      // indices into the parameter list
   size_t o_w = 0, o_b = 0, o_g = 0, o_be = 0;       // float offsets into the packed buffer
+  size_t o_cw = 0;                                  // weight image in the chain kernel's layout (layers of a chain only)
+  bool chained = false;
+};
+
+// A run of layers executed by ONE launch of tconv_chain.hip: the two residual blocks of a level + its down / up conv
+// (+ final_conv on the last up level).  `tmpl` holds everything that does not depend on the call.
+struct ChainPlan {
+  ChainArgs tmpl{};
+  int len = 0;               // per-sample length at the chain's input
+  int n_f[2] = {0, 0};       // rows x pitch of the two fp32 tiles, per row of R = 1 (scaled by the row count at launch)
+  bool valid = false;
+  bool with_head = false;
 };
 
 struct ResBlock {
@@ -36,5 +49,6 @@ struct adx_unet {
   size_t o_tlin_raw = 0, o_tlin_b = 0;  // concatenated [sum_c][2 dim] block-Linear weight (staging) and bias
   size_t packed_floats = 0;
   bool packed_once = false;
+  std::vector<adx::ChainPlan> down_chains, up_chains;   // per level; !valid: the level runs layer by layer
 };
 

@@ -193,7 +193,11 @@ def test_cfg2_train_step_b64_fullsize_loss_vs_oracle_and_split_vs_exact(tmp_path
     rows.sort(reverse=True)
     _record("cfg2_train_b64", {"loss": loss, "loss_oracle_fwd": want_loss, "loss_exact_kernels": exact["loss"],
                                "worst split-vs-exact (rel L2, tensor)": rows[:8], "median": rows[len(rows) // 2][0]})
-    # two fp32-grade evaluations of the same sums: they differ like two summation orders do.  Tensors whose value is a
-    # near-total cancellation (BatchNorm bias gradients: 1e-3 of their mass survives) carry that relative to the mass.
+    # two fp32-grade evaluations of the same sums: they differ like two summation orders do.  The BatchNorm affine gradients
+    # are sums of 64 x H x W signed terms that cancel to ~1e-3 of their mass (the B = 16 test above measures the fp32 oracle
+    # itself 8e-3 away from fp64 on them), so they carry the summation-order difference relative to that mass: measured
+    # 1.1e-2 .. 1.3e-2 on layer1's, 1e-6 in the median over all tensors.
+    is_bn = lambda k: ".bn1." in k or ".bn2." in k or ".downsample.1." in k  # noqa: E731
+    _record("cfg2_train_b64_worst_non_bn", {"worst": next((r for r in rows if not is_bn(r[1])), None)})
     for err, k in rows:
-        assert err <= 2e-3, (k, err)
+        assert err <= (5e-2 if is_bn(k) else 2e-3), (k, err)
