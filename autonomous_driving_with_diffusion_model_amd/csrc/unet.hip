@@ -78,8 +78,9 @@ struct Builder {
 // ---- chains (tconv_chain.hip): which runs of layers go into one launch ---------------------------------------------------
 constexpr int kChainMaxChannels = 128;     // all channels of a layer in one workgroup: every workgroup streams every weight
 
+// Off by default: measured slower than the launches it replaces (tconv_chain.hip header).  ADX_UNET_CHAIN=1 turns it on.
 static bool chains_enabled() {
-  static const bool on = [] { const char* e = getenv("ADX_UNET_NO_CHAIN"); return !(e != nullptr && e[0] == '1'); }();
+  static const bool on = [] { const char* e = getenv("ADX_UNET_CHAIN"); return e != nullptr && e[0] == '1'; }();
   return on;
 }
 
@@ -98,7 +99,7 @@ static ChainStage& chain_add(ChainArgs& a, const ConvLayer& L, int src, int dst,
 
 // LDS layout of a chain for `bt` samples per workgroup; returns the bytes, fills cell_off / f_off / xch_off
 static size_t chain_layout(ChainArgs& a, int bt) {
-  size_t cell16[kChainMaxCells] = {0, 0, 0, 0}, f[2] = {0, 0}, xch = 0;
+  size_t cell16[kChainMaxCells] = {0, 0, 0, 0}, f[2] = {0, 0};
   auto need = [&](int buf, size_t rows, int pitch) { if (buf >= 0) cell16[buf] = std::max(cell16[buf], (rows + 1) * (size_t)pitch); };
   need(a.st[0].src, (size_t)bt * a.in_len, 2 * (a.in_cpad / 8) + 1);
   for (int i = 0; i < a.n_stages; ++i) {
@@ -108,21 +109,28 @@ static size_t chain_layout(ChainArgs& a, int bt) {
     if (st.r_src >= 0) need(st.r_src, (size_t)bt * st.lout, st.r_pitch);
     const size_t rows_pad = (size_t)round_up(bt * st.lout, 16);
     f[st.f_dst] = std::max(f[st.f_dst], rows_pad * (size_t)(st.cout_pad + 4));
-    xch = std::max(xch, (rows_pad / 16) * (size_t)st.n_ct * 8);
   }
   size_t off = 0;     // floats
   for (int k = 0; k < kChainMaxCells; ++k) { a.cell_off[k] = (int)off; off += cell16[k] * 4; }
   for (int k = 0; k < 2; ++k) { a.f_off[k] = (int)off; off += (f[k] + 3) / 4 * 4; }
-  a.xch_off = (int)off;
-  off += xch;
+  for (int i = 0; i < a.n_stages; ++i) {       // per-stage parameters: 4 vectors + the workgroup's time-bias rows
+    a.st[i].par = (int)off;
+    off += (size_t)(4 + (a.st[i].tb_col >= 0 ? bt : 0)) * a.st[i].cout_pad;
+  }
+  a.args_off = (int)off;
+  off += (sizeof(ChainArgs) + 3) / 4;
   return off * sizeof(float);
 }
 
 // b0 / b1: the level's two residual blocks; tail: its down / up conv (may be null); h0 / h1: final_conv behind the last up level
 static void plan_chain(ChainPlan* cp, const ResBlock& b0, const ResBlock& b1, const ConvLayer* tail, const ConvLayer* h0,
-                       const ConvLayer* h1, bool up_level) {
+                       const ConvLayer* h1, bool up_level, int level) {
   cp->valid = false;
+  // ADX_CHAIN_MASK: bit i = down level i, bit 8 + i = up level i (diagnostic: which levels are chained; default all)
+  static const unsigned mask = [] { const char* e = getenv("ADX_CHAIN_MASK"); return e ? (unsigned)strtoul(e, nullptr, 0) : ~0u; }();
+  if (((mask >> (up_level ? 8 + level : level)) & 1u) == 0) return;
   if (!chains_enabled() || !b0.has_r || b1.has_r) return;      // block 0 changes the channel count (R = 1x1 conv), block 1 keeps it
+  if (!chain_residual_ok(&b0.b.d)) return;
   if (b0.cout > kChainMaxChannels || b1.cout != b0.cout) return;
   const ConvLayer* all[] = {&b0.a, &b0.b, &b0.r, &b1.a, &b1.b, tail, h0, h1};
   for (const ConvLayer* L : all)
@@ -138,7 +146,7 @@ static void plan_chain(ChainPlan* cp, const ResBlock& b0, const ResBlock& b1, co
     ChainStage r;
     chain_fill_stage(&r, &b0.r.d);
     s1.r_src = 0; s1.r_log2_ncell = r.log2_ncell; s1.r_nsteps = r.nsteps; s1.r_pitch = r.src_pitch;
-    s1.r_w_off = (int)b0.r.o_cw; s1.r_b_off = b0.r.p_b >= 0 ? (int)b0.r.o_b : -1;
+    s1.r_b_off = b0.r.p_b >= 0 ? (int)b0.r.o_b : -1;        // R's weight steps: behind b0.b's in the image at b0.b.o_cw
   }
   chain_add(a, b1.a, 2, 1, 0, -1, b1.tb_off);
   ChainStage& s3 = chain_add(a, b1.b, 1, tail != nullptr ? 0 : -1, 1, up_level ? -1 : 0, -1);
@@ -155,11 +163,11 @@ static void plan_chain(ChainPlan* cp, const ResBlock& b0, const ResBlock& b1, co
   } else if (up_level) {
     s3.out = 0;
   }
-  // must fit with the smallest row tile; the launch picks the largest `bt` that fits
+  // a workgroup's rows = bt x the longest length of the chain (an up conv doubles it): at most 32 = two row tiles per wave
+  cp->max_len = 0;
+  for (int i = 0; i < a.n_stages; ++i) cp->max_len = std::max(cp->max_len, a.st[i].lout);
   const int bt_min = std::max(1, 16 / cp->len);
-  int max_rows = 0;
-  for (int i = 0; i < a.n_stages; ++i) max_rows = std::max(max_rows, bt_min * a.st[i].lout);
-  if (max_rows > 64 || chain_layout(a, bt_min) > kChainMaxLds) return;
+  if (bt_min * cp->max_len > 32 || chain_layout(a, bt_min) > kChainMaxLds) return;
   cp->valid = true;
 }
 
@@ -239,23 +247,29 @@ static int build(adx_unet* u) {
     for (ConvLayer* L : ls)
       if (L != nullptr && !L->chained) { L->chained = true; L->o_cw = B.take(chain_packed_floats(&L->d)); }
   };
+  auto give_block0 = [&](ResBlock& b) {      // block 0's second conv carries the block's 1x1 residual conv behind it
+    if (!b.a.chained) { b.a.chained = true; b.a.o_cw = B.take(chain_packed_floats(&b.a.d)); }
+    if (!b.b.chained) { b.b.chained = true; b.b.o_cw = B.take(chain_packed_floats(&b.b.d) + chain_packed_floats(&b.r.d)); }
+  };
   for (int i = 0; i < n; ++i) {
     ResBlock& b0 = u->blocks[2 * i];
     ResBlock& b1 = u->blocks[2 * i + 1];
     ConvLayer* dn = i < n - 1 ? &u->downs[i] : nullptr;
-    plan_chain(&u->down_chains[i], b0, b1, dn, nullptr, nullptr, false);             // first pass: does the level qualify?
+    plan_chain(&u->down_chains[i], b0, b1, dn, nullptr, nullptr, false, i);             // first pass: does the level qualify?
     if (!u->down_chains[i].valid) continue;
-    give_images({&b0.a, &b0.b, &b0.r, &b1.a, &b1.b, dn});
-    plan_chain(&u->down_chains[i], b0, b1, dn, nullptr, nullptr, false);             // second pass: with the images' offsets
+    give_block0(b0);
+    give_images({&b1.a, &b1.b, dn});
+    plan_chain(&u->down_chains[i], b0, b1, dn, nullptr, nullptr, false, i);             // second pass: with the images' offsets
   }
   for (int i = 0; i < n - 1; ++i) {
     ResBlock& b0 = u->blocks[2 * n + 2 + 2 * i];
     ResBlock& b1 = u->blocks[2 * n + 2 + 2 * i + 1];
     const bool last = i == n - 2;
-    plan_chain(&u->up_chains[i], b0, b1, &u->ups[i], last ? &u->head0 : nullptr, last ? &u->head1 : nullptr, true);
+    plan_chain(&u->up_chains[i], b0, b1, &u->ups[i], last ? &u->head0 : nullptr, last ? &u->head1 : nullptr, true, i);
     if (!u->up_chains[i].valid) continue;
-    give_images({&b0.a, &b0.b, &b0.r, &b1.a, &b1.b, &u->ups[i], last ? &u->head0 : nullptr, last ? &u->head1 : nullptr});
-    plan_chain(&u->up_chains[i], b0, b1, &u->ups[i], last ? &u->head0 : nullptr, last ? &u->head1 : nullptr, true);
+    give_block0(b0);
+    give_images({&b1.a, &b1.b, &u->ups[i], last ? &u->head0 : nullptr, last ? &u->head1 : nullptr});
+    plan_chain(&u->up_chains[i], b0, b1, &u->ups[i], last ? &u->head0 : nullptr, last ? &u->head1 : nullptr, true, i);
   }
   u->packed_floats = B.off;
   // validate every layer's geometry now so that forward() cannot fail on shape grounds (any layer one of the three
@@ -280,9 +294,10 @@ static int copy_f(float* dst, const float* src, size_t n, hipStream_t) {
   return ADX_OK;
 }
 
-static int pack_layer(const ConvLayer& L, const float* const* P, float* base, hipStream_t s) {
+static int pack_layer(const ConvLayer& L, const float* const* P, float* base, hipStream_t s, const ConvLayer* rider = nullptr) {
   int rc = tconv_pack(&L.d, P[L.p_w], base + L.o_w, s);
-  if (rc == ADX_OK && L.chained) rc = chain_pack(&L.d, P[L.p_w], base + L.o_cw, s);
+  if (rc == ADX_OK && L.chained)       // chain image; `rider` = the block's 1x1 residual conv, stored behind this conv's steps
+    rc = chain_pack(&L.d, P[L.p_w], rider != nullptr ? &rider->d : nullptr, rider != nullptr ? P[rider->p_w] : nullptr, base + L.o_cw, s);
   if (rc == ADX_OK && L.p_b >= 0) rc = copy_f(base + L.o_b, P[L.p_b], L.d.cout, s);
   if (rc == ADX_OK && L.p_g >= 0) rc = copy_f(base + L.o_g, P[L.p_g], L.d.cout, s);
   if (rc == ADX_OK && L.p_be >= 0) rc = copy_f(base + L.o_be, P[L.p_be], L.d.cout, s);
@@ -410,7 +425,7 @@ int adx_unet_pack(adx_unet* u, const float* const* P, int32_t n_params, const fl
   int rc = ADX_OK;
   for (auto& b : u->blocks) {
     if (rc == ADX_OK) rc = pack_layer(b.a, P, base, s);
-    if (rc == ADX_OK) rc = pack_layer(b.b, P, base, s);
+    if (rc == ADX_OK) rc = pack_layer(b.b, P, base, s, (b.has_r && b.b.chained) ? &b.r : nullptr);
     if (rc == ADX_OK && b.has_r) rc = pack_layer(b.r, P, base, s);
     // concatenate the block's time_mlp Linear into the fused [sum_c][2 dim] matrix
     if (rc == ADX_OK) rc = copy_f(base + u->o_tlin_raw + (size_t)b.tb_off * 2 * dim, P[b.p_tw], (size_t)b.cout * 2 * dim, s);
@@ -540,14 +555,14 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
   static const int chain_rows = [] { const char* e = getenv("ADX_CHAIN_ROWS"); return e ? atoi(e) : 0; }();   // 16 / 32: A/B
   auto run_chain = [&](const ChainPlan& cp, const Act& in0, const Act* in1, const Act& o0, const Act* o1) -> int {
     ChainArgs a = cp.tmpl;
-    // rows per workgroup: 32 where that still gives the chip a hundred workgroups, else 16 (more, smaller workgroups)
-    int target = chain_rows > 0 ? chain_rows : (((int64_t)rows * cp.len >= 32 * 96) ? 32 : 16);
-    int bt = std::max(1, target / cp.len);
+    // samples per workgroup: as many as keep its rows (bt x the chain's longest length) within 32 where that still gives
+    // the chip ~a hundred workgroups, else the fewest that fill a 16-row tile (more, smaller workgroups)
+    const int bt_min = std::max(1, 16 / cp.len), bt_max = std::max(bt_min, 32 / cp.max_len);
+    int bt = (chain_rows == 16 || ceil_div(rows, bt_max) < 96) ? bt_min : bt_max;
+    if (chain_rows == 32) bt = bt_max;
     size_t lds = chain_layout(a, bt);
-    int max_rows = 0;
-    for (int k = 0; k < a.n_stages; ++k) max_rows = std::max(max_rows, bt * a.st[k].lout);
-    if (lds > kChainMaxLds || max_rows > 64) {
-      bt = std::max(1, 16 / cp.len);
+    if (lds > kChainMaxLds) {
+      bt = bt_min;
       lds = chain_layout(a, bt);
     }
     a.packed = base; a.tb = tb; a.tb_stride = u->sum_c;
@@ -560,6 +575,10 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
     a.out[0] = ChainOut{const_cast<float*>(o0.p), o0.sb, o0.sc, o0.sl, dense4(o0) ? 1 : 0};
     if (o1 != nullptr) a.out[1] = ChainOut{const_cast<float*>(o1->p), o1->sb, o1->sc, o1->sl, dense4(*o1) ? 1 : 0};
     a.batch = rows; a.bt = bt;
+    static const int rotate = [] { const char* e = getenv("ADX_CHAIN_ROTATE"); return e ? atoi(e) : 0; }();     // measured: no gain (the weight stream is not what a stage waits for)
+    a.rotate = rotate;
+    static const bool dbg = getenv("ADX_CHAIN_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[chain] rows %d len %d bt %d grid %d lds %zu stages %d in_vec %d\n", rows, cp.len, bt, ceil_div(rows, bt), lds, a.n_stages, a.in_vec);
     return chain_launch(a, ceil_div(rows, bt), lds, s);
   };
 

@@ -22,8 +22,7 @@ struct ConvLayer {
 // (+ final_conv on the last up level).  `tmpl` holds everything that does not depend on the call.
 struct ChainPlan {
   ChainArgs tmpl{};
-  int len = 0;               // per-sample length at the chain's input
-  int n_f[2] = {0, 0};       // rows x pitch of the two fp32 tiles, per row of R = 1 (scaled by the row count at launch)
+  int len = 0, max_len = 0;  // per-sample length at the chain's input; the longest output length of its stages
   bool valid = false;
   bool with_head = false;
 };

@@ -1,0 +1,32 @@
+"""Whole UNet forwards with the chained levels on (ADX_UNET_CHAIN=1 is read once per process, hence a process of its own)
+against the CPU oracle; prints one line per case: name rows horizon max_abs_err.  See csrc/tconv_chain.hip."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import unet as U  # noqa: E402
+from autonomous_driving_with_diffusion_model_amd.utils import procedural as P  # noqa: E402
+from helpers import oracle_sd  # noqa: E402
+from test_gpu_model import make_model  # noqa: E402
+
+DEV = "cuda:0"
+for name, rows, H in (("NO_GUIDANCE", 128, 32), ("FREE_GUIDANCE", 2, 16), ("FREE_GUIDANCE", 7, 32), ("CLASSIFIER_GUIDANCE", 5, 16)):
+    m, _ = make_model(name, H)
+    d = P.synthetic_batch(rows, H, image_hw=(32, 32), seed=12)
+    feat = P._uniform("feat", 12, (rows, 64), -3.0, 3.0)
+    m.perception.forward = lambda img, f=feat: f.to(DEV)
+    cond = d["target"] if name == "FREE_GUIDANCE" else None
+    kw = dict(cond=cond.to(DEV)) if cond is not None else {}
+    if name == "CLASSIFIER_GUIDANCE":
+        kw["return_action_and_time_only"] = True
+    with torch.no_grad():
+        y = m(d["trajs"].to(DEV), d["imgs"].to(DEV), d["t"].to(DEV), **kw)
+        y = y[0] if isinstance(y, tuple) else y
+    want = U.unet_forward(oracle_sd(name), d["trajs"], None, d["t"], cond, use_cond=name, img_feature=feat)
+    if want.shape[-1] != y.shape[-1]:
+        want = want[..., -y.shape[-1]:]
+    print("CASE", name, rows, H, (y.cpu() - want).abs().max().item(), flush=True)

@@ -380,3 +380,20 @@ def test_unet_other_widths_and_depths_vs_oracle(dim, mults, H):
         m.perception.forward = lambda img: feat.to(DEV).requires_grad_()
         with pytest.raises(ValueError, match="sampling only"):
             m(d["trajs"].to(DEV), d["imgs"].to(DEV), d["t"].to(DEV), cond=None if cond is None else cond.to(DEV))
+
+
+def test_chained_levels_opt_in_vs_oracle():
+    """csrc/tconv_chain.hip: the 64/128-channel levels (two residual blocks + down / up conv, + final_conv) as one launch
+    each, activations LDS-resident.  Off by default (measured slower than the launches it replaces: DESIGN.md section 8);
+    ADX_UNET_CHAIN=1 turns it on, and it must then still compute the reference's forward (modeling/temporal.py:197-245)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "chain_worker.py")], env=dict(os.environ, ADX_UNET_CHAIN="1"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    cases = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("CASE")]
+    assert len(cases) == 4, r.stdout
+    for _, name, rows, H, err in cases:
+        assert float(err) <= 2e-5, (name, rows, H, err)

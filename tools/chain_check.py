@@ -1,5 +1,5 @@
 """UNet forward (temporal stack only, encoder stubbed) against the CPU oracle at several (rows, horizon, guidance), and its
-time per forward: the quick check for the chained levels (csrc/tconv_chain.hip).  ADX_UNET_NO_CHAIN=1 for the A/B."""
+time per forward: the quick check for the chained levels (csrc/tconv_chain.hip).  ADX_UNET_CHAIN=0 for the A/B."""
 import os, sys, time
 import torch
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
