@@ -11,13 +11,12 @@
 // which is why only the 64- and 128-channel levels are chained and the 256/512-channel levels keep one launch per layer
 // with the weights split over workgroups (tconv_hs.hip).
 //
-// STATUS (round 3): correct (3e-6 against the oracle through whole forwards) but NOT faster than the launches it replaces, so
-// the executor leaves it off unless ADX_UNET_CHAIN=1.  Measured (rocprofv3, SQ counters, tools/chain_time.py): a chain takes
-// 35-60 us against 29-42 us for its 5-7 launches.  Neither the weight stream nor the matrix work matters (zero weights or no
-// MFMAs: same time); a wave retires one instruction per ~12 clocks at one or two waves per SIMD -- the per-layer kernels
-// show the same rate -- and this kernel's stage costs ~1700 instructions per wave (descriptor, per-step addressing of a
-// general reduction, pairwise statistics, re-split) where a whole per-layer launch costs ~1100 spread over 4x more waves.
-// The budget a chain has to meet to win is ~450 instructions per stage and wave.
+// What the time of such a kernel is made of (rocprofv3 SQ counters, round 3): at one or two waves per SIMD a wave retires one
+// instruction per ~12 clocks whatever it is -- the per-layer kernels show the same rate -- and neither the weight stream nor
+// the matrix work is visible (zero weights or no MFMAs: same time).  A stage's time IS its instruction count per wave, so
+// everything here is written for few instructions on a wave's path: one 16 x 16 tile per wave and pass (8 waves share a
+// stage's tiles), the tap of a K-step wave-uniform (inputs padded to 32 channels), the 1x1 residual conv as extra steps of
+// the same weight stream, the stage table and every per-channel parameter in LDS before the first stage starts.
 //
 // Arithmetic = tconv_hs.hip's: split-fp16 operands (x = hi + 2^-11 lo), three v_mfma_f32_16x16x32_f16 per product, fp32
 // accumulation; GroupNorm statistics by pairwise (Chan) merges of (mean, M2) in a fixed order; Mish with the hardware
@@ -26,6 +25,7 @@
 // place), (b) re-split into 16-byte cells of 8 channels (hi cell next to lo cell) = the next stage's A operand, (c) in
 // global memory where a later launch needs it (the level's skip output, the chain's result).
 #include <algorithm>
+#include <cstddef>
 #include <vector>
 
 #include "tconv_chain.h"
@@ -35,7 +35,8 @@ namespace adx {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// -DADX_CHAIN_TRACE: thread 0 of every workgroup stamps the shader clock at its phase boundaries (tools/chain_trace.py)
+// -DADX_CHAIN_TRACE: thread 0 of every workgroup stamps the shader clock at its phase boundaries (tools/chain_trace.py);
+// every stamp costs a scalar-memory round trip, so a traced run is several times slower than a real one
 #ifdef ADX_CHAIN_TRACE
 __device__ unsigned long long g_chain_trace[64 * 256];
 #define CH_STAMP(i)                                                                                        \
@@ -49,9 +50,9 @@ __device__ unsigned long long g_chain_trace[64 * 256];
 constexpr float kChLoScale = 2048.0f;
 constexpr float kChLoInv = 1.0f / 2048.0f;
 #ifndef ADX_CHAIN_PF
-#define ADX_CHAIN_PF 10
+#define ADX_CHAIN_PF 8
 #endif
-constexpr int kChPF = ADX_CHAIN_PF;         // weight-fragment ring depth: K-steps (2 KB each) in flight per wave; the k5 layers have 10 n steps
+constexpr int kChPF = ADX_CHAIN_PF;       // weight-fragment ring depth: K-steps (2 KB each) in flight per wave
 constexpr int kChNT = 64 * kChainWaves;
 
 template <int CTRL>
@@ -75,15 +76,16 @@ __device__ __forceinline__ void ch_split8(const float (&v)[8], h8& hi, h8& lo) {
   }
 }
 
-// (mean, M2) of two equally sized sets of n elements each -> of their union (Chan et al.); symmetric in its arguments,
-// so both partners of an exchange compute the same bits
+// (mean, M2) of two equally sized sets of n elements each -> of their union (Chan et al.), written symmetrically so that
+// both partners of an exchange compute the same bits
 __device__ __forceinline__ void ch_merge(float& m, float& s, float mo, float so, float n_each) {
   const float d = mo - m;
   m = 0.5f * (m + mo);
   s = (s + so) + (d * d) * (0.5f * n_each);
 }
 
-// Chain input: global [B][C][L] (two sources = skip concat, arbitrary strides) -> split cells, rows = (sample, position)
+// Chain input: global [B][C][L] (two sources = skip concat, arbitrary strides) -> split cells, rows = (sample, position);
+// channels beyond the real ones (inputs are padded to >= 32) are zero cells
 __device__ __forceinline__ void ch_stage_input(const ChainArgs& ca, u32x4* cells, int b0, int tid) {
   const int lin = ca.in_len, cin = ca.in_c0 + ca.in_c1;
   const int ncell = ca.in_cpad >> 3, pitch = 2 * ncell + 1;
@@ -150,130 +152,34 @@ __device__ __forceinline__ void ch_stage_input(const ChainArgs& ca, u32x4* cells
   for (int it = tid; it < pitch; it += kChNT) cells[rows * pitch + it] = u32x4{0u, 0u, 0u, 0u};   // the all-zero row
 }
 
-// One reduction (conv taps x input channels) of NR row tiles x one 16-channel tile over steps step0 .. step0 + nsteps - 1
-// of the tile's weight image [step][plane][64 lanes] x 16 bytes; the fragment ring `wq` holds steps
-// 0 .. PF-1 ON ENTRY (the caller issued them earlier: the previous stage's epilogue ran under their latency) and keeps
-// being refilled PF steps ahead through the tile's buffer descriptor `wrs` (loads past the image return zeros without
-// traffic), so that a second reduction stored behind this one (the 1x1 residual conv, step0 = this one's step count)
-// finds ITS first steps in the ring when nsteps is a multiple of PF.  Row r of tile i reads LDS row
-// rbase[i] + input position (or the zero row).
-template <int NR>
-__device__ __forceinline__ void ch_gemm(const u32x4* __restrict__ cells, int pitch, int zrow, int kind, int taps, int stride,
-                                        int pad, int lin, int log2_ncell, int nsteps, const __amdgpu_buffer_rsrc_t wrs, int step0,
-                                        int rot, int lane16, u32x4 (&wq)[kChPF][2], const int (&rbase)[2], const int (&rl)[2],
-                                        const bool (&rok)[2], int kg, f32x4 (&accm)[2], f32x4 (&accx)[2]) {
-  const bool kind0 = kind == 0;
-  const int ncm1 = (1 << log2_ncell) - 1;
-  u32x4 ah[NR], al[NR];
-  auto fetch = [&](int step) {
-    const int kc = 4 * step + kg;                       // flattened (tap, 8-channel cell)
-    const int tap = kc >> log2_ncell, cell = kc & ncm1;
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      const int vt = rl[i] + pad - tap;
-      const int ip = kind0 ? rl[i] * stride + tap - pad : vt >> 1;
-      const bool ok = rok[i] & ((unsigned)ip < (unsigned)lin) & (kind0 | ((vt & 1) == 0)) & (tap < taps);
-      const u32x4* xp = cells + (ok ? rbase[i] + ip : zrow) * pitch + 2 * cell;
-      ah[i] = xp[0];
-      al[i] = xp[1];
-    }
-  };
-  // the reduction's steps are visited in the order rot, rot + 1, .., nsteps - 1, 0, .., rot - 1 (rot differs between
-  // workgroups: they all stream the same weight image, and in lockstep they would all pull on the same L2 lines at once)
-  auto phys = [&](int j) { const int p = j + rot; return p >= nsteps ? p - nsteps : p; };
-  fetch(phys(0));
-  auto compute = [&](const u32x4 (&w)[2], int next_step) {
-    h8 ch[NR], cl[NR];
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      ch[i] = __builtin_bit_cast(h8, ah[i]);
-      cl[i] = __builtin_bit_cast(h8, al[i]);
-    }
-    fetch(next_step);
-    __builtin_amdgcn_sched_barrier(0);      // the next step's LDS reads stay in front of this step's MFMAs
-    const h8 wh = __builtin_bit_cast(h8, w[0]);
-    const h8 wl = __builtin_bit_cast(h8, w[1]);
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      accm[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[i], wh, accm[i], 0, 0, 0);
-      accx[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[i], wl, accx[i], 0, 0, 0);
-      accx[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl[i], wh, accx[i], 0, 0, 0);
-    }
-  };
-  int j0 = 0;
-  for (; j0 + kChPF <= nsteps; j0 += kChPF) {
-#pragma unroll
-    for (int s = 0; s < kChPF; ++s) {
-      compute(wq[s], phys(min(j0 + s + 1, nsteps - 1)));
-      const int jn = j0 + s + kChPF;                        // logical index of the refill; past this reduction: what lies behind it
-      const int so = (step0 + (jn < nsteps ? phys(jn) : jn)) * 2048;   // (past the tile's image the range check returns zeros, no traffic)
-      wq[s][0] = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, so, 0);
-      wq[s][1] = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, so + 1024, 0);
-    }
-  }
-#pragma unroll
-  for (int s = 0; s < kChPF; ++s)
-    if (j0 + s < nsteps) compute(wq[s], phys(min(j0 + s + 1, nsteps - 1)));
+// buffer descriptor of one 16-channel tile's weight image ([step][plane][64 lanes] x 16 bytes; the residual conv's steps
+// behind the main conv's): uniform base, the lane supplies 16 * lane, the step is an SGPR offset; reads past the image
+// return zeros without traffic (the ring simply runs off the end)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ch_wrsrc(const float* pk, int w_off, int nsteps, int ct) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pk + w_off + (size_t)ct * nsteps * 512), 0, nsteps * 2048, 0x00020000);
 }
-
-// logical steps 0 .. PF-1 of a reduction of `nsteps` steps visited from `rot` (what lies behind the reduction is not rotated)
-__device__ __forceinline__ void ch_ring_fill(u32x4 (&wq)[kChPF][2], const __amdgpu_buffer_rsrc_t wrs, int lane16, int nsteps, int rot) {
+__device__ __forceinline__ void ch_ring_fill(u32x4 (&wq)[kChPF][2], const __amdgpu_buffer_rsrc_t wrs, int lane16) {
 #pragma unroll
   for (int s = 0; s < kChPF; ++s) {
-    int p = s;
-    if (s < nsteps) { p = s + rot; if (p >= nsteps) p -= nsteps; }
-    wq[s][0] = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, p * 2048, 0);
-    wq[s][1] = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, p * 2048 + 1024, 0);
+    wq[s][0] = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, s * 2048, 0);
+    wq[s][1] = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, s * 2048 + 1024, 0);
   }
-}
-__device__ __forceinline__ int ch_rot(int seed, int nsteps) { return seed % nsteps; }
-
-// Which tiles of a stage a wave owns.  A wave multiplies up to TWO row tiles (tiles 2g, 2g + 1: with 32 positions per
-// sample these are the two halves of one sample, so its GroupNorm statistics stay inside the wave) against one 16-channel
-// tile per pass, so the weight fragments of a channel tile are fetched by as few waves as possible (the per-CU fill rate,
-// ~64 B/clk, is what a chain's time is made of); waves beyond n_ct * ceil(n_rt / 2) idle in the K loops.
-struct ChTiles {
-  int ct0, ct_step, rt0, my_nr;
-};
-__device__ __forceinline__ ChTiles ch_tiles(const ChainStage& st, int bt, int wave) {
-  ChTiles t;
-  const int n_rt = (bt * st.lout + 15) >> 4;
-  const int n_rg = (n_rt + 1) >> 1;                 // row groups of two tiles
-  if (st.n_ct >= kChainWaves) {                     // n_rg == 1 (rows <= 32): every wave walks its channel tiles
-    t.ct0 = wave; t.ct_step = kChainWaves; t.rt0 = 0;
-    t.my_nr = min(n_rt, 2);
-  } else {
-    t.ct0 = wave & (st.n_ct - 1); t.ct_step = st.n_ct;
-    const int rg = wave / st.n_ct;
-    t.rt0 = 2 * rg;
-    t.my_nr = rg < n_rg ? min(n_rt - 2 * rg, 2) : 0;
-  }
-  return t;
-}
-// buffer descriptor of one 16-channel tile's weight image ([step][plane][64 lanes] x 16 bytes; the residual conv's steps
-// behind the main conv's): uniform base, the lane supplies 16 * lane, the step is an SGPR offset
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t ch_wrsrc(const float* pk, const ChainStage& st, int ct) {
-  const int tile_bytes = (st.nsteps + st.r_nsteps) * 2048;
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pk + st.w_off + (size_t)ct * (tile_bytes / 4)), 0, tile_bytes, 0x00020000);
 }
 
 // The argument block lives in the kernarg segment, i.e. in HOST memory on this platform: every 64-byte line of it a wave
-// touches for the first time is a ~2 us round trip, and the compiler reads fields where they are used -- a chain that walks
-// its stage table that way pays that latency several times per stage (measured: 6 us of a 7 us stage).  So the block is
-// copied into LDS once (all lines in flight together) and a stage's descriptor is then one LDS read per lane + readlanes.
+// touches for the first time is a ~2 us round trip, and the compiler reads fields where they are used.  The stage table is
+// therefore copied into LDS once (all lines in flight together); a stage's descriptor is then one LDS read per lane and
+// one v_readlane per field.
 constexpr int kChStageWords = (int)(sizeof(ChainStage) / 4);
 static_assert(sizeof(ChainStage) % 4 == 0 && kChStageWords <= 64, "ChainStage must fit one dword per lane");
-constexpr int kChOutWords = (int)(sizeof(ChainOut) / 4);
-static_assert(sizeof(ChainOut) % 4 == 0 && kChOutWords <= 64, "ChainOut must fit one dword per lane");
 
-template <typename T, int W>
-__device__ __forceinline__ T ch_from_lds(const int* words, int lane) {
-  const int v = words[min(lane, W - 1)];
-  int raw[W];
+__device__ __forceinline__ ChainStage ch_stage_from_lds(const int* words, int lane) {
+  const int v = words[min(lane, kChStageWords - 1)];
+  int raw[kChStageWords];
 #pragma unroll
-  for (int k = 0; k < W; ++k) raw[k] = __builtin_amdgcn_readlane(v, k);
-  T t;
-  __builtin_memcpy(&t, raw, sizeof(T));
+  for (int k = 0; k < kChStageWords; ++k) raw[k] = __builtin_amdgcn_readlane(v, k);
+  ChainStage t;
+  __builtin_memcpy(&t, raw, sizeof(ChainStage));
   return t;
 }
 
@@ -284,230 +190,195 @@ __global__ void __launch_bounds__(kChNT) tconv_chain_kernel(const ChainArgs ca) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, kg = lane >> 4;
   const int lane16 = lane * 16;
-  const int b0 = blockIdx.x * ca.bt;
-  const int rseed = ca.rotate ? (int)blockIdx.x * 3 + wave : 0;     // where this wave enters every reduction (see ch_gemm)
+  const int bt = ca.bt, batch = ca.batch, n_stages = ca.n_stages;
+  const int b0 = blockIdx.x * bt;
   const float* __restrict__ pk = ca.packed;
-
   CH_STAMP(0);
-  int* largs = reinterpret_cast<int*>(smem + ca.args_off);
-  {
+
+  int* ltab = reinterpret_cast<int*>(smem + ca.tab_lds);
 #if defined(__HIP_DEVICE_COMPILE__)
-    typedef const __attribute__((address_space(4))) int* kernarg_words;
-    kernarg_words kraw = (kernarg_words)__builtin_amdgcn_kernarg_segment_ptr();     // ChainArgs is the only argument
-    for (int i = tid; i < (int)(sizeof(ChainArgs) / 4); i += kChNT) largs[i] = kraw[i];
-#endif
-  }
-  const int* lstages = largs + (int)(offsetof(ChainArgs, st) / 4);
-  const int* louts = largs + (int)(offsetof(ChainArgs, out) / 4);
-  const int n_stages = ca.n_stages, bt = ca.bt, batch = ca.batch;
-  u32x4 wq[kChPF][2];
-  {   // the first stage's first weight fragments travel while the input is staged
-    const ChTiles t0 = ch_tiles(ca.st[0], ca.bt, wave);
-    if (t0.my_nr > 0) ch_ring_fill(wq, ch_wrsrc(pk, ca.st[0], t0.ct0), lane16, ca.st[0].nsteps, ch_rot(rseed, ca.st[0].nsteps));
-  }
-  // every stage's per-channel parameters and this workgroup's time-bias rows -> LDS, once: the epilogues then issue no
-  // global load at all (a load issued behind the weight ring returns behind it: in order).  One item per thread and
-  // trip, all stages in one flat index space, so that the loads of a trip are in flight together.
-  __syncthreads();            // the argument block is in LDS
   {
-    const int per_stage = 4 * 128 + bt * 128;              // upper bound of a stage's items (cout_pad <= 128: host)
-    const int o_cout = (int)(offsetof(ChainStage, cout) / 4), o_cp = (int)(offsetof(ChainStage, cout_pad) / 4);
-    const int o_par = (int)(offsetof(ChainStage, par) / 4), o_b = (int)(offsetof(ChainStage, b_off) / 4);
-    const int o_g = (int)(offsetof(ChainStage, g_off) / 4), o_be = (int)(offsetof(ChainStage, be_off) / 4);
-    const int o_rs = (int)(offsetof(ChainStage, r_src) / 4), o_rb = (int)(offsetof(ChainStage, r_b_off) / 4);
-    const int o_tb = (int)(offsetof(ChainStage, tb_col) / 4);
-    for (int it = tid; it < n_stages * per_stage; it += kChNT) {
-      const int k = it / per_stage, e = it - k * per_stage;
-      const int* sw = lstages + k * kChStageWords;         // per-lane reads of the LDS copy (k differs between lanes)
-      struct { int cout, cout_pad, par, b_off, g_off, be_off, r_src, r_b_off, tb_col; } sk =
-          {sw[o_cout], sw[o_cp], sw[o_par], sw[o_b], sw[o_g], sw[o_be], sw[o_rs], sw[o_rb], sw[o_tb]};
-      const int cp = sk.cout_pad;
-      float* par = smem + sk.par;
-      if (e < 4 * 128) {
-        const int which = e >> 7, c = e & 127;
-        if (c < cp) {
-          const bool ok = c < sk.cout;
-          float v = which == 1 ? 1.f : 0.f;
-          if (which == 0 && ok && sk.b_off >= 0) v = pk[sk.b_off + c];
-          if (which == 1 && ok && sk.g_off >= 0) v = pk[sk.g_off + c];
-          if (which == 2 && ok && sk.g_off >= 0) v = pk[sk.be_off + c];
-          if (which == 3 && ok && sk.r_src >= 0 && sk.r_b_off >= 0) v = pk[sk.r_b_off + c];
-          par[which * cp + c] = v;
-        }
-      } else if (sk.tb_col >= 0) {
-        const int sb = (e - 4 * 128) >> 7, c = e & 127;
-        if (c < cp) {
-          const int b = min(b0 + sb, batch - 1);
-          par[(4 + sb) * cp + c] = c < sk.cout ? ca.tb[(int64_t)b * ca.tb_stride + sk.tb_col + c] : 0.f;
-        }
+    typedef const __attribute__((address_space(4))) int* kernarg_words;
+    kernarg_words kraw = (kernarg_words)__builtin_amdgcn_kernarg_segment_ptr() + (int)(offsetof(ChainArgs, st) / 4);
+    for (int i = tid; i < n_stages * kChStageWords; i += kChNT) ltab[i] = kraw[i];
+  }
+#endif
+  // the first weight fragments of this wave's first tile travel while everything else is staged
+  u32x4 wq[kChPF][2];
+  if (wave < ca.st[0].n_tiles)
+    ch_ring_fill(wq, ch_wrsrc(pk, ca.st[0].w_off, ca.st[0].ns_main + ca.st[0].ns_r, wave >> ca.st[0].log2_nrt), lane16);
+  {   // per-channel parameters of every stage (one block), this workgroup's rows of the time-bias matrix
+    float* lpar = smem + ca.par_lds;
+    for (int i = tid; i < ca.par_floats; i += kChNT) lpar[i] = pk[ca.par_src + i];
+    for (int k = 0; k < ca.n_tb; ++k) {
+      const int cp = ca.tb_cout[k], lg = 31 - __builtin_clz(cp);       // padded channel count: a power of two
+      float* dst = smem + ca.tb_lds[k];
+      for (int e = tid; e < bt * cp; e += kChNT) {
+        const int sb = e >> lg, c = e & (cp - 1);
+        dst[e] = ca.tb[(int64_t)min(b0 + sb, batch - 1) * ca.tb_stride + ca.tb_col[k] + c];
       }
     }
   }
-  ch_stage_input(ca, reinterpret_cast<u32x4*>(smem + ca.cell_off[ca.st[0].src]), b0, tid);
+  ch_stage_input(ca, reinterpret_cast<u32x4*>(smem + ca.in_cells), b0, tid);
   __syncthreads();
   CH_STAMP(1);
 
   for (int si = 0; si < n_stages; ++si) {
-    const ChainStage st = ch_from_lds<ChainStage, kChStageWords>(lstages + si * kChStageWords, lane);   // in scalar registers
-    // of the next stage only what the weight prefetch needs
-    ChainStage nx;
-    {
-      const int* nw = lstages + min(si + 1, n_stages - 1) * kChStageWords;
-      nx.n_ct = __builtin_amdgcn_readfirstlane(nw[offsetof(ChainStage, n_ct) / 4]);
-      nx.lout = __builtin_amdgcn_readfirstlane(nw[offsetof(ChainStage, lout) / 4]);
-      nx.w_off = __builtin_amdgcn_readfirstlane(nw[offsetof(ChainStage, w_off) / 4]);
-      nx.nsteps = __builtin_amdgcn_readfirstlane(nw[offsetof(ChainStage, nsteps) / 4]);
-      nx.r_nsteps = __builtin_amdgcn_readfirstlane(nw[offsetof(ChainStage, r_nsteps) / 4]);
-    }
-    const int rows_out = bt * st.lout;
-    const int n_ct = st.n_ct;
-    const ChTiles T = ch_tiles(st, bt, wave);
-    const int my_nr = T.my_nr;
-    // per-lane row geometry of my row tiles, as A-operand rows (row = 16 rt + r16)
-    int rbase[2], rl[2], rrow[2], rzero[2];
-    bool rok[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = 16 * (T.rt0 + i) + r16;
-      rok[i] = i < my_nr && m < rows_out;
-      rl[i] = m & (st.lout - 1);
-      rbase[i] = (m >> st.log2_lout) * st.lin;
-      rrow[i] = m;                     // the 1x1 residual conv reads the block input at the output row itself
-      rzero[i] = 0;
-    }
-    const int* lcell = largs + (int)(offsetof(ChainArgs, cell_off) / 4);
-    const u32x4* cells = reinterpret_cast<const u32x4*>(smem + lcell[st.src]);
-    const int zrow = bt * st.lin;
-    float* F = smem + largs[(int)(offsetof(ChainArgs, f_off) / 4) + st.f_dst];
-    const int fp = st.cout_pad + 4;    // fp32 tile pitch
-    const bool gn = st.g_off >= 0;
-    const int rot = ch_rot(rseed, st.nsteps);
-    const float* par = smem + st.par;            // this stage's parameters in LDS: bias | gamma | beta | residual bias | time bias
+    const ChainStage st = ch_stage_from_lds(ltab + si * kChStageWords, lane);     // in scalar registers
+    const int flags = st.flags;
+    const int lout = 1 << st.log2_lout, n_ct = 1 << st.log2_nct, cp = 16 << st.log2_nct, fp = cp + 4;
+    (void)n_ct;
+    const int kind0 = (st.conv & 255) == 0, taps = (st.conv >> 8) & 255, stride = (st.conv >> 16) & 255, pad = st.conv >> 24;
+    const u32x4* cells = reinterpret_cast<const u32x4*>(smem + st.src);
+    const u32x4* rcells = reinterpret_cast<const u32x4*>(smem + st.r_src);
+    float* F = smem + st.f_dst;
+    const float* par = smem + st.par;
+    const int nsteps = st.ns_main + st.ns_r;
+    const int cgl = (flags >> 8) & 15;
 
-    for (int ct = T.ct0; ct < n_ct && my_nr > 0; ct += T.ct_step) {
-      f32x4 v[2], rv[2];
-      const __amdgpu_buffer_rsrc_t wrs = ch_wrsrc(pk, st, ct);
-      {
-        f32x4 accm[2], accx[2];
+    for (int t = wave; t < st.n_tiles; t += kChainWaves) {
+      // row tiles fastest: the two halves of a 32-position sample are tiles t, t + 1 -- same trip of this loop, so their
+      // GroupNorm partials meet at one barrier
+      const int rt = t & ((1 << st.log2_nrt) - 1), ct = t >> st.log2_nrt;
+      const int m = 16 * rt + r16;                       // this lane's row as an A operand
+      const bool rok = m < st.rows_out;
+      const int l = m & (lout - 1), rb = (m >> st.log2_lout) * st.lin;
+      const __amdgpu_buffer_rsrc_t wrs = ch_wrsrc(pk, st.w_off, nsteps, ct);
+      // ---- one weight stream: the conv's steps (tap-major; the four cells of a step lie in one tap, so the tap is wave-
+      // uniform and the lane's LDS row changes only with it), then the 1x1 residual conv's steps on the block input --------
+      f32x4 am = f32x4{0.f, 0.f, 0.f, 0.f}, ax = am, rm = am, rx = am;
+      auto main_row = [&](int tap) {
+        const int vt = l + pad - tap;
+        const int ip = kind0 ? l * stride + tap - pad : vt >> 1;
+        const bool ok = rok & ((unsigned)ip < (unsigned)st.lin) & (kind0 | ((vt & 1) == 0));
+        return cells + (ok ? rb + ip : st.zrow) * st.src_pitch + 2 * kg;
+      };
+      const u32x4* r_rowp = rcells + ((rok && (flags & kChResConv)) ? m : st.r_zrow) * st.r_pitch + 2 * kg;   // (none: a zero row)
+      const u32x4* rowp = main_row(0);
+      int f_sub = 0, f_tap = 0, cur_spt = 1 << st.log2_spt;
+      u32x4 ah, al;
+      auto fetch = [&]() {
+        const u32x4* xp = rowp + 8 * f_sub;              // 4 cells = 8 sixteen-byte units per step
+        ah = xp[0];
+        al = xp[1];
+        if (++f_sub == cur_spt) {                        // uniform: next tap, or on to the residual conv's input
+          f_sub = 0;
+          if (++f_tap < taps) rowp = main_row(f_tap);
+          else { rowp = r_rowp; cur_spt = 1 << 30; }
+        }
+      };
+      fetch();
+      auto compute = [&](const u32x4 (&w)[2], int j) {
+        const h8 ch = __builtin_bit_cast(h8, ah);
+        const h8 cl = __builtin_bit_cast(h8, al);
+        fetch();                                         // (one step past the end reads a valid row: unused)
+        __builtin_amdgcn_sched_barrier(0);               // the next step's LDS reads stay in front of this step's MFMAs
+        const h8 wh = __builtin_bit_cast(h8, w[0]);
+        const h8 wl = __builtin_bit_cast(h8, w[1]);
+        if (j < st.ns_main) {
+          am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, wh, am, 0, 0, 0);
+          ax = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, wl, ax, 0, 0, 0);
+          ax = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl, wh, ax, 0, 0, 0);
+        } else {
+          rm = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, wh, rm, 0, 0, 0);
+          rx = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, wl, rx, 0, 0, 0);
+          rx = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl, wh, rx, 0, 0, 0);
+        }
+      };
+      int j0 = 0;
+      for (; j0 + kChPF <= nsteps; j0 += kChPF) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { accm[i] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[i] = accm[i]; }
-        if (my_nr == 1) ch_gemm<1>(cells, st.src_pitch, zrow, st.kind, st.taps, st.stride, st.pad, st.lin, st.log2_ncell, st.nsteps, wrs, 0, rot, lane16, wq, rbase, rl, rok, kg, accm, accx);
-        else ch_gemm<2>(cells, st.src_pitch, zrow, st.kind, st.taps, st.stride, st.pad, st.lin, st.log2_ncell, st.nsteps, wrs, 0, rot, lane16, wq, rbase, rl, rok, kg, accm, accx);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) v[i] = accm[i] + accx[i] * kChLoInv;
+        for (int s = 0; s < kChPF; ++s) {
+          compute(wq[s], j0 + s);
+          const int so = (j0 + s + kChPF) * 2048;
+          wq[s][0] = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, so, 0);
+          wq[s][1] = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, so + 1024, 0);
+        }
       }
-      rv[0] = f32x4{0.f, 0.f, 0.f, 0.f}; rv[1] = rv[0];
-      if (st.r_src >= 0) {
-        f32x4 racm[2], racx[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { racm[i] = f32x4{0.f, 0.f, 0.f, 0.f}; racx[i] = racm[i]; }             // R(x): a 1x1 conv of the block input, same rows, its own accumulators; its steps lie
-        // behind the main reduction's in the image and (nsteps % PF == 0: checked on the host) already sit in the ring
-        const u32x4* rcells = reinterpret_cast<const u32x4*>(smem + lcell[st.r_src]);
-        const int rz = bt * st.lout;
-        if (my_nr == 1) ch_gemm<1>(rcells, st.r_pitch, rz, 0, 1, 1, 0, 1, st.r_log2_ncell, st.r_nsteps, wrs, st.nsteps, 0, lane16, wq, rrow, rzero, rok, kg, racm, racx);
-        else ch_gemm<2>(rcells, st.r_pitch, rz, 0, 1, 1, 0, 1, st.r_log2_ncell, st.r_nsteps, wrs, st.nsteps, 0, lane16, wq, rrow, rzero, rok, kg, racm, racx);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) rv[i] = racm[i] + racx[i] * kChLoInv;
-      }
+      for (int s = 0; s < kChPF; ++s)
+        if (j0 + s < nsteps) compute(wq[s], j0 + s);
       CH_STAMP(2 + 4 * si);
-      // the ring is empty now: send for what this wave multiplies next -- its next channel tile of this stage, or its
-      // first tile of the next stage -- so that the epilogue, the barriers and the re-split run under that latency
-      if (ct + T.ct_step < n_ct) {
-        ch_ring_fill(wq, ch_wrsrc(pk, st, ct + T.ct_step), lane16, st.nsteps, rot);
-      } else if (si + 1 < n_stages) {
-        const ChTiles tn = ch_tiles(nx, bt, wave);
-        if (tn.my_nr > 0) ch_ring_fill(wq, ch_wrsrc(pk, nx, tn.ct0), lane16, nx.nsteps, ch_rot(rseed, nx.nsteps));
+      // the ring is empty: send for this wave's next tile -- of this stage, or of the next one -- so that the epilogue, the
+      // barriers and the re-split run under that latency
+      if (t + kChainWaves < st.n_tiles) {
+        ch_ring_fill(wq, ch_wrsrc(pk, st.w_off, nsteps, (t + kChainWaves) >> st.log2_nrt), lane16);
+      } else if (wave < st.nx_n_tiles) {
+        ch_ring_fill(wq, ch_wrsrc(pk, st.nx_w_off, st.nx_nsteps, wave >> st.nx_log2_nrt), lane16);
       }
-      // ---- epilogue of this channel tile, from the accumulators: lane = (channel r16, rows 4 kg .. 4 kg + 3 of a tile) ----
+      // ---- epilogue from the accumulators: lane = (channel r16 of the tile, rows 4 kg .. 4 kg + 3) ---------------------------
       const int c = 16 * ct + r16;
-      const bool cok = c < st.cout;
-      const int cp = st.cout_pad;
-      const float bias = par[c], gm = par[cp + c], be = par[2 * cp + c], rbias = par[3 * cp + c];   // zeros / ones where absent
-      float gmean[2] = {0.f, 0.f}, gm2[2] = {0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < 2; ++i) v[i] += bias;
-      const int cgl = st.cg_log2;
-      if (gn) {
-        // GroupNorm statistics of (sample, group): 4 positions per lane -> channel lanes of the group -> row quads of
-        // the sample inside the tile -> (lout = 32) the sample's second row tile through LDS
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          float m = 0.25f * ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3]));
-          const f32x4 d = v[i] - m;
-          float s = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
-          float n = 4.f;
-          if (cgl >= 1) { ch_merge(m, s, ch_dpp<0xB1>(m), ch_dpp<0xB1>(s), n); n *= 2.f; }
-          if (cgl >= 2) { ch_merge(m, s, ch_dpp<0x4E>(m), ch_dpp<0x4E>(s), n); n *= 2.f; }
-          if (cgl >= 3) { ch_merge(m, s, ch_dpp<0x141>(m), ch_dpp<0x141>(s), n); n *= 2.f; }
-          if (cgl >= 4) { ch_merge(m, s, ch_dpp<0x140>(m), ch_dpp<0x140>(s), n); n *= 2.f; }
-          if (st.lout >= 8) { ch_merge(m, s, __shfl_xor(m, 16, 64), __shfl_xor(s, 16, 64), n); n *= 2.f; }
-          if (st.lout >= 16) { ch_merge(m, s, __shfl_xor(m, 32, 64), __shfl_xor(s, 32, 64), n); n *= 2.f; }
-          gmean[i] = m;
-          gm2[i] = s;
+      f32x4 v = am + ax * kChLoInv;
+      v += par[c];
+      const int m0 = 16 * rt + 4 * kg;
+      const int sb = m0 >> st.log2_lout, l0 = m0 & (lout - 1);
+      f32x4 o = v;
+      if (flags & kChGn) {
+        // statistics of (sample, group): 4 positions per lane -> the group's channel lanes -> the row quads of the sample
+        // inside the tile -> (32 positions per sample) the sample's other row tile, which another wave holds, through LDS
+        float mu = 0.25f * ((v[0] + v[1]) + (v[2] + v[3]));
+        const f32x4 d = v - mu;
+        float sq = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        float n = 4.f;
+        if (cgl >= 1) { ch_merge(mu, sq, ch_dpp<0xB1>(mu), ch_dpp<0xB1>(sq), n); n *= 2.f; }
+        if (cgl >= 2) { ch_merge(mu, sq, ch_dpp<0x4E>(mu), ch_dpp<0x4E>(sq), n); n *= 2.f; }
+        if (cgl >= 3) { ch_merge(mu, sq, ch_dpp<0x141>(mu), ch_dpp<0x141>(sq), n); n *= 2.f; }
+        if (cgl >= 4) { ch_merge(mu, sq, ch_dpp<0x140>(mu), ch_dpp<0x140>(sq), n); n *= 2.f; }
+        if (lout >= 8) { ch_merge(mu, sq, __shfl_xor(mu, 16, 64), __shfl_xor(sq, 16, 64), n); n *= 2.f; }
+        if (lout >= 16) { ch_merge(mu, sq, __shfl_xor(mu, 32, 64), __shfl_xor(sq, 32, 64), n); n *= 2.f; }
+        if (lout >= 32) {              // uniform; the host gives such a stage a multiple of 8 tiles: every wave takes the barrier
+          float* xch = smem + ca.xch_lds;
+          const int gi = (ct << 2) + (r16 >> cgl);
+          if (kg == 0 && (r16 & ((1 << cgl) - 1)) == 0) {
+            xch[(rt * (n_ct << 2) + gi) * 2] = mu;
+            xch[(rt * (n_ct << 2) + gi) * 2 + 1] = sq;
+          }
+          __syncthreads();
+          const float* p0 = xch + ((rt & ~1) * (n_ct << 2) + gi) * 2;
+          const float* p1 = p0 + (n_ct << 3);
+          mu = p0[0]; sq = p0[1];
+          ch_merge(mu, sq, p1[0], p1[1], n);
         }
-        if (st.lout >= 32 && my_nr == 2) {       // the wave's two tiles are the two halves of one sample
-          float m = gmean[0], sq = gm2[0];
-          ch_merge(m, sq, gmean[1], gm2[1], (float)(16 << cgl));
-          gmean[0] = gmean[1] = m;
-          gm2[0] = gm2[1] = sq;
-        }
+        const float sc = __builtin_amdgcn_rsqf(sq * st.inv_n + st.eps) * par[cp + c];
+        const float be = par[2 * cp + c];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = ch_mish((v[k] - mu) * sc + be);
       }
+      if (flags & kChTb) o += smem[st.tbl + sb * cp + c];
+      if (flags & kChResConv) o += (rm + rx * kChLoInv) + par[3 * cp + c];
+      float* fr = F + m0 * fp + c;
+      if (flags & kChResIdentity) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        if (i >= my_nr) continue;
-        const int m0 = 16 * (T.rt0 + i) + 4 * kg;
-        const int sb = m0 >> st.log2_lout, l0 = m0 & (st.lout - 1);
-        const int b = b0 + sb;
-        const bool live = m0 < rows_out && b < batch && cok;
-        f32x4 o = v[i];
-        if (gn) {
-          const float inv_n = 1.0f / (float)(st.lout << cgl);
-          const float rstd = 1.0f / sqrtf(gm2[i] * inv_n + st.eps);
-          const float sc = rstd * gm;
+        for (int k = 0; k < 4; ++k) o[k] += fr[k * fp];
+      }
+      if (m0 < st.rows_out) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) o[k] = ch_mish((v[i][k] - gmean[i]) * sc + be);
-        }
-        if (st.tb_col >= 0) o += par[(4 + sb) * cp + c];
-        if (st.r_src >= 0) o += rv[i] + rbias;
-        float* fr = F + (size_t)m0 * fp + c;
-        if (st.res_identity) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) o[k] += fr[(size_t)k * fp];
-        }
-        if (m0 < rows_out) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) fr[(size_t)k * fp] = o[k];
-        }
-        if (st.out >= 0) {
-          const ChainOut go = ch_from_lds<ChainOut, kChOutWords>(louts + st.out * kChOutWords, lane);
-          if (live) {
-          float* yp = go.p + (int64_t)b * go.sb + (int64_t)c * go.sc + (int64_t)l0 * go.sl;
-          if (go.vec) {
+        for (int k = 0; k < 4; ++k) fr[k * fp] = o[k];
+        if ((flags & kChOut) && c < st.cout && b0 + sb < batch) {
+          const ChainOut& go = ca.out[(flags >> 12) & 1];
+          float* yp = go.p + (int64_t)(b0 + sb) * go.sb + (int64_t)c * go.sc + (int64_t)l0 * go.sl;
+          if (flags & kChOutVec) {
             *reinterpret_cast<f32x4*>(yp) = o;
           } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) yp[(int64_t)k * go.sl] = o[k];
           }
-          }
         }
       }
     }
     CH_STAMP(3 + 4 * si);
-    if (my_nr == 0 && si + 1 < n_stages) {         // a wave without tiles here may have some in the next stage
-      const ChTiles tn = ch_tiles(nx, bt, wave);
-      if (tn.my_nr > 0) ch_ring_fill(wq, ch_wrsrc(pk, nx, tn.ct0), lane16, nx.nsteps, ch_rot(rseed, nx.nsteps));
-    }
+    // a wave without tiles in this stage still fetches for its tile of the next one
+    if (wave >= st.n_tiles && wave < st.nx_n_tiles)
+      ch_ring_fill(wq, ch_wrsrc(pk, st.nx_w_off, st.nx_nsteps, wave >> st.nx_log2_nrt), lane16);
     __syncthreads();
     CH_STAMP(4 + 4 * si);
-    // ---- fp32 tile -> split cells of the next stage's input (one (row, 8-channel cell) per thread and trip) ----------
-    if (st.dst >= 0) {
-      u32x4* dcells = reinterpret_cast<u32x4*>(smem + lcell[st.dst]);
-      const int ncell = st.cout_pad >> 3;
-      const int dp = st.dst_pitch;
-      const int items = rows_out * ncell;
-      for (int it = tid; it < items; it += kChNT) {
-        const int cell = it % ncell, row = it / ncell;
-        const float* fr = F + (size_t)row * fp + 8 * cell;
+    // ---- fp32 tile -> split cells of the next stage's input: one (row, 8-channel cell) per thread and trip ---------------
+    if (flags & kChCells) {
+      u32x4* dcells = reinterpret_cast<u32x4*>(smem + st.dst);
+      const int lg_nc = st.log2_nct + 1, dp = st.dst_pitch;
+      for (int it = tid; it < (st.rows_out << lg_nc); it += kChNT) {
+        const int cell = it & ((1 << lg_nc) - 1), row = it >> lg_nc;
+        const float* fr = F + row * fp + 8 * cell;
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(fr);
         const f32x4 a1 = *reinterpret_cast<const f32x4*>(fr + 4);
         const float t8[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
@@ -517,7 +388,7 @@ __global__ void __launch_bounds__(kChNT) tconv_chain_kernel(const ChainArgs ca) 
         dst[0] = __builtin_bit_cast(u32x4, hi);
         dst[1] = __builtin_bit_cast(u32x4, lo);
       }
-      for (int it = tid; it < dp; it += kChNT) dcells[rows_out * dp + it] = u32x4{0u, 0u, 0u, 0u};
+      if (tid < dp) dcells[st.rows_out * dp + tid] = u32x4{0u, 0u, 0u, 0u};
       __syncthreads();
     }
     CH_STAMP(5 + 4 * si);
@@ -539,8 +410,9 @@ extern "C" int adx_debug_chain_trace_clear() {
 
 // Weight image of a chain stage: [cout_pad16 / 16][steps][2 planes][64 lanes][8 halfs] (tconv_hs.hip's short-K fragment
 // order: element j of lane ln at `step` is W[n = 16 tile + (ln & 15)][flattened cell kc = 4 step + (ln >> 4): tap = kc /
-// ncell, ci = 8 (kc % ncell) + j], split into hi / lo planes).  A stage with a 1x1 residual conv stores that conv's steps
-// behind the main reduction's inside every tile (`tile_steps` = both, `step0` = where this conv's steps begin).
+// ncell, ci = 8 (kc % ncell) + j], split into hi / lo planes; ncell = padded input channels / 8, a multiple of 4, so a step
+// never straddles taps).  A stage with a 1x1 residual conv stores that conv's steps behind the main reduction's inside
+// every tile (`tile_steps` = both, `step0` = where this conv's steps begin).
 __global__ void chain_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ packed, int layout, int flip, int taps,
                                   int cin, int cout, int ncell, int nsteps, int tile_steps, int step0, size_t total) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -571,23 +443,20 @@ static int ilog2_exact_ch(int v) {
   return (1 << l) == v ? l : -1;
 }
 
-int chain_steps(const adx_tconv_desc* d) { return ceil_div(d->taps * (round_up(d->c0 + d->c1, 16) / 8), 4); }
+int chain_cin_pad(const adx_tconv_desc* d) { return std::max(32, round_up(d->c0 + d->c1, 16)); }
+int chain_steps(const adx_tconv_desc* d) { return d->taps * (chain_cin_pad(d) / 8) / 4; }
 
 bool chain_layer_ok(const adx_tconv_desc* d) {
   if (!tconv_hs_supported(d)) return false;
-  const int cin_pad = round_up(d->c0 + d->c1, 16);
-  if (ilog2_exact_ch(cin_pad / 8) < 0) return false;
+  if (ilog2_exact_ch(chain_cin_pad(d) / 8) < 0) return false;
   if (d->lout < 4 || d->lout > 32 || d->lin > 32) return false;
-  const int n_ct = round_up(d->cout, 16) / 16;
-  if (n_ct < kChainWaves ? ilog2_exact_ch(n_ct) < 0 : n_ct % kChainWaves != 0) return false;
+  if (ilog2_exact_ch(round_up(d->cout, 16) / 16) < 0) return false;
   if (d->groups > 0) {
     const int cg = d->cout / d->groups;
     if (cg != 2 && cg != 4 && cg != 8 && cg != 16) return false;       // a group lies inside one 16-channel tile
   }
   return true;
 }
-
-bool chain_residual_ok(const adx_tconv_desc* main) { return chain_steps(main) % kChPF == 0; }
 
 size_t chain_packed_floats(const adx_tconv_desc* d) {
   return (size_t)(round_up(d->cout, 16) / 16) * chain_steps(d) * 512;    // 2048 bytes per (tile, step)
@@ -601,29 +470,16 @@ int chain_pack(const adx_tconv_desc* d, const float* w, const adx_tconv_desc* r,
     const size_t total = (size_t)tiles * ns * 512;
     chain_pack_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
         w, reinterpret_cast<_Float16*>(packed), d->kind == 1 ? 1 - d->w_layout : d->w_layout, d->w_flip, d->taps,
-        d->c0 + d->c1, d->cout, round_up(d->c0 + d->c1, 16) / 8, ns, ns + nr, 0, total);
+        d->c0 + d->c1, d->cout, chain_cin_pad(d) / 8, ns, ns + nr, 0, total);
   }
   if (r != nullptr) {
     const size_t total = (size_t)tiles * nr * 512;
     chain_pack_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
         rw, reinterpret_cast<_Float16*>(packed), r->w_layout, r->w_flip, r->taps, r->c0 + r->c1, r->cout,
-        round_up(r->c0 + r->c1, 16) / 8, nr, ns + nr, ns, total);
+        chain_cin_pad(r) / 8, nr, ns + nr, ns, total);
   }
   ADX_LAUNCH_CHECK();
   return ADX_OK;
-}
-
-void chain_fill_stage(ChainStage* st, const adx_tconv_desc* d) {
-  const int cin_pad = round_up(d->c0 + d->c1, 16);
-  st->kind = d->kind; st->taps = d->taps; st->stride = d->stride; st->pad = d->pad;
-  st->log2_ncell = ilog2_exact_ch(cin_pad / 8);
-  st->nsteps = chain_steps(d);
-  st->lin = d->lin; st->lout = d->lout; st->log2_lout = ilog2_exact_ch(d->lout);
-  st->cout = d->cout; st->cout_pad = round_up(d->cout, 16); st->n_ct = st->cout_pad / 16;
-  st->cg_log2 = d->groups > 0 ? ilog2_exact_ch(d->cout / d->groups) : 0;
-  st->eps = d->eps;
-  st->src_pitch = 2 * (cin_pad / 8) + 1;
-  st->dst_pitch = 2 * (st->cout_pad / 8) + 1;
 }
 
 int chain_launch(const ChainArgs& ca, int grid, size_t lds_bytes, hipStream_t s) {

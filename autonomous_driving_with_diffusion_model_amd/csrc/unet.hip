@@ -78,47 +78,103 @@ struct Builder {
 // ---- chains (tconv_chain.hip): which runs of layers go into one launch ---------------------------------------------------
 constexpr int kChainMaxChannels = 128;     // all channels of a layer in one workgroup: every workgroup streams every weight
 
-// Off by default: measured slower than the launches it replaces (tconv_chain.hip header).  ADX_UNET_CHAIN=1 turns it on.
+// ADX_UNET_CHAIN=0 turns the chains off (every level layer by layer: the A/B)
 static bool chains_enabled() {
-  static const bool on = [] { const char* e = getenv("ADX_UNET_CHAIN"); return e != nullptr && e[0] == '1'; }();
+  static const bool on = [] { const char* e = getenv("ADX_UNET_CHAIN"); return !(e != nullptr && e[0] == '0'); }();
   return on;
 }
 
-static ChainStage& chain_add(ChainArgs& a, const ConvLayer& L, int src, int dst, int f_dst, int out, int tb_col) {
-  ChainStage& st = a.st[a.n_stages++];
-  memset(&st, 0, sizeof(st));
-  chain_fill_stage(&st, &L.d);
-  st.src = src; st.dst = dst; st.f_dst = f_dst; st.out = out; st.tb_col = tb_col;
-  st.w_off = (int)L.o_cw;
-  st.b_off = L.p_b >= 0 ? (int)L.o_b : -1;
-  st.g_off = L.p_g >= 0 ? (int)L.o_g : -1;
-  st.be_off = L.p_be >= 0 ? (int)L.o_be : -1;
-  st.r_src = -1;
-  return st;
-}
+static int ilog2_floor(int v) { int l = 0; while ((2 << l) <= v) ++l; return l; }
 
-// LDS layout of a chain for `bt` samples per workgroup; returns the bytes, fills cell_off / f_off / xch_off
-static size_t chain_layout(ChainArgs& a, int bt) {
-  size_t cell16[kChainMaxCells] = {0, 0, 0, 0}, f[2] = {0, 0};
+// The kernel's argument block for `rows` samples, `bt` per workgroup: LDS layout + every stage descriptor.  Returns the
+// dynamic LDS bytes (0: this bt does not fit / is not allowed).  Pointers and strides are filled by the caller.
+static size_t chain_args(const ChainPlan& cp, int bt, ChainArgs& a) {
+  memset(&a, 0, sizeof(a));
+  const int n = (int)cp.st.size();
+  a.n_stages = n; a.bt = bt;
+  a.in_c0 = cp.in_c0; a.in_c1 = cp.in_c1; a.in_len = cp.len;
+  a.in_cpad = chain_cin_pad(&cp.st[0].L->d);
+  // cell buffers (16-byte units), fp32 tiles, exchange area
+  size_t cell16[kChainMaxCells] = {0, 0, 0, 0}, f[2] = {0, 0}, xch = 0, tb_floats = 0;
   auto need = [&](int buf, size_t rows, int pitch) { if (buf >= 0) cell16[buf] = std::max(cell16[buf], (rows + 1) * (size_t)pitch); };
-  need(a.st[0].src, (size_t)bt * a.in_len, 2 * (a.in_cpad / 8) + 1);
-  for (int i = 0; i < a.n_stages; ++i) {
-    const ChainStage& st = a.st[i];
-    need(st.src, (size_t)bt * st.lin, st.src_pitch);
-    need(st.dst, (size_t)bt * st.lout, st.dst_pitch);
-    if (st.r_src >= 0) need(st.r_src, (size_t)bt * st.lout, st.r_pitch);
-    const size_t rows_pad = (size_t)round_up(bt * st.lout, 16);
-    f[st.f_dst] = std::max(f[st.f_dst], rows_pad * (size_t)(st.cout_pad + 4));
+  for (int i = 0; i < n; ++i) {
+    const ChainStagePlan& sp = cp.st[i];
+    const adx_tconv_desc& d = sp.L->d;
+    const int cout_pad = round_up(d.cout, 16);
+    need(sp.src, (size_t)bt * d.lin, 2 * (chain_cin_pad(&d) / 8) + 1);
+    need(sp.dst, (size_t)bt * d.lout, 2 * (cout_pad / 8) + 1);
+    if (sp.R != nullptr) need(sp.r_src, (size_t)bt * d.lout, 2 * (chain_cin_pad(&sp.R->d) / 8) + 1);
+    const size_t rows_pad = (size_t)round_up(bt * d.lout, 16);
+    if (rows_pad > 64) return 0;
+    f[sp.f] = std::max(f[sp.f], rows_pad * (size_t)(cout_pad + 4));
+    if (d.groups > 0 && d.lout >= 32) {
+      const size_t tiles = (rows_pad / 16) * (cout_pad / 16);
+      if (tiles % kChainWaves != 0) return 0;            // every wave must reach the exchange barrier the same number of times
+      xch = std::max(xch, tiles * 8);
+    }
+    if (sp.tb_col >= 0) tb_floats += (size_t)bt * cout_pad;
   }
   size_t off = 0;     // floats
-  for (int k = 0; k < kChainMaxCells; ++k) { a.cell_off[k] = (int)off; off += cell16[k] * 4; }
-  for (int k = 0; k < 2; ++k) { a.f_off[k] = (int)off; off += (f[k] + 3) / 4 * 4; }
-  for (int i = 0; i < a.n_stages; ++i) {       // per-stage parameters: 4 vectors + the workgroup's time-bias rows
-    a.st[i].par = (int)off;
-    off += (size_t)(4 + (a.st[i].tb_col >= 0 ? bt : 0)) * a.st[i].cout_pad;
+  int cell_off[kChainMaxCells], f_off[2];
+  for (int k = 0; k < kChainMaxCells; ++k) { cell_off[k] = (int)off; off += cell16[k] * 4; }
+  for (int k = 0; k < 2; ++k) { f_off[k] = (int)off; off += (f[k] + 3) / 4 * 4; }
+  a.par_lds = (int)off; a.par_floats = (int)cp.par_floats; a.par_src = (int)cp.o_par;
+  off += (cp.par_floats + 3) / 4 * 4;
+  const int tb_base = (int)off;
+  off += tb_floats;
+  a.xch_lds = (int)off;
+  off += xch;
+  a.tab_lds = (int)off;
+  off += (size_t)n * (sizeof(ChainStage) / 4);
+  a.in_cells = cell_off[cp.st[0].src];
+  int tb_next = tb_base;
+  for (int i = 0; i < n; ++i) {
+    const ChainStagePlan& sp = cp.st[i];
+    const adx_tconv_desc& d = sp.L->d;
+    ChainStage& st = a.st[i];
+    const int cin_pad = chain_cin_pad(&d), cout_pad = round_up(d.cout, 16);
+    const int cg = d.groups > 0 ? d.cout / d.groups : 1;
+    st.flags = (d.groups > 0 ? kChGn : 0) | (sp.tb_col >= 0 ? kChTb : 0) | (sp.res_identity ? kChResIdentity : 0) |
+               (sp.R != nullptr ? kChResConv : 0) | (sp.out >= 0 ? kChOut : 0) | (sp.dst >= 0 ? kChCells : 0) |
+               (ilog2_floor(cg) << 8) | ((sp.out >= 0 ? sp.out : 0) << 12);
+    st.conv = d.kind | (d.taps << 8) | (d.stride << 16) | (d.pad << 24);
+    st.log2_spt = ilog2_floor(cin_pad / 32);
+    st.ns_main = chain_steps(&d);
+    st.ns_r = sp.R != nullptr ? chain_steps(&sp.R->d) : 0;
+    st.lin = d.lin; st.log2_lout = ilog2_floor(d.lout);
+    st.cout = d.cout; st.log2_nct = ilog2_floor(cout_pad / 16);
+    st.w_off = (int)sp.L->o_cw;
+    st.src = cell_off[sp.src]; st.src_pitch = 2 * (cin_pad / 8) + 1;
+    if (sp.R != nullptr) {
+      const int rpad = chain_cin_pad(&sp.R->d);
+      st.r_src = cell_off[sp.r_src]; st.r_pitch = 2 * (rpad / 8) + 1; st.r_log2_spt = ilog2_floor(rpad / 32);
+      st.r_zrow = bt * d.lout;
+    } else {
+      st.r_src = st.src; st.r_pitch = st.src_pitch; st.r_log2_spt = 0; st.r_zrow = bt * d.lin;
+    }
+    st.dst = sp.dst >= 0 ? cell_off[sp.dst] : 0; st.dst_pitch = 2 * (cout_pad / 8) + 1;
+    st.f_dst = f_off[sp.f];
+    st.par = a.par_lds + (int)sp.par_off;
+    if (sp.tb_col >= 0) {
+      st.tbl = tb_next;
+      a.tb_col[a.n_tb] = sp.tb_col; a.tb_cout[a.n_tb] = cout_pad; a.tb_lds[a.n_tb] = tb_next;
+      ++a.n_tb;
+      tb_next += bt * cout_pad;
+    }
+    st.rows_out = bt * d.lout; st.zrow = bt * d.lin;
+    st.inv_n = 1.0f / (float)(cg * d.lout); st.eps = d.eps;
+    const int nrt = ceil_div(bt * d.lout, 16);
+    if ((nrt & (nrt - 1)) != 0) return 0;                    // row tiles per stage: a power of two (tile index arithmetic)
+    st.log2_nrt = ilog2_floor(nrt);
+    st.n_tiles = (cout_pad / 16) * nrt;
   }
-  a.args_off = (int)off;
-  off += (sizeof(ChainArgs) + 3) / 4;
+  for (int i = 0; i < n; ++i) {
+    ChainStage& st = a.st[i];
+    if (i + 1 < n) {
+      const ChainStage& nx = a.st[i + 1];
+      st.nx_w_off = nx.w_off; st.nx_nsteps = nx.ns_main + nx.ns_r; st.nx_log2_nrt = nx.log2_nrt; st.nx_n_tiles = nx.n_tiles;
+    }
+  }
   return off * sizeof(float);
 }
 
@@ -126,48 +182,62 @@ static size_t chain_layout(ChainArgs& a, int bt) {
 static void plan_chain(ChainPlan* cp, const ResBlock& b0, const ResBlock& b1, const ConvLayer* tail, const ConvLayer* h0,
                        const ConvLayer* h1, bool up_level, int level) {
   cp->valid = false;
+  cp->st.clear();
   // ADX_CHAIN_MASK: bit i = down level i, bit 8 + i = up level i (diagnostic: which levels are chained; default all)
   static const unsigned mask = [] { const char* e = getenv("ADX_CHAIN_MASK"); return e ? (unsigned)strtoul(e, nullptr, 0) : ~0u; }();
   if (((mask >> (up_level ? 8 + level : level)) & 1u) == 0) return;
   if (!chains_enabled() || !b0.has_r || b1.has_r) return;      // block 0 changes the channel count (R = 1x1 conv), block 1 keeps it
-  if (!chain_residual_ok(&b0.b.d)) return;
   if (b0.cout > kChainMaxChannels || b1.cout != b0.cout) return;
   const ConvLayer* all[] = {&b0.a, &b0.b, &b0.r, &b1.a, &b1.b, tail, h0, h1};
-  for (const ConvLayer* L : all)
-    if (L != nullptr && !chain_layer_ok(&L->d)) return;
-  ChainArgs& a = cp->tmpl;
-  memset(&a, 0, sizeof(a));
-  a.in_c0 = b0.c0; a.in_c1 = b0.c1; a.in_cpad = round_up(b0.c0 + b0.c1, 16); a.in_len = b0.a.d.lin;
-  cp->len = b0.a.d.lin;
-  // cell buffers: 0 = block input (and, later, block 1's output), 1 = a block's inner activation, 2 = block 0's output
-  chain_add(a, b0.a, 0, 1, 0, -1, b0.tb_off);
-  ChainStage& s1 = chain_add(a, b0.b, 1, 2, 1, -1, -1);
-  {
-    ChainStage r;
-    chain_fill_stage(&r, &b0.r.d);
-    s1.r_src = 0; s1.r_log2_ncell = r.log2_ncell; s1.r_nsteps = r.nsteps; s1.r_pitch = r.src_pitch;
-    s1.r_b_off = b0.r.p_b >= 0 ? (int)b0.r.o_b : -1;        // R's weight steps: behind b0.b's in the image at b0.b.o_cw
+  static const int max_steps = [] { const char* e = getenv("ADX_CHAIN_MAX_STEPS"); return e ? atoi(e) : 48; }();
+  for (const ConvLayer* L : all) {
+    if (L == nullptr) continue;
+    if (!chain_layer_ok(&L->d)) return;
+    // One wave walks ALL K-steps of its tile: a reduction of more than ~48 steps (the 1024 -> 256 / 512 -> 128 convs on the
+    // concatenated input of the deeper up levels: 80) is faster as its own launch with the reduction split over waves and
+    // workgroups (measured: that level as a chain +1.3 us at 128 rows, +4.1 us at 2 rows)
+    if (chain_steps(&L->d) > max_steps) return;
   }
-  chain_add(a, b1.a, 2, 1, 0, -1, b1.tb_off);
-  ChainStage& s3 = chain_add(a, b1.b, 1, tail != nullptr ? 0 : -1, 1, up_level ? -1 : 0, -1);
-  s3.res_identity = 1;
+  cp->in_c0 = b0.c0; cp->in_c1 = b0.c1; cp->len = b0.a.d.lin;
+  auto add = [&](const ConvLayer& L, int src, int dst, int f, int out, int tb_col) -> ChainStagePlan& {
+    ChainStagePlan sp;
+    sp.L = &L; sp.src = src; sp.dst = dst; sp.f = f; sp.out = out; sp.tb_col = tb_col;
+    cp->st.push_back(sp);
+    return cp->st.back();
+  };
+  // cell buffers: 0 = block input (and, later, block 1's output), 1 = a block's inner activation, 2 = block 0's output
+  add(b0.a, 0, 1, 0, -1, b0.tb_off);
+  {
+    ChainStagePlan& s1 = add(b0.b, 1, 2, 1, -1, -1);
+    s1.R = &b0.r; s1.r_src = 0;
+  }
+  add(b1.a, 2, 1, 0, -1, b1.tb_off);
+  {
+    ChainStagePlan& s3 = add(b1.b, 1, tail != nullptr ? 0 : -1, 1, up_level ? (tail != nullptr ? -1 : 0) : 0, -1);
+    s3.res_identity = true;
+  }
   cp->with_head = false;
   if (tail != nullptr) {
     const bool head = up_level && h0 != nullptr && h1 != nullptr;
-    chain_add(a, *tail, 0, head ? 1 : -1, 0, head ? -1 : (up_level ? 0 : 1), -1);
+    add(*tail, 0, head ? 1 : -1, 0, head ? -1 : (up_level ? 0 : 1), -1);
     if (head) {
-      chain_add(a, *h0, 1, 2, 1, -1, -1);
-      chain_add(a, *h1, 2, -1, 0, 0, -1);
+      add(*h0, 1, 2, 1, -1, -1);
+      add(*h1, 2, -1, 0, 0, -1);
       cp->with_head = true;
     }
-  } else if (up_level) {
-    s3.out = 0;
   }
-  // a workgroup's rows = bt x the longest length of the chain (an up conv doubles it): at most 32 = two row tiles per wave
+  // the chain's parameter block: [bias | gamma | beta | residual bias] x cout_pad per stage
+  cp->par_floats = 0;
   cp->max_len = 0;
-  for (int i = 0; i < a.n_stages; ++i) cp->max_len = std::max(cp->max_len, a.st[i].lout);
-  const int bt_min = std::max(1, 16 / cp->len);
-  if (bt_min * cp->max_len > 32 || chain_layout(a, bt_min) > kChainMaxLds) return;
+  for (auto& sp : cp->st) {
+    sp.par_off = cp->par_floats;
+    cp->par_floats += (size_t)4 * round_up(sp.L->d.cout, 16);
+    cp->max_len = std::max(cp->max_len, sp.L->d.lout);
+  }
+  // must run with the fewest samples per workgroup that fill a 16-row tile
+  ChainArgs a;
+  const size_t lds = chain_args(*cp, std::max(1, 16 / cp->len), a);
+  if (lds == 0 || lds > kChainMaxLds) { cp->st.clear(); return; }
   cp->valid = true;
 }
 
@@ -243,33 +313,29 @@ static int build(adx_unet* u) {
   // weight image in the chain kernel's layout
   u->down_chains.assign(n, ChainPlan{});
   u->up_chains.assign(n > 1 ? n - 1 : 0, ChainPlan{});
-  auto give_images = [&](std::initializer_list<ConvLayer*> ls) {
-    for (ConvLayer* L : ls)
-      if (L != nullptr && !L->chained) { L->chained = true; L->o_cw = B.take(chain_packed_floats(&L->d)); }
-  };
-  auto give_block0 = [&](ResBlock& b) {      // block 0's second conv carries the block's 1x1 residual conv behind it
-    if (!b.a.chained) { b.a.chained = true; b.a.o_cw = B.take(chain_packed_floats(&b.a.d)); }
-    if (!b.b.chained) { b.b.chained = true; b.b.o_cw = B.take(chain_packed_floats(&b.b.d) + chain_packed_floats(&b.r.d)); }
+  auto give_images = [&](ChainPlan& cp) {      // called once the level qualifies; plan_chain is then run again (offsets)
+    for (auto& sp : cp.st) {
+      ConvLayer* L = const_cast<ConvLayer*>(sp.L);
+      if (!L->chained) {
+        L->chained = true;
+        L->o_cw = B.take(chain_packed_floats(&L->d) + (sp.R != nullptr ? chain_packed_floats(&sp.R->d) : 0));
+      }
+    }
+    cp.o_par = B.take(cp.par_floats);
   };
   for (int i = 0; i < n; ++i) {
     ResBlock& b0 = u->blocks[2 * i];
     ResBlock& b1 = u->blocks[2 * i + 1];
     ConvLayer* dn = i < n - 1 ? &u->downs[i] : nullptr;
-    plan_chain(&u->down_chains[i], b0, b1, dn, nullptr, nullptr, false, i);             // first pass: does the level qualify?
-    if (!u->down_chains[i].valid) continue;
-    give_block0(b0);
-    give_images({&b1.a, &b1.b, dn});
-    plan_chain(&u->down_chains[i], b0, b1, dn, nullptr, nullptr, false, i);             // second pass: with the images' offsets
+    plan_chain(&u->down_chains[i], b0, b1, dn, nullptr, nullptr, false, i);
+    if (u->down_chains[i].valid) give_images(u->down_chains[i]);
   }
   for (int i = 0; i < n - 1; ++i) {
     ResBlock& b0 = u->blocks[2 * n + 2 + 2 * i];
     ResBlock& b1 = u->blocks[2 * n + 2 + 2 * i + 1];
     const bool last = i == n - 2;
     plan_chain(&u->up_chains[i], b0, b1, &u->ups[i], last ? &u->head0 : nullptr, last ? &u->head1 : nullptr, true, i);
-    if (!u->up_chains[i].valid) continue;
-    give_block0(b0);
-    give_images({&b1.a, &b1.b, &u->ups[i], last ? &u->head0 : nullptr, last ? &u->head1 : nullptr});
-    plan_chain(&u->up_chains[i], b0, b1, &u->ups[i], last ? &u->head0 : nullptr, last ? &u->head1 : nullptr, true, i);
+    if (u->up_chains[i].valid) give_images(u->up_chains[i]);
   }
   u->packed_floats = B.off;
   // validate every layer's geometry now so that forward() cannot fail on shape grounds (any layer one of the three
@@ -435,6 +501,21 @@ int adx_unet_pack(adx_unet* u, const float* const* P, int32_t n_params, const fl
   for (auto& l : u->ups) if (rc == ADX_OK) rc = pack_layer(l, P, base, s);
   if (rc == ADX_OK) rc = pack_layer(u->head0, P, base, s);
   if (rc == ADX_OK) rc = pack_layer(u->head1, P, base, s);
+  // the chains' parameter blocks: [bias | gamma | beta | residual bias] x cout_pad per stage (zero where a stage has none)
+  for (const std::vector<ChainPlan>* cps : {&u->down_chains, &u->up_chains})
+    for (const ChainPlan& cp : *cps) {
+      if (!cp.valid || rc != ADX_OK) continue;
+      batch_fill_add(base + cp.o_par, cp.par_floats);
+      rc = batch_fill_flush(s);            // stream order: the zeros land before the copies queued below
+      for (const ChainStagePlan& sp : cp.st) {
+        float* dst = base + cp.o_par + sp.par_off;
+        const int cpad = round_up(sp.L->d.cout, 16), co = sp.L->d.cout;
+        if (rc == ADX_OK && sp.L->p_b >= 0) rc = copy_f(dst, P[sp.L->p_b], co, s);
+        if (rc == ADX_OK && sp.L->p_g >= 0) rc = copy_f(dst + cpad, P[sp.L->p_g], co, s);
+        if (rc == ADX_OK && sp.L->p_be >= 0) rc = copy_f(dst + 2 * cpad, P[sp.L->p_be], co, s);
+        if (rc == ADX_OK && sp.R != nullptr && sp.R->p_b >= 0) rc = copy_f(dst + 3 * cpad, P[sp.R->p_b], co, s);
+      }
+    }
   if (rc == ADX_OK) rc = batch_copy_flush(s);      // the fused Linear below is packed from the concatenated copy
   if (rc == ADX_OK) rc = tconv_pack(&u->tlin.d, base + u->o_tlin_raw, base + u->tlin.o_w, s);
   if (rc == ADX_OK) rc = copy_f(base + u->o_freqs, freqs, dim / 2, s);
@@ -554,16 +635,16 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
   // one launch for a whole level (tconv_chain.hip) where the plan allows it
   static const int chain_rows = [] { const char* e = getenv("ADX_CHAIN_ROWS"); return e ? atoi(e) : 0; }();   // 16 / 32: A/B
   auto run_chain = [&](const ChainPlan& cp, const Act& in0, const Act* in1, const Act& o0, const Act* o1) -> int {
-    ChainArgs a = cp.tmpl;
     // samples per workgroup: as many as keep its rows (bt x the chain's longest length) within 32 where that still gives
     // the chip ~a hundred workgroups, else the fewest that fill a 16-row tile (more, smaller workgroups)
     const int bt_min = std::max(1, 16 / cp.len), bt_max = std::max(bt_min, 32 / cp.max_len);
     int bt = (chain_rows == 16 || ceil_div(rows, bt_max) < 96) ? bt_min : bt_max;
     if (chain_rows == 32) bt = bt_max;
-    size_t lds = chain_layout(a, bt);
-    if (lds > kChainMaxLds) {
+    ChainArgs a;
+    size_t lds = chain_args(cp, bt, a);
+    if (lds == 0 || lds > kChainMaxLds) {
       bt = bt_min;
-      lds = chain_layout(a, bt);
+      lds = chain_args(cp, bt, a);
     }
     a.packed = base; a.tb = tb; a.tb_stride = u->sum_c;
     a.in0 = in0.p; a.in0_sb = in0.sb; a.in0_sc = in0.sc; a.in0_sl = in0.sl;
@@ -572,11 +653,12 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
       return t.sl == 1 && t.sc % 4 == 0 && t.sb % 4 == 0 && (reinterpret_cast<uintptr_t>(t.p) & 15) == 0;
     };
     a.in_vec = cp.len % 4 == 0 && dense4(in0) && (in1 == nullptr || dense4(*in1));
-    a.out[0] = ChainOut{const_cast<float*>(o0.p), o0.sb, o0.sc, o0.sl, dense4(o0) ? 1 : 0};
-    if (o1 != nullptr) a.out[1] = ChainOut{const_cast<float*>(o1->p), o1->sb, o1->sc, o1->sl, dense4(*o1) ? 1 : 0};
-    a.batch = rows; a.bt = bt;
-    static const int rotate = [] { const char* e = getenv("ADX_CHAIN_ROTATE"); return e ? atoi(e) : 0; }();     // measured: no gain (the weight stream is not what a stage waits for)
-    a.rotate = rotate;
+    const Act* outs[2] = {&o0, o1};
+    for (int k = 0; k < 2; ++k)
+      if (outs[k] != nullptr) a.out[k] = ChainOut{const_cast<float*>(outs[k]->p), outs[k]->sb, outs[k]->sc, outs[k]->sl};
+    for (int k = 0; k < a.n_stages; ++k)
+      if ((a.st[k].flags & kChOut) && dense4(*outs[(a.st[k].flags >> 12) & 1])) a.st[k].flags |= kChOutVec;
+    a.batch = rows;
     static const bool dbg = getenv("ADX_CHAIN_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "[chain] rows %d len %d bt %d grid %d lds %zu stages %d in_vec %d\n", rows, cp.len, bt, ceil_div(rows, bt), lds, a.n_stages, a.in_vec);
     return chain_launch(a, ceil_div(rows, bt), lds, s);

@@ -18,21 +18,33 @@ struct ConvLayer {
   bool chained = false;
 };
 
-// A run of layers executed by ONE launch of tconv_chain.hip: the two residual blocks of a level + its down / up conv
-// (+ final_conv on the last up level).  `tmpl` holds everything that does not depend on the call.
-struct ChainPlan {
-  ChainArgs tmpl{};
-  int len = 0, max_len = 0;  // per-sample length at the chain's input; the longest output length of its stages
-  bool valid = false;
-  bool with_head = false;
-};
-
 struct ResBlock {
   ConvLayer a, b, r;
   bool has_r = false;
   int p_tw = -1, p_tb = -1;  // time_mlp.1 weight / bias
   int tb_off = 0;            // column offset in the fused time-bias matrix
   int c0 = 0, c1 = 0, cout = 0, len = 0;
+};
+
+// A run of layers executed by ONE launch of tconv_chain.hip: the two residual blocks of a level + its down / up conv
+// (+ final_conv on the last up level).  The plan is what does not depend on the call; chain_args() turns it into the
+// kernel's argument block for a batch and a choice of samples per workgroup.
+struct ChainStagePlan {
+  const ConvLayer* L = nullptr;      // the conv
+  const ConvLayer* R = nullptr;      // 1x1 residual conv riding behind it (block 0's second conv), or null
+  int src = 0, r_src = 0, dst = -1;  // LDS cell buffers (index); dst -1: the result is not needed as cells
+  int f = 0;                         // fp32 result tile (0 / 1)
+  int out = -1;                      // global output slot
+  int tb_col = -1;                   // column of the time-bias matrix (block first convs)
+  bool res_identity = false;
+  size_t par_off = 0;                // float offset of [bias | gamma | beta | residual bias] inside the chain's parameter block
+};
+struct ChainPlan {
+  std::vector<ChainStagePlan> st;
+  int in_c0 = 0, in_c1 = 0, len = 0, max_len = 0;
+  size_t o_par = 0, par_floats = 0;  // the parameter block in the packed buffer
+  bool valid = false;
+  bool with_head = false;
 };
 
 }  // namespace adx
