@@ -1,7 +1,7 @@
 # Round profile (run on the GPU box through gpurun): kernel stats of the whole bench, PMC traffic of the two roofline
 # kernels (separate --pmc passes, --kernel-trace only), the per-layer timeline of the temporal stack, the kernel make-up of
 # the two deployed ticks (B = 1: classifier-free and classifier guidance), the default bench.
-R=${R:-r02}
+R=${R:-r03}
 rm -rf gpurun_out/${R}_stats gpurun_out/${R}_pmc_fetch gpurun_out/${R}_pmc_write gpurun_out/${R}_tconv_trace
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-deployed > gpurun_out/${R}_bench_under_rocprof.json 2> gpurun_out/${R}_bench_under_rocprof.err
