@@ -193,11 +193,14 @@ def test_cfg2_train_step_b64_fullsize_loss_vs_oracle_and_split_vs_exact(tmp_path
     rows.sort(reverse=True)
     _record("cfg2_train_b64", {"loss": loss, "loss_oracle_fwd": want_loss, "loss_exact_kernels": exact["loss"],
                                "worst split-vs-exact (rel L2, tensor)": rows[:8], "median": rows[len(rows) // 2][0]})
-    # two fp32-grade evaluations of the same sums: they differ like two summation orders do.  The BatchNorm affine gradients
-    # are sums of 64 x H x W signed terms that cancel to ~1e-3 of their mass (the B = 16 test above measures the fp32 oracle
-    # itself 8e-3 away from fp64 on them), so they carry the summation-order difference relative to that mass: measured
-    # 1.1e-2 .. 1.3e-2 on layer1's, 1e-6 in the median over all tensors.
-    is_bn = lambda k: ".bn1." in k or ".bn2." in k or ".downsample.1." in k  # noqa: E731
-    _record("cfg2_train_b64_worst_non_bn", {"worst": next((r for r in rows if not is_bn(r[1])), None)})
+    # Two fp32-grade evaluations of the same sums: they differ like two summation orders do.  Every BatchNorm backward of the
+    # encoder is a difference of sums of 64 x H x W signed terms that cancel to ~1e-3 of their mass (the B = 16 test above
+    # measures the fp32 ORACLE itself 6e-3 .. 8e-3 away from fp64 on the perception tensors), and the gradient that reaches
+    # a layer has been through every BatchNorm above it: measured 1.0e-2 .. 1.3e-2 on the perception tensors from layer2
+    # downwards, 7e-7 in the median over all 306 tensors (the temporal stack's 196 sit there).  A wrong kernel shows as O(1).
+    noisy = lambda k: k.startswith("perception.")  # noqa: E731
+    others = [r for r in rows if not noisy(r[1])]
+    _record("cfg2_train_b64_others", {"worst": others[:5], "median": others[len(others) // 2]})
+    assert rows[len(rows) // 2][0] <= 5e-6
     for err, k in rows:
-        assert err <= (5e-2 if is_bn(k) else 2e-3), (k, err)
+        assert err <= (5e-2 if noisy(k) else 1e-4), (k, err)       # measured: 1.3e-2 / 2.2e-6
