@@ -1,5 +1,6 @@
-"""Whole UNet forwards with the chained levels on (ADX_UNET_CHAIN=1 is read once per process, hence a process of its own)
-against the CPU oracle; prints one line per case: name rows horizon max_abs_err.  See csrc/tconv_chain.hip."""
+"""Whole UNet forwards against the CPU oracle in a process of its own, so that the switches that are read once per process
+(ADX_UNET_CHAIN=0: the 64/128-channel levels layer by layer instead of one launch each, csrc/tconv_chain.hip) can be set for
+it; prints one line per case: name rows horizon max_abs_err."""
 import os
 import sys
 

@@ -382,15 +382,16 @@ def test_unet_other_widths_and_depths_vs_oracle(dim, mults, H):
             m(d["trajs"].to(DEV), d["imgs"].to(DEV), d["t"].to(DEV), cond=None if cond is None else cond.to(DEV))
 
 
-def test_chained_levels_opt_in_vs_oracle():
-    """csrc/tconv_chain.hip: the 64/128-channel levels (two residual blocks + down / up conv, + final_conv) as one launch
-    each, activations LDS-resident.  Off by default (measured slower than the launches it replaces: DESIGN.md section 8);
-    ADX_UNET_CHAIN=1 turns it on, and it must then still compute the reference's forward (modeling/temporal.py:197-245)."""
+def test_levels_layer_by_layer_vs_oracle():
+    """csrc/tconv_chain.hip runs the 64/128-channel levels (two residual blocks + down / up conv, + final_conv) as one launch
+    each, and every other test in this file goes through it.  ADX_UNET_CHAIN=0 (read once per process, hence a process of its
+    own) sends those levels through the per-layer kernels again -- the path ragged horizons, exact-fp32 mode and wider models
+    still take -- and it must compute the same forward (modeling/temporal.py:197-245)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "chain_worker.py")], env=dict(os.environ, ADX_UNET_CHAIN="1"),
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "chain_worker.py")], env=dict(os.environ, ADX_UNET_CHAIN="0"),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     cases = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("CASE")]
