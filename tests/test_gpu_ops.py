@@ -76,6 +76,27 @@ def test_conv1d_block_split_reduction_tiny_batch(c0, c1, cout, L, B):
     assert torch.equal(_ops().tconv(x0.to(DEV), w.to(DEV), b.to(DEV), scratch=small, **kw), y_plain)
 
 
+@pytest.mark.parametrize("c0,c1,cout,L,B", [(7, 0, 48, 32, 3), (48, 0, 48, 32, 2), (96, 96, 48, 16, 3), (192, 0, 192, 8, 2),
+                                            (384, 0, 384, 4, 1), (512, 512, 256, 1, 3), (256, 0, 256, 1, 2), (24, 0, 24, 16, 2)])
+def test_conv1d_block_general_shapes(c0, c1, cout, L, B):
+    """Shapes neither MFMA kernel tiles -- GroupNorm(8, C) with groups of 6 / 12 / 24 / 48 / 3 channels (MODEL.DIM = 48, 96, 24:
+    modeling/helpers.py:105-107 takes any C divisible by 8), groups of 32 elements (one position: the bottom of the up path
+    at horizon 8) -- run on csrc/tconv_generic.hip: same operator, same bar, concat input / time bias / residual included."""
+    name = f"gen.{c0}.{c1}.{cout}.{L}"
+    x0 = uni(name + ".x0", (B, c0, L))
+    x1 = uni(name + ".x1", (B, c1, L)) if c1 else None
+    cin = c0 + c1
+    w = uni(name + ".w", (cout, cin, 5), lo=-(3.0 / (5 * cin)) ** 0.5, hi=(3.0 / (5 * cin)) ** 0.5)
+    b, g, be = uni(name + ".b", (cout,), lo=-.1, hi=.1), uni(name + ".g", (cout,), lo=.9, hi=1.1), uni(name + ".be", (cout,), lo=-.1, hi=.1)
+    tb = uni(name + ".tb", (B, cout + 5))[:, 3:3 + cout]
+    res = uni(name + ".res", (B, cout, L))
+    xin = x0 if x1 is None else torch.cat([x0, x1], 1)
+    ref = F.mish(F.group_norm(F.conv1d(xin, w, b, padding=2), 8, g, be, 1e-5)) + tb[:, :, None] + res
+    y = _ops().tconv(x0.to(DEV), w.to(DEV), b.to(DEV), x1=None if x1 is None else x1.to(DEV), pad=2,
+                     gn_weight=g.to(DEV), gn_bias=be.to(DEV), groups=8, tbias=tb.to(DEV), res=res.to(DEV))
+    close(y.cpu(), ref, 2e-5)
+
+
 @pytest.mark.parametrize("c,L,B", [(64, 32, 3), (128, 16, 5), (256, 8, 2), (64, 16, 4), (256, 4, 9)])
 def test_downsample(c, L, B):
     x, w, b = uni(f"dn.x.{c}", (B, c, L)), uni(f"dn.w.{c}", (c, c, 3), lo=-.1, hi=.1), uni(f"dn.b.{c}", (c,))
