@@ -31,7 +31,7 @@ class TConvIO(C.Structure):
                 ("tbias", vp), ("tbias_stride", i64),
                 ("res", vp), ("res_sb", i64), ("res_sc", i64), ("res_sl", i64),
                 ("y", vp), ("y_sb", i64), ("y_sc", i64), ("y_sl", i64), ("batch", i32), ("pre", vp), ("stats", vp),
-                ("scratch", vp), ("scratch_floats", i64)]
+                ("scratch", vp), ("scratch_floats", i64), ("tickets", vp)]
 
 
 class EmbedWeights(C.Structure):

@@ -53,6 +53,14 @@ struct HsArgs {
   // ordering between the two is the kernel boundary: no fences, no counters, nothing to get wrong.
   int ksplit, cper;
   float* part;
+  // tickets != nullptr: no reduce launch.  Every workgroup publishes its partial tile with write-through (sc1) stores, drains
+  // them, and one lane draws a ticket from the (row tile, slab)'s counter with a relaxed agent-scope atomic; the workgroup
+  // that draws the last one reads all partial tiles back with sc1 loads (they bypass its L1; nothing needs a fence: the
+  // hand-off recipe of cdna_hip_programming.md, Guideline 16) and runs the epilogue, then zeroes the counter for the next launch.
+  // (Round 2 tried this with __threadfence() on both sides: a device-scope release / acquire pair writes back and invalidates
+  // an XCD's L2, 18 us per layer.)
+  unsigned* tickets;
+  size_t part_bytes;
 };
 
 __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
@@ -165,9 +173,10 @@ __device__ __forceinline__ float mish_fast(float x) {
 // Fused epilogue on the summed tile, four consecutive positions of one (sample, channel) per thread: no barrier, the
 // GroupNorm statistics are segment sums inside a wave (a group = cg * lout / 4 consecutive lanes, 16 / 32 / 64).
 // Valid when lout >= 4 and (no GroupNorm or 64 <= cg * lout <= 256); other geometries use tconv_epilogue.
-template <int NW, int TILE>      // NW = number of partial tiles at P (compile time), or 0: `nparts` of them (run time)
+template <int NW, int TILE, bool SC1 = false>   // NW = number of partial tiles at P (compile time), or 0: `nparts` of them (run time);
+                                               // SC1: they were published by other workgroups of THIS launch: loads that bypass the L1
 __device__ __forceinline__ void hs_epilogue4(const TConvArgs& a, const float* P, int pc, int ptile, int tid, int nt,
-                                             int b0, int nparts = 0) {
+                                             int b0, int nparts = 0, size_t part_bytes = 0, const float* part_base = nullptr) {
   if (tid >= TILE / 4) return;
   // four consecutive elements of the [sample][channel][pos] tile: with lout >= 4 they are 4 positions of ONE channel;
   // with lout == 2 (the 512-channel level at horizon 16) they are 2 positions of channel cA and 2 of cA + 1, which lie in
@@ -204,7 +213,24 @@ __device__ __forceinline__ void hs_epilogue4(const TConvArgs& a, const float* P,
     }
   }
   const float* pp = P + (e0 >> a.log2_lout) * pc + l0;     // line (sample, channel) of the partial tile (pc == lout when lout < 8)
-  f32x4 v = *reinterpret_cast<const f32x4*>(pp);
+  f32x4 v;
+  if (SC1) {
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(part_base), 0, (int)part_bytes, 0x00020000);
+    const int o0 = (int)((pp - part_base) * sizeof(float));
+    v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, o0, 0, 16));          // aux 16 = sc1
+    for (int w0 = 1; w0 < nparts; w0 += 8) {
+      f32x4 t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int w = w0 + j < nparts ? w0 + j : 0;
+        t[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, o0 + w * ptile * (int)sizeof(float), 0, 16));
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (w0 + j < nparts) v += t[j];
+    }
+  } else {
+  v = *reinterpret_cast<const f32x4*>(pp);
   if (NW > 0) {
 #pragma unroll
     for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4*>(pp + w * ptile);   // fixed order: deterministic
@@ -223,6 +249,7 @@ __device__ __forceinline__ void hs_epilogue4(const TConvArgs& a, const float* P,
       for (int j = 0; j < 8; ++j)
         if (w0 + j < nparts) v += t[j];
     }
+  }
   }
   v += f32x4{biasA, biasA, two ? biasB : biasA, two ? biasB : biasA};
   if (a.io.pre != nullptr && live)          // dense [B][cout][lout]: the four elements are contiguous in both cases
@@ -406,9 +433,30 @@ __global__ void __launch_bounds__(64 * NW) tconv_hs_kernel(const HsArgs ha) {
       f32x4 v = *reinterpret_cast<const f32x4*>(smem + off);
 #pragma unroll
       for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4*>(smem + w * ha.ptile + off);
-      float* dst = ha.part + ((size_t)(rowtile * a.ntiles + nt) * ha.ksplit + kpart) * ha.ptile + off;
-      *reinterpret_cast<f32x4*>(dst) = v;
+      const size_t poff = ((size_t)(rowtile * a.ntiles + nt) * ha.ksplit + kpart) * ha.ptile + off;
+      if (ha.tickets == nullptr) {
+        *reinterpret_cast<f32x4*>(ha.part + poff) = v;
+      } else {
+        const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(ha.part, 0, (int)ha.part_bytes, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), prs, (int)(poff * sizeof(float)), 0, 16);   // sc1
+      }
     }
+    if (ha.tickets == nullptr) return;               // tconv_hs_reduce_kernel adds the tiles up
+    // ---- ticket: the last workgroup of this (row tile, slab) to publish runs the epilogue -----------------------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores ...
+    __syncthreads();                                  // ... before ONE lane signals
+    int* last = reinterpret_cast<int*>(smem);         // (the partial tiles in LDS are dead: every wave passed the barrier)
+    if (tid == 0) {
+      unsigned* ctr = ha.tickets + (rowtile * a.ntiles + nt);
+      const unsigned t = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int is_last = t == (unsigned)(ha.ksplit - 1);
+      if (is_last) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      *last = is_last;
+    }
+    __syncthreads();
+    if (*last == 0) return;
+    const float* P = ha.part + (size_t)(rowtile * a.ntiles + nt) * ha.ksplit * ha.ptile;
+    hs_epilogue4<0, TILE, true>(a, P, ha.pc, ha.ptile, tid, nt, b0, ha.ksplit, ha.part_bytes, ha.part);
     return;
   }
   if (ha.fast_epi) {
@@ -931,7 +979,7 @@ static int hs_prepare(const adx_tconv_desc* d, const adx_tconv_io* io, HsTile* t
   const size_t epi_bytes = ((size_t)t.nw * ha.ptile + 2 * 16 * t.nf) * sizeof(float);
   if (epi_bytes > t.lds_bytes) t.lds_bytes = epi_bytes;
   ADX_REQUIRE(t.lds_bytes <= kMaxHsLds, "tconv_hs: LDS tile of %zu bytes exceeds %zu", t.lds_bytes, kMaxHsLds);
-  ha.ksplit = 1; ha.cper = a.cin_pad; ha.part = nullptr;
+  ha.ksplit = 1; ha.cper = a.cin_pad; ha.part = nullptr; ha.tickets = nullptr; ha.part_bytes = 0;
   return ADX_OK;
 }
 
@@ -966,6 +1014,12 @@ int tconv_hs_forward(const adx_tconv_desc* d, const adx_tconv_io* io, hipStream_
       ha.ksplit = S;
       ha.cper = (a.ncb / S) * 16;
       ha.part = io->scratch;
+      ha.part_bytes = (size_t)grid * S * ha.ptile * sizeof(float);
+      if (io->tickets != nullptr && grid <= 64 && ha.part_bytes < 0x7FFFFFFFu) {
+        // one launch: the last workgroup of each (row tile, slab) to publish its partial tile adds them up (HsArgs::tickets)
+        ha.tickets = io->tickets;
+        return t.nf == 2 ? hs_launch<2, 8, 4>(ha, grid * S, t.lds_bytes, s) : hs_launch<1, 8, 6>(ha, grid * S, t.lds_bytes, s);
+      }
       // the staged chunk now holds cper channels at most
       rc = t.nf == 2 ? hs_launch<2, 8, 4>(ha, grid * S, t.lds_bytes, s) : hs_launch<1, 8, 6>(ha, grid * S, t.lds_bytes, s);
       if (rc != ADX_OK) return rc;

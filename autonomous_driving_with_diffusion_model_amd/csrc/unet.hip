@@ -391,6 +391,8 @@ static adx_tconv_io make_io(const ConvLayer& L, const float* base, const Act& x0
 // order by the launches it is handed to, so two calls on different streams never share it).
 constexpr size_t kSplitScratchFloats = (size_t)2 << 20;
 static thread_local float* t_split_scratch = nullptr;
+static thread_local uint32_t* t_split_tickets = nullptr;     // 64 words, zero between calls (adx_tconv_io::tickets)
+constexpr size_t kTicketWords = 64;
 
 static int run_conv(const ConvLayer& L, const float* base, const Act& x0, const Act* x1, const float* tbias,
                     int64_t tb_stride, const Act* res, float* y, int64_t y_sb, int64_t y_sc, int64_t y_sl, int rows,
@@ -412,6 +414,7 @@ static adx_tconv_io make_io(const ConvLayer& L, const float* base, const Act& x0
   io.batch = rows;
   io.scratch = t_split_scratch;
   io.scratch_floats = t_split_scratch != nullptr ? (int64_t)kSplitScratchFloats : 0;
+  io.tickets = t_split_tickets;
   return io;
 }
 
@@ -555,7 +558,7 @@ size_t adx_unet_workspace_bytes(const adx_unet* u, int32_t rows) {
   const int dim = u->cfg.dim;
   size_t f = align64((size_t)rows * dim) + align64((size_t)rows * 2 * dim) + align64((size_t)rows * u->sum_c);
   f += act_floats(u, rows) * (size_t)(kRing + u->n_levels);
-  f += kSplitScratchFloats;
+  f += kSplitScratchFloats + kTicketWords;
   return f * sizeof(float);
 }
 
@@ -590,9 +593,13 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
   std::vector<float*> skips(u->n_levels);
   for (auto& p : skips) p = take(af);
   struct ScratchScope {   // handed to every conv of this call through make_io
-    explicit ScratchScope(float* p) { t_split_scratch = p; }
-    ~ScratchScope() { t_split_scratch = nullptr; }
-  } scratch_scope(take(kSplitScratchFloats));
+    ScratchScope(float* p, uint32_t* t) { t_split_scratch = p; t_split_tickets = t; }
+    ~ScratchScope() { t_split_scratch = nullptr; t_split_tickets = nullptr; }
+  };
+  float* const split_scratch = take(kSplitScratchFloats);
+  static const bool tickets_on = [] { const char* e = getenv("ADX_TCONV_NO_TICKET"); return !(e != nullptr && e[0] == '1'); }();
+  uint32_t* const split_tickets = reinterpret_cast<uint32_t*>(take(kTicketWords));
+  ScratchScope scratch_scope(split_scratch, tickets_on ? split_tickets : nullptr);
 
   int rc = ADX_OK;
   if (io->time_bias != nullptr) {

@@ -245,7 +245,9 @@ class TemporalMapUnet(nn.Module):
     def _workspace(self, rows: int, device):
         nbytes = L.lib().adx_unet_workspace_bytes(self._native(), rows)
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            # zero-filled once: the workspace holds the ticket words of the split reductions (adx_tconv_io::tickets), which
+            # every call leaves zero again
+            self._ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)
         return self._ws
 
     @torch.no_grad()

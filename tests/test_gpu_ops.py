@@ -74,6 +74,14 @@ def test_conv1d_block_split_reduction_tiny_batch(c0, c1, cout, L, B):
     close(y_split.cpu(), y_plain.cpu(), 4e-6)
     small = torch.full((1024,), float("nan"), device=DEV)            # too small for any split: falls back to one launch
     assert torch.equal(_ops().tconv(x0.to(DEV), w.to(DEV), b.to(DEV), scratch=small, **kw), y_plain)
+    # with ticket words the last workgroup to publish its partial tile adds them up in the same launch: same sums in the
+    # same order as the reduce launch, and the words are zero again afterwards (three calls in a row on the same words)
+    tickets = torch.zeros(64, dtype=torch.int32, device=DEV)
+    for _ in range(3):
+        scratch.fill_(float("nan"))
+        y_ticket = _ops().tconv(x0.to(DEV), w.to(DEV), b.to(DEV), scratch=scratch, tickets=tickets, **kw)
+        assert torch.equal(y_ticket, y_split)
+        assert int(tickets.abs().sum()) == 0
 
 
 @pytest.mark.parametrize("c0,c1,cout,L,B", [(7, 0, 48, 32, 3), (48, 0, 48, 32, 2), (96, 96, 48, 16, 3), (192, 0, 192, 8, 2),

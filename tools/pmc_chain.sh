@@ -26,7 +26,7 @@ for d in sorted(glob.glob("gpurun_out/pmc_chain[ABC]")):
     if not f: print(d, "no csv"); continue
     acc = {}
     for r in csv.DictReader(open(f[0])):
-        for key in ("tconv_chain_kernel", "tconv_hsd_kernel"):
+        for key in ("tconv_chain_kernel", "tconv_hsd_kernel", "tconv_hs_kernel<2", "tconv_hs_kernel<1"):
             if key in r["Kernel_Name"]:
                 acc.setdefault((key, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
     for k, v in sorted(acc.items()):
