@@ -437,7 +437,8 @@ def launch_ranks(n: int) -> int:
     import socket
     import subprocess
     have = visible_gpu_count()                # no torch.cuda / HIP call in the parent: it forks the ranks
-    if have < n and "--launch-check" not in sys.argv and os.environ.get("ADX_BENCH_SAME_DEVICE") != "1":
+    # (0 = could not tell -- no visibility variable, no readable KFD topology: start the ranks and let them find out)
+    if 0 < have < n and "--launch-check" not in sys.argv and os.environ.get("ADX_BENCH_SAME_DEVICE") != "1":
         print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
         return 2
     with socket.socket() as so:
