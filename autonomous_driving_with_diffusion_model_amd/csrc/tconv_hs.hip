@@ -316,9 +316,14 @@ __global__ void __launch_bounds__(64 * NW) tconv_hs_kernel(const HsArgs ha) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { accm[j][i] = 0.f; accx[j][i] = 0.f; }
 
-  // weight image: [32-channel tile][K-step][plane][lane] x 16 bytes
-  const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(a.io.packed_w) + (size_t)nt * NF * a.nkb * 128 + lane;
-  const size_t tile_stride = (size_t)a.nkb * 128;
+  // weight image: [32-channel tile][K-step][plane][lane] x 16 bytes.  Read through a buffer descriptor over this workgroup's
+  // NF tiles: the lane supplies 16 * lane, the (wave-uniform) K-step is an SGPR offset -- one instruction per 16-byte load
+  // and no per-lane 64-bit address arithmetic in the K loop (round 3: at this occupancy a wave's time is its instruction
+  // count; the loop went from ~60 to ~30 instructions per step)
+  const int tile_bytes = a.nkb * 2048;
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.io.packed_w) + (size_t)nt * NF * a.nkb * 512, 0, NF * tile_bytes, 0x00020000);
+  const int lane16 = lane * 16;
   u32x4 wq[PF][NF][2];
 
   for (int c0 = cbeg; c0 < cend; c0 += a.ck) {
@@ -332,11 +337,11 @@ __global__ void __launch_bounds__(64 * NW) tconv_hs_kernel(const HsArgs ha) {
     while (lcb >= ncbc) { lcb -= ncbc; ++ltap; }
     auto issue = [&](u32x4 (&dst)[NF][2]) {
       const int tp = min(ltap, a.taps - 1);  // past-the-end slots re-read a valid block and are never used
-      const u32x4* src = wp + (size_t)(tp * a.ncb + cb0 + lcb) * 128;
+      const int so = (tp * a.ncb + cb0 + lcb) * 2048;          // wave-uniform
 #pragma unroll
       for (int j = 0; j < NF; ++j) {
-        dst[j][0] = src[j * tile_stride];
-        dst[j][1] = src[j * tile_stride + 64];
+        dst[j][0] = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, so + j * tile_bytes, 0);
+        dst[j][1] = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, so + j * tile_bytes + 1024, 0);
       }
       lcb += NW;
       while (lcb >= ncbc) { lcb -= ncbc; ++ltap; }
@@ -354,18 +359,24 @@ __global__ void __launch_bounds__(64 * NW) tconv_hs_kernel(const HsArgs ha) {
     while (ccb >= ncbc) { ccb -= ncbc; ++ctap; }
     u32x4 ah, al;
     const bool kind0 = a.kind == 0;
+    // the tap of a step is wave-uniform, so the lane's LDS row is recomputed only when it changes (conv: ip = l stride + tap -
+    // pad; ConvTranspose1d, stride 2: o = 2 i - pad + tap  <=>  i = (o + pad - tap) / 2 when that is even)
+    auto row_of = [&](int tap) {
+      const int vt = l + a.pad - tap;
+      const int ip = kind0 ? l * a.stride + tap - a.pad : vt >> 1;
+      const bool ok = ((unsigned)ip < (unsigned)a.lin) & (kind0 | ((vt & 1) == 0)) & (tap < a.taps);
+      return cells + (ok ? bl * a.lin + ip : zrow) * pitch + 2 * kg;
+    };
+    const u32x4* rowp = row_of(ctap);
     auto fetch_a = [&]() {     // fragment of step (ctap, ccb); then advance to this wave's next step
-      // branch-free (a branch per K-step costs more than the MFMAs it guards): conv: ip = l stride + tap - pad;
-      // ConvTranspose1d, stride 2: o = 2 i - pad + tap  <=>  i = (o + pad - tap) / 2 when that is even
-      const int vt = l + a.pad - ctap;
-      const int ip = kind0 ? l * a.stride + ctap - a.pad : vt >> 1;
-      const bool ok = ((unsigned)ip < (unsigned)a.lin) & (kind0 | ((vt & 1) == 0)) & (ctap < a.taps);
-      const int row = ok ? bl * a.lin + ip : zrow;
-      const u32x4* xp = cells + row * pitch + 4 * ccb + 2 * kg;
+      const u32x4* xp = rowp + 4 * ccb;
       ah = xp[0];
       al = xp[1];
       ccb += NW;
-      while (ccb >= ncbc) { ccb -= ncbc; ++ctap; }
+      if (ccb >= ncbc) {       // uniform
+        do { ccb -= ncbc; ++ctap; } while (ccb >= ncbc);
+        rowp = row_of(ctap);
+      }
     };
     if (nbw > 0) fetch_a();
     auto compute = [&](const u32x4 (&w)[NF][2]) {
