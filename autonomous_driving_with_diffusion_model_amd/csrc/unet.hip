@@ -584,6 +584,9 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
   float* ws = (float*)workspace;
   size_t off = 0;
   auto take = [&](size_t n) { float* p = ws + off; off += align64(n); return p; };
+  // the ticket words come FIRST: their place must not depend on `rows` (they are zero between calls, whatever batch the
+  // caller's workspace was last used with)
+  uint32_t* const split_tickets = reinterpret_cast<uint32_t*>(take(kTicketWords));
   float* te = take((size_t)rows * dim);
   float* mc = take((size_t)rows * 2 * dim);
   float* tb = take((size_t)rows * u->sum_c);
@@ -598,7 +601,6 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
   };
   float* const split_scratch = take(kSplitScratchFloats);
   static const bool tickets_on = [] { const char* e = getenv("ADX_TCONV_NO_TICKET"); return !(e != nullptr && e[0] == '1'); }();
-  uint32_t* const split_tickets = reinterpret_cast<uint32_t*>(take(kTicketWords));
   ScratchScope scratch_scope(split_scratch, tickets_on ? split_tickets : nullptr);
 
   int rc = ADX_OK;
