@@ -108,6 +108,8 @@ _SIGS = {
     "adx_trajpred_destroy": (None, [vp]),
     "adx_trajpred_num_params": (i32, [vp]),
     "adx_trajpred_packed_bytes": (C.c_size_t, [vp]),
+    "adx_trajpred_scratch_bytes": (C.c_size_t, [vp, i32, i32]),
+    "adx_trajpred_set_scratch": (i32, [vp, vp, C.c_size_t]),
     "adx_trajpred_pack": (i32, [vp, C.POINTER(vp), i32, vp, vp, vp]),
     "adx_trajpred_forward": (i32, [vp, vp, vp, i64, i64, vp, vp, i32, i32, vp]),
     "adx_trajpred_backward": (i32, [vp, vp, vp, i64, i64, vp, vp, vp, i32, i32, vp]),

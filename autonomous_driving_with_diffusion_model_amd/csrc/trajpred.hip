@@ -5,7 +5,7 @@
 //   used at modeling/temporal.py:238-241 and interact.py:158-160; its input gradient is what
 //   GuidanceLoss asks autograd for (control/guidance.py:47-50).
 //
-// T = horizon-1 <= 31 rows x 64 features per sample is a 8 KB tile, so this is latency-bound
+// T = horizon-1 <= 31 rows x 64 features per sample is a 8 KB tile (32..63 rows: see kMaxTP), so this is latency-bound
 // small-matrix work: plain fp32 FMA with the weight read coalesced (K-major copy for x @ W^T,
 // PyTorch layout for the transposed products of the backward pass) and the activation operand
 // broadcast from LDS, 8 rows per thread.  The backward kernel saves nothing from the forward:
@@ -23,7 +23,8 @@ constexpr int E = 64;        // hidden_dim (must equal MODEL.DIM)
 constexpr int NH = 4;        // heads
 constexpr int DH = 16;       // head dim
 constexpr int FF = 256;      // dim_feedforward
-constexpr int TP = 32;       // padded rows
+constexpr int kMaxTP = 64;   // padded rows: the kernels are instantiated for TP = 32 (T <= 31, everything in LDS) and TP = 64
+                             // (T <= 63: QKV, the attention probabilities and the feed-forward tile live in a global scratch)
 constexpr int NT = 1024;     // threads per workgroup (one workgroup per sample; LDS allows one per CU anyway: 4 waves per SIMD
                              // hide the latencies of the ~60 dependent phases a single wave per SIMD exposed)
 constexpr int NL = 2;        // encoder layers
@@ -82,7 +83,7 @@ __global__ void transpose_copy_kernel(const float* __restrict__ w, float* __rest
 // small GEMMs on an LDS-resident [TP][K] tile
 // out[t][n] = sum_k in[t][k] * wt[k][n] (+ bias[n]);  wt is K-major in global memory
 // RT = rows per thread: chosen per call so that N * (TP / RT) items fill the workgroup (N = 64: RT 2; 192, 256: RT 8)
-template <bool ACCUM, int RT>
+template <int TP, bool ACCUM, int RT>
 __device__ __forceinline__ void mm_fwd(float* out, int ldo, const float* in, int ldi, const float* __restrict__ wt,
                                        const float* __restrict__ bias, int K, int N, int tid) {
   for (int item = tid; item < N * (TP / RT); item += NT) {
@@ -175,22 +176,28 @@ __device__ __forceinline__ void colsum_acc(float* gb, int N, FA fa, int T, int t
 // LDS plan (floats).  X: layer input; QKV; P: attention probs [NH][TP][TP]; O: attention output,
 // later reused; Y: pre-norm sums / scratch; H1: norm1 output; F: feed-forward pre-activation;
 // XH1/XH2: normalised values for the LayerNorm backward; small per-row vectors at the end.
+template <int TP>
 struct Lds {
   float* X; float* QKV; float* P; float* O; float* Y; float* H1; float* F; float* XH1; float* XH2; float* R1; float* R2; float* R3;
   float* INb;   // NL + 1 saved [TP][E] tiles (layer inputs + gradient scratch)
   __device__ __forceinline__ float* IN(int i) const { return INb + i * TP * E; }
 };
-constexpr int kLdsFloats = TP * E * 6 + TP * 3 * E + NH * TP * TP + TP * FF + 3 * TP + (NL + 1) * TP * E;
+// TP = 32: everything in LDS (148 KB).  TP = 64: the nine [TP][E] tiles and the row vectors (145 KB); QKV, P and F (176 KB per
+// sample) in global memory, where one workgroup's writes reach its own later reads through __syncthreads() like LDS ones.
+template <int TP> constexpr int big_floats() { return TP * 3 * E + NH * TP * TP + TP * FF; }
+template <int TP> constexpr int lds_floats() { return TP * E * 6 + 3 * TP + (NL + 1) * TP * E + (TP == 32 ? big_floats<TP>() : 0); }
 
-__device__ __forceinline__ Lds carve(float* s) {
-  Lds l;
+template <int TP>
+__device__ __forceinline__ Lds<TP> carve(float* s, float* big) {
+  Lds<TP> l;
+  if (TP == 32) { big = s; s += big_floats<TP>(); }
+  l.QKV = big; big += TP * 3 * E;
+  l.P = big; big += NH * TP * TP;
+  l.F = big;
   l.X = s; s += TP * E;
-  l.QKV = s; s += TP * 3 * E;
-  l.P = s; s += NH * TP * TP;
   l.O = s; s += TP * E;
   l.Y = s; s += TP * E;
   l.H1 = s; s += TP * E;
-  l.F = s; s += TP * FF;
   l.XH1 = s; s += TP * E;
   l.XH2 = s; s += TP * E;
   l.R1 = s; s += TP;
@@ -201,6 +208,7 @@ __device__ __forceinline__ Lds carve(float* s) {
 }
 
 // x0 = input_proj(action) + pos_emb(arange(T)) + time_embed   (helpers.py:52-57)
+template <int TP>
 __device__ __forceinline__ void embed_rows(float* X, const float* __restrict__ act, int64_t act_stride,
                                            const float* __restrict__ te, const float* __restrict__ P,
                                            const TPLayout& L, int T, int tid) {
@@ -250,11 +258,12 @@ __device__ __forceinline__ Drop make_drop(uint32_t seed_lo, uint32_t seed_hi, ui
 }
 
 // one encoder layer, forward; leaves every intermediate the backward needs in LDS
-__device__ __forceinline__ void layer_forward(const Lds& l, const float* __restrict__ P, const TPLayer& y, int T,
+template <int TP>
+__device__ __forceinline__ void layer_forward(const Lds<TP>& l, const float* __restrict__ P, const TPLayer& y, int T,
                                               int tid, const Drop& dr, int li) {
   const uint32_t k_att = drop_site(dr, 4 * li + 0), k_d1 = drop_site(dr, 4 * li + 1), k_in = drop_site(dr, 4 * li + 2),
                  k_d2 = drop_site(dr, 4 * li + 3);
-  mm_fwd<false, 8>(l.QKV, 3 * E, l.X, E, P + y.w_in_t, P + y.b_in, E, 3 * E, tid);
+  mm_fwd<TP, false, 8>(l.QKV, 3 * E, l.X, E, P + y.w_in_t, P + y.b_in, E, 3 * E, tid);
   __syncthreads();
   // scores + softmax: one thread per (head, query row)
   for (int idx = tid; idx < NH * TP; idx += NT) {
@@ -296,13 +305,13 @@ __device__ __forceinline__ void layer_forward(const Lds& l, const float* __restr
   }
   __syncthreads();
   // Y = X + dropout1(out_proj(O))   (H1 is free until the LayerNorm below writes it)
-  mm_fwd<false, 2>(l.H1, E, l.O, E, P + y.w_out_t, P + y.b_out, E, E, tid);
+  mm_fwd<TP, false, 2>(l.H1, E, l.O, E, P + y.w_out_t, P + y.b_out, E, E, tid);
   __syncthreads();
   for (int idx = tid; idx < TP * E; idx += NT) l.Y[idx] = l.X[idx] + l.H1[idx] * drop_mul(dr, k_d1, (uint32_t)idx);
   __syncthreads();
   layer_norm_rows(l.H1, l.Y, E, P + y.g1, P + y.be1, l.XH1, l.R1, T, tid);
   __syncthreads();
-  mm_fwd<false, 8>(l.F, FF, l.H1, E, P + y.w1_t, P + y.b1, E, FF, tid);
+  mm_fwd<TP, false, 8>(l.F, FF, l.H1, E, P + y.w1_t, P + y.b1, E, FF, tid);
   __syncthreads();
   // Y = H1 + linear2(silu(F))
   for (int idx = tid; idx < TP * E; idx += NT) l.Y[idx] = l.H1[idx];
@@ -355,7 +364,8 @@ __device__ __forceinline__ void layer_forward(const Lds& l, const float* __restr
 // d(layer input) on exit.  Requires layer_forward() to have just run on this layer's input.
 // G != nullptr (training): parameter gradients are accumulated into the gradient image G, which has the packed
 // buffer's layout (PyTorch-layout slots); Xin = this layer's input tile.
-__device__ __forceinline__ void layer_backward(const Lds& l, float* D, const float* __restrict__ P, const TPLayer& y,
+template <int TP>
+__device__ __forceinline__ void layer_backward(const Lds<TP>& l, float* D, const float* __restrict__ P, const TPLayer& y,
                                                int T, int tid, float* G, const float* Xin, const Drop& dr, int li) {
   const uint32_t k_att = drop_site(dr, 4 * li + 0), k_d1 = drop_site(dr, 4 * li + 1), k_in = drop_site(dr, 4 * li + 2),
                  k_d2 = drop_site(dr, 4 * li + 3);
@@ -409,7 +419,7 @@ __device__ __forceinline__ void layer_backward(const Lds& l, float* D, const flo
     colsum_acc(G + y.b1, FF, [&](int t, int n) { return l.F[t * FF + n]; }, T, tid);
   }
   // dH1 = dy2 + dF @ W1   (W1 is [256][64]: K = 256 rows, N = 64 contiguous)
-  mm_fwd<true, 2>(l.Y, E, l.F, FF, P + y.w1, nullptr, FF, E, tid);
+  mm_fwd<TP, true, 2>(l.Y, E, l.F, FF, P + y.w1, nullptr, FF, E, tid);
   __syncthreads();
   if (G != nullptr) {  // norm1 affine
     for (int i = tid; i < E; i += NT) {
@@ -430,7 +440,7 @@ __device__ __forceinline__ void layer_backward(const Lds& l, float* D, const flo
     colsum_acc(G + y.b_out, E, [&](int t, int n) { return l.XH2[t * E + n]; }, T, tid);
   }
   // dO = dsa @ Wout  (Wout [64][64], row j = output feature)
-  mm_fwd<false, 2>(l.Y, E, l.XH2, E, P + y.w_out, nullptr, E, E, tid);    // Y = dO
+  mm_fwd<TP, false, 2>(l.Y, E, l.XH2, E, P + y.w_out, nullptr, E, E, tid);    // Y = dO
   __syncthreads();
   // dP[h][t][s] = sum_d dO[t][hd] V[s][hd];  dS = P * (dP - sum_s dP P), written into F (dead by now)
   for (int idx = tid; idx < NH * TP; idx += NT) {
@@ -480,9 +490,9 @@ __device__ __forceinline__ void layer_backward(const Lds& l, float* D, const flo
     colsum_acc(G + y.b_in + 2 * E, E, [&](int t, int n) { return l.XH1[t * E + n]; }, T, tid);
   }
   // dX = d(y1) + [dq dk dv] @ Win   (Win [192][64]); D already holds d(y1)
-  mm_fwd<true, 2>(D, E, l.O, E, P + y.w_in, nullptr, E, E, tid);
-  mm_fwd<true, 2>(D, E, l.H1, E, P + y.w_in + E * E, nullptr, E, E, tid);
-  mm_fwd<true, 2>(D, E, l.XH1, E, P + y.w_in + 2 * E * E, nullptr, E, E, tid);
+  mm_fwd<TP, true, 2>(D, E, l.O, E, P + y.w_in, nullptr, E, E, tid);
+  mm_fwd<TP, true, 2>(D, E, l.H1, E, P + y.w_in + E * E, nullptr, E, E, tid);
+  mm_fwd<TP, true, 2>(D, E, l.XH1, E, P + y.w_in + 2 * E * E, nullptr, E, E, tid);
   __syncthreads();
 }
 
@@ -505,6 +515,7 @@ struct TrajArgs {
   float* loss;               // [B] or null
   // training: gradient image with the packed buffer's layout (atomically accumulated) and d(time_embed) [B][64]
   float* G; float* dte;
+  float* big;                // TP = 64: [B][big_floats<64>()] scratch for QKV / P / F (unused at TP = 32)
   // training: dropout (thresh = p * 2^32, 0 = off)
   uint32_t drop_thresh, seed_lo, seed_hi; float drop_scale;
 };
@@ -513,21 +524,23 @@ struct TrajArgs {
 // The normalised values and 1/std of the final norm go to their own places (the IN(NL) tile, which the backward pass
 // then turns into d(layer output) in place, and R3): the last layer's intermediates stay intact, so its backward needs
 // no recomputation.
-__device__ __forceinline__ void head_forward(const Lds& l, const float* __restrict__ P, const TPLayout& L, int T,
+template <int TP>
+__device__ __forceinline__ void head_forward(const Lds<TP>& l, const float* __restrict__ P, const TPLayout& L, int T,
                                              int tid) {
   layer_norm_rows(l.Y, l.X, E, P + L.gf, P + L.bef, l.IN(NL), l.R3, T, tid);
   __syncthreads();
 }
 
+template <int TP>
 __global__ void __launch_bounds__(NT) trajpred_forward_kernel(const TrajArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const Lds l = carve(smem);
+  const Lds<TP> l = carve<TP>(smem, a.big + (size_t)blockIdx.x * big_floats<TP>());
   const int b = blockIdx.x, tid = threadIdx.x;
-  embed_rows(l.X, a.action + (int64_t)b * a.act_sb, a.act_st, a.te + (int64_t)b * E, a.P, a.L, a.T, tid);
+  embed_rows<TP>(l.X, a.action + (int64_t)b * a.act_sb, a.act_st, a.te + (int64_t)b * E, a.P, a.L, a.T, tid);
   __syncthreads();
   const Drop dr = make_drop(a.seed_lo, a.seed_hi, a.drop_thresh, a.drop_scale, b);
-  for (int li = 0; li < NL; ++li) layer_forward(l, a.P, a.L.layer[li], a.T, tid, dr, li);
-  head_forward(l, a.P, a.L, a.T, tid);
+  for (int li = 0; li < NL; ++li) layer_forward<TP>(l, a.P, a.L.layer[li], a.T, tid, dr, li);
+  head_forward<TP>(l, a.P, a.L, a.T, tid);
   const int od = a.L.out_dim;
   for (int idx = tid; idx < a.T * od; idx += NT) {
     const int t = idx / od, j = idx - t * od;
@@ -539,23 +552,24 @@ __global__ void __launch_bounds__(NT) trajpred_forward_kernel(const TrajArgs a) 
 
 // forward with every layer's input kept (IN(li)); on return the LAST layer's intermediates and the head's normalised
 // output (l.Y), normalised values (IN(NL)) and 1/std (R3) are in LDS
-__device__ __forceinline__ void forward_keep(const Lds& l, const TrajArgs& a, int b, int tid, const Drop& dr) {
+template <int TP>
+__device__ __forceinline__ void forward_keep(const Lds<TP>& l, const TrajArgs& a, int b, int tid, const Drop& dr) {
   const int T = a.T;
-  embed_rows(l.X, a.action + (int64_t)b * a.act_sb, a.act_st, a.te + (int64_t)b * E, a.P, a.L, T, tid);
+  embed_rows<TP>(l.X, a.action + (int64_t)b * a.act_sb, a.act_st, a.te + (int64_t)b * E, a.P, a.L, T, tid);
   __syncthreads();
   for (int li = 0; li < NL; ++li) {
     for (int idx = tid; idx < TP * E; idx += NT) l.IN(li)[idx] = l.X[idx];
     __syncthreads();
-    layer_forward(l, a.P, a.L.layer[li], T, tid, dr, li);
+    layer_forward<TP>(l, a.P, a.L.layer[li], T, tid, dr, li);
   }
-  head_forward(l, a.P, a.L, T, tid);
+  head_forward<TP>(l, a.P, a.L, T, tid);
 }
 
 // shared by the backward and the fused guidance kernels, after forward_keep(): back-propagation of d(out) [T][out_dim]
 // (given by `dout(t, j)`) down to d(action) [T][3] in l.O.  The last layer is back-propagated from the intermediates the
 // forward left; the layers below are recomputed from their saved inputs first.
-template <typename DOut>
-__device__ __forceinline__ void backward_core(const Lds& l, const TrajArgs& a, int b, int tid, const Drop& dr, DOut dout) {
+template <int TP, typename DOut>
+__device__ __forceinline__ void backward_core(const Lds<TP>& l, const TrajArgs& a, int b, int tid, const Drop& dr, DOut dout) {
   const float* P = a.P;
   const TPLayout& L = a.L;
   const int T = a.T, od = L.out_dim;
@@ -600,9 +614,9 @@ __device__ __forceinline__ void backward_core(const Lds& l, const TrajArgs& a, i
     if (li != NL - 1) {
       for (int idx = tid; idx < TP * E; idx += NT) l.X[idx] = l.IN(li)[idx];
       __syncthreads();
-      layer_forward(l, P, L.layer[li], T, tid, dr, li);     // recompute this layer's internals (same masks)
+      layer_forward<TP>(l, P, L.layer[li], T, tid, dr, li);     // recompute this layer's internals (same masks)
     }
-    layer_backward(l, D, P, L.layer[li], T, tid, G, l.IN(li), dr, li);
+    layer_backward<TP>(l, D, P, L.layer[li], T, tid, G, l.IN(li), dr, li);
     for (int idx = tid; idx < TP * E; idx += NT)
       if ((idx >> 6) >= T) D[idx] = 0.f;
     __syncthreads();
@@ -633,15 +647,16 @@ __device__ __forceinline__ void backward_core(const Lds& l, const TrajArgs& a, i
   __syncthreads();
 }
 
+template <int TP>
 __global__ void __launch_bounds__(NT) trajpred_backward_kernel(const TrajArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const Lds l = carve(smem);
+  const Lds<TP> l = carve<TP>(smem, a.big + (size_t)blockIdx.x * big_floats<TP>());
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* g = a.gout + (int64_t)b * a.gout_sb;
   const int64_t gst = a.gout_st;
   const Drop dr = make_drop(a.seed_lo, a.seed_hi, a.drop_thresh, a.drop_scale, b);
-  forward_keep(l, a, b, tid, dr);
-  backward_core(l, a, b, tid, dr, [&](int t, int j) { return g[(int64_t)t * gst + j]; });
+  forward_keep<TP>(l, a, b, tid, dr);
+  backward_core<TP>(l, a, b, tid, dr, [&](int t, int j) { return g[(int64_t)t * gst + j]; });
   if (a.gact != nullptr)
     for (int idx = tid; idx < a.T * IN_DIM; idx += NT) {
       const int t = idx / IN_DIM, i = idx - t * IN_DIM;
@@ -653,9 +668,10 @@ __global__ void __launch_bounds__(NT) trajpred_backward_kernel(const TrajArgs a)
 //   x = cat([0; state_pred(action[:-1])], action);  choose h* by TargetGuidance's rule;
 //   g_x = 2 (x[h*, :2] - target) at (h*, :2);  g_a = d(state)/d(action)^T g_x[1:, :4];
 //   x[:, :4] -= scale/15 * std * g_x[:, :4];  x[:, 4:] -= scale * std * g_a;  clip(-1, 1)
+template <int TP>
 __global__ void __launch_bounds__(NT) guided_output_kernel(const TrajArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const Lds l = carve(smem);
+  const Lds<TP> l = carve<TP>(smem, a.big + (size_t)blockIdx.x * big_floats<TP>());
   __shared__ float st[TP + 1][4];
   __shared__ int hstar;
   __shared__ float gxy[2];
@@ -664,7 +680,7 @@ __global__ void __launch_bounds__(NT) guided_output_kernel(const TrajArgs a) {
   const float* act = a.action + (int64_t)b * a.act_sb;
   // ONE forward (layer inputs kept) serves both the state rows and the gradient below
   const Drop dr_off{0u, 0u, 1.f};      // guidance runs the state head in eval mode
-  forward_keep(l, a, b, tid, dr_off);
+  forward_keep<TP>(l, a, b, tid, dr_off);
   for (int idx = tid; idx < H * od; idx += NT) {
     const int h = idx / od, j = idx - h * od;
     float acc = 0.f;
@@ -701,7 +717,7 @@ __global__ void __launch_bounds__(NT) guided_output_kernel(const TrajArgs a) {
   const float g0 = gxy[0], g1 = gxy[1];
   // gradient w.r.t. the action through the state path (row h* of x is state row h*-1; row 0 is the dummy zero)
   if (hs > 0) {
-    backward_core(l, a, b, tid, dr_off, [&](int t, int j) { return (t == hs - 1 && j < 2) ? (j == 0 ? g0 : g1) : 0.f; });
+    backward_core<TP>(l, a, b, tid, dr_off, [&](int t, int j) { return (t == hs - 1 && j < 2) ? (j == 0 ? g0 : g1) : 0.f; });
   } else {
     for (int idx = tid; idx < TP * IN_DIM; idx += NT) l.O[idx] = 0.f;
     __syncthreads();
@@ -730,6 +746,8 @@ using namespace adx;
 struct adx_trajpred {
   TPLayout L;
   bool packed = false;
+  float* big = nullptr;        // T >= 32: per-sample scratch of the 64-row kernels (adx_trajpred_set_scratch; caller-owned)
+  size_t big_bytes = 0;
 };
 
 extern "C" {
@@ -742,6 +760,19 @@ int adx_trajpred_create(int32_t out_dim, adx_trajpred** out) {
   return ADX_OK;
 }
 void adx_trajpred_destroy(adx_trajpred* t) { delete t; }
+
+// Sequences of 32..63 rows run the 64-row kernels, which keep QKV, the attention probabilities and the feed-forward tile
+// of every sample in global memory: the caller lends that scratch (no initialisation needed; it must stay alive and
+// unshared while launches that use it are in flight).  0 bytes for T <= 31.
+size_t adx_trajpred_scratch_bytes(const adx_trajpred* t, int32_t batch, int32_t T) {
+  return (t && T >= 32 && batch > 0) ? (size_t)batch * big_floats<64>() * sizeof(float) : 0;
+}
+int adx_trajpred_set_scratch(adx_trajpred* t, void* scratch, size_t bytes) {
+  ADX_REQUIRE(t != nullptr && (scratch != nullptr || bytes == 0), "adx_trajpred_set_scratch: null argument");
+  t->big = (float*)scratch;
+  t->big_bytes = bytes;
+  return ADX_OK;
+}
 int adx_trajpred_num_params(const adx_trajpred* t) { return t ? 2 + NL * 12 + 2 + 2 : 0; }
 size_t adx_trajpred_packed_bytes(const adx_trajpred* t) { return t ? (size_t)t->L.total * sizeof(float) : 0; }
 
@@ -807,8 +838,8 @@ static int tp_common(adx_trajpred* t, const void* packed, int batch, int T, Traj
     set_error("trajpred: weights were never packed (call adx_trajpred_pack first)");
     return ADX_ERR_STATE;
   }
-  ADX_REQUIRE(batch >= 1 && T >= 1 && T < TP, "trajpred: batch %d / sequence length %d unsupported (T <= %d)", batch, T,
-              TP - 1);
+  ADX_REQUIRE(batch >= 1 && T >= 1 && T < kMaxTP, "trajpred: batch %d / sequence length %d unsupported (T <= %d)", batch, T,
+              kMaxTP - 1);
   memset(a, 0, sizeof(*a));
   a->P = (const float*)packed;
   a->L = t->L;
@@ -816,15 +847,39 @@ static int tp_common(adx_trajpred* t, const void* packed, int batch, int T, Traj
   a->T = T;
   static bool attr_set = false;
   if (!attr_set) {
-    const void* fns[3] = {reinterpret_cast<const void*>(&trajpred_forward_kernel),
-                          reinterpret_cast<const void*>(&trajpred_backward_kernel),
-                          reinterpret_cast<const void*>(&guided_output_kernel)};
-    for (const void* f : fns)
-      ADX_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsFloats * sizeof(float))));
+    const void* f32s[3] = {reinterpret_cast<const void*>(&trajpred_forward_kernel<32>),
+                           reinterpret_cast<const void*>(&trajpred_backward_kernel<32>),
+                           reinterpret_cast<const void*>(&guided_output_kernel<32>)};
+    const void* f64s[3] = {reinterpret_cast<const void*>(&trajpred_forward_kernel<64>),
+                           reinterpret_cast<const void*>(&trajpred_backward_kernel<64>),
+                           reinterpret_cast<const void*>(&guided_output_kernel<64>)};
+    for (const void* f : f32s)
+      ADX_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats<32>() * sizeof(float))));
+    for (const void* f : f64s)
+      ADX_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats<64>() * sizeof(float))));
     attr_set = true;
+  }
+  if (T >= 32) {
+    const size_t need = adx_trajpred_scratch_bytes(t, batch, T);
+    if (t->big == nullptr || t->big_bytes < need) {
+      set_error("trajpred: sequence length %d (32..63 rows) needs %zu bytes of scratch for %d samples, %zu were lent "
+                "(adx_trajpred_scratch_bytes / adx_trajpred_set_scratch)", T, need, batch, t->big_bytes);
+      return ADX_ERR_STATE;
+    }
+    a->big = t->big;
   }
   return ADX_OK;
 }
+
+// the 32-row instantiation when the sequence fits it, the 64-row one otherwise
+#define ADX_TP_LAUNCH(kernel, a, batch, s)                                                                         \
+  do {                                                                                                             \
+    if ((a).T < 32)                                                                                                \
+      kernel<32><<<dim3(batch), dim3(NT), lds_floats<32>() * sizeof(float), (s)>>>(a);                             \
+    else                                                                                                           \
+      kernel<64><<<dim3(batch), dim3(NT), lds_floats<64>() * sizeof(float), (s)>>>(a);                             \
+    ADX_LAUNCH_CHECK();                                                                                            \
+  } while (0)
 
 int adx_trajpred_forward(adx_trajpred* t, const void* packed, const float* action, int64_t act_sb, int64_t act_st,
                          const float* time_embed, float* out, int32_t batch, int32_t T, adx_stream stream) {
@@ -834,8 +889,7 @@ int adx_trajpred_forward(adx_trajpred* t, const void* packed, const float* actio
   ADX_REQUIRE(action && time_embed && out, "adx_trajpred_forward: null tensor");
   a.action = action; a.act_sb = act_sb; a.act_st = act_st; a.te = time_embed;
   a.out = out; a.out_sb = (int64_t)T * t->L.out_dim; a.out_st = t->L.out_dim;
-  trajpred_forward_kernel<<<dim3(batch), dim3(NT), kLdsFloats * sizeof(float), (hipStream_t)stream>>>(a);
-  ADX_LAUNCH_CHECK();
+  ADX_TP_LAUNCH(trajpred_forward_kernel, a, batch, (hipStream_t)stream);
   return ADX_OK;
 }
 
@@ -852,8 +906,7 @@ int adx_trajpred_forward_train(adx_trajpred* t, const void* packed, const float*
   ADX_REQUIRE(action && time_embed && out, "adx_trajpred_forward_train: null tensor");
   a.action = action; a.act_sb = act_sb; a.act_st = act_st; a.te = time_embed;
   a.out = out; a.out_sb = (int64_t)T * t->L.out_dim; a.out_st = t->L.out_dim;
-  trajpred_forward_kernel<<<dim3(batch), dim3(NT), kLdsFloats * sizeof(float), (hipStream_t)stream>>>(a);
-  ADX_LAUNCH_CHECK();
+  ADX_TP_LAUNCH(trajpred_forward_kernel, a, batch, (hipStream_t)stream);
   return ADX_OK;
 }
 
@@ -867,8 +920,7 @@ int adx_trajpred_backward(adx_trajpred* t, const void* packed, const float* acti
   a.action = action; a.act_sb = act_sb; a.act_st = act_st; a.te = time_embed;
   a.gout = grad_out; a.gout_sb = (int64_t)T * t->L.out_dim; a.gout_st = t->L.out_dim;
   a.gact = grad_action; a.gact_sb = (int64_t)T * IN_DIM; a.gact_st = IN_DIM;
-  trajpred_backward_kernel<<<dim3(batch), dim3(NT), kLdsFloats * sizeof(float), (hipStream_t)stream>>>(a);
-  ADX_LAUNCH_CHECK();
+  ADX_TP_LAUNCH(trajpred_backward_kernel, a, batch, (hipStream_t)stream);
   return ADX_OK;
 }
 
@@ -889,8 +941,7 @@ int adx_trajpred_backward_params(adx_trajpred* t, const void* packed, const floa
   a.gout = grad_out; a.gout_sb = (int64_t)T * t->L.out_dim; a.gout_st = t->L.out_dim;
   a.gact = grad_action; a.gact_sb = (int64_t)T * IN_DIM; a.gact_st = IN_DIM;
   a.G = (float*)grad_image; a.dte = d_time_embed;
-  trajpred_backward_kernel<<<dim3(batch), dim3(NT), kLdsFloats * sizeof(float), (hipStream_t)stream>>>(a);
-  ADX_LAUNCH_CHECK();
+  ADX_TP_LAUNCH(trajpred_backward_kernel, a, batch, (hipStream_t)stream);
   return ADX_OK;
 }
 
@@ -920,8 +971,7 @@ int adx_guided_output(adx_trajpred* t, const void* packed, const float* action /
   ADX_REQUIRE(action && time_embed && target && x_guided, "adx_guided_output: null tensor");
   a.action = action; a.act_sb = (int64_t)(T + 1) * IN_DIM; a.act_st = IN_DIM; a.te = time_embed;
   a.target = target; a.xg = x_guided; a.grad_scale = model_std; a.scale = scale; a.loss = loss;
-  guided_output_kernel<<<dim3(batch), dim3(NT), kLdsFloats * sizeof(float), (hipStream_t)stream>>>(a);
-  ADX_LAUNCH_CHECK();
+  ADX_TP_LAUNCH(guided_output_kernel, a, batch, (hipStream_t)stream);
   return ADX_OK;
 }
 

@@ -29,7 +29,7 @@ class _TrajPredictTrainFn(torch.autograd.Function):
         te = L.require_gpu_f32(time_embed.detach(), "time_embed")
         B, T, _ = action_c.shape
         out = torch.empty((B, T, module.out_dim), dtype=torch.float32, device=action_c.device)
-        h, packed = module._ensure_packed(action_c.device)
+        h, packed = module._ensure_packed(action_c.device, B, T)
         ctx.drop_p, ctx.seed = float(module.dropout_p), module._next_seed()
         L.check(L.lib().adx_trajpred_forward_train(h, packed.data_ptr(), action_c.data_ptr(), action_c.stride(0),
                                                    action_c.stride(1), te.data_ptr(), out.data_ptr(), B, T, ctx.drop_p,
@@ -45,7 +45,7 @@ class _TrajPredictTrainFn(torch.autograd.Function):
         module, params = ctx.module, ctx.params
         B, T, _ = action_c.shape
         g = L.require_gpu_f32(grad_out, "grad_out")
-        h, packed = module._ensure_packed(g.device)
+        h, packed = module._ensure_packed(g.device, B, T)
         image = torch.empty(packed.numel() // 4, dtype=torch.float32, device=g.device)
         ga = torch.empty((B, T, 3), dtype=torch.float32, device=g.device) if ctx.needs_action else None
         dte = torch.empty((B, module.hidden_dim), dtype=torch.float32, device=g.device)
@@ -66,7 +66,7 @@ class _TrajPredictFn(torch.autograd.Function):
         te = L.require_gpu_f32(time_embed.detach(), "time_embed")
         B, T, _ = action_c.shape
         out = torch.empty((B, T, module.out_dim), dtype=torch.float32, device=action_c.device)
-        h, packed = module._ensure_packed(action_c.device)
+        h, packed = module._ensure_packed(action_c.device, B, T)
         L.check(L.lib().adx_trajpred_forward(h, packed.data_ptr(), action_c.data_ptr(), action_c.stride(0),
                                              action_c.stride(1), te.data_ptr(), out.data_ptr(), B, T,
                                              L.stream_ptr(action_c.device)), "adx_trajpred_forward")
@@ -81,7 +81,7 @@ class _TrajPredictFn(torch.autograd.Function):
         B, T, _ = action_c.shape
         g = L.require_gpu_f32(grad_out, "grad_out")
         ga = torch.empty((B, T, 3), dtype=torch.float32, device=g.device)
-        h, packed = module._ensure_packed(g.device)
+        h, packed = module._ensure_packed(g.device, B, T)
         L.check(L.lib().adx_trajpred_backward(h, packed.data_ptr(), action_c.data_ptr(), action_c.stride(0),
                                               action_c.stride(1), te.data_ptr(), g.data_ptr(), ga.data_ptr(), B, T,
                                               L.stream_ptr(g.device)), "adx_trajpred_backward")
@@ -101,6 +101,7 @@ class TrajPredict(nn.Module):
         populate(self, self._entries, init_prefix="state_pred.")
         self._handle = None
         self._packed = None
+        self._ws = None
         self._pack_key = None
         self._freqs = None
         # nn.TransformerEncoderLayer's default (modeling/helpers.py:35-41 does not override it); train mode only
@@ -148,7 +149,9 @@ class TrajPredict(nn.Module):
         self._param_list = None
         return super().load_state_dict(*a, **k)
 
-    def _ensure_packed(self, device):
+    def _ensure_packed(self, device, batch=0, T=0):
+        """The native handle and the packed weight image; for sequences of 32..63 rows also lends the handle the scratch
+        its 64-row kernels need for `batch` samples (`_ws`: GraphedSampler watches its address like the other workspaces)."""
         ps = self._params()
         key = (ps[0].data_ptr(), sum(L.write_stamp(p) for p in ps))
         h = self._native()
@@ -163,6 +166,10 @@ class TrajPredict(nn.Module):
             L.check(L.lib().adx_trajpred_pack(h, L.ptr_array(ts), n, self._freqs.data_ptr(), self._packed.data_ptr(),
                                               L.stream_ptr(device)), "adx_trajpred_pack")
             self._pack_key = key
+        need = L.lib().adx_trajpred_scratch_bytes(h, batch, T)
+        if need and (self._ws is None or self._ws.device != device or self._ws.numel() < need):
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+            L.check(L.lib().adx_trajpred_set_scratch(h, self._ws.data_ptr(), self._ws.numel()), "adx_trajpred_set_scratch")
         return h, self._packed
 
     def _param_offsets(self):
@@ -175,8 +182,8 @@ class TrajPredict(nn.Module):
         return self._offs
 
     def forward(self, x: torch.Tensor, time_embed: torch.Tensor) -> torch.Tensor:
-        if x.dim() != 3 or x.shape[2] != self.in_dim or x.shape[1] > 31:
-            raise ValueError(f"x must be [B, T <= 31, {self.in_dim}], got {tuple(x.shape)}")
+        if x.dim() != 3 or x.shape[2] != self.in_dim or x.shape[1] > 63:
+            raise ValueError(f"x must be [B, T <= 63, {self.in_dim}], got {tuple(x.shape)}")
         if self.training:
             # train mode applies nn.TransformerEncoderLayer's dropout (self.dropout_p, 0.1 like the reference) with
             # regenerable hash masks; they follow the same distribution as torch's but not its Philox stream
@@ -193,7 +200,7 @@ class TrajPredict(nn.Module):
         B, H, _ = a.shape
         tg = L.require_gpu_f32(target.reshape(-1, 2).expand(B, 2) if target.numel() == 2 else target, "target")
         out = torch.empty((B, H, self.out_dim + 3), dtype=torch.float32, device=a.device)
-        h, packed = self._ensure_packed(a.device)
+        h, packed = self._ensure_packed(a.device, B, H - 1)
         L.check(L.lib().adx_guided_output(h, packed.data_ptr(), a.data_ptr(), te.data_ptr(), tg.data_ptr(),
                                           float(model_std), float(scale), out.data_ptr(), None, B, H - 1,
                                           L.stream_ptr(a.device)), "adx_guided_output")

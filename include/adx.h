@@ -262,6 +262,12 @@ int adx_trajpred_create(int32_t out_dim, adx_trajpred** out);
 void adx_trajpred_destroy(adx_trajpred* t);
 int adx_trajpred_num_params(const adx_trajpred* t);       /* state_pred.* named_parameters() count (30) */
 size_t adx_trajpred_packed_bytes(const adx_trajpred* t);
+/* Sequence lengths: T = horizon - 1 from 1 to 63 (modeling/temporal.py:119 builds the head for any horizon).  T <= 31 keeps
+ * every activation of a sample in LDS; T = 32..63 runs a 64-row instantiation that keeps three large tiles per sample in
+ * a scratch the caller lends (no initialisation; alive and unshared while launches that use it are in flight).
+ * adx_trajpred_scratch_bytes is 0 for T <= 31; the calls below fail with ADX_ERR_STATE when the lent scratch is too small. */
+size_t adx_trajpred_scratch_bytes(const adx_trajpred* t, int32_t batch, int32_t T);
+int adx_trajpred_set_scratch(adx_trajpred* t, void* scratch, size_t bytes);
 int adx_trajpred_pack(adx_trajpred* t, const float* const* params, int32_t n, const float* freqs, void* packed,
                       adx_stream s);
 /* out[B][T][out_dim] = state_pred(action[B][T][3] (strides act_sb, act_st), time_embed[B][64]) */

@@ -252,6 +252,28 @@ def test_classifier_guidance_loop_vs_golden_and_batched_vmap(golden):
     close_traj(got.cpu(), want, TRAJ_TOL)
 
 
+@pytest.mark.parametrize("H", [40, 64])
+def test_classifier_guidance_loop_long_horizons_vs_oracle(H):
+    """Classifier guidance above horizon 32 (modeling/temporal.py:119 builds state_pred for any horizon; T = H - 1 = 39 / 63
+    rows run TrajPredict's 64-row kernels): the eager loop and the graph replay against the oracle's loop."""
+    from autonomous_driving_with_diffusion_model_amd import scheduler as S
+    from autonomous_driving_with_diffusion_model_amd.sampling import GraphedSampler, generate_traj
+    from helpers import SCHED_KW
+    Bn = 3
+    d = P.synthetic_batch(Bn, H, image_hw=IMG_SMALL, seed=40 + H)
+    m, cfg = make_model("CLASSIFIER_GUIDANCE", H)
+    cfg.GUIDANCE.LOSS_LIST = [["TargetGuidance", []]]
+    cfg.GUIDANCE.CLASSIFIER_SCALE, cfg.EVAL.SAMPLE_STEPS = 15.0, 4
+    got = generate_traj(m, _sched(cfg), cfg, d["imgs"].to(DEV), d["target"].to(DEV), d["init_trajs"].to(DEV))
+    want = OS.generate_traj(oracle_sd("CLASSIFIER_GUIDANCE"), d["imgs"], d["init_trajs"], d["target"],
+                            use_cond="CLASSIFIER_GUIDANCE", n_steps=4, classifier_scale=15.0, hoist_perception=True)
+    close_traj(got.cpu(), want, TRAJ_TOL)
+    sch = S.GuidanceDDIMScheduler(cfg=cfg, thresholding=True, **SCHED_KW)
+    gs = GraphedSampler(m, sch, cfg)
+    for _ in range(2):        # capture, then replay
+        assert torch.equal(gs(d["imgs"].to(DEV), d["target"].to(DEV), d["init_trajs"].to(DEV)), got)
+
+
 @pytest.mark.parametrize("use_cond,B", [("FREE_GUIDANCE", 1), ("NO_GUIDANCE", 2), ("CLASSIFIER_GUIDANCE", 2)])
 def test_graphed_sampler_replays_the_eager_loop_bit_for_bit(use_cond, B):
     """sampling.GraphedSampler: the DDIM loop captured as one HIP graph; replays with new inputs (camera frame

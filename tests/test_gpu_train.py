@@ -96,7 +96,7 @@ def test_traj_predict_parameter_gradients_vs_oracle_autograd():
     keys = [k for k in sd if k.startswith("state_pred.")]
     for k in keys:
         sd[k].requires_grad_()
-    for B, T in ((3, 15), (1, 31), (5, 7)):
+    for B, T in ((3, 15), (1, 31), (5, 7), (3, 32), (2, 47), (1, 63)):   # T >= 32: the 64-row kernels (scratch in global memory)
         for k in keys:
             sd[k].grad = None
         m.zero_grad()
@@ -134,7 +134,7 @@ def _dropout_masks(seed, p, B, T):
     lo, hi = seed & 0xFFFFFFFF, seed >> 32
     b = np.arange(B, dtype=np.uint64)
     base = _lowbias32(_lowbias32(lo ^ ((b * 0x9E3779B9) & 0xFFFFFFFF)) ^ hi)          # [B]
-    TP, E, FF, NH = 32, 64, 256, 4
+    TP, E, FF, NH = (32 if T < 32 else 64), 64, 256, 4      # attention-site indices use the kernel's row pitch
     masks = {}
     for li in range(2):
         for site, shape in ((0, (NH, T, T)), (1, (T, E)), (2, (T, FF)), (3, (T, E))):
@@ -150,7 +150,7 @@ def _dropout_masks(seed, p, B, T):
     return masks
 
 
-@pytest.mark.parametrize("B,T", [(3, 15), (2, 31)])
+@pytest.mark.parametrize("B,T", [(3, 15), (2, 31), (2, 40)])
 def test_traj_predict_dropout_matches_oracle_with_the_same_masks(B, T):
     """Train-mode dropout (p = 0.1 like nn.TransformerEncoderLayer): the kernel's hash masks are rebuilt on the host
     and fed to the oracle; output, d(action), d(time_embed) and every parameter gradient must agree -- this pins

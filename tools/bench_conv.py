@@ -16,7 +16,7 @@ for cin, cout, k, s, p, h, w in SHAPES:
     if os.environ.get("ZERO") == "1":     # all-zero operands: same instruction stream, no toggling in the matrix pipe
         x.zero_(); wt.zero_()
     y, packed = ops.conv2d(x, wt, stride=s, pad=p)
-    res = None if k == 7 else torch.randn_like(y)
+    res = None if k == 7 or os.environ.get("RES") == "0" else torch.randn_like(y)
     sc, sh = torch.rand(cout, device=DEV), torch.rand(cout, device=DEV)
     for _ in range(3):
         ops.conv2d(x, wt, stride=s, pad=p, packed=packed, out=y, scale=sc, shift=sh, res=res, relu=True)
