@@ -102,6 +102,8 @@ _SIGS = {
     "adx_conv2d_packed_bytes": (C.c_size_t, [C.POINTER(Conv2dDesc)]),
     "adx_conv2d_pack": (i32, [C.POINTER(Conv2dDesc), vp, vp, vp]),
     "adx_conv2d_forward": (i32, [C.POINTER(Conv2dDesc), vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "adx_conv2d_cells_supported": (i32, [C.POINTER(Conv2dDesc), i32, i32, i32]),
+    "adx_conv2d_forward_cells": (i32, [C.POINTER(Conv2dDesc), vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "adx_conv2d_wgrad_scratch_bytes": (C.c_size_t, []),
     "adx_conv2d_wgrad": (i32, [C.POINTER(Conv2dDesc), vp, vp, vp, i32, i32, i32, vp, vp]),
     "adx_trajpred_create": (i32, [i32, C.POINTER(vp)]),

@@ -38,6 +38,11 @@ void set_error(const char* fmt, ...);
   } while (0)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// __builtin_bit_cast(T, vec[i]) on an ext_vector ELEMENT lvalue is miscompiled by this clang (ROCm 7.2: it reads element 0
+// whatever i is); an element passed by value is a scalar rvalue and safe -- use these for vector elements.
+__device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kWave = 64;

@@ -326,9 +326,48 @@ int maxpool_launch(const float* x, float* y, int planes, int H, int W, int OH, i
   return ADX_OK;
 }
 
+// the same on a map in the cell layout (conv2d_hs.hip: per image [C / 8][hi, lo][HW] cells of eight fp16 channels): one cell
+// group per wave at a time, value = hi + lo / 2^11, the same lane-strided partial sums and wave reduction per channel
+__global__ void __launch_bounds__(1024) avgpool_fc_cells_kernel(const uint4* __restrict__ x, const float* __restrict__ fw,
+                                                                 const float* __restrict__ fb, float* __restrict__ out,
+                                                                 int C, int HW, int out_dim) {
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  __shared__ float pooled[512];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint4* src = x + (size_t)n * (C / 8) * 2 * HW;
+  const float inv = 1.0f / (float)HW;
+  for (int g = wave; g < C / 8; g += 16) {
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = lane; i < HW; i += 64) {
+      const h8 hi = __builtin_bit_cast(h8, src[(size_t)(2 * g) * HW + i]);
+      const h8 lo = __builtin_bit_cast(h8, src[(size_t)(2 * g + 1) * HW + i]);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s[q] += (float)hi[q] + (float)lo[q] * (1.f / 2048.f);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float t = wave_sum(s[q]);
+      if (lane == 0) pooled[8 * g + q] = t * inv;
+    }
+  }
+  __syncthreads();
+  for (int j = wave; j < out_dim; j += 16) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += fw[(size_t)j * C + c] * pooled[c];
+    s = wave_sum(s);
+    if (lane == 0) out[(size_t)n * out_dim + j] = s + fb[j];
+  }
+}
+
 int avgpool_fc_launch(const float* x, const float* fw, const float* fb, float* out, int batch, int C, int HW, int out_dim,
-                      hipStream_t s) {
+                      hipStream_t s, int x_cells) {
   ADX_REQUIRE(C <= 512, "avgpool_fc: at most 512 channels");
+  if (x_cells) {
+    ADX_REQUIRE(C % 8 == 0, "avgpool_fc: the cell layout holds channels in groups of eight");
+    avgpool_fc_cells_kernel<<<dim3(batch), dim3(1024), 0, s>>>(reinterpret_cast<const uint4*>(x), fw, fb, out, C, HW, out_dim);
+    ADX_LAUNCH_CHECK();
+    return ADX_OK;
+  }
   avgpool_fc_kernel<<<dim3(batch), dim3(1024), 0, s>>>(x, fw, fb, out, C, HW, out_dim);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
@@ -343,8 +382,9 @@ static size_t align64f(size_t v) { return (v + 63) / 64 * 64; }
 static int conv_out(int h, int k, int s, int p) { return conv_out_dim(h, k, s, p); }
 
 static int conv2d_launch(const ConvSpec& L, const float* base, const float* x, const float* res, float* y, int N, int H,
-                         int W, int relu, hipStream_t s) {
-  return conv2d_launch_raw(L, x, base + L.o_w, base + L.o_scale, base + L.o_shift, res, y, N, H, W, relu, s);
+                         int W, int relu, hipStream_t s, int fmt = 0) {
+  return conv2d_launch_raw(L, x, base + L.o_w, base + L.o_scale, base + L.o_shift, res, y, N, H, W, relu, s, nullptr, 0, nullptr, 0,
+                           nullptr, fmt);
 }
 
 static thread_local float* t_split_scratch = nullptr;
@@ -353,7 +393,7 @@ void conv2d_set_split_scratch(float* p, size_t floats) { t_split_scratch = p; t_
 
 int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const float* scale, const float* shift,
                       const float* res, float* y, int N, int H, int W, int relu, hipStream_t s, const uint32_t* x_amax,
-                      int x_amax_n, float* stats_part, size_t stats_floats, int* stats_p) {
+                      int x_amax_n, float* stats_part, size_t stats_floats, int* stats_p, int fmt) {
   if (stats_p != nullptr) *stats_p = 0;
   static bool env_read = false;
   if (!env_read) {
@@ -374,6 +414,9 @@ int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const f
   a.d2s_cin = 0; a.d2s_h = 0; a.d2s_w = 0; a.stem_seg_tiles = 0; a.stem_nseg = 1;
   a.ksplit = 1; a.cper = 0; a.part = t_split_scratch; a.part_stride = t_split_floats;   // part_stride: capacity until the launch fixes it
   a.stats_part = nullptr; a.stats_p = 0;
+  a.x_cells = (fmt & kFmtXCells) != 0; a.y_cells = (fmt & kFmtYCells) != 0; a.res_cells = (fmt & kFmtResCells) != 0 && res != nullptr;
+  ADX_REQUIRE(fmt == 0 || (stats_part == nullptr && conv2d_hs3x3_plain(L, N, H, W)),
+              "conv2d: the cell layout belongs to plain launches of the pipelined 3x3 kernel (%d -> %d, k%d s%d)", L.cin, L.cout, L.k, L.stride);
   if (conv2d_hs_eligible(L)) {
     if (stats_part != nullptr && stats_p != nullptr && conv2d_hs_stats_tiles(L, a) > 0 &&
         (size_t)conv2d_hs_stats_tiles(L, a) * L.cout * 2 <= stats_floats) {
@@ -465,6 +508,27 @@ int adx_conv2d_forward(const adx_conv2d_desc* d, const float* x, const float* pa
   ADX_REQUIRE((scale == nullptr) == (shift == nullptr), "adx_conv2d_forward: scale and shift go together");
   ADX_REQUIRE(n >= 1 && h + 2 * d->pad >= d->k && w + 2 * d->pad >= d->k, "adx_conv2d_forward: input too small");
   return conv2d_launch_raw(L, x, packed_w, scale, shift, res, y, n, h, w, relu, (hipStream_t)stream);
+}
+
+int adx_conv2d_cells_supported(const adx_conv2d_desc* d, int32_t n, int32_t h, int32_t w) {
+  ConvSpec L;
+  if (d == nullptr || spec_from_desc(d, &L) != ADX_OK) return 0;
+  return conv2d_hs3x3_plain(L, n, h, w) ? 1 : 0;
+}
+
+int adx_conv2d_forward_cells(const adx_conv2d_desc* d, const void* x, const float* packed_w, const float* scale,
+                             const float* shift, const void* res, void* y, int32_t n, int32_t h, int32_t w, int32_t relu,
+                             int32_t fmt, adx_stream stream) {
+  ConvSpec L;
+  int rc = spec_from_desc(d, &L);
+  if (rc != ADX_OK) return rc;
+  ADX_REQUIRE(x && packed_w && y, "adx_conv2d_forward_cells: null tensor");
+  ADX_REQUIRE((scale == nullptr) == (shift == nullptr), "adx_conv2d_forward_cells: scale and shift go together");
+  ADX_REQUIRE(fmt >= 0 && fmt <= 7 && (fmt & kFmtYCells), "adx_conv2d_forward_cells: fmt %d (the output is a cell tensor)", fmt);
+  ADX_REQUIRE(conv2d_hs3x3_plain(L, n, h, w), "adx_conv2d_forward_cells: not a plain launch of the pipelined 3x3 kernel "
+              "(adx_conv2d_cells_supported)");
+  return conv2d_launch_raw(L, (const float*)x, packed_w, scale, shift, (const float*)res, (float*)y, n, h, w, relu,
+                           (hipStream_t)stream, nullptr, 0, nullptr, 0, nullptr, fmt);
 }
 
 // conv1 3x3 stride 2 on the split-fp16 kernel + a 1x1 stride-2 downsample of the same shape: one fused launch
@@ -622,38 +686,70 @@ static int resnet_forward_impl(adx_resnet* r, const void* packed, void* workspac
       if (rc != ADX_OK) return rc;
     }
   }
+  // Activation formats (conv2d_hs.hip: XCELLS).  Where a layer's 3x3 stride-1 convs run as plain launches of the pipelined
+  // kernel, everything from the first one's output to the last one's is a CELL tensor (same bytes, same buffers): the next
+  // layer's fused stride-2 launch and the average pool read cells too.  What stays fp32 NCHW: the pooled stem map, the two
+  // outputs of a stride-2 launch, and all of a layer whose launches split their reduction (small batches).
   int cur = 0, H = h2, W = w2;
-  for (size_t b = 0; b < r->block_has_ds.size(); ++b) {
+  bool cur_cells = false;            // format of buf[cur], the block input
+  const size_t nblocks = r->block_has_ds.size();
+  for (size_t b = 0; b < nblocks; ++b) {
     const ConvSpec& c1 = r->convs[ci++];
     const ConvSpec& c2 = r->convs[ci++];
     const int mid = (cur + 1) % 3, outb = (cur + 2) % 3;
     const int OH = conv_out(H, 3, c1.stride, 1), OW = conv_out(W, 3, c1.stride, 1);
     const float* identity = buf[cur];
+    bool id_cells = cur_cells, mid_cells = false;
+    const bool c2_plain = conv2d_hs3x3_plain(c2, batch, OH, OW);
     if (r->block_has_ds[b] && resnet_fuses_ds(c1, r->convs[ci + 0])) {
       const ConvSpec& ds = r->convs[ci++];
       rc = conv2d_hs_launch_block_s2(c1, ds, buf[cur], base + c1.o_w, base + c1.o_scale, base + c1.o_shift, buf[mid],
-                                     base + ds.o_w, base + ds.o_scale, base + ds.o_shift, buf[outb], batch, H, W, s);
+                                     base + ds.o_w, base + ds.o_scale, base + ds.o_shift, buf[outb], batch, H, W, s, cur_cells);
       if (rc != ADX_OK) return rc;
       identity = buf[outb];
+      id_cells = false;
     } else {
-      rc = conv2d_launch(c1, base, buf[cur], nullptr, buf[mid], batch, H, W, 1, s);  // conv1 + bn1 + relu
+      const bool c1_plain = c1.stride == 1 && conv2d_hs3x3_plain(c1, batch, H, W);
+      ADX_REQUIRE(!cur_cells || c1_plain, "adx_resnet_forward: internal error (cell-layout input of a launch that cannot read it)");
+      mid_cells = c1_plain && c2_plain && !r->block_has_ds[b];
+      rc = conv2d_launch(c1, base, buf[cur], nullptr, buf[mid], batch, H, W, 1, s,            // conv1 + bn1 + relu
+                         (cur_cells ? kFmtXCells : 0) | (mid_cells ? kFmtYCells : 0));
       if (rc != ADX_OK) return rc;
       if (r->block_has_ds[b]) {
         const ConvSpec& ds = r->convs[ci++];
+        ADX_REQUIRE(!cur_cells, "adx_resnet_forward: internal error (cell-layout input of the downsample conv)");
         rc = conv2d_launch(ds, base, buf[cur], nullptr, buf[outb], batch, H, W, 0, s);  // downsample conv + bn
         if (rc != ADX_OK) return rc;
         identity = buf[outb];
+        id_cells = false;
       }
     }
     // conv2 + bn2 + identity + relu.  With a downsample the identity lives in buf[outb] and the result
     // overwrites buf[cur] (the block input is dead by then); otherwise the result goes to buf[outb].
     float* dst = r->block_has_ds[b] ? buf[cur] : buf[outb];
-    rc = conv2d_launch(c2, base, buf[mid], identity, dst, batch, OH, OW, 1, s);
+    // the block output is a cell tensor when conv2 is a plain launch and whoever reads it reads cells: the next block's plain
+    // conv1 + conv2 (as input and as residual), the next layer's fused stride-2 launch, or the average pool
+    bool out_cells = false;
+    if (c2_plain) {
+      if (b + 1 == nblocks) {
+        out_cells = true;
+      } else if (r->block_has_ds[b + 1]) {
+        out_cells = resnet_fuses_ds(r->convs[ci], r->convs[ci + 2]);
+      } else {
+        out_cells = r->convs[ci].stride == 1 && conv2d_hs3x3_plain(r->convs[ci], batch, OH, OW) &&
+                    conv2d_hs3x3_plain(r->convs[ci + 1], batch, OH, OW);
+      }
+    }
+    ADX_REQUIRE(out_cells || !(mid_cells || id_cells),
+                "adx_resnet_forward: internal error (a conv with cell-layout operands whose reader wants fp32)");
+    rc = conv2d_launch(c2, base, buf[mid], identity, dst, batch, OH, OW, 1, s,
+                       (mid_cells ? kFmtXCells : 0) | (out_cells ? kFmtYCells : 0) | (id_cells ? kFmtResCells : 0));
     if (rc != ADX_OK) return rc;
     if (!r->block_has_ds[b]) cur = outb;
+    cur_cells = out_cells;
     H = OH; W = OW;
   }
-  return avgpool_fc_launch(buf[cur], base + r->o_fcw, base + r->o_fcb, feature, batch, 512, H * W, r->out_dim, s);
+  return avgpool_fc_launch(buf[cur], base + r->o_fcw, base + r->o_fcb, feature, batch, 512, H * W, r->out_dim, s, cur_cells);
 }
 
 }  // extern "C"

@@ -34,6 +34,7 @@ namespace adx {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kHsCout = 64;          // output channels per workgroup
 constexpr int kHsCC = 16;            // channels per chunk = K of one MFMA
@@ -61,7 +62,7 @@ __device__ __forceinline__ float hs_dpp(float v) {
 // PBUF: LDS copies of the patch (2: one barrier per stage; 1: an extra barrier per chunk, for the large stride-2
 // patches); DS: also evaluate the BasicBlock's 1x1 stride-2 downsample conv (modeling/resnet.py:223-232) on the
 // centre tap's operand fragments -- same input pixels, its own weights / BN / output tensor.
-template <int STRIDE, int K, int ROWS, int PBUF, bool DS>
+template <int STRIDE, int K, int ROWS, int PBUF, bool DS, bool XCELLS = false>
 __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
   static_assert(!DS || (K == 3 && STRIDE == 2 && PBUF == 1), "the fused downsample rides on the 3x3 stride-2 conv");
   constexpr int TH = 4 * ROWS;
@@ -120,7 +121,9 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
     const int py = p / PW, px = p - py * PW;
     const int iy = iy0 + py, ix = ix0 + px;
     const bool ok = e < NITEM && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-    goff[k] = ok ? (uint32_t)((hg * 8 * hw + (size_t)iy * a.W + ix) * sizeof(float)) : kOutside;
+    goff[k] = !ok ? kOutside
+                  : XCELLS ? (uint32_t)(hg * 8 * hw * sizeof(float) + ((size_t)iy * a.W + ix) * 16)   // cell layout (conv2d_hs3x3_kernel)
+                           : (uint32_t)((hg * 8 * hw + (size_t)iy * a.W + ix) * sizeof(float));
     pcell[k] = hg * 2 * PLANE + (STRIDE == 2 ? py * PW + (px & 1) * EVW + (px >> 1) : p);
   }
   if (tid < 2 * kHsCout) {
@@ -178,11 +181,22 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
   auto load_p = [&](int chunk, int k0, int k1) {
     const uint32_t cbase = (uint32_t)chunk * kHsCC * plane_bytes;
 #pragma unroll
-    for (int k = k0; k < k1; ++k)
+    for (int k = k0; k < k1; ++k) {
+      if (XCELLS) {
+        const u32x4 h4 = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, goff[k], cbase, 0);
+        const u32x4 l4 = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, goff[k], cbase + 4 * plane_bytes, 0);
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        pv[kSliced ? 0 : k][j] =
-            __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, goff[k], cbase + j * plane_bytes, 0));
+        for (int j = 0; j < 4; ++j) {
+          pv[kSliced ? 0 : k][j] = u2f(h4[j]);
+          pv[kSliced ? 0 : k][4 + j] = u2f(l4[j]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          pv[kSliced ? 0 : k][j] =
+              __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, goff[k], cbase + j * plane_bytes, 0));
+      }
+    }
     if (DS && k0 == 0) wdv = wdsrc[(size_t)chunk * 256 + tid];
   };
   auto store_p = [&](int buf, int k0, int k1) {
@@ -192,7 +206,15 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
       const int e = tid + 256 * k;
       if (PIT * 256 == NITEM || e < NITEM) {
         u32x4 hi, lo;
-        split8(pv[kSliced ? 0 : k], xs, hi, lo);
+        if (XCELLS) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            hi[j] = __builtin_bit_cast(uint32_t, pv[kSliced ? 0 : k][j]);
+            lo[j] = __builtin_bit_cast(uint32_t, pv[kSliced ? 0 : k][4 + j]);
+          }
+        } else {
+          split8(pv[kSliced ? 0 : k], xs, hi, lo);
+        }
         pd[pcell[k]] = hi;
         pd[pcell[k] + PLANE] = lo;
       }
@@ -389,7 +411,13 @@ __device__ __forceinline__ void hs_trace_id() {
 #define HS_TRACE(slot)
 #endif
 
-template <int MODE, bool STATS = false>
+// XCELLS / YCELLS: the input / output tensor is in the CELL layout instead of fp32 NCHW -- per image [C / 8][plane: hi, lo][H][W]
+// cells of 16 bytes = the 8 channels of one pixel already split into fp16 hi / lo, i.e. exactly what the staging writes to
+// LDS.  Same bytes per tensor, but the consumer's staging is two 16-byte loads + two LDS writes per cell pair where the fp32
+// layout costs eight 4-byte loads and ~48 VALU instructions, once per 64-channel output slab; the producer splits each
+// element once.  The products are bit-identical either way (the halves are the ones the consumer would have computed); a
+// residual read from cells (Conv2dArgs::res_cells) is hi + lo / 2^11, the tensor to 2^-23.  Inference executor only.
+template <int MODE, bool STATS = false, bool XCELLS = false, bool YCELLS = false>
 __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(const Conv2dArgs a) {
   constexpr int NT = MODE == 0 ? 256 : 512;            // threads
   constexpr int TH = MODE == 1 ? 16 : 8;               // output rows per workgroup
@@ -447,7 +475,9 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
     const int py = p / PW, px = p - py * PW;
     const int iy = iy0 + py, ix = ix0 + px;
     const bool ok = e < NITEM && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-    goff[k] = ok ? (uint32_t)((hg * 8 * hw + (size_t)iy * a.W + ix) * sizeof(float)) : kOutside;
+    goff[k] = !ok ? kOutside
+                  : XCELLS ? (uint32_t)(hg * 8 * hw * sizeof(float) + ((size_t)iy * a.W + ix) * 16)   // cell (2 chunk + hg, hi, iy, ix)
+                           : (uint32_t)((hg * 8 * hw + (size_t)iy * a.W + ix) * sizeof(float));
     pcell[k] = e < NITEM ? hg * 2 * PLANE + p : -1;
   }
   // weight cells of this thread: global offset inside a stage (slab-major) and LDS cell, or the dummy
@@ -517,13 +547,31 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
   };
   auto load_p = [&](int chunk, int k, int set) {
     const uint32_t cbase = (uint32_t)chunk * kHsCC * plane_bytes;
+    if (XCELLS) {           // the hi cell and, one plane (H W cells) further, the lo cell
+      const u32x4 h4 = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, goff[k], cbase, 0);
+      const u32x4 l4 = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, goff[k], cbase + 4 * plane_bytes, 0);
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      pv[set][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, goff[k], cbase + j * plane_bytes, 0));
+      for (int j = 0; j < 4; ++j) {
+        pv[set][j] = u2f(h4[j]);
+        pv[set][4 + j] = u2f(l4[j]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        pv[set][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, goff[k], cbase + j * plane_bytes, 0));
+    }
   };
   auto store_p = [&](int set, int k, int buf) {
     u32x4 hi, lo;
-    split8(pv[set], xs, hi, lo);
+    if (XCELLS) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        hi[j] = __builtin_bit_cast(uint32_t, pv[set][j]);
+        lo[j] = __builtin_bit_cast(uint32_t, pv[set][4 + j]);
+      }
+    } else {
+      split8(pv[set], xs, hi, lo);
+    }
     u32x4* pd = patch + buf * 4 * PLANE + pcell[k];
     u32x4* d0 = pcell[k] >= 0 ? pd : dummy;
     u32x4* d1 = pcell[k] >= 0 ? pd + PLANE : dummy + 1;
@@ -601,12 +649,109 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
       const_cast<float*>(a.res != nullptr ? a.res + img : a.y), 0, a.res != nullptr ? img_bytes : 0, 0x00020000);
   const float* sst = ss + slab * 64;
   const uint32_t cbase_o = (uint32_t)cout0 * plane_ob;
-  uint32_t voff[2];
+  const uint32_t cplane = (uint32_t)(a.OH * a.OW) * 16u;                  // one plane of cells of the output map, bytes
+  const uint32_t cell0 = (uint32_t)(cout0 >> 3) * 2u * cplane;            // first cell (hi plane) of this wave's 64 channels
+  bool inside[2];
+  uint32_t pix[2];
 #pragma unroll
   for (int rr = 0; rr < 2; ++rr) {
     const int oy = oy0 + rowpair * 2 + rr;
-    voff[rr] = (oy < a.OH && ox < a.OW) ? (uint32_t)(oy * a.OW + ox) * 4u + (uint32_t)(4 * khalf) * plane_ob : kOutside;
+    inside[rr] = oy < a.OH && ox < a.OW;
+    pix[rr] = (uint32_t)(oy * a.OW + ox);
   }
+  auto half4 = [](uint32_t h0, uint32_t h1, uint32_t l0, uint32_t l1, float* out) {   // 4 channels: hi + lo / 2^11
+    const f16x2 a0 = __builtin_bit_cast(f16x2, h0), a1 = __builtin_bit_cast(f16x2, h1);
+    const f16x2 b0 = __builtin_bit_cast(f16x2, l0), b1 = __builtin_bit_cast(f16x2, l1);
+    out[0] = (float)a0[0] + (float)b0[0] * (1.f / kLoScale);
+    out[1] = (float)a0[1] + (float)b0[1] * (1.f / kLoScale);
+    out[2] = (float)a1[0] + (float)b1[0] * (1.f / kLoScale);
+    out[3] = (float)a1[1] + (float)b1[1] * (1.f / kLoScale);
+  };
+  if constexpr (YCELLS) {
+    // Cell output.  A lane's accumulators are channels {0-3, 8-11, 16-19, 24-27} + 4 khalf of its pixel and lane + 32 holds the
+    // other halves of the same cells: four v_permlane32_swap per pair of cells leave lanes 0-31 with cells 0 and 2 of the
+    // 32-channel group and lanes 32-63 with cells 1 and 3, eight channels each -- BN, residual, ReLU, split, two 16-byte stores.
+    const uint32_t khoff = (uint32_t)khalf * 2u * cplane;                  // this lane's cells are the odd ones: one cell further
+    uint32_t vcell[2], vres[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      vcell[rr] = inside[rr] ? pix[rr] * 16u + khoff : kOutside;
+      vres[rr] = !inside[rr] ? kOutside : a.res_cells ? vcell[rr] : pix[rr] * 4u + (uint32_t)(8 * khalf) * plane_ob;
+    }
+    uint32_t rraw[2][2][2][8];          // residual of cell (rr, half, i): 8 floats, or the hi and lo cells as they are
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          if (a.res_cells) {
+            const uint32_t so = cell0 + (uint32_t)(half * 4 + 2 * i) * 2u * cplane;
+            const u32x4 h4 = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, vres[rr], so, 0);
+            const u32x4 l4 = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, vres[rr], so + cplane, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { rraw[rr][half][i][j] = h4[j]; rraw[rr][half][i][4 + j] = l4[j]; }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              rraw[rr][half][i][j] = __builtin_amdgcn_raw_buffer_load_b32(rrsrc, vres[rr], cbase_o + (uint32_t)(half * 32 + 16 * i + j) * plane_ob, 0);
+          }
+        }
+#ifdef ADX_HS_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    HS_TRACE(6);
+#endif
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = (accm[rr][half][r] + accl[rr][half][r] * (1.f / kLoScale)) * xs_inv;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, v[8 * i + j]),
+                                                             __builtin_bit_cast(uint32_t, v[8 * i + 4 + j]), false, false);
+            v[8 * i + j] = u2f(sw[0]);
+            v[8 * i + 4 + j] = u2f(sw[1]);
+          }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int cl = half * 32 + 16 * i + 8 * khalf;           // first of the lane's eight channels within the slab
+          float rv8[8];
+          if (a.res_cells) {
+            half4(rraw[rr][half][i][0], rraw[rr][half][i][1], rraw[rr][half][i][4], rraw[rr][half][i][5], rv8);
+            half4(rraw[rr][half][i][2], rraw[rr][half][i][3], rraw[rr][half][i][6], rraw[rr][half][i][7], rv8 + 4);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rv8[j] = __builtin_bit_cast(float, rraw[rr][half][i][j]);
+          }
+          float o[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float t = v[8 * i + j] * sst[cl + j] + sst[64 * CT + cl + j];
+            t += rv8[j];
+            o[j] = a.relu ? __builtin_fmaxf(t, 0.f) : t;
+          }
+          u32x4 hi, lo;
+          split8(o, 1.f, hi, lo);
+          const uint32_t so = cell0 + (uint32_t)(half * 4 + 2 * i) * 2u * cplane;
+          __builtin_amdgcn_raw_buffer_store_b128(hi, yrsrc, vcell[rr], so, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(lo, yrsrc, vcell[rr], so + cplane, 0);
+          // A VALU write to the data registers of a 16-byte buffer store in the next issue slot can reach the store (seen on
+          // gfx950: one dword of ~1e-4 of the cells, run to run different); the compiler's hazard recogniser inserts the wait
+          // state only for stores WITHOUT an SGPR offset, these have one.
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_nop 1");
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+  } else {
+  uint32_t voff[2];
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) voff[rr] = inside[rr] ? pix[rr] * 4u + (uint32_t)(4 * khalf) * plane_ob : kOutside;
   float rv[2][2][16];
 #pragma unroll
   for (int rr = 0; rr < 2; ++rr)
@@ -676,6 +821,7 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
         }
   };
   if (a.relu) finish(std::true_type{}); else finish(std::false_type{});
+  }
   HS_TRACE(4);
 #ifdef ADX_HS_TRACE
   __builtin_amdgcn_s_waitcnt(0);
@@ -804,7 +950,6 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_stem_kernel(const Conv2dArgs
 #pragma unroll
     for (int k = 0; k < PIT; ++k) {
       if (PIT * NT == ITEMS || tid + NT * k < ITEMS) {
-        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
         f16x2 h, l;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -1067,7 +1212,7 @@ int conv2d_hs_pack(const ConvSpec& c, const float* w, void* packed, int dgrad, h
   return ADX_OK;
 }
 
-template <int STRIDE, int K, int ROWS, int PBUF, bool DS>
+template <int STRIDE, int K, int ROWS, int PBUF, bool DS, bool XCELLS = false>
 static int hs_launch_t(Conv2dArgs a, hipStream_t s) {
   constexpr int TH = 4 * ROWS;
   constexpr int PH = (TH - 1) * STRIDE + K, PW = (kTileW - 1) * STRIDE + K;
@@ -1076,7 +1221,7 @@ static int hs_launch_t(Conv2dArgs a, hipStream_t s) {
   static_assert(lds <= 80 * 1024, "two workgroups per CU need <= 80 KB each");
   static bool attr = false;
   if (!attr) {
-    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs_kernel<STRIDE, K, ROWS, PBUF, DS>),
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs_kernel<STRIDE, K, ROWS, PBUF, DS, XCELLS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = true;
   }
@@ -1084,7 +1229,7 @@ static int hs_launch_t(Conv2dArgs a, hipStream_t s) {
   const size_t grid = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y * a.N;
   ADX_REQUIRE(grid < (1u << 31), "conv2d_hs: grid too large");
   ADX_REQUIRE((size_t)a.Cout * a.OH * a.OW * sizeof(float) < 0x7FFFFFFFu, "conv2d_hs: one image of the output exceeds the 32-bit byte offsets");
-  conv2d_hs_kernel<STRIDE, K, ROWS, PBUF, DS><<<dim3((unsigned)grid), dim3(256), lds, s>>>(a);
+  conv2d_hs_kernel<STRIDE, K, ROWS, PBUF, DS, XCELLS><<<dim3((unsigned)grid), dim3(256), lds, s>>>(a);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
 }
@@ -1138,7 +1283,7 @@ int conv2d_hs_stem_pool(const ConvSpec& L, const float* x, const float* w, const
 
 int conv2d_hs_launch_block_s2(const ConvSpec& c1, const ConvSpec& ds, const float* x, const float* w1, const float* scale1,
                               const float* shift1, float* y1, const float* wd, const float* scaled, const float* shiftd,
-                              float* yd, int N, int H, int W, hipStream_t s) {
+                              float* yd, int N, int H, int W, hipStream_t s, int x_cells) {
   ADX_REQUIRE(x && w1 && scale1 && shift1 && y1 && wd && scaled && shiftd && yd, "conv2d_hs block launch: null pointer");
   Conv2dArgs a{};
   a.x = x; a.w = w1; a.scale = scale1; a.shift = shift1; a.res = nullptr; a.y = y1; a.x_amax = nullptr; a.x_amax_n = 0;
@@ -1147,6 +1292,7 @@ int conv2d_hs_launch_block_s2(const ConvSpec& c1, const ConvSpec& ds, const floa
   a.OH = conv_out_dim(H, 3, 2, 1); a.OW = conv_out_dim(W, 3, 2, 1);
   a.KH = 3; a.KW = 3; a.stride = 2; a.pad = 1; a.relu = 1;
   a.cin_pad = c1.cin_pad; a.cc = c1.cc;
+  a.x_cells = x_cells;
   (void)ds;
   return conv2d_hs_launch(c1, a, s);
 }
@@ -1229,6 +1375,22 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
     }
   }
   a.part = nullptr;
+  if (a.x_cells || a.y_cells || a.res_cells) {
+    // the executor keeps a layer's 3x3 convs in the cell layout from the first one's output to the last one's (the stride-2
+    // kernel and the average pool read cells too), so a cell operand always comes with a cell output
+    ADX_REQUIRE(a.y_cells && a.x_amax == nullptr, "conv2d_hs: cell-layout operands come with a cell-layout output (and no dynamic range)");
+    static bool cattr = false;
+    if (!cattr) {
+      const void* fns[2] = {reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, false, true, true>),
+                            reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, false, false, true>)};
+      for (const void* f : fns) ADX_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      cattr = true;
+    }
+    if (a.x_cells) conv2d_hs3x3_kernel<MODE, false, true, true><<<dim3((unsigned)grid), dim3(NT), lds, s>>>(a);
+    else conv2d_hs3x3_kernel<MODE, false, false, true><<<dim3((unsigned)grid), dim3(NT), lds, s>>>(a);
+    ADX_LAUNCH_CHECK();
+    return ADX_OK;
+  }
   conv2d_hs3x3_kernel<MODE><<<dim3((unsigned)grid), dim3(NT), lds, s>>>(a);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
@@ -1257,6 +1419,18 @@ static int hs3x3_mode(const ConvSpec& L, const Conv2dArgs& a) {
   if ((long)a.N * ceil_div(a.OH, 8) * ceil_div(a.OW, kTileW) * (a.Cout / kHsCout) <= 256) mode = 0;
   if (mode_env >= 0 && !(mode_env == 2 && a.Cout % 128 != 0)) mode = mode_env;
   return mode;
+}
+
+bool conv2d_hs3x3_plain(const ConvSpec& L, int N, int H, int W) {
+  static const bool off = [] { const char* e = getenv("ADX_CONV_CELLS"); return e != nullptr && e[0] == '0'; }();   // A/B: fp32 NCHW between all layers
+  if (off || !conv2d_hs_eligible(L) || L.dgrad) return false;
+  Conv2dArgs a{};
+  a.N = N; a.Cin = L.cin; a.Cout = L.cout; a.H = H; a.W = W;
+  a.OH = conv_out_dim(H, L.k, L.stride, L.pad); a.OW = conv_out_dim(W, L.k, L.stride, L.pad);
+  const int mode = hs3x3_mode(L, a);
+  if (mode < 0 || L.cin % 16 != 0 || L.cout % 64 != 0) return false;
+  const long grid0 = (long)a.N * ceil_div(a.OH, 8) * ceil_div(a.OW, kTileW) * (a.Cout / kHsCout);
+  return mode != 0 || grid0 > 64 || L.cin_pad / kHsCC < 8;       // hs3x3_launch<0> splits the reduction of smaller launches
 }
 
 int conv2d_hs_stats_tiles(const ConvSpec& L, const Conv2dArgs& a) {
@@ -1324,7 +1498,13 @@ int conv2d_hs_launch(const ConvSpec& L, Conv2dArgs a, hipStream_t s) {
     ADX_REQUIRE(a.stats_part == nullptr, "conv2d_hs: statistics requested from a launch the pipelined kernel does not serve");
     return hs_launch_t<1, 3, 2, 2, false>(a, s);
   }
-  if (L.k == 3 && L.stride == 2 && L.pad == 1) return ds ? hs_launch_t<2, 3, 1, 1, true>(a, s) : hs_launch_t<2, 3, 1, 1, false>(a, s);
+  if (L.k == 3 && L.stride == 2 && L.pad == 1) {
+    if (a.x_cells) {
+      ADX_REQUIRE(ds && a.x_amax == nullptr, "conv2d_hs: a cell-layout input of the stride-2 conv needs the fused downsample launch");
+      return hs_launch_t<2, 3, 1, 1, true, true>(a, s);
+    }
+    return ds ? hs_launch_t<2, 3, 1, 1, true>(a, s) : hs_launch_t<2, 3, 1, 1, false>(a, s);
+  }
   set_error("conv2d_hs: no kernel for k=%d stride=%d pad=%d%s", L.k, L.stride, L.pad, ds ? " with a fused downsample" : "");
   return ADX_ERR_INVALID;
 }

@@ -57,7 +57,12 @@ struct Conv2dArgs {
   // (p = (image, row tile, column tile)), pixels outside the map excluded; bn statistics then need no pass over the output
   float* stats_part;
   int stats_p;
+  // conv2d_hs3x3 only (inference executor): x / y / res in the cell layout instead of fp32 NCHW (conv2d_hs.hip: XCELLS)
+  int x_cells, y_cells, res_cells;
 };
+
+// activation formats of one launch of the inference executor (bits)
+constexpr int kFmtXCells = 1, kFmtYCells = 2, kFmtResCells = 4;
 
 
 }  // namespace adx
@@ -79,7 +84,10 @@ namespace adx {
 int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const float* scale, const float* shift,
                       const float* res, float* y, int N, int H, int W, int relu, hipStream_t s,
                       const uint32_t* x_amax = nullptr, int x_amax_n = 0, float* stats_part = nullptr, size_t stats_floats = 0,
-                      int* stats_p = nullptr);
+                      int* stats_p = nullptr, int fmt = 0);
+// true when this launch will run the pipelined 3x3 stride-1 kernel as ONE launch (no split reduction): the launches whose
+// input / output / residual may be in the cell layout (fmt: kFmt*)
+bool conv2d_hs3x3_plain(const ConvSpec& L, int N, int H, int W);
 // stats_part (optional, stats_floats floats): where the launch may leave per-workgroup partial sums of its output and of its
 // squares ([Cout][2][P] floats); *stats_p = P when it did (the pipelined 3x3 stride-1 kernel does), 0 when the caller has to
 // compute the statistics from the output itself
@@ -119,7 +127,7 @@ int conv2d_hs_stem_pool(const ConvSpec& L, const float* x, const float* w, const
 // conv2d_hs_eligible (the downsample's weights packed with conv2d_hs_pack_ds)
 int conv2d_hs_launch_block_s2(const ConvSpec& c1, const ConvSpec& ds, const float* x, const float* w1, const float* scale1,
                               const float* shift1, float* y1, const float* wd, const float* scaled, const float* shiftd,
-                              float* yd, int N, int H, int W, hipStream_t s);
+                              float* yd, int N, int H, int W, hipStream_t s, int x_cells = 0);     // x_cells: x in the cell layout
 // conv2d_wgrad_hs.hip: weight gradient of the 3x3 convs on the fp16 matrix cores; dw must be zero on entry
 bool conv2d_wgrad_hs_eligible(int Cin, int Cout, int k, int stride, int pad);
 int conv2d_wgrad_hs(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, int stride,
@@ -127,6 +135,6 @@ int conv2d_wgrad_hs(const float* x, const float* dy, float* dw, int N, int Cin, 
 inline int conv_out_dim(int h, int k, int s, int p) { return (h + 2 * p - k) / s + 1; }
 int maxpool_launch(const float* x, float* y, int planes, int H, int W, int OH, int OW, hipStream_t s);
 int avgpool_fc_launch(const float* x, const float* fw, const float* fb, float* out, int batch, int C, int HW, int out_dim,
-                      hipStream_t s);
+                      hipStream_t s, int x_cells = 0);
 
 }  // namespace adx

@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_planes_kernel(const float* _
       for (int k = 0; k < 4; ++k) {
         const float xh = (rw[k] - mu) * rs;
         v[k] = ga * rs * (dz[k] - m1 - xh * m2);
-        const uint32_t vb = __builtin_bit_cast(uint32_t, v[k]) & 0x7FFFFFFFu;
+        const uint32_t vb = f2u(v[k]) & 0x7FFFFFFFu;          // (adx_common.h: never bit_cast a vector element in place)
         b = vb > b ? vb : b;
       }
       w4[i] = v;

@@ -124,6 +124,38 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, *, stride: int = 1, pad: int =
     return y, packed
 
 
+def to_cells(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [N, C, H, W] (C % 8 == 0) -> the cell layout of csrc/conv2d_hs.hip as a uint8 tensor of the same byte size:
+    per image [C / 8][hi, lo][H][W] cells of eight fp16 channels, hi = fp16(x), lo = fp16((x - hi) * 2^11)."""
+    n, c, h, w = x.shape
+    hi = x.to(torch.float16)
+    lo = ((x - hi.float()) * 2048.0).to(torch.float16)
+    cells = torch.stack([hi.view(n, c // 8, 8, h, w), lo.view(n, c // 8, 8, h, w)], dim=2)      # [N, C/8, 2, 8, H, W]
+    return cells.permute(0, 1, 2, 4, 5, 3).contiguous().view(torch.uint8).reshape(-1)
+
+
+def from_cells(cells: torch.Tensor, shape) -> torch.Tensor:
+    """Inverse of to_cells up to the split's 2^-23: hi + lo / 2^11 as fp32 [N, C, H, W]."""
+    n, c, h, w = shape
+    v = cells.view(torch.float16).view(n, c // 8, 2, h, w, 8).float()
+    return (v[:, :, 0] + v[:, :, 1] / 2048.0).permute(0, 1, 4, 2, 3).reshape(n, c, h, w).contiguous()
+
+
+def conv2d_cells(x: torch.Tensor, packed: torch.Tensor, cin: int, cout: int, n: int, h: int, w: int, *, x_cells: bool,
+                 scale=None, shift=None, res=None, res_cells: bool = False, relu: bool = False) -> torch.Tensor:
+    """3x3 stride-1 pad-1 conv with a cell-layout output (and optionally cell-layout input / residual); returns the
+    output cells (uint8, fp32 byte size).  Only for launches adx_conv2d_cells_supported accepts."""
+    d = L.Conv2dDesc(cin, cout, 3, 1, 1)
+    if not L.lib().adx_conv2d_cells_supported(C.byref(d), n, h, w):
+        raise ValueError(f"conv2d_cells: {cin}->{cout} at {n}x{h}x{w} is not a plain launch of the pipelined 3x3 kernel")
+    y = torch.empty(n * cout * h * w * 4, dtype=torch.uint8, device=x.device)
+    fmt = (1 if x_cells else 0) | 2 | (4 if (res is not None and res_cells) else 0)
+    L.check(L.lib().adx_conv2d_forward_cells(C.byref(d), x.data_ptr(), packed.data_ptr(), L.ptr(scale), L.ptr(shift), L.ptr(res),
+                                             y.data_ptr(), n, h, w, int(relu), fmt, L.stream_ptr(x.device)),
+            "adx_conv2d_forward_cells")
+    return y
+
+
 def conv2d_weight_grad(x: torch.Tensor, dy: torch.Tensor, k: int, *, stride: int = 1, pad: int = 0,
                        estimate_range: bool = True) -> torch.Tensor:
     """d(loss)/d(weight) of conv2d(x, weight, stride, pad) given dy = d(loss)/d(output): [cout, cin, k, k]."""

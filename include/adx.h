@@ -229,6 +229,16 @@ int adx_conv2d_pack(const adx_conv2d_desc* d, const float* w /* [cout][cin][k][k
 int adx_conv2d_forward(const adx_conv2d_desc* d, const float* x, const float* packed_w, const float* scale,
                        const float* shift, const float* res, float* y, int32_t n, int32_t h, int32_t w,
                        int32_t relu, adx_stream s);
+/* The pipelined 3x3 stride-1 kernel can also read and write CELL tensors: per image [C / 8][plane: hi, lo][H][W] cells of
+ * 16 bytes = the 8 channels of one pixel split into fp16 halves, x = hi + lo / 2^11 (hi = fp16(x), lo = fp16((x - hi) 2^11)) --
+ * the layout its staging writes to LDS, so a consumer copies cells where it would convert fp32 values; same bytes per tensor
+ * as fp32 NCHW.  adx_resnet_forward keeps the activations between such launches in this layout (modeling/resnet.py:87-102
+ * BasicBlock chain); these two entry points expose the launch for tests and other callers.  fmt: bit 0 = x is a cell tensor,
+ * bit 1 = y is (required), bit 2 = res is.  adx_conv2d_cells_supported: 1 when (desc, n, h, w) runs as one such launch. */
+int adx_conv2d_cells_supported(const adx_conv2d_desc* d, int32_t n, int32_t h, int32_t w);
+int adx_conv2d_forward_cells(const adx_conv2d_desc* d, const void* x, const float* packed_w, const float* scale,
+                             const float* shift, const void* res, void* y, int32_t n, int32_t h, int32_t w, int32_t relu,
+                             int32_t fmt, adx_stream s);
 /* Weight gradient of the same convolution (torch.nn.grad.conv2d_weight; train.py:242 reaches it through
  * loss.backward()): dw [cout][cin][k][k] = sum over batch and pixels of dy (x) x.  dy is [n][cout][oh][ow].
  * scratch: NULL, or >= adx_conv2d_wgrad_scratch_bytes() of device memory in which the range of dy is estimated

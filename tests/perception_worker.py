@@ -1,0 +1,28 @@
+"""Perception features in a process of its own, so that ADX_CONV_CELLS=0 (read once per process: fp32 NCHW between all the
+3x3 convs instead of the cell layout, csrc/conv2d_hs.hip) can be set for it.  argv: output file; saves {case: feature}."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from autonomous_driving_with_diffusion_model_amd.utils import procedural as P  # noqa: E402
+from test_gpu_model import make_model  # noqa: E402
+
+CASES = (((256, 900), 2), ((256, 900), 6), ((256, 900), 12), ((128, 131), 9), ((70, 101), 40))
+
+
+def features():
+    m, _ = make_model("NO_GUIDANCE", 16)
+    out = {}
+    for hw, b in CASES:
+        img = P.synthetic_batch(b, 16, image_hw=hw, seed=5 + b)["imgs"]
+        with torch.no_grad():
+            out[f"{hw[0]}x{hw[1]}b{b}"] = m.perception(img.to("cuda:0")).cpu()
+    return out
+
+
+if __name__ == "__main__":
+    torch.save(features(), sys.argv[1])

@@ -90,6 +90,40 @@ def test_conv3x3_fused_bn_residual_relu_epilogue():
     assert e_hip <= BAR * e_f32 + 2e-7, (e_hip, e_f32)
 
 
+@split_only
+@pytest.mark.parametrize("cin,cout,n,h,w", [(64, 64, 2, 64, 225), (64, 64, 1, 16, 16), (128, 128, 3, 32, 113), (64, 128, 5, 13, 37),
+                                            (256, 256, 20, 16, 57), (512, 512, 40, 8, 29), (512, 512, 12, 8, 29)])
+def test_conv3x3_cell_layout_operands_match_the_fp32_layout_bit_for_bit(cin, cout, n, h, w):
+    """The pipelined 3x3 kernel reading / writing CELL tensors (csrc/conv2d_hs.hip: per image [C / 8][hi, lo][H][W] cells of
+    eight fp16 channels; adx_conv2d_forward_cells): a cell output is exactly the split of the fp32-layout launch's output
+    (same products, same epilogue arithmetic), whether the input came as fp32 or as cells; a residual read from cells is
+    hi + lo / 2^11 instead of the fp32 value, so that case agrees to 2^-22 of the magnitudes involved.  The shapes take all
+    three tile modes (4 waves; 8 waves 16 rows for >= 256 channels on tall maps; 8 waves 128 channels on 8-row maps): the
+    8-wave code orders its stores differently, which is where a missing wait state after the 16-byte stores showed."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(cin + n)
+    x, wt = _case(cin, cout, 3, h, w, n, seed=cin + w)
+    x, wt = x.to(DEV), wt.to(DEV)
+    sc, sh = (torch.rand(cout, generator=g) + 0.5).to(DEV), torch.randn(cout, generator=g).to(DEV)
+    res = torch.randn(n, cout, h, w, generator=g).to(DEV)
+    y0, packed = ops.conv2d(x, wt, stride=1, pad=1, scale=sc, shift=sh, res=res, relu=True)
+    want = ops.to_cells(y0)
+    xc, rc = ops.to_cells(x), ops.to_cells(res)
+    assert torch.equal(ops.from_cells(ops.to_cells(y0), y0.shape), ops.from_cells(want, y0.shape))
+    for rep in range(3):                 # the store hazard was a run-to-run effect
+        for x_cells in (False, True):
+            got = ops.conv2d_cells(xc if x_cells else x, packed, cin, cout, n, h, w, x_cells=x_cells, scale=sc, shift=sh, res=res,
+                                   relu=True)
+            assert torch.equal(got, want), (x_cells, rep, (ops.from_cells(got, y0.shape) - y0).abs().max().item())
+            got = ops.conv2d_cells(xc if x_cells else x, packed, cin, cout, n, h, w, x_cells=x_cells, scale=sc, shift=sh, res=rc,
+                                   res_cells=True, relu=True)
+            err = (ops.from_cells(got, y0.shape) - y0).abs().max().item()
+            assert err <= 2.0 ** -21 * max(1.0, y0.abs().max().item(), res.abs().max().item()), (x_cells, rep, err)
+    # no epilogue operands at all
+    y1, _ = ops.conv2d(x, wt, stride=1, pad=1, packed=packed)
+    assert torch.equal(ops.conv2d_cells(xc, packed, cin, cout, n, h, w, x_cells=True), ops.to_cells(y1))
+
+
 @pytest.mark.parametrize("cin,cout,h,w", [(64, 128, 64, 225), (256, 512, 16, 57), (128, 256, 9, 31), (64, 64, 7, 8)])
 def test_conv3x3_s2_split_fp16_is_fp32_grade(cin, cout, h, w):
     x, wt = _case(cin, cout, 3, h, w, 2, seed=cin + w)

@@ -62,6 +62,35 @@ def test_resnet_ragged_sizes_and_batch():
         close(f, R.resnet34_forward(sd, "perception.", img), 1e-4)
 
 
+def test_perception_cell_layout_vs_fp32_layout_and_oracle(tmp_path):
+    """csrc/conv2d_hs.hip: between plain launches of the pipelined 3x3 kernel the activations travel as 16-byte cells of
+    eight channels already split into fp16 hi / lo (the stride-2 kernel and the average pool read them too); launches that
+    split their reduction (few tiles) keep fp32 NCHW, so the batch decides layer by layer: B = 2 at 256x900 has cells in
+    layer1 only, B = 6 in layers 1-3, B = 12 everywhere.  Products are bit-identical in both layouts and a residual read
+    from cells is the tensor to 2^-23, so the features must agree far inside the oracle tolerance -- and with
+    ADX_CONV_CELLS=0 (a process of its own) the old path is still there to compare against."""
+    import os
+    import subprocess
+    import sys
+    import perception_worker as W
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "fp32_layout.pt")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "perception_worker.py"), out],
+                       env=dict(os.environ, ADX_CONV_CELLS="0"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    plain = torch.load(out)
+    cells = W.features()
+    sd = oracle_sd("NO_GUIDANCE")
+    for (hw, b) in W.CASES:
+        key = f"{hw[0]}x{hw[1]}b{b}"
+        scale = plain[key].abs().max().item()
+        err = (cells[key] - plain[key]).abs().max().item()
+        assert err <= 2e-6 * max(1.0, scale), (key, err, scale)
+        if b <= 6:
+            img = P.synthetic_batch(b, 16, image_hw=hw, seed=5 + b)["imgs"]
+            close(cells[key], R.resnet34_forward(sd, "perception.", img), 2e-4, rtol=1e-5)
+
+
 @pytest.mark.parametrize("H", [16, 32])
 def test_unet_forward_vs_golden(golden, H):
     g = golden("unet")
