@@ -688,8 +688,8 @@ static int resnet_forward_impl(adx_resnet* r, const void* packed, void* workspac
   }
   // Activation formats (conv2d_hs.hip: XCELLS).  Where a layer's 3x3 stride-1 convs run as plain launches of the pipelined
   // kernel, everything from the first one's output to the last one's is a CELL tensor (same bytes, same buffers): the next
-  // layer's fused stride-2 launch and the average pool read cells too.  What stays fp32 NCHW: the pooled stem map, the two
-  // outputs of a stride-2 launch, and all of a layer whose launches split their reduction (small batches).
+  // layer's fused stride-2 launch reads AND writes cells (both of its outputs) and the average pool reads them.  What stays
+  // fp32 NCHW: the pooled stem map, and all of a layer whose launches split their reduction (small batches).
   int cur = 0, H = h2, W = w2;
   bool cur_cells = false;            // format of buf[cur], the block input
   const size_t nblocks = r->block_has_ds.size();
@@ -703,11 +703,13 @@ static int resnet_forward_impl(adx_resnet* r, const void* packed, void* workspac
     const bool c2_plain = conv2d_hs3x3_plain(c2, batch, OH, OW);
     if (r->block_has_ds[b] && resnet_fuses_ds(c1, r->convs[ci + 0])) {
       const ConvSpec& ds = r->convs[ci++];
+      mid_cells = c2_plain;            // conv2 reads conv1's output and the downsample's (its residual): cells if it can
       rc = conv2d_hs_launch_block_s2(c1, ds, buf[cur], base + c1.o_w, base + c1.o_scale, base + c1.o_shift, buf[mid],
-                                     base + ds.o_w, base + ds.o_scale, base + ds.o_shift, buf[outb], batch, H, W, s, cur_cells);
+                                     base + ds.o_w, base + ds.o_scale, base + ds.o_shift, buf[outb], batch, H, W, s, cur_cells,
+                                     mid_cells);
       if (rc != ADX_OK) return rc;
       identity = buf[outb];
-      id_cells = false;
+      id_cells = mid_cells;
     } else {
       const bool c1_plain = c1.stride == 1 && conv2d_hs3x3_plain(c1, batch, H, W);
       ADX_REQUIRE(!cur_cells || c1_plain, "adx_resnet_forward: internal error (cell-layout input of a launch that cannot read it)");

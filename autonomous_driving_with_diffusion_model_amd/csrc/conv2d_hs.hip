@@ -58,11 +58,51 @@ __device__ __forceinline__ float hs_dpp(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
 
+// Cell-layout store of one lane's 16 accumulator values of a 32-channel group (v[r]: channel (r & 3) + 8 (r >> 2) + 4 khalf
+// of the lane's pixel; lane + 32 holds the other halves of the same cells).  Four v_permlane32_swap per pair of cells
+// leave lanes 0-31 with cells 0 and 2 of the group and lanes 32-63 with cells 1 and 3, eight channels each (v[8 i + 0..7] =
+// cell 2 i + khalf); then affine (sc / sh: LDS, indexed by the channel within the group's 64-channel slab), optional
+// residual (res8[i]: the eight values of cell 2 i + khalf, or null), ReLU, split, two 16-byte stores per cell.
+// so: SGPR byte offset of the group's first hi cell; cplane: bytes of one plane of cells; vcell: the lane's pixel * 16 +
+// khalf * 2 * cplane, or the out-of-range offset.
+__device__ __forceinline__ void cells_store32(float (&v)[16], const float* sc, const float* sh, int cl0, const float (*res8)[8],
+                                              bool relu, __amdgpu_buffer_rsrc_t yrsrc, uint32_t vcell, uint32_t so, uint32_t cplane) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const auto sw = __builtin_amdgcn_permlane32_swap(f2u(v[8 * i + j]), f2u(v[8 * i + 4 + j]), false, false);
+      v[8 * i + j] = u2f(sw[0]);
+      v[8 * i + 4 + j] = u2f(sw[1]);
+    }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = v[8 * i + j] * sc[cl0 + 16 * i + j] + sh[cl0 + 16 * i + j];
+      if (res8 != nullptr) t += res8[i][j];
+      o[j] = relu ? __builtin_fmaxf(t, 0.f) : t;
+    }
+    u32x4 hi, lo;
+    split8(o, 1.f, hi, lo);
+    const uint32_t sc2 = so + (uint32_t)(2 * i) * 2u * cplane;
+    __builtin_amdgcn_raw_buffer_store_b128(hi, yrsrc, vcell, sc2, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(lo, yrsrc, vcell, sc2 + cplane, 0);
+    // A VALU write to the data registers of a 16-byte buffer store in the next issue slot can reach the store (seen on
+    // gfx950: one dword of ~1e-4 of the cells, run to run different); the compiler's hazard recogniser inserts the wait
+    // state only for stores WITHOUT an SGPR offset, these have one.
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 1");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // STRIDE/K: the convolution; ROWS: output rows per wave (tile = 4*ROWS rows x 32 columns x 64 channels);
 // PBUF: LDS copies of the patch (2: one barrier per stage; 1: an extra barrier per chunk, for the large stride-2
 // patches); DS: also evaluate the BasicBlock's 1x1 stride-2 downsample conv (modeling/resnet.py:223-232) on the
 // centre tap's operand fragments -- same input pixels, its own weights / BN / output tensor.
-template <int STRIDE, int K, int ROWS, int PBUF, bool DS, bool XCELLS = false>
+template <int STRIDE, int K, int ROWS, int PBUF, bool DS, bool XCELLS = false, bool YCELLS = false>
 __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
   static_assert(!DS || (K == 3 && STRIDE == 2 && PBUF == 1), "the fused downsample rides on the 3x3 stride-2 conv");
   constexpr int TH = 4 * ROWS;
@@ -334,6 +374,32 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
   const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.res != nullptr ? a.res + img : a.y), 0, a.res != nullptr ? img_bytes : 0, 0x00020000);
   const uint32_t cbase_o = (uint32_t)(d2s ? cout0 - cls * a.d2s_cin : cout0) * plane_ob;
+  if constexpr (YCELLS) {
+    // both outputs as cell tensors (conv2d_hs3x3_kernel reads them: conv2 of the block takes y as its input and y_ds as its
+    // residual); no residual and no depth-to-space store on this path (the host checks)
+    const uint32_t cplane = (uint32_t)(a.OH * a.OW) * 16u;
+    const uint32_t cell0 = (uint32_t)(cout0 >> 3) * 2u * cplane;
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr) {
+      const int oy = oy0 + wave * ROWS + rr;
+      const uint32_t vcell = (oy < a.OH && ox < a.OW) ? (uint32_t)(oy * a.OW + ox) * 16u + (uint32_t)khalf * 2u * cplane : kOut;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = (accm[rr][half][r] + accl[rr][half][r] * (1.f / kLoScale)) * xs_inv;
+        cells_store32(v, ss, ss + kHsCout, half * 32 + 8 * khalf, nullptr, a.relu != 0, yrsrc, vcell,
+                      cell0 + (uint32_t)(half * 4) * 2u * cplane, cplane);
+        if (DS) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = (adm[rr][half][r] + adl[rr][half][r] * (1.f / kLoScale)) * xs_inv;
+          cells_store32(v, ss + 2 * kHsCout, ss + 3 * kHsCout, half * 32 + 8 * khalf, nullptr, false, drsrc, vcell,
+                        cell0 + (uint32_t)(half * 4) * 2u * cplane, cplane);
+        }
+      }
+    }
+    return;
+  }
   uint32_t voff[ROWS];
 #pragma unroll
   for (int rr = 0; rr < ROWS; ++rr) {
@@ -668,9 +734,7 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
     out[3] = (float)a1[1] + (float)b1[1] * (1.f / kLoScale);
   };
   if constexpr (YCELLS) {
-    // Cell output.  A lane's accumulators are channels {0-3, 8-11, 16-19, 24-27} + 4 khalf of its pixel and lane + 32 holds the
-    // other halves of the same cells: four v_permlane32_swap per pair of cells leave lanes 0-31 with cells 0 and 2 of the
-    // 32-channel group and lanes 32-63 with cells 1 and 3, eight channels each -- BN, residual, ReLU, split, two 16-byte stores.
+    // cell output (cells_store32); the residual is fetched first: as cells, or as fp32 values at the channels the lane owns AFTER the swap
     const uint32_t khoff = (uint32_t)khalf * 2u * cplane;                  // this lane's cells are the odd ones: one cell further
     uint32_t vcell[2], vres[2];
 #pragma unroll
@@ -708,45 +772,19 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
         float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = (accm[rr][half][r] + accl[rr][half][r] * (1.f / kLoScale)) * xs_inv;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, v[8 * i + j]),
-                                                             __builtin_bit_cast(uint32_t, v[8 * i + 4 + j]), false, false);
-            v[8 * i + j] = u2f(sw[0]);
-            v[8 * i + 4 + j] = u2f(sw[1]);
-          }
+        float res8[2][8];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const int cl = half * 32 + 16 * i + 8 * khalf;           // first of the lane's eight channels within the slab
-          float rv8[8];
           if (a.res_cells) {
-            half4(rraw[rr][half][i][0], rraw[rr][half][i][1], rraw[rr][half][i][4], rraw[rr][half][i][5], rv8);
-            half4(rraw[rr][half][i][2], rraw[rr][half][i][3], rraw[rr][half][i][6], rraw[rr][half][i][7], rv8 + 4);
+            half4(rraw[rr][half][i][0], rraw[rr][half][i][1], rraw[rr][half][i][4], rraw[rr][half][i][5], res8[i]);
+            half4(rraw[rr][half][i][2], rraw[rr][half][i][3], rraw[rr][half][i][6], rraw[rr][half][i][7], res8[i] + 4);
           } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) rv8[j] = __builtin_bit_cast(float, rraw[rr][half][i][j]);
+            for (int j = 0; j < 8; ++j) res8[i][j] = u2f(rraw[rr][half][i][j]);
           }
-          float o[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            float t = v[8 * i + j] * sst[cl + j] + sst[64 * CT + cl + j];
-            t += rv8[j];
-            o[j] = a.relu ? __builtin_fmaxf(t, 0.f) : t;
-          }
-          u32x4 hi, lo;
-          split8(o, 1.f, hi, lo);
-          const uint32_t so = cell0 + (uint32_t)(half * 4 + 2 * i) * 2u * cplane;
-          __builtin_amdgcn_raw_buffer_store_b128(hi, yrsrc, vcell[rr], so, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(lo, yrsrc, vcell[rr], so + cplane, 0);
-          // A VALU write to the data registers of a 16-byte buffer store in the next issue slot can reach the store (seen on
-          // gfx950: one dword of ~1e-4 of the cells, run to run different); the compiler's hazard recogniser inserts the wait
-          // state only for stores WITHOUT an SGPR offset, these have one.
-          __builtin_amdgcn_sched_barrier(0);
-          asm volatile("s_nop 1");
-          __builtin_amdgcn_sched_barrier(0);
         }
+        cells_store32(v, sst, sst + 64 * CT, half * 32 + 8 * khalf, res8, a.relu != 0, yrsrc, vcell[rr],
+                      cell0 + (uint32_t)(half * 4) * 2u * cplane, cplane);
       }
   } else {
   uint32_t voff[2];
@@ -1212,7 +1250,7 @@ int conv2d_hs_pack(const ConvSpec& c, const float* w, void* packed, int dgrad, h
   return ADX_OK;
 }
 
-template <int STRIDE, int K, int ROWS, int PBUF, bool DS, bool XCELLS = false>
+template <int STRIDE, int K, int ROWS, int PBUF, bool DS, bool XCELLS = false, bool YCELLS = false>
 static int hs_launch_t(Conv2dArgs a, hipStream_t s) {
   constexpr int TH = 4 * ROWS;
   constexpr int PH = (TH - 1) * STRIDE + K, PW = (kTileW - 1) * STRIDE + K;
@@ -1221,7 +1259,7 @@ static int hs_launch_t(Conv2dArgs a, hipStream_t s) {
   static_assert(lds <= 80 * 1024, "two workgroups per CU need <= 80 KB each");
   static bool attr = false;
   if (!attr) {
-    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs_kernel<STRIDE, K, ROWS, PBUF, DS, XCELLS>),
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs_kernel<STRIDE, K, ROWS, PBUF, DS, XCELLS, YCELLS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = true;
   }
@@ -1229,7 +1267,7 @@ static int hs_launch_t(Conv2dArgs a, hipStream_t s) {
   const size_t grid = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y * a.N;
   ADX_REQUIRE(grid < (1u << 31), "conv2d_hs: grid too large");
   ADX_REQUIRE((size_t)a.Cout * a.OH * a.OW * sizeof(float) < 0x7FFFFFFFu, "conv2d_hs: one image of the output exceeds the 32-bit byte offsets");
-  conv2d_hs_kernel<STRIDE, K, ROWS, PBUF, DS, XCELLS><<<dim3((unsigned)grid), dim3(256), lds, s>>>(a);
+  conv2d_hs_kernel<STRIDE, K, ROWS, PBUF, DS, XCELLS, YCELLS><<<dim3((unsigned)grid), dim3(256), lds, s>>>(a);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
 }
@@ -1283,7 +1321,7 @@ int conv2d_hs_stem_pool(const ConvSpec& L, const float* x, const float* w, const
 
 int conv2d_hs_launch_block_s2(const ConvSpec& c1, const ConvSpec& ds, const float* x, const float* w1, const float* scale1,
                               const float* shift1, float* y1, const float* wd, const float* scaled, const float* shiftd,
-                              float* yd, int N, int H, int W, hipStream_t s, int x_cells) {
+                              float* yd, int N, int H, int W, hipStream_t s, int x_cells, int y_cells) {
   ADX_REQUIRE(x && w1 && scale1 && shift1 && y1 && wd && scaled && shiftd && yd, "conv2d_hs block launch: null pointer");
   Conv2dArgs a{};
   a.x = x; a.w = w1; a.scale = scale1; a.shift = shift1; a.res = nullptr; a.y = y1; a.x_amax = nullptr; a.x_amax_n = 0;
@@ -1293,6 +1331,7 @@ int conv2d_hs_launch_block_s2(const ConvSpec& c1, const ConvSpec& ds, const floa
   a.KH = 3; a.KW = 3; a.stride = 2; a.pad = 1; a.relu = 1;
   a.cin_pad = c1.cin_pad; a.cc = c1.cc;
   a.x_cells = x_cells;
+  a.y_cells = y_cells;
   (void)ds;
   return conv2d_hs_launch(c1, a, s);
 }
@@ -1499,9 +1538,11 @@ int conv2d_hs_launch(const ConvSpec& L, Conv2dArgs a, hipStream_t s) {
     return hs_launch_t<1, 3, 2, 2, false>(a, s);
   }
   if (L.k == 3 && L.stride == 2 && L.pad == 1) {
-    if (a.x_cells) {
-      ADX_REQUIRE(ds && a.x_amax == nullptr, "conv2d_hs: a cell-layout input of the stride-2 conv needs the fused downsample launch");
-      return hs_launch_t<2, 3, 1, 1, true, true>(a, s);
+    if (a.x_cells || a.y_cells) {
+      ADX_REQUIRE(ds && a.x_amax == nullptr && a.res == nullptr && a.d2s_cin == 0,
+                  "conv2d_hs: cell-layout operands of the stride-2 conv need the fused downsample launch (no residual, no dynamic range)");
+      if (a.x_cells && a.y_cells) return hs_launch_t<2, 3, 1, 1, true, true, true>(a, s);
+      return a.x_cells ? hs_launch_t<2, 3, 1, 1, true, true, false>(a, s) : hs_launch_t<2, 3, 1, 1, true, false, true>(a, s);
     }
     return ds ? hs_launch_t<2, 3, 1, 1, true>(a, s) : hs_launch_t<2, 3, 1, 1, false>(a, s);
   }

@@ -127,7 +127,7 @@ int conv2d_hs_stem_pool(const ConvSpec& L, const float* x, const float* w, const
 // conv2d_hs_eligible (the downsample's weights packed with conv2d_hs_pack_ds)
 int conv2d_hs_launch_block_s2(const ConvSpec& c1, const ConvSpec& ds, const float* x, const float* w1, const float* scale1,
                               const float* shift1, float* y1, const float* wd, const float* scaled, const float* shiftd,
-                              float* yd, int N, int H, int W, hipStream_t s, int x_cells = 0);     // x_cells: x in the cell layout
+                              float* yd, int N, int H, int W, hipStream_t s, int x_cells = 0, int y_cells = 0);   // x / both outputs in the cell layout
 // conv2d_wgrad_hs.hip: weight gradient of the 3x3 convs on the fp16 matrix cores; dw must be zero on entry
 bool conv2d_wgrad_hs_eligible(int Cin, int Cout, int k, int stride, int pad);
 int conv2d_wgrad_hs(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, int stride,

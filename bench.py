@@ -118,8 +118,9 @@ def rocprof_avg_ms(prefix):
 
 def conv2d_roofline(dev, reps=10):
     """Dominant kernel of the timed region: conv2d_hs3x3_kernel (the 29 stride-1 3x3 convs of one
-    perception pass).  Every distinct shape is launched alone through the C ABI and timed with HIP events on the
-    launch stream; the launch-mix average is what rocprofv3's per-kernel average shows.
+    perception pass).  Every distinct shape is launched alone through the C ABI, in each operand layout the executor uses for it
+    (fp32 NCHW or pre-split cells, adx_conv2d_forward_cells), and timed with HIP events on the launch stream; the
+    launch-mix average is what rocprofv3's per-kernel average shows.
 
     The kernel produces an fp32-grade result on the fp16 matrix cores: every operand is split into an fp16 hi and a
     scaled fp16 lo part and each algorithmic multiply-add is issued as three v_mfma_f32_32x32x16_f16 products
@@ -133,21 +134,44 @@ def conv2d_roofline(dev, reps=10):
     tot_ms = tot_fl = tot_bytes = 0.0
     count = 0
     per_shape = []
+    first = True
     for (cin, cout, k, s, p, h, w), cnt in shapes.items():
         x = torch.randn((B, cin, h, w), device=dev)
         wt = torch.randn((cout, cin, k, k), device=dev) * (1.0 / (cin * k * k)) ** 0.5
         sc, sh = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev) * 0.1
+        res = torch.randn((B, cout, h, w), device=dev)
         y, packed = ops.conv2d(x, wt, stride=s, pad=p, scale=sc, shift=sh, relu=True)
-        ms = time_events(lambda: ops.conv2d(x, wt, stride=s, pad=p, scale=sc, shift=sh, relu=True, packed=packed, out=y), reps)
+        xc, rc = ops.to_cells(x), ops.to_cells(res)
+        kw = dict(scale=sc, shift=sh, relu=True)
+        run = lambda **f: (lambda: ops.conv2d_cells(xc if f["x_cells"] else x, packed, cin, cout, B, h, w, **f, **kw))  # noqa: E731
+        # the launches of this shape as adx_resnet_forward issues them (csrc/conv2d.hip): the layer's first 3x3 stride-1 conv reads
+        # fp32 (the pooled stem map, or conv1's output of a stride-2 block together with the downsample's as the residual),
+        # every other one reads cells; conv2 of the later blocks adds a cell residual; all of them write cells
+        nb = (cnt + 1) // 2
+        if first:        # layer1: conv1 of block 0 (fp32 in, no residual), conv2 of block 0 (cells in, the pooled map as residual)
+            variants = [("fp32 in", run(x_cells=False), 1), ("cells in, fp32 residual", run(x_cells=True, res=res), 1)]
+        else:            # conv2 of the stride-2 block
+            variants = [("fp32 in, fp32 residual", run(x_cells=False, res=res), 1)]
+        variants += [("cells in", run(x_cells=True), nb - 1), ("cells in, cell residual", run(x_cells=True, res=rc, res_cells=True), nb - 1)]
+        first = False
+        assert sum(v[2] for v in variants) == cnt, (cnt, variants)
+        ms = 0.0
+        detail = {}
+        for name, fn, c in variants:
+            fn()
+            t = time_events(fn, reps)
+            detail[name] = round(t, 4)
+            ms += t * c
+        ms /= cnt
         fl = conv_flops(B, cin, cout, k, s, p, h, w)
         byts = 4.0 * (x.numel() + y.numel() + wt.numel())
-        per_shape.append({"shape": f"{cin}->{cout} k{k} @{h}x{w}", "count": cnt, "ms": round(ms, 4),
+        per_shape.append({"shape": f"{cin}->{cout} k{k} @{h}x{w}", "count": cnt, "ms": round(ms, 4), "ms_by_operand_layout": detail,
                           "algorithmic_tflops": round(fl / ms / 1e9, 1), "issued_mfma_tflops": round(3 * fl / ms / 1e9, 1)})
         tot_ms += ms * cnt
         tot_fl += fl * cnt
         tot_bytes += byts * cnt
         count += cnt
-        del x, y, wt, packed
+        del x, y, wt, packed, xc, rc, res
     avg_ms = tot_ms / count
     equiv = tot_fl / count / avg_ms / 1e9      # algorithmic TFLOP/s
     achieved = 3.0 * equiv                     # fp16 MFMA TFLOP/s issued
