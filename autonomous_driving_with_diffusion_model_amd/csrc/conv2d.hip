@@ -667,6 +667,7 @@ static int resnet_forward_impl(adx_resnet* r, const void* packed, void* workspac
   } scratch_scope;
   size_t ci = 0;
   int rc;
+  bool pooled_cells = false;
   {
     const ConvSpec& c0 = r->convs[ci++];
     static int fuse = -1;           // ADX_STEM_POOL=0 keeps the stem and the pool as two launches
@@ -676,8 +677,11 @@ static int resnet_forward_impl(adx_resnet* r, const void* packed, void* workspac
     }
     if ((fuse || frames_u8 != nullptr) && conv2d_hs_eligible(c0)) {
       scratch_scope.set(stem, (size_t)batch * 64 * h1 * w1);     // the unpooled stem map is never written on this path
+      // the pooled map's readers are layer1's first block: conv1 (input) and conv2 (residual); cells if both read cells
+      pooled_cells = !r->block_has_ds.empty() && !r->block_has_ds[0] && r->convs[1].stride == 1 &&
+                     conv2d_hs3x3_plain(r->convs[1], batch, h2, w2) && conv2d_hs3x3_plain(r->convs[2], batch, h2, w2);
       rc = conv2d_hs_stem_pool(c0, img, base + c0.o_w, base + c0.o_scale, base + c0.o_shift, buf[0], batch, h, w, s,
-                               frames_u8, mean, stdv);
+                               frames_u8, mean, stdv, pooled_cells);
       if (rc != ADX_OK) return rc;
     } else {
       rc = conv2d_launch(c0, base, img, nullptr, stem, batch, h, w, 1, s);
@@ -689,9 +693,9 @@ static int resnet_forward_impl(adx_resnet* r, const void* packed, void* workspac
   // Activation formats (conv2d_hs.hip: XCELLS).  Where a layer's 3x3 stride-1 convs run as plain launches of the pipelined
   // kernel, everything from the first one's output to the last one's is a CELL tensor (same bytes, same buffers): the next
   // layer's fused stride-2 launch reads AND writes cells (both of its outputs) and the average pool reads them.  What stays
-  // fp32 NCHW: the pooled stem map, and all of a layer whose launches split their reduction (small batches).
+  // fp32 NCHW: all of a layer whose launches split their reduction (small batches) -- and the pooled stem map then.
   int cur = 0, H = h2, W = w2;
-  bool cur_cells = false;            // format of buf[cur], the block input
+  bool cur_cells = pooled_cells;     // format of buf[cur], the block input
   const size_t nblocks = r->block_has_ds.size();
   for (size_t b = 0; b < nblocks; ++b) {
     const ConvSpec& c1 = r->convs[ci++];

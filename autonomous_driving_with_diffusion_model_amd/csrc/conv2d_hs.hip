@@ -65,6 +65,7 @@ __device__ __forceinline__ float hs_dpp(float v) {
 // residual (res8[i]: the eight values of cell 2 i + khalf, or null), ReLU, split, two 16-byte stores per cell.
 // so: SGPR byte offset of the group's first hi cell; cplane: bytes of one plane of cells; vcell: the lane's pixel * 16 +
 // khalf * 2 * cplane, or the out-of-range offset.
+template <bool AFFINE = true>
 __device__ __forceinline__ void cells_store32(float (&v)[16], const float* sc, const float* sh, int cl0, const float (*res8)[8],
                                               bool relu, __amdgpu_buffer_rsrc_t yrsrc, uint32_t vcell, uint32_t so, uint32_t cplane) {
 #pragma unroll
@@ -80,7 +81,7 @@ __device__ __forceinline__ void cells_store32(float (&v)[16], const float* sc, c
     float o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float t = v[8 * i + j] * sc[cl0 + 16 * i + j] + sh[cl0 + 16 * i + j];
+      float t = AFFINE ? v[8 * i + j] * sc[cl0 + 16 * i + j] + sh[cl0 + 16 * i + j] : v[8 * i + j];
       if (res8 != nullptr) t += res8[i][j];
       o[j] = relu ? __builtin_fmaxf(t, 0.f) : t;
     }
@@ -1134,6 +1135,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_stem_kernel(const Conv2dArgs
       const int pr = ty * 4 + wave, pq = tx * 16 + (l31 >> 1);
       const bool st = pr < PHo && (l31 & 1) == 0 && pq < PWo && tx >= tx_own;
       const uint32_t voff = st ? (uint32_t)(pr * PWo + pq) * 4u + (uint32_t)(4 * khalf) * plane_ob : kOutside;
+      float mm[2][16];          // a.y_cells: the pooled values, stored as cells below
 #pragma unroll
       for (int half = 0; half < 2; ++half)
 #pragma unroll
@@ -1147,8 +1149,16 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_stem_kernel(const Conv2dArgs
           const float m = pool_max3(left, vm[half][r], right);
           cpark[2 * (half * 16 + r)] = vm[half][r];      // lane 31 parks its column for the next tile, the others hit a dummy row
           const int cu = half * 32 + (r & 3) + 8 * (r >> 2);       // + 4 * khalf, which rides in voff
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, m), yrsrc, voff, cu * plane_ob, 0);
+          mm[half][r] = m;
+          if (!a.y_cells) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, m), yrsrc, voff, cu * plane_ob, 0);
         }
+      if (a.y_cells) {          // the pooled map as a cell tensor (conv2d_hs3x3_kernel: XCELLS): layer1's first conv copies cells
+        const uint32_t cplane = (uint32_t)(PHo * PWo) * 16u;
+        const uint32_t vcell = st ? (uint32_t)(pr * PWo + pq) * 16u + (uint32_t)khalf * 2u * cplane : kOutside;
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+          cells_store32<false>(mm[half], nullptr, nullptr, 0, nullptr, false, yrsrc, vcell, (uint32_t)(half * 4) * 2u * cplane, cplane);
+      }
     }
 #ifdef ADX_HS_TRACE
     { const long long t = (long long)__builtin_readcyclecounter(); tr_e += t - tr_t; tr_t = t; }
@@ -1302,7 +1312,7 @@ static int hs_stem_launch(Conv2dArgs a, hipStream_t s) {
 
 int conv2d_hs_stem_pool(const ConvSpec& L, const float* x, const float* w, const float* scale, const float* shift,
                         float* pooled, int N, int H, int W, hipStream_t s, const uint8_t* frames_u8, const float* mean,
-                        const float* stdv) {
+                        const float* stdv, int y_cells) {
   ADX_REQUIRE((x || frames_u8) && w && scale && shift && pooled, "conv2d_hs_stem_pool: null pointer");
   ADX_REQUIRE((size_t)3 * H * W * sizeof(float) < 0xC0000000u, "conv2d_hs_stem_pool: image too large for 32-bit offsets");
   Conv2dArgs a{};
@@ -1316,6 +1326,7 @@ int conv2d_hs_stem_pool(const ConvSpec& L, const float* x, const float* w, const
   a.OH = conv_out_dim(H, 7, 2, 3); a.OW = conv_out_dim(W, 7, 2, 3);
   a.KH = 7; a.KW = 7; a.stride = 2; a.pad = 3; a.relu = 1;
   a.cin_pad = L.cin_pad; a.cc = L.cc;
+  a.y_cells = y_cells;
   return frames_u8 != nullptr ? hs_stem_launch<true, true>(a, s) : hs_stem_launch<true>(a, s);
 }
 

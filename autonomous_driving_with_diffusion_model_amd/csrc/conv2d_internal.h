@@ -122,7 +122,7 @@ void conv2d_set_split_scratch(float* p, size_t floats);
 // stem conv + BN + ReLU + MaxPool2d(3, 2, 1) in one pass: writes only the pooled map [N][64][PH][PW]
 int conv2d_hs_stem_pool(const ConvSpec& L, const float* x, const float* w, const float* scale, const float* shift,
                         float* pooled, int N, int H, int W, hipStream_t s, const uint8_t* frames_u8 = nullptr,
-                        const float* mean = nullptr, const float* stdv = nullptr);
+                        const float* mean = nullptr, const float* stdv = nullptr, int y_cells = 0);      // y_cells: pooled as a cell tensor
 // conv1 (3x3 stride 2, +BN+ReLU) and the block's downsample (1x1 stride 2, +BN) in one pass over x; both must be
 // conv2d_hs_eligible (the downsample's weights packed with conv2d_hs_pack_ds)
 int conv2d_hs_launch_block_s2(const ConvSpec& c1, const ConvSpec& ds, const float* x, const float* w1, const float* scale1,

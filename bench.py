@@ -134,7 +134,6 @@ def conv2d_roofline(dev, reps=10):
     tot_ms = tot_fl = tot_bytes = 0.0
     count = 0
     per_shape = []
-    first = True
     for (cin, cout, k, s, p, h, w), cnt in shapes.items():
         x = torch.randn((B, cin, h, w), device=dev)
         wt = torch.randn((cout, cin, k, k), device=dev) * (1.0 / (cin * k * k)) ** 0.5
@@ -144,16 +143,11 @@ def conv2d_roofline(dev, reps=10):
         xc, rc = ops.to_cells(x), ops.to_cells(res)
         kw = dict(scale=sc, shift=sh, relu=True)
         run = lambda **f: (lambda: ops.conv2d_cells(xc if f["x_cells"] else x, packed, cin, cout, B, h, w, **f, **kw))  # noqa: E731
-        # the launches of this shape as adx_resnet_forward issues them (csrc/conv2d.hip): the layer's first 3x3 stride-1 conv reads
-        # fp32 (the pooled stem map, or conv1's output of a stride-2 block together with the downsample's as the residual),
-        # every other one reads cells; conv2 of the later blocks adds a cell residual; all of them write cells
-        nb = (cnt + 1) // 2
-        if first:        # layer1: conv1 of block 0 (fp32 in, no residual), conv2 of block 0 (cells in, the pooled map as residual)
-            variants = [("fp32 in", run(x_cells=False), 1), ("cells in, fp32 residual", run(x_cells=True, res=res), 1)]
-        else:            # conv2 of the stride-2 block
-            variants = [("fp32 in, fp32 residual", run(x_cells=False, res=res), 1)]
-        variants += [("cells in", run(x_cells=True), nb - 1), ("cells in, cell residual", run(x_cells=True, res=rc, res_cells=True), nb - 1)]
-        first = False
+        # the launches of this shape as adx_resnet_forward issues them at this batch (csrc/conv2d.hip): every 3x3 stride-1 conv reads and
+        # writes cells (the pooled stem map and both outputs of the stride-2 launches are cell tensors too); conv2 of every block
+        # adds a cell residual.  Layer1 has as many conv1 as conv2 launches here, the other layers' first conv1 is the stride-2 one.
+        n2 = (cnt + 1) // 2
+        variants = [("cells in", run(x_cells=True), cnt - n2), ("cells in, cell residual", run(x_cells=True, res=rc, res_cells=True), n2)]
         assert sum(v[2] for v in variants) == cnt, (cnt, variants)
         ms = 0.0
         detail = {}
