@@ -665,74 +665,90 @@ static int resnet_forward_impl(adx_resnet* r, const void* packed, void* workspac
     void set(float* p, size_t n) { conv2d_set_split_scratch(p, n); }
     ~ScratchScope() { conv2d_set_split_scratch(nullptr, 0); }
   } scratch_scope;
-  size_t ci = 0;
-  int rc;
-  bool pooled_cells = false;
-  {
-    const ConvSpec& c0 = r->convs[ci++];
-    static int fuse = -1;           // ADX_STEM_POOL=0 keeps the stem and the pool as two launches
-    if (fuse < 0) {
-      const char* e = getenv("ADX_STEM_POOL");
-      fuse = (e != nullptr && e[0] == '0') ? 0 : 1;
-    }
+  const size_t nblocks = r->block_has_ds.size();
+
+  struct Cursor { size_t ci; int cur, H, W; bool cells; };
+  static int fuse = -1;           // ADX_STEM_POOL=0 keeps the stem and the pool as two launches
+  if (fuse < 0) {
+    const char* e = getenv("ADX_STEM_POOL");
+    fuse = (e != nullptr && e[0] == '0') ? 0 : 1;
+  }
+
+  // stem (+ pool) of images [n0, n0 + n)
+  auto run_stem = [&](Cursor& st, int n0, int n, int nf) -> int {
+    const ConvSpec& c0 = r->convs[0];
+    const float* im = img != nullptr ? img + (size_t)n0 * 3 * h * w : nullptr;
+    const uint8_t* fr = frames_u8 != nullptr ? frames_u8 + (size_t)n0 * 3 * h * w : nullptr;
+    float* pooled = buf[0] + (size_t)n0 * 64 * h2 * w2;
+    bool pooled_cells = false;
+    int rc;
     if ((fuse || frames_u8 != nullptr) && conv2d_hs_eligible(c0)) {
       scratch_scope.set(stem, (size_t)batch * 64 * h1 * w1);     // the unpooled stem map is never written on this path
       // the pooled map's readers are layer1's first block: conv1 (input) and conv2 (residual); cells if both read cells
-      pooled_cells = !r->block_has_ds.empty() && !r->block_has_ds[0] && r->convs[1].stride == 1 &&
-                     conv2d_hs3x3_plain(r->convs[1], batch, h2, w2) && conv2d_hs3x3_plain(r->convs[2], batch, h2, w2);
-      rc = conv2d_hs_stem_pool(c0, img, base + c0.o_w, base + c0.o_scale, base + c0.o_shift, buf[0], batch, h, w, s,
-                               frames_u8, mean, stdv, pooled_cells);
+      pooled_cells = nblocks > 0 && !r->block_has_ds[0] && r->convs[1].stride == 1 && conv2d_hs3x3_plain(r->convs[1], nf, h2, w2) &&
+                     conv2d_hs3x3_plain(r->convs[2], nf, h2, w2);
+      rc = conv2d_hs_stem_pool(c0, im, base + c0.o_w, base + c0.o_scale, base + c0.o_shift, pooled, n, h, w, s, fr, mean, stdv,
+                               pooled_cells);
       if (rc != ADX_OK) return rc;
     } else {
-      rc = conv2d_launch(c0, base, img, nullptr, stem, batch, h, w, 1, s);
+      float* sm = stem + (size_t)n0 * 64 * h1 * w1;
+      rc = conv2d_launch(c0, base, im, nullptr, sm, n, h, w, 1, s);
       if (rc != ADX_OK) return rc;
-      rc = maxpool_launch(stem, buf[0], batch * 64, h1, w1, h2, w2, s);
+      rc = maxpool_launch(sm, pooled, n * 64, h1, w1, h2, w2, s);
       if (rc != ADX_OK) return rc;
     }
-  }
+    st = Cursor{1, 0, h2, w2, pooled_cells};
+    return ADX_OK;
+  };
+
   // Activation formats (conv2d_hs.hip: XCELLS).  Where a layer's 3x3 stride-1 convs run as plain launches of the pipelined
   // kernel, everything from the first one's output to the last one's is a CELL tensor (same bytes, same buffers): the next
-  // layer's fused stride-2 launch reads AND writes cells (both of its outputs) and the average pool reads them.  What stays
-  // fp32 NCHW: all of a layer whose launches split their reduction (small batches) -- and the pooled stem map then.
-  int cur = 0, H = h2, W = w2;
-  bool cur_cells = pooled_cells;     // format of buf[cur], the block input
-  const size_t nblocks = r->block_has_ds.size();
-  for (size_t b = 0; b < nblocks; ++b) {
+  // layer's fused stride-2 launch reads AND writes cells (both of its outputs), the fused stem + pool launch writes them and
+  // the average pool reads them.  What stays fp32 NCHW: all of a layer whose launches split their reduction (small batches)
+  // -- and the pooled stem map then.
+  // One BasicBlock for images [n0, n0 + n); nf = the batch the format decisions are made for.
+  auto run_block = [&](size_t b, Cursor& st, int n0, int n, int nf) -> int {
+    size_t ci = st.ci;
+    const int cur = st.cur, H = st.H, W = st.W;
+    const bool cur_cells = st.cells;
     const ConvSpec& c1 = r->convs[ci++];
     const ConvSpec& c2 = r->convs[ci++];
     const int mid = (cur + 1) % 3, outb = (cur + 2) % 3;
     const int OH = conv_out(H, 3, c1.stride, 1), OW = conv_out(W, 3, c1.stride, 1);
-    const float* identity = buf[cur];
+    const size_t off_in = (size_t)n0 * c1.cin * H * W, off_out = (size_t)n0 * c1.cout * OH * OW;
+    const float* xin = buf[cur] + off_in;
+    const float* identity = xin;
     bool id_cells = cur_cells, mid_cells = false;
-    const bool c2_plain = conv2d_hs3x3_plain(c2, batch, OH, OW);
+    const bool c2_plain = conv2d_hs3x3_plain(c2, nf, OH, OW);
+    int rc;
     if (r->block_has_ds[b] && resnet_fuses_ds(c1, r->convs[ci + 0])) {
       const ConvSpec& ds = r->convs[ci++];
       mid_cells = c2_plain;            // conv2 reads conv1's output and the downsample's (its residual): cells if it can
-      rc = conv2d_hs_launch_block_s2(c1, ds, buf[cur], base + c1.o_w, base + c1.o_scale, base + c1.o_shift, buf[mid],
-                                     base + ds.o_w, base + ds.o_scale, base + ds.o_shift, buf[outb], batch, H, W, s, cur_cells,
+      rc = conv2d_hs_launch_block_s2(c1, ds, xin, base + c1.o_w, base + c1.o_scale, base + c1.o_shift, buf[mid] + off_out,
+                                     base + ds.o_w, base + ds.o_scale, base + ds.o_shift, buf[outb] + off_out, n, H, W, s, cur_cells,
                                      mid_cells);
       if (rc != ADX_OK) return rc;
-      identity = buf[outb];
+      identity = buf[outb] + off_out;
       id_cells = mid_cells;
     } else {
-      const bool c1_plain = c1.stride == 1 && conv2d_hs3x3_plain(c1, batch, H, W);
+      const bool c1_plain = c1.stride == 1 && conv2d_hs3x3_plain(c1, nf, H, W);
       ADX_REQUIRE(!cur_cells || c1_plain, "adx_resnet_forward: internal error (cell-layout input of a launch that cannot read it)");
       mid_cells = c1_plain && c2_plain && !r->block_has_ds[b];
-      rc = conv2d_launch(c1, base, buf[cur], nullptr, buf[mid], batch, H, W, 1, s,            // conv1 + bn1 + relu
+      rc = conv2d_launch(c1, base, xin, nullptr, buf[mid] + off_out, n, H, W, 1, s,            // conv1 + bn1 + relu
                          (cur_cells ? kFmtXCells : 0) | (mid_cells ? kFmtYCells : 0));
       if (rc != ADX_OK) return rc;
       if (r->block_has_ds[b]) {
         const ConvSpec& ds = r->convs[ci++];
         ADX_REQUIRE(!cur_cells, "adx_resnet_forward: internal error (cell-layout input of the downsample conv)");
-        rc = conv2d_launch(ds, base, buf[cur], nullptr, buf[outb], batch, H, W, 0, s);  // downsample conv + bn
+        rc = conv2d_launch(ds, base, xin, nullptr, buf[outb] + off_out, n, H, W, 0, s);  // downsample conv + bn
         if (rc != ADX_OK) return rc;
-        identity = buf[outb];
+        identity = buf[outb] + off_out;
         id_cells = false;
       }
     }
     // conv2 + bn2 + identity + relu.  With a downsample the identity lives in buf[outb] and the result
     // overwrites buf[cur] (the block input is dead by then); otherwise the result goes to buf[outb].
-    float* dst = r->block_has_ds[b] ? buf[cur] : buf[outb];
+    float* dst = (r->block_has_ds[b] ? buf[cur] : buf[outb]) + off_out;
     // the block output is a cell tensor when conv2 is a plain launch and whoever reads it reads cells: the next block's plain
     // conv1 + conv2 (as input and as residual), the next layer's fused stride-2 launch, or the average pool
     bool out_cells = false;
@@ -742,20 +758,31 @@ static int resnet_forward_impl(adx_resnet* r, const void* packed, void* workspac
       } else if (r->block_has_ds[b + 1]) {
         out_cells = resnet_fuses_ds(r->convs[ci], r->convs[ci + 2]);
       } else {
-        out_cells = r->convs[ci].stride == 1 && conv2d_hs3x3_plain(r->convs[ci], batch, OH, OW) &&
-                    conv2d_hs3x3_plain(r->convs[ci + 1], batch, OH, OW);
+        out_cells = r->convs[ci].stride == 1 && conv2d_hs3x3_plain(r->convs[ci], nf, OH, OW) &&
+                    conv2d_hs3x3_plain(r->convs[ci + 1], nf, OH, OW);
       }
     }
     ADX_REQUIRE(out_cells || !(mid_cells || id_cells),
                 "adx_resnet_forward: internal error (a conv with cell-layout operands whose reader wants fp32)");
-    rc = conv2d_launch(c2, base, buf[mid], identity, dst, batch, OH, OW, 1, s,
+    rc = conv2d_launch(c2, base, buf[mid] + off_out, identity, dst, n, OH, OW, 1, s,
                        (mid_cells ? kFmtXCells : 0) | (out_cells ? kFmtYCells : 0) | (id_cells ? kFmtResCells : 0));
     if (rc != ADX_OK) return rc;
-    if (!r->block_has_ds[b]) cur = outb;
-    cur_cells = out_cells;
-    H = OH; W = OW;
+    st = Cursor{ci, r->block_has_ds[b] ? cur : outb, OH, OW, out_cells};
+    return ADX_OK;
+  };
+
+  // (Running stem, layer1 and layer2's first block in batch chunks of 16, so that a 59 MB activation is still in the 256 MB
+  // Infinity Cache when the next launch reads it, was measured: layer1's convs already find most of their input there at
+  // B = 64 -- inside a pass they take 0.20 ms where the same launch repeated on fixed buffers takes 0.25 -- and the chunked
+  // stem launch has too few workgroups: +-1 % end to end for 2..4 chunks, -13 % for 8.  Not kept.)
+  Cursor st{};
+  int rc = run_stem(st, 0, batch, batch);
+  if (rc != ADX_OK) return rc;
+  for (size_t b = 0; b < nblocks; ++b) {
+    rc = run_block(b, st, 0, batch, batch);
+    if (rc != ADX_OK) return rc;
   }
-  return avgpool_fc_launch(buf[cur], base + r->o_fcw, base + r->o_fcb, feature, batch, 512, H * W, r->out_dim, s, cur_cells);
+  return avgpool_fc_launch(buf[st.cur], base + r->o_fcw, base + r->o_fcb, feature, batch, 512, st.H * st.W, r->out_dim, s, st.cells);
 }
 
 }  // extern "C"
