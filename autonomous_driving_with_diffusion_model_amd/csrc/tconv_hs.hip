@@ -1018,15 +1018,20 @@ int tconv_hs_forward(const adx_tconv_desc* d, const adx_tconv_io* io, hipStream_
   // costs ~4 us, so only reductions of >= 256 K-steps per workgroup (x2 fragments at 64 channels/group) or >= 1024 staged
   // channels are split.
   const bool worth = a.taps * a.ncb * t.nf >= 256 || a.cin_pad >= 1024;
-  if (split_on && worth && io->scratch != nullptr && ha.fast_epi && grid <= 32 && a.ncb >= 8) {
-    int S = 16;
+  // Round 3: with the ticket reduction the second launch is gone, and a grid of 33..128 workgroups (the 512-channel layers at
+  // UNet batch 128: 128 workgroups on 256 CUs, each streaming a 655 KB weight slab through one CU's L1) takes a split in TWO:
+  // 341 -> 332 us per forward at 128 rows (tools/chain_time.py); in four: 395 us (the partial tiles' round trip).
+  static const int split_grid = [] { const char* e = getenv("ADX_TCONV_KSPLIT_GRID"); return e ? atoi(e) : 128; }();
+  if (split_on && worth && io->scratch != nullptr && ha.fast_epi && grid <= split_grid && a.ncb >= 8 &&
+      (grid <= 32 || io->tickets != nullptr)) {
+    int S = grid <= 32 ? 16 : 2;
     while (S > 1 && (a.ncb % S != 0 || a.ncb / S < 2 || (size_t)grid * S * ha.ptile > (size_t)io->scratch_floats || grid * S > 512)) S >>= 1;
     if (S > 1) {
       ha.ksplit = S;
       ha.cper = (a.ncb / S) * 16;
       ha.part = io->scratch;
       ha.part_bytes = (size_t)grid * S * ha.ptile * sizeof(float);
-      if (io->tickets != nullptr && grid <= 64 && ha.part_bytes < 0x7FFFFFFFu) {
+      if (io->tickets != nullptr && grid <= 256 && ha.part_bytes < 0x7FFFFFFFu) {
         // one launch: the last workgroup of each (row tile, slab) to publish its partial tile adds them up (HsArgs::tickets)
         ha.tickets = io->tickets;
         return t.nf == 2 ? hs_launch<2, 8, 4>(ha, grid * S, t.lds_bytes, s) : hs_launch<1, 8, 6>(ha, grid * S, t.lds_bytes, s);

@@ -392,7 +392,7 @@ static adx_tconv_io make_io(const ConvLayer& L, const float* base, const Act& x0
 constexpr size_t kSplitScratchFloats = (size_t)2 << 20;
 static thread_local float* t_split_scratch = nullptr;
 static thread_local uint32_t* t_split_tickets = nullptr;     // 64 words, zero between calls (adx_tconv_io::tickets)
-constexpr size_t kTicketWords = 64;
+constexpr size_t kTicketWords = 256;
 
 static int run_conv(const ConvLayer& L, const float* base, const Act& x0, const Act* x1, const float* tbias,
                     int64_t tb_stride, const Act* res, float* y, int64_t y_sb, int64_t y_sc, int64_t y_sl, int rows,

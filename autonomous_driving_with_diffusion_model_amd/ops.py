@@ -24,7 +24,7 @@ def tconv(x0: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     """Temporal conv (+bias) [-> GroupNorm(groups) -> Mish] [+ tbias[:, :, None]] [+ res].
 
     scratch: optional float32 device buffer (adx_tconv_io::scratch) that allows a tiny-batch launch to split its
-    reduction over more workgroups; tickets: with it, 64 ZERO int32 device words (adx_tconv_io::tickets): the split
+    reduction over more workgroups; tickets: with it, 256 ZERO int32 device words (adx_tconv_io::tickets): the split
     reduction then needs no reduce launch and leaves the words zero.
 
     x0/x1: [B, C, L] views with arbitrary strides (x1 is concatenated after x0 along C);
@@ -70,7 +70,7 @@ def tconv(x0: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         assert scratch.is_cuda and scratch.dtype == torch.float32 and scratch.is_contiguous()
         io.scratch, io.scratch_floats = scratch.data_ptr(), scratch.numel()
         if tickets is not None:
-            assert tickets.is_cuda and tickets.dtype == torch.int32 and tickets.numel() >= 64 and tickets.is_contiguous()
+            assert tickets.is_cuda and tickets.dtype == torch.int32 and tickets.numel() >= 256 and tickets.is_contiguous()
             io.tickets = tickets.data_ptr()
     L.check(L.lib().adx_tconv_forward(C.byref(d), C.byref(io), s), "adx_tconv_forward")
     return y

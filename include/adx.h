@@ -88,9 +88,10 @@ typedef struct adx_tconv_io {
   /* optional device scratch (scratch_floats floats, contents irrelevant): lets a launch whose grid would occupy a few CUs
    * only (tiny batches) split its reduction over more workgroups and finish with a reduce launch.  NULL: never split. */
   float* scratch; int64_t scratch_floats;
-  /* optional (NULL: absent), with `scratch`: 64 device words that are ZERO when the call is enqueued.  A split reduction then
+  /* optional (NULL: absent), with `scratch`: 256 device words that are ZERO when the call is enqueued.  A split reduction then
    * needs no reduce launch: the last workgroup to publish its partial tile adds them up and leaves the words zero again, so
-   * the same 64 words serve every later call on the same stream. */
+   * the same words serve every later call on the same stream (one word per workgroup of the unsplit grid, which is at
+   * most 128 for a launch that splits). */
   uint32_t* tickets;
 } adx_tconv_io;
 
@@ -137,7 +138,7 @@ int adx_unet_num_params(const adx_unet* u);
 size_t adx_unet_packed_bytes(const adx_unet* u);
 int adx_unet_pack(adx_unet* u, const float* const* params, int32_t n_params, const float* freqs,
                   void* packed, adx_stream s);
-/* The workspace must be ZERO-FILLED by the caller once, when it is allocated: its first 64 words are the ticket words of
+/* The workspace must be ZERO-FILLED by the caller once, when it is allocated: its first 256 words are the ticket words of
  * adx_tconv_io::tickets (at a place that does not depend on `rows`; the library leaves them zero after every call). */
 size_t adx_unet_workspace_bytes(const adx_unet* u, int32_t rows);
 

@@ -51,7 +51,8 @@ def test_conv1d_block(c0, c1, cout, L, B):
 
 
 @pytest.mark.parametrize("c0,c1,cout,L,B", [(512, 0, 512, 2, 1), (512, 0, 512, 2, 2), (512, 0, 512, 4, 1), (512, 512, 256, 2, 2),
-                                            (256, 256, 128, 4, 1), (256, 0, 512, 2, 2), (512, 0, 512, 4, 3), (256, 0, 256, 4, 2)])
+                                            (256, 256, 128, 4, 1), (256, 0, 512, 2, 2), (512, 0, 512, 4, 3), (256, 0, 256, 4, 2),
+                                            (512, 0, 512, 4, 128), (512, 512, 256, 4, 128), (256, 0, 512, 4, 97)])
 def test_conv1d_block_split_reduction_tiny_batch(c0, c1, cout, L, B):
     """Deployed batch sizes (B = 1: 1 or 2 UNet rows, H = 16): with a scratch buffer the K-split kernel spreads the
     input channels over more workgroups and a reduce launch runs the epilogue (tconv_hs.hip, HsArgs::ksplit).  Same
@@ -76,11 +77,15 @@ def test_conv1d_block_split_reduction_tiny_batch(c0, c1, cout, L, B):
     assert torch.equal(_ops().tconv(x0.to(DEV), w.to(DEV), b.to(DEV), scratch=small, **kw), y_plain)
     # with ticket words the last workgroup to publish its partial tile adds them up in the same launch: same sums in the
     # same order as the reduce launch, and the words are zero again afterwards (three calls in a row on the same words)
-    tickets = torch.zeros(64, dtype=torch.int32, device=DEV)
+    tickets = torch.zeros(256, dtype=torch.int32, device=DEV)
     for _ in range(3):
         scratch.fill_(float("nan"))
         y_ticket = _ops().tconv(x0.to(DEV), w.to(DEV), b.to(DEV), scratch=scratch, tickets=tickets, **kw)
-        assert torch.equal(y_ticket, y_split)
+        if B <= 3:
+            assert torch.equal(y_ticket, y_split)
+        else:        # UNet batch ~128: grids of 33..128 workgroups split in two, and only through the ticket path
+            close(y_ticket.cpu(), ref, 2e-5)
+            close(y_ticket.cpu(), y_plain.cpu(), 4e-6)
         assert int(tickets.abs().sum()) == 0
 
 
