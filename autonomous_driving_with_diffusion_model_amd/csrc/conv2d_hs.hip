@@ -489,7 +489,7 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
   constexpr int NT = MODE == 0 ? 256 : 512;            // threads
   constexpr int TH = MODE == 1 ? 16 : 8;               // output rows per workgroup
   constexpr int CT = MODE == 2 ? 2 : 1;                // 64-channel slabs per workgroup
-  constexpr int K = 3, PH = TH + 2, PW = 34, PLANE = PH * PW, NITEM = 2 * PLANE;
+  constexpr int K = 3, PH = TH + 2, PW = YCELLS ? 38 : 34, PLANE = PH * PW, NITEM = 2 * PLANE;    // YCELLS: up to three image segments per row
   constexpr int PIT = (NITEM + NT - 1) / NT;           // patch rounds = slices, one per stage while they last
   constexpr int NW = 9 * 256, WST = 3 * 256 * CT;      // weight cells per chunk and 64-channel slab / per stage
   constexpr int WIT = (WST + NT - 1) / NT;
@@ -516,22 +516,35 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
   const int ct = bid % a.cout_tiles; bid /= a.cout_tiles;
   const int tx = bid % a.tiles_x; bid /= a.tiles_x;
   const int ty = bid % a.tiles_y; bid /= a.tiles_y;
-  const int n = bid;
+  const int n = YCELLS ? 0 : bid;
   const int oy0 = ty * TH, ox0 = tx * kTileW;
   const int iy0 = oy0 - a.pad, ix0 = ox0 - a.pad;
   const int cout0 = (ct * CT + slab) * kHsCout;
   const int l31 = lane & 31, khalf = lane >> 5;
+  // YCELLS (the inference executor's launches): column tiles run over the VIRTUAL width N x vw -- the images of the batch side
+  // by side, vw = W columns each (or W rounded up to 32, which is the per-image tiling) -- so a map 225 / 113 / 57 / 29 wide
+  // pays no padded MFMA columns: 450 tiles instead of 512 per tile row at B = 64 (-12 / 12 / 11 / 9 %).  A 32-column tile then
+  // spans up to three images (W >= 16); in the staged patch row every image segment keeps its own left / right halo cell, so
+  // the lane of virtual column v reads cell (lane + 2 seg + kw) and the main loop is the one of the per-image tiling.
+  const int vx0 = tx * kTileW;
+  const int n0 = YCELLS ? vx0 / a.vw : 0, x0 = YCELLS ? vx0 - n0 * a.vw : 0;
+  const int vl = vx0 + l31;
+  const int nl = YCELLS ? vl / a.vw : 0, xl = YCELLS ? vl - nl * a.vw : 0, seg = nl - n0;
+  const bool lane_valid = !YCELLS || (nl < a.N && xl < a.W);
   const size_t hw = (size_t)a.H * a.W;
   const int nchunks_all = a.cin_pad / kHsCC;
   const int nchunks = a.ksplit > 1 ? a.cper : nchunks_all;       // chunks THIS workgroup reduces over
   const int chunk0 = kpart * nchunks;
-  const float* xin = a.x + ((size_t)n * a.Cin + (size_t)chunk0 * kHsCC) * hw;
+  const float* xin = a.x + ((size_t)n * a.Cin + (size_t)chunk0 * kHsCC) * hw;      // YCELLS: n = 0, chunk0 = 0: the whole tensor
   const int nstages = nchunks * K;
   const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.w) + ((size_t)ct * CT * nchunks_all + chunk0) * NW;
   constexpr uint32_t kOutside = 0xC0000000u;
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(xin), 0, (int)((size_t)(a.Cin - chunk0 * kHsCC) * hw * sizeof(float)), 0x00020000);
+      const_cast<float*>(xin), 0,
+      (int)(uint32_t)((YCELLS ? (size_t)a.N * a.Cin : (size_t)(a.Cin - chunk0 * kHsCC)) * hw * sizeof(float)), 0x00020000);
   const uint32_t plane_bytes = (uint32_t)(hw * sizeof(float));
+  // YCELLS: widths of the tile's image segments in output columns (s0 + s1 + s2 = 32; an image is at least 16 columns wide)
+  const int s0 = min(kTileW, a.vw - x0), s1 = min(kTileW - s0, a.vw);
   uint32_t goff[PIT];
   int pcell[PIT];
 #pragma unroll
@@ -540,11 +553,19 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
     const int hg = e >= PLANE ? 1 : 0;
     const int p = e - hg * PLANE;
     const int py = p / PW, px = p - py * PW;
-    const int iy = iy0 + py, ix = ix0 + px;
-    const bool ok = e < NITEM && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    const int iy = iy0 + py;
+    int ix = ix0 + px, ni = n;
+    if constexpr (YCELLS) {        // patch column px -> (image, input column): [seg 0: x0 - 1 .. x0 + s0] [seg 1: -1 .. s1] [seg 2: -1 .. ]
+      const int sg = px < s0 + 2 ? 0 : (px < s0 + s1 + 4 ? 1 : 2);
+      const int first = sg == 0 ? 0 : (sg == 1 ? s0 + 2 : s0 + s1 + 4);
+      ix = (sg == 0 ? x0 : 0) - 1 + (px - first);
+      ni = n0 + sg;
+    }
+    const bool ok = e < NITEM && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && ni < a.N;
+    const size_t ioff = YCELLS ? (size_t)ni * a.Cin * hw * sizeof(float) : 0;
     goff[k] = !ok ? kOutside
-                  : XCELLS ? (uint32_t)(hg * 8 * hw * sizeof(float) + ((size_t)iy * a.W + ix) * 16)   // cell (2 chunk + hg, hi, iy, ix)
-                           : (uint32_t)((hg * 8 * hw + (size_t)iy * a.W + ix) * sizeof(float));
+                  : XCELLS ? (uint32_t)(ioff + hg * 8 * hw * sizeof(float) + ((size_t)iy * a.W + ix) * 16)   // cell (2 chunk + hg, hi, iy, ix)
+                           : (uint32_t)(ioff + (hg * 8 * hw + (size_t)iy * a.W + ix) * sizeof(float));
     pcell[k] = e < NITEM ? hg * 2 * PLANE + p : -1;
   }
   // weight cells of this thread: global offset inside a stage (slab-major) and LDS cell, or the dummy
@@ -646,7 +667,7 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
     *d1 = lo;
   };
 
-  const int pb_lane = khalf * 2 * PLANE + (rowpair * 2) * PW + l31;
+  const int pb_lane = khalf * 2 * PLANE + (rowpair * 2) * PW + l31 + (YCELLS ? 2 * seg : 0);
   const int wa_lane = slab * 768 + khalf * 64 + l31;
 
   // prologue: stage 0 complete in LDS; weights of stage 1 and the first slice of chunk 1 in flight
@@ -706,10 +727,12 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
   // epilogue through buffer descriptors: one instruction per access (wave-uniform channel offset in an SGPR, the
   // lane's pixel in one 32-bit VGPR); lanes outside the map carry the out-of-range offset, so their loads return 0
   // and their stores are dropped; without a residual the descriptor is empty and every load returns 0
-  const int ox = ox0 + l31;
+  const int ox = YCELLS ? xl : ox0 + l31;
   const uint32_t plane_ob = (uint32_t)(a.OH * a.OW) * (uint32_t)sizeof(float);
   const size_t img = (size_t)n * a.Cout * a.OH * a.OW;
-  const int img_bytes = (int)(a.Cout * plane_ob);
+  // YCELLS: the descriptors cover the whole tensors and the lane's image rides in its offset
+  const int img_bytes = (int)(uint32_t)((YCELLS ? (uint32_t)a.N : 1u) * (uint32_t)a.Cout * plane_ob);
+  const uint32_t img_off = YCELLS ? (uint32_t)nl * (uint32_t)a.Cout * plane_ob : 0u;
   float* const ybase = a.ksplit > 1 ? a.part + (size_t)kpart * a.part_stride : a.y;
   const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(ybase + img, 0, img_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -723,7 +746,7 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
 #pragma unroll
   for (int rr = 0; rr < 2; ++rr) {
     const int oy = oy0 + rowpair * 2 + rr;
-    inside[rr] = oy < a.OH && ox < a.OW;
+    inside[rr] = lane_valid && oy < a.OH && ox < a.OW;
     pix[rr] = (uint32_t)(oy * a.OW + ox);
   }
   auto half4 = [](uint32_t h0, uint32_t h1, uint32_t l0, uint32_t l1, float* out) {   // 4 channels: hi + lo / 2^11
@@ -740,8 +763,8 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
     uint32_t vcell[2], vres[2];
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
-      vcell[rr] = inside[rr] ? pix[rr] * 16u + khoff : kOutside;
-      vres[rr] = !inside[rr] ? kOutside : a.res_cells ? vcell[rr] : pix[rr] * 4u + (uint32_t)(8 * khalf) * plane_ob;
+      vcell[rr] = inside[rr] ? img_off + pix[rr] * 16u + khoff : kOutside;
+      vres[rr] = !inside[rr] ? kOutside : a.res_cells ? vcell[rr] : img_off + pix[rr] * 4u + (uint32_t)(8 * khalf) * plane_ob;
     }
     uint32_t rraw[2][2][2][8];          // residual of cell (rr, half, i): 8 floats, or the hi and lo cells as they are
 #pragma unroll
@@ -1429,15 +1452,25 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
     // the executor keeps a layer's 3x3 convs in the cell layout from the first one's output to the last one's (the stride-2
     // kernel and the average pool read cells too), so a cell operand always comes with a cell output
     ADX_REQUIRE(a.y_cells && a.x_amax == nullptr, "conv2d_hs: cell-layout operands come with a cell-layout output (and no dynamic range)");
+    constexpr size_t clds = (size_t)2 * 64 * (TH + 2) * 38 + (size_t)2 * 3 * 256 * CT * 16 + (2 * 64 * CT + 8) * sizeof(float) + 48;
+    static_assert(clds <= (MODE == 0 ? 80 : 160) * 1024, "LDS budget");
     static bool cattr = false;
     if (!cattr) {
       const void* fns[2] = {reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, false, true, true>),
                             reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, false, false, true>)};
-      for (const void* f : fns) ADX_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      for (const void* f : fns) ADX_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
       cattr = true;
     }
-    if (a.x_cells) conv2d_hs3x3_kernel<MODE, false, true, true><<<dim3((unsigned)grid), dim3(NT), lds, s>>>(a);
-    else conv2d_hs3x3_kernel<MODE, false, false, true><<<dim3((unsigned)grid), dim3(NT), lds, s>>>(a);
+    // column tiles over the images side by side (conv2d_hs3x3_kernel: YCELLS): no padded MFMA columns at the right edge of
+    // every image.  Maps narrower than 16 columns (a tile would span more than three images) keep the per-image tiling.
+    static const bool vcat_on = [] { const char* e = getenv("ADX_CONV_VCAT"); return !(e != nullptr && e[0] == '0'); }();
+    a.vw = (vcat_on && a.N > 1 && a.OW >= 16) ? a.OW : round_up(a.OW, kTileW);
+    a.tiles_x = ceil_div(a.N * a.vw, kTileW);
+    const size_t cgrid = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y;
+    ADX_REQUIRE((size_t)a.N * a.Cout * a.OH * a.OW * sizeof(float) < 0xC0000000u && (size_t)a.N * a.Cin * a.H * a.W * sizeof(float) < 0xC0000000u,
+                "conv2d_hs: a cell-layout tensor exceeds the 32-bit byte offsets");
+    if (a.x_cells) conv2d_hs3x3_kernel<MODE, false, true, true><<<dim3((unsigned)cgrid), dim3(NT), clds, s>>>(a);
+    else conv2d_hs3x3_kernel<MODE, false, false, true><<<dim3((unsigned)cgrid), dim3(NT), clds, s>>>(a);
     ADX_LAUNCH_CHECK();
     return ADX_OK;
   }

@@ -59,6 +59,7 @@ struct Conv2dArgs {
   int stats_p;
   // conv2d_hs3x3 only (inference executor): x / y / res in the cell layout instead of fp32 NCHW (conv2d_hs.hip: XCELLS)
   int x_cells, y_cells, res_cells;
+  int vw;       // y_cells: virtual width of one image in the column tiling (W: images side by side; W rounded up to 32: per image)
 };
 
 // activation formats of one launch of the inference executor (bits)
