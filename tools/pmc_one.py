@@ -8,8 +8,9 @@ dev = "cuda:0"
 x = torch.randn(64, cin, h, w, device=dev).relu_()
 wt = torch.randn(cin, cin, 3, 3, device=dev) * 0.05
 sc, sh = torch.rand(cin, device=dev), torch.rand(cin, device=dev)
-y, packed = ops.conv2d(x, wt, stride=1, pad=1)
-res = torch.randn_like(y)
-for _ in range(4):
-    ops.conv2d(x, wt, stride=1, pad=1, packed=packed, out=y, scale=sc, shift=sh, res=res, relu=True)
+_, packed = ops.conv2d(x, wt, stride=1, pad=1)
+res = torch.randn_like(x)
+xc, rc = ops.to_cells(x), ops.to_cells(res)
+for _ in range(4):          # as the executor launches it at B = 64: cell tensors in and out, cell residual
+    ops.conv2d_cells(xc, packed, cin, cin, 64, h, w, x_cells=True, scale=sc, shift=sh, res=rc, res_cells=True, relu=True)
 torch.cuda.synchronize()
