@@ -100,8 +100,8 @@ def pmc_traffic(key):
 
 
 def rocprof_avg_ms(prefix):
-    """Launch-weighted average duration of the kernels whose name contains `prefix` in the newest committed
-    rocprofv3 --kernel-trace --stats summary of this command (profiles/r*_bench_kernel_stats.csv)."""
+    """Launch-weighted average duration of the kernels whose name contains `prefix` (a string, or several that must all
+    occur) in the newest committed rocprofv3 --kernel-trace --stats summary of this command (profiles/r*_bench_kernel_stats.csv)."""
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")))
@@ -110,7 +110,7 @@ def rocprof_avg_ms(prefix):
     calls = tot = 0
     with open(files[-1]) as f:
         for row in csv.DictReader(f):
-            if prefix in row["Name"]:
+            if all(part in row["Name"] for part in ([prefix] if isinstance(prefix, str) else prefix)):
                 calls += int(row["Calls"])
                 tot += int(row["TotalDurationNs"])
     return round(tot / calls / 1e6, 4) if calls else None
@@ -158,7 +158,7 @@ def conv2d_roofline(dev, reps=10):
             ms += t * c
         ms /= cnt
         fl = conv_flops(B, cin, cout, k, s, p, h, w)
-        byts = 4.0 * (x.numel() + y.numel() + wt.numel())
+        byts = 4.0 * (x.numel() + y.numel() + wt.numel() + res.numel() * n2 / cnt)     # conv2 of every block also reads its residual
         per_shape.append({"shape": f"{cin}->{cout} k{k} @{h}x{w}", "count": cnt, "ms": round(ms, 4), "ms_by_operand_layout": detail,
                           "algorithmic_tflops": round(fl / ms / 1e9, 1), "issued_mfma_tflops": round(3 * fl / ms / 1e9, 1)})
         tot_ms += ms * cnt
@@ -177,7 +177,9 @@ def conv2d_roofline(dev, reps=10):
             "achieved_note": "achieved / frac (the contract figures, SURVEY 8d) = ALGORITHMIC conv flops (2*M*N*K) per launch / "
                              "HIP-event launch time, against the dense fp16 MFMA peak; achieved_issued / frac_issued = the fp16 "
                              "MFMA flops the kernel actually issues (3 x algorithmic: hi*hi + hi*lo + lo*hi) / the same time",
-            "avg_launch_ms_rocprof": rocprof_avg_ms("conv2d_hs3x3_kernel"),
+            # the inference instantiations (cell tensors in and out: "<MODE, false, true, true>"); the same summary also holds the
+            # training leg's fp32-layout launches of this kernel
+            "avg_launch_ms_rocprof": rocprof_avg_ms(["conv2d_hs3x3_kernel", "true, true>("]),
             "fp32_mfma_peak_tflops": PEAK_F32_TFLOPS, "frac_of_fp32_mfma_peak": round(equiv / PEAK_F32_TFLOPS, 3),
             "traffic": pmc_traffic("conv2d_hs3x3_kernel"),
             "traffic_note": "bytes/launch, 2 x FETCH_SIZE (gfx950 correction, calibrated: tools/micro/fetch_calib.hip) + WRITE_SIZE from profiles/" + os.path.basename(pmc_traffic_file() or "(none)") + " (separate rocprofv3 --pmc passes)",
