@@ -18,8 +18,14 @@ wt = torch.randn(cout, cin, 3, 3, device=DEV) * 0.05
 y, packed = ops.conv2d(x, wt, stride=1, pad=1)
 res = torch.randn_like(y)
 sc, sh = torch.rand(cout, device=DEV), torch.rand(cout, device=DEV)
-for _ in range(3):
-    ops.conv2d(x, wt, stride=1, pad=1, packed=packed, out=y, scale=sc, shift=sh, res=res, relu=True)
+import os
+if os.environ.get("CELLS", "1") == "1":      # as the executor launches it at this batch: cell tensors in and out, cell residual
+    xc, rc_ = ops.to_cells(x), ops.to_cells(res)
+    for _ in range(3):
+        ops.conv2d_cells(xc, packed, cin, cout, B, h, w, x_cells=True, scale=sc, shift=sh, res=rc_, res_cells=True, relu=True)
+else:
+    for _ in range(3):
+        ops.conv2d(x, wt, stride=1, pad=1, packed=packed, out=y, scale=sc, shift=sh, res=res, relu=True)
 torch.cuda.synchronize()
 lib = ctypes.CDLL(_lib.LIB_PATH)
 n = 16384
