@@ -92,10 +92,9 @@ __device__ __forceinline__ void cells_store32(float (&v)[16], const float* sc, c
     __builtin_amdgcn_raw_buffer_store_b128(lo, yrsrc, vcell, sc2 + cplane, 0);
     // A VALU write to the data registers of a 16-byte buffer store in the next issue slot can reach the store (seen on
     // gfx950: one dword of ~1e-4 of the cells, run to run different); the compiler's hazard recogniser inserts the wait
-    // state only for stores WITHOUT an SGPR offset, these have one.
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_nop 1");
-    __builtin_amdgcn_sched_barrier(0);
+    // state only for stores WITHOUT an SGPR offset, these have one.  The statement below keeps both data operands alive
+    // across one wait state, wherever the scheduler puts it: nothing can write them before it.
+    asm volatile("s_nop 0" ::"v"(hi), "v"(lo));
   }
 }
 
@@ -749,13 +748,14 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
     inside[rr] = lane_valid && oy < a.OH && ox < a.OW;
     pix[rr] = (uint32_t)(oy * a.OW + ox);
   }
-  auto half4 = [](uint32_t h0, uint32_t h1, uint32_t l0, uint32_t l1, float* out) {   // 4 channels: hi + lo / 2^11
-    const f16x2 a0 = __builtin_bit_cast(f16x2, h0), a1 = __builtin_bit_cast(f16x2, h1);
-    const f16x2 b0 = __builtin_bit_cast(f16x2, l0), b1 = __builtin_bit_cast(f16x2, l1);
-    out[0] = (float)a0[0] + (float)b0[0] * (1.f / kLoScale);
-    out[1] = (float)a0[1] + (float)b0[1] * (1.f / kLoScale);
-    out[2] = (float)a1[0] + (float)b1[0] * (1.f / kLoScale);
-    out[3] = (float)a1[1] + (float)b1[1] * (1.f / kLoScale);
+  // 4 channels of a cell pair: hi + lo / 2^11, one v_fma_mix_f32 per value (fp16 operands converted inside the instruction; the
+  // product with a power of two is exact, so this is the same value as convert, multiply, add -- in a third of the instructions)
+  auto half4 = [](uint32_t h0, uint32_t h1, uint32_t l0, uint32_t l1, float* out) {
+    const float inv = 1.f / kLoScale;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(out[0]) : "v"(l0), "s"(inv), "v"(h0));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(out[1]) : "v"(l0), "s"(inv), "v"(h0));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(out[2]) : "v"(l1), "s"(inv), "v"(h1));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(out[3]) : "v"(l1), "s"(inv), "v"(h1));
   };
   if constexpr (YCELLS) {
     // cell output (cells_store32); the residual is fetched first: as cells, or as fp32 values at the channels the lane owns AFTER the swap
@@ -795,7 +795,7 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
       for (int half = 0; half < 2; ++half) {
         float v[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = (accm[rr][half][r] + accl[rr][half][r] * (1.f / kLoScale)) * xs_inv;
+        for (int r = 0; r < 16; ++r) v[r] = accm[rr][half][r] + accl[rr][half][r] * (1.f / kLoScale);      // no dynamic range here: xs = 1
         float res8[2][8];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
