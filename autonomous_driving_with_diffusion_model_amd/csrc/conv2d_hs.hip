@@ -1512,6 +1512,9 @@ bool conv2d_hs3x3_plain(const ConvSpec& L, int N, int H, int W) {
   a.OH = conv_out_dim(H, L.k, L.stride, L.pad); a.OW = conv_out_dim(W, L.k, L.stride, L.pad);
   const int mode = hs3x3_mode(L, a);
   if (mode < 0 || L.cin % 16 != 0 || L.cout % 64 != 0) return false;
+  // the cell kernels address whole tensors through one descriptor with 32-bit offsets (batches of ~870 frames at 256x900 and up
+  // stay on the fp32 layout with its per-image descriptors)
+  if ((size_t)N * L.cin * H * W * sizeof(float) >= 0xC0000000u || (size_t)N * L.cout * a.OH * a.OW * sizeof(float) >= 0xC0000000u) return false;
   const long grid0 = (long)a.N * ceil_div(a.OH, 8) * ceil_div(a.OW, kTileW) * (a.Cout / kHsCout);
   return mode != 0 || grid0 > 64 || L.cin_pad / kHsCC < 8;       // hs3x3_launch<0> splits the reduction of smaller launches
 }
