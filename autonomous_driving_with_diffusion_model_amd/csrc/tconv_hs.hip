@@ -289,7 +289,7 @@ __device__ __forceinline__ void hs_epilogue4(const TConvArgs& a, const float* P,
 }
 
 template <int NF, int NW, int PF>
-__global__ void __launch_bounds__(64 * NW) tconv_hs_kernel(const HsArgs ha) {
+__device__ __forceinline__ void tconv_hs_body(const HsArgs& ha, const int bid) {
   constexpr int NT = 64 * NW;
   const TConvArgs& a = ha.t;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -297,8 +297,8 @@ __global__ void __launch_bounds__(64 * NW) tconv_hs_kernel(const HsArgs ha) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nt = blockIdx.x % a.ntiles;   // blocks b, b + 8 share an XCD: with ntiles | 8 or 8 | ntiles one XCD's L2 serves one weight slab
-  const int rest = blockIdx.x / a.ntiles;
+  const int nt = bid % a.ntiles;   // blocks b, b + 8 share an XCD: with ntiles | 8 or 8 | ntiles one XCD's L2 serves one weight slab
+  const int rest = bid / a.ntiles;
   const int kpart = ha.ksplit > 1 ? rest % ha.ksplit : 0;
   const int rowtile = ha.ksplit > 1 ? rest / ha.ksplit : rest;
   const int b0 = rowtile * a.bt;
@@ -476,6 +476,11 @@ __global__ void __launch_bounds__(64 * NW) tconv_hs_kernel(const HsArgs ha) {
   } else {
     tconv_epilogue<NT, NW, TILE>(a, smem, tid, lane, wave, nt, b0);
   }
+}
+
+template <int NF, int NW, int PF>
+__global__ void __launch_bounds__(64 * NW) tconv_hs_kernel(const HsArgs ha) {
+  tconv_hs_body<NF, NW, PF>(ha, (int)blockIdx.x);
 }
 
 // second half of a split reduction (HsArgs::ksplit > 1): one workgroup per (row tile, channel slab)
@@ -729,6 +734,24 @@ template <int PF, bool UT>
 __global__ void __launch_bounds__(256) tconv_hsd_pair_kernel(const HsdPair pr) {
   if ((int)blockIdx.x < pr.n_a) tconv_hsd_body<PF, UT>(pr.a, (int)blockIdx.x);
   else tconv_hsd_body<PF, UT>(pr.b, (int)blockIdx.x - pr.n_a);
+}
+
+// A K-split conv and a short-K conv that read the same input and nothing of each other in ONE launch (a residual block's
+// first conv beside its 1x1 residual conv where the first is too long for the short-K kernel: the 256/512-channel levels).
+// The short-K workgroups use the first four of the launch's eight waves.
+struct HsMixed {
+  HsArgs a;
+  HsdArgs b;
+  int n_a;
+};
+template <int NF, int NW, int PF, bool UT>
+__global__ void __launch_bounds__(64 * NW) tconv_hs_mixed_kernel(const HsMixed pr) {
+  if ((int)blockIdx.x < pr.n_a) {
+    tconv_hs_body<NF, NW, PF>(pr.a, (int)blockIdx.x);
+  } else {
+    if (threadIdx.x >= 256) return;          // (a finished wave no longer takes part in the workgroup's barriers)
+    tconv_hsd_body<kHsdPF, UT>(pr.b, (int)blockIdx.x - pr.n_a);
+  }
 }
 
 // weight image of the short-K variant: [cout_pad32 / 16][nsteps][2 planes][64 lanes][8 halfs]; element j of lane ln at
@@ -994,18 +1017,23 @@ static int hs_prepare(const adx_tconv_desc* d, const adx_tconv_io* io, HsTile* t
   return ADX_OK;
 }
 
-int tconv_hs_forward(const adx_tconv_desc* d, const adx_tconv_io* io, hipStream_t s) {
+// How the K-split kernel serves one conv: its arguments with the split decision made, the grid, and whether a reduce launch
+// has to follow (a split without ticket words).
+struct HsPlan {
   HsTile t;
   HsArgs ha;
+  int grid;            // workgroups of the main launch (the unsplit grid x ksplit)
+  int base_grid;       // (row tile, slab) pairs
+  bool reduce;         // tconv_hs_reduce_kernel must run after it
+};
+
+static int hs_plan(const adx_tconv_desc* d, const adx_tconv_io* io, HsPlan* p) {
+  HsTile& t = p->t;
+  HsArgs& ha = p->ha;
   int rc = hs_prepare(d, io, &t, &ha);
   if (rc != ADX_OK) return rc;
-  {
-    HsdArgs da;
-    size_t lds;
-    int grid_d;
-    if (hsd_prepare(d, ha, t, &da, &lds, &grid_d)) return hsd_launch(da, grid_d, lds, s);
-  }
   const int grid = ceil_div(io->batch, t.bt) * t.ntiles;
+  p->grid = grid; p->base_grid = grid; p->reduce = false;
   // a grid that fits the chip one workgroup per CU must not be packed two per CU (the dispatcher does that with
   // 128 workgroups on 256 CUs): the two would share one CU's L2->L1 fill rate, which is what bounds the K loop
   static const size_t min_lds = [] { const char* e = getenv("ADX_TCONV_MIN_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();   // measured: no gain, off by default
@@ -1028,24 +1056,57 @@ int tconv_hs_forward(const adx_tconv_desc* d, const adx_tconv_io* io, hipStream_
     while (S > 1 && (a.ncb % S != 0 || a.ncb / S < 2 || (size_t)grid * S * ha.ptile > (size_t)io->scratch_floats || grid * S > 512)) S >>= 1;
     if (S > 1) {
       ha.ksplit = S;
-      ha.cper = (a.ncb / S) * 16;
+      ha.cper = (a.ncb / S) * 16;          // the staged chunk now holds cper channels at most
       ha.part = io->scratch;
       ha.part_bytes = (size_t)grid * S * ha.ptile * sizeof(float);
+      p->grid = grid * S;
       if (io->tickets != nullptr && grid <= 256 && ha.part_bytes < 0x7FFFFFFFu) {
         // one launch: the last workgroup of each (row tile, slab) to publish its partial tile adds them up (HsArgs::tickets)
         ha.tickets = io->tickets;
-        return t.nf == 2 ? hs_launch<2, 8, 4>(ha, grid * S, t.lds_bytes, s) : hs_launch<1, 8, 6>(ha, grid * S, t.lds_bytes, s);
+      } else {
+        p->reduce = true;
       }
-      // the staged chunk now holds cper channels at most
-      rc = t.nf == 2 ? hs_launch<2, 8, 4>(ha, grid * S, t.lds_bytes, s) : hs_launch<1, 8, 6>(ha, grid * S, t.lds_bytes, s);
-      if (rc != ADX_OK) return rc;
-      if (t.nf == 2) tconv_hs_reduce_kernel<2><<<dim3(grid), dim3(512), 0, s>>>(ha);
-      else tconv_hs_reduce_kernel<1><<<dim3(grid), dim3(256), 0, s>>>(ha);
-      ADX_LAUNCH_CHECK();
-      return ADX_OK;
     }
   }
-  return t.nf == 2 ? hs_launch<2, 8, 4>(ha, grid, t.lds_bytes, s) : hs_launch<1, 8, 6>(ha, grid, t.lds_bytes, s);
+  return ADX_OK;
+}
+
+int tconv_hs_forward(const adx_tconv_desc* d, const adx_tconv_io* io, hipStream_t s) {
+  {
+    HsTile t;
+    HsArgs ha;
+    int rc = hs_prepare(d, io, &t, &ha);
+    if (rc != ADX_OK) return rc;
+    HsdArgs da;
+    size_t lds;
+    int grid_d;
+    if (hsd_prepare(d, ha, t, &da, &lds, &grid_d)) return hsd_launch(da, grid_d, lds, s);
+  }
+  HsPlan p;
+  int rc = hs_plan(d, io, &p);
+  if (rc != ADX_OK) return rc;
+  rc = p.t.nf == 2 ? hs_launch<2, 8, 4>(p.ha, p.grid, p.t.lds_bytes, s) : hs_launch<1, 8, 6>(p.ha, p.grid, p.t.lds_bytes, s);
+  if (rc != ADX_OK || !p.reduce) return rc;
+  if (p.t.nf == 2) tconv_hs_reduce_kernel<2><<<dim3(p.base_grid), dim3(512), 0, s>>>(p.ha);
+  else tconv_hs_reduce_kernel<1><<<dim3(p.base_grid), dim3(256), 0, s>>>(p.ha);
+  ADX_LAUNCH_CHECK();
+  return ADX_OK;
+}
+
+template <int NF, int PF>
+static int hs_launch_mixed(const HsMixed& pr, int grid, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_hs_mixed_kernel<NF, 8, PF, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxHsLds));
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_hs_mixed_kernel<NF, 8, PF, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxHsLds));
+    attr_set = true;
+  }
+  if (pr.b.log2_ncell >= 2) tconv_hs_mixed_kernel<NF, 8, PF, true><<<dim3(grid), dim3(512), lds, s>>>(pr);
+  else tconv_hs_mixed_kernel<NF, 8, PF, false><<<dim3(grid), dim3(512), lds, s>>>(pr);
+  ADX_LAUNCH_CHECK();
+  return ADX_OK;
 }
 
 #ifdef ADX_TCONV_TRACE
@@ -1065,10 +1126,23 @@ int tconv_hs_forward_pair(const adx_tconv_desc* da, const adx_tconv_io* ioa, con
   size_t la = 0, lb = 0;
   int ga = 0, gb = 0;
   if (pair_on && tconv_hs_supported(da) && tconv_hs_supported(db) && hs_prepare(da, ioa, &ta, &ha) == ADX_OK &&
-      hs_prepare(db, iob, &tb, &hb) == ADX_OK && hsd_prepare(da, ha, ta, &pr.a, &la, &ga) &&
-      hsd_prepare(db, hb, tb, &pr.b, &lb, &gb) && (pr.a.log2_ncell >= 2) == (pr.b.log2_ncell >= 2)) {
-    pr.n_a = ga;
-    return hsd_launch_pair(pr, ga + gb, la > lb ? la : lb, s);
+      hs_prepare(db, iob, &tb, &hb) == ADX_OK) {
+    const bool a_short = hsd_prepare(da, ha, ta, &pr.a, &la, &ga), b_short = hsd_prepare(db, hb, tb, &pr.b, &lb, &gb);
+    if (a_short && b_short && (pr.a.log2_ncell >= 2) == (pr.b.log2_ncell >= 2)) {
+      pr.n_a = ga;
+      return hsd_launch_pair(pr, ga + gb, la > lb ? la : lb, s);
+    }
+    // `a` on the K-split kernel (one launch: unsplit, or split with ticket words) beside a short-K `b`
+    static const bool mixed_on = [] { const char* e = getenv("ADX_TCONV_NO_MIXED"); return !(e != nullptr && e[0] == '1'); }();
+    HsPlan p;
+    if (mixed_on && !a_short && b_short && hs_plan(da, ioa, &p) == ADX_OK && !p.reduce) {
+      HsMixed mx;
+      mx.a = p.ha;
+      mx.b = pr.b;
+      mx.n_a = p.grid;
+      const size_t lds = p.t.lds_bytes > lb ? p.t.lds_bytes : lb;
+      return p.t.nf == 2 ? hs_launch_mixed<2, 4>(mx, p.grid + gb, lds, s) : hs_launch_mixed<1, 6>(mx, p.grid + gb, lds, s);
+    }
   }
   int rc = tconv_forward(da, ioa, s);
   if (rc == ADX_OK) rc = tconv_forward(db, iob, s);
