@@ -68,12 +68,13 @@ def test_host_side_validation_without_gpu(built):
 
 def test_cell_layout_host_side(built):
     """The cell layout of csrc/conv2d_hs.hip on the host: ops.to_cells / from_cells (pure torch) place the 8 channels of a
-    pixel as one 16-byte cell per plane, per image [C / 8][hi, lo][H][W], and lose at most 2^-22 of the value; which launches
+    pixel as one 16-byte cell per plane, per image [C / 8][hi, lo][H][W], and lose at most 2^-22 of the value (values far below
+    fp16's normal range: the lo half's subnormal step); which launches
     may use it is a host decision (adx_conv2d_cells_supported: plain launches of the pipelined 3x3 kernel only)."""
     import torch
     from autonomous_driving_with_diffusion_model_amd import ops
     n, c, h, w = 2, 16, 3, 5
-    x = torch.randn(n, c, h, w) * torch.logspace(-3, 3, c).view(1, c, 1, 1)
+    x = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(5)) * torch.logspace(-3, 3, c).view(1, c, 1, 1)
     cells = ops.to_cells(x)
     assert cells.dtype == torch.uint8 and cells.numel() == x.numel() * 4
     halves = cells.view(torch.float16).view(n, c // 8, 2, h, w, 8)
@@ -81,7 +82,8 @@ def test_cell_layout_host_side(built):
     assert torch.equal(halves[1, 1, 0, 2, 4], hi[1, 8:16, 2, 4])                      # image 1, cell group 1, hi plane, pixel (2, 4)
     assert torch.equal(halves[0, 0, 1, 1, 3], ((x - hi.float()) * 2048).to(torch.float16)[0, 0:8, 1, 3])
     back = ops.from_cells(cells, x.shape)
-    assert float(((back - x).abs() / x.abs().clamp_min(1e-30)).max()) <= 2.0 ** -21
+    # 2^-22 of the value, plus the lo half's fp16 subnormal step (2^-24 / 2^11) where the value is far below 1
+    assert bool(((back - x).abs() <= 2.0 ** -21 * x.abs() + 6e-11).all())
     lib = built.lib()
     d3 = built.Conv2dDesc(64, 64, 3, 1, 1)
     assert lib.adx_conv2d_cells_supported(ctypes.byref(d3), 64, 64, 225) == 1        # 4096 tiles: a plain launch
