@@ -55,7 +55,9 @@ def test_resnet_full_size_vs_golden(golden):
 def test_resnet_ragged_sizes_and_batch():
     sd = oracle_sd("NO_GUIDANCE")
     m, _ = make_model("NO_GUIDANCE", 16)
-    for hw, b in (((70, 101), 3), ((33, 47), 1), ((128, 131), 2)):
+    # the larger cases change layout decisions layer by layer (cell tensors and batch-wide column tiles where a layer's convs are
+    # plain launches, fp32 NCHW where they split their reduction; maps narrower than 16 columns tile per image)
+    for hw, b in (((70, 101), 3), ((33, 47), 1), ((128, 131), 2), ((200, 333), 3), ((129, 515), 9), ((97, 131), 33), ((64, 2048), 2)):
         img = P.synthetic_batch(b, 16, image_hw=hw, seed=5)["imgs"]
         with torch.no_grad():
             f = m.perception(img.to(DEV)).cpu()
