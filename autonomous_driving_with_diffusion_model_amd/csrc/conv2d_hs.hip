@@ -1247,6 +1247,65 @@ __global__ void conv2d_hs_pack_kernel(const float* __restrict__ w, _Float16* __r
   p[(cell + 128) * 8 + j] = lo;     // plane 1 is 2 * 64 cells further
 }
 
+// The same for up to kHsPackJobs weight tensors in ONE launch (the training step re-lays every conv weight every step: 36
+// forward images and 29 data-gradient images, each a ~5 us launch of its own otherwise).  The job table travels in the kernel
+// arguments; a block finds its job by scanning the (wave-uniform) first-block column.
+constexpr int kHsPackJobs = 48;
+struct HsPackTable {
+  const float* w[kHsPackJobs];
+  _Float16* p[kHsPackJobs];
+  int M[kHsPackJobs], Kc[kHsPackJobs], Kreal[kHsPackJobs], taps[kHsPackJobs], dgrad[kHsPackJobs];
+  unsigned first[kHsPackJobs + 1];     // first block of job j; first[n] = the grid
+  int n;
+};
+__global__ void __launch_bounds__(256) conv2d_hs_pack_many_kernel(const HsPackTable t) {
+  int j = 0;
+  while (j + 1 < t.n && blockIdx.x >= t.first[j + 1]) ++j;
+  const int M = t.M[j], Kc = t.Kc[j], Kreal = t.Kreal[j], taps = t.taps[j], dgrad = t.dgrad[j];
+  const float* __restrict__ w = t.w[j];
+  _Float16* __restrict__ p = t.p[j];
+  const size_t total = (size_t)M * Kc * taps;
+  const size_t idx = (size_t)(blockIdx.x - t.first[j]) * 256 + threadIdx.x;   // over [M/64][Kc/16][tap][k-half][64][8]
+  if (idx >= total) return;
+  const int e = idx & 7;
+  const int ml = (idx >> 3) & 63;
+  const int h = (idx >> 9) & 1;
+  size_t rest = idx >> 10;
+  const int tap = rest % taps; rest /= taps;
+  const int nchunks = Kc / kHsCC;
+  const int chunk = rest % nchunks;
+  const int ct = rest / nchunks;
+  const int m = ct * 64 + ml, kc = chunk * kHsCC + h * 8 + e;
+  float v = 0.f;
+  if (kc < Kreal) v = dgrad ? w[((size_t)kc * M + m) * taps + (taps - 1 - tap)] : w[((size_t)m * Kreal + kc) * taps + tap];
+  const _Float16 hi = (_Float16)v;
+  const _Float16 lo = (_Float16)((v - (float)hi) * kLoScale);
+  const size_t cell = ((((size_t)(ct * nchunks + chunk) * taps + tap) * 2 + 0) * 2 + h) * 64 + ml;
+  p[cell * 8 + e] = hi;
+  p[(cell + 128) * 8 + e] = lo;
+}
+
+int conv2d_hs_pack_many(const HsPackJob* jobs, int n, hipStream_t s) {
+  for (int j0 = 0; j0 < n; j0 += kHsPackJobs) {
+    HsPackTable t;
+    t.n = std::min(kHsPackJobs, n - j0);
+    unsigned blocks = 0;
+    for (int j = 0; j < t.n; ++j) {
+      const HsPackJob& q = jobs[j0 + j];
+      ADX_REQUIRE(q.w != nullptr && q.packed != nullptr && q.cin_pad % kHsCC == 0 && q.cout % kHsCout == 0,
+                  "conv2d_hs_pack_many: job %d is not a split-fp16 weight image", j0 + j);
+      t.w[j] = q.w; t.p[j] = (_Float16*)q.packed;
+      t.M[j] = q.cout; t.Kc[j] = q.cin_pad; t.Kreal[j] = q.cin; t.taps[j] = q.taps; t.dgrad[j] = q.dgrad;
+      t.first[j] = blocks;
+      blocks += (unsigned)(((size_t)q.cout * q.cin_pad * q.taps + 255) / 256);
+    }
+    t.first[t.n] = blocks;
+    conv2d_hs_pack_many_kernel<<<dim3(blocks), dim3(256), 0, s>>>(t);
+    ADX_LAUNCH_CHECK();
+  }
+  return ADX_OK;
+}
+
 bool conv2d_hs_eligible(const ConvSpec& L) {
   static int exact = -1;
   if (exact < 0) {
@@ -1269,6 +1328,8 @@ size_t conv2d_packed_floats(const ConvSpec& L) {
   const size_t direct = (size_t)L.k * L.k * L.cin_pad * L.cout;
   return direct;
 }
+
+bool conv2d_hs_pack_batchable(const ConvSpec& c, int dgrad) { return conv2d_hs_eligible(c) && !(hs_is_stem(c) && !dgrad); }
 
 int conv2d_hs_pack(const ConvSpec& c, const float* w, void* packed, int dgrad, hipStream_t s) {
   if (hs_is_stem(c) && !dgrad) {

@@ -104,6 +104,11 @@ bool conv2d_hs_eligible(const ConvSpec& L);
 // floats a layer's packed weight image takes (direct image, plus the Winograd F(2,3) image where that path applies)
 size_t conv2d_packed_floats(const ConvSpec& L);
 int conv2d_hs_pack(const ConvSpec& consumer, const float* w, void* packed, int dgrad, hipStream_t s);
+// several split-fp16 weight images in one launch (not the stem's): cout / cin as conv2d_hs_pack takes them from a ConvSpec
+// (dgrad = 1: the spec of the data-gradient conv, i.e. cout = the forward cin and cin_pad = cin = the forward cout)
+struct HsPackJob { const float* w; void* packed; int cout, cin_pad, cin, taps, dgrad; };
+bool conv2d_hs_pack_batchable(const ConvSpec& consumer, int dgrad);
+int conv2d_hs_pack_many(const HsPackJob* jobs, int n, hipStream_t s);
 int conv2d_hs_launch(const ConvSpec& L, Conv2dArgs a, hipStream_t s);
 // partial-sum slots (workgroups per 64-channel slab) the pipelined 3x3 stride-1 kernel would fill for this launch, 0 if another
 // kernel serves it

@@ -823,7 +823,7 @@ void adx_resnet_tape_destroy(adx_resnet_tape* t) { delete t; }
 size_t adx_resnet_train_workspace_bytes(const adx_resnet* r, int32_t batch, int32_t h, int32_t w) {
   if (!r || batch < 1 || h < 32 || w < 32) return 0;
   size_t f = al64(r->convs.size() * 2 * 512 * 2) + 2 * al64(512) + al64(kStatsPartFloats);   // forward: per-conv sums, scale, shift, conv-epilogue partial sums
-  size_t big = 0, wmax = 0;
+  size_t big = 0, wmax = 0, wall = 0;
   auto conv = [&](const ConvSpec& L, int H, int W, bool apply = true) {
     const int OH = conv_out_dim(H, L.k, L.stride, L.pad), OW = conv_out_dim(W, L.k, L.stride, L.pad);
     const size_t n = (size_t)batch * L.cout * OH * OW;
@@ -831,6 +831,7 @@ size_t adx_resnet_train_workspace_bytes(const adx_resnet* r, int32_t batch, int3
     big = std::max(big, n);
     big = std::max(big, (size_t)batch * L.cin * H * W);
     wmax = std::max(wmax, (size_t)L.k * L.k * L.cout * L.cin);
+    if (L.k == 3 && L.stride == 1) wall += al64((size_t)L.k * L.k * L.cout * L.cin);
   };
   size_t ci = 0;
   conv(r->convs[ci++], h, w, false);        // the stem's post-BN map is never formed (fused BN + ReLU + pool pass)
@@ -847,7 +848,7 @@ size_t adx_resnet_train_workspace_bytes(const adx_resnet* r, int32_t batch, int3
     conv(c2, OH, OW);
     H = OH; W = OW;
   }
-  f += al64(r->convs.size() * 2 * 512 * 2) + al64(kAmaxPartials) + al64((size_t)512 * 256 * 9) + 5 * al64(big) + 2 * al64(wmax);   // backward: sums, amax, 3x3 image of a 1x1 gradient, 5 gradient buffers, dgrad weights
+  f += al64(r->convs.size() * 2 * 512 * 2) + al64(kAmaxPartials) + al64((size_t)512 * 256 * 9) + 5 * al64(big) + 2 * al64(wmax) + wall;   // backward: sums, amax, 3x3 image of a 1x1 gradient, 5 gradient buffers, dgrad weights (one scratch pair + a slot per stride-1 3x3 conv)
   return (f + 1024) * sizeof(float);
 }
 
@@ -861,10 +862,22 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
   ADX_REQUIRE(batch >= 1 && h >= 32 && w >= 32, "adx_resnet_forward_train: image too small");
   hipStream_t s = (hipStream_t)stream;
   float* base = (float*)packed;
-  // weights change every step: re-lay them here (conv images only; BN is applied from batch statistics)
-  for (const ConvSpec& L : r->convs) {
-    int rc = conv2d_pack_spec(L, T[L.t_w], base + L.o_w, 0, s);
-    if (rc != ADX_OK) return rc;
+  // weights change every step: re-lay them here (conv images only; BN is applied from batch statistics) -- the split-fp16
+  // images of the 3x3 convs in ONE launch, the stem and the exact-fp32 1x1 images on their own
+  {
+    std::vector<HsPackJob> jobs;
+    for (const ConvSpec& L : r->convs) {
+      if (conv2d_hs_pack_batchable(L, 0)) {
+        jobs.push_back(HsPackJob{T[L.t_w], base + L.o_w, L.cout, L.cin_pad, L.cin, L.k * L.k, 0});
+      } else {
+        int rc = conv2d_pack_spec(L, T[L.t_w], base + L.o_w, 0, s);
+        if (rc != ADX_OK) return rc;
+      }
+    }
+    if (!jobs.empty()) {
+      int rc = conv2d_hs_pack_many(jobs.data(), (int)jobs.size(), s);
+      if (rc != ADX_OK) return rc;
+    }
   }
   Bump2 ws{(float*)workspace, 0, workspace_bytes / sizeof(float)};
   tape->recs.clear();
@@ -980,6 +993,28 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
   for (auto& p : gb) p = ws.take(big);
   float* wimg = ws.take(wmax);
   float* wbuild = ws.take(wmax);     // the stride-2 data gradient's 2x2 weights before packing (16 cin cout <= 9 x 512 x 512)
+  // data-gradient weight images of the stride-1 3x3 convs: all of them in one launch, each in its own slot (the others are
+  // built where they are used, in `wimg`)
+  std::vector<const float*> dgrad_img(r->convs.size(), nullptr);
+  {
+    std::vector<HsPackJob> jobs;
+    for (auto& rec : tape->recs) {
+      const ConvSpec& L = *rec.L;
+      if (!(L.k == 3 && L.stride == 1)) continue;
+      ConvSpec g{};
+      g.cin = L.cout; g.cout = L.cin; g.k = L.k; g.stride = 1; g.pad = L.k - 1 - L.pad; g.cc = 16; g.cin_pad = L.cout; g.dgrad = 1;
+      if (!conv2d_hs_pack_batchable(g, 1)) continue;
+      float* slot = ws.take((size_t)L.k * L.k * L.cout * L.cin);
+      if (!ws.ok) break;
+      dgrad_img[&L - r->convs.data()] = slot;
+      jobs.push_back(HsPackJob{T[L.t_w], slot, g.cout, g.cin_pad, g.cin, L.k * L.k, 1});
+    }
+    ADX_REQUIRE(ws.ok, "adx_resnet_backward: workspace of %zu bytes too small", workspace_bytes);
+    if (!jobs.empty()) {
+      const int rp = conv2d_hs_pack_many(jobs.data(), (int)jobs.size(), s);
+      if (rp != ADX_OK) return rp;
+    }
+  }
   ADX_REQUIRE(ws.ok, "adx_resnet_backward: workspace of %zu bytes too small", workspace_bytes);
   int rc = ADX_OK;
 
@@ -1024,6 +1059,9 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
     // data gradient
     ConvSpec g{};
     g.cin = L.cout; g.cout = L.cin; g.k = L.k; g.stride = 1; g.pad = L.k - 1 - L.pad; g.cc = 16; g.cin_pad = L.cout; g.dgrad = 1;
+    if (const float* pre = dgrad_img[&L - r->convs.data()]) {      // stride-1 3x3: image packed with the others at the start
+      return conv2d_launch_raw(g, draw, pre, nullptr, nullptr, dx_has ? dx : nullptr, dx, batch, rec.OH, rec.OW, 0, s, amax, n_amax);
+    }
     rc2 = conv2d_pack_spec(g, T[L.t_w], wimg, 1, s);
     if (rc2 != ADX_OK) return rc2;
     if (L.stride == 1) {

@@ -38,9 +38,10 @@ class _PerceptionTrainFn(torch.autograd.Function):
         except Exception:
             tape.release()
             raise
-        for b in module.buffers():
-            if b.dtype == torch.int64:
-                b += 1                      # num_batches_tracked
+        # num_batches_tracked of the 36 BatchNorm layers: one multi-tensor add, not 36 launches
+        counters = [b for b in module.buffers() if b.dtype == torch.int64]
+        if counters:
+            torch._foreach_add_(counters, 1)
         module.invalidate()                 # running statistics moved: eval-mode image is stale
         ctx.module, ctx.tape, ctx.ws, ctx.nbytes, ctx.ts, ctx.img = module, tape, ws, nbytes, ts, img
         return out
