@@ -483,13 +483,12 @@ __device__ __forceinline__ void hs_trace_id() {
 // layout costs eight 4-byte loads and ~48 VALU instructions, once per 64-channel output slab; the producer splits each
 // element once.  The products are bit-identical either way (the halves are the ones the consumer would have computed); a
 // residual read from cells (Conv2dArgs::res_cells) is hi + lo / 2^11, the tensor to 2^-23.  Inference executor only.
-template <int MODE, bool STATS = false, bool XCELLS = false, bool YCELLS = false, bool VTB = false>
+template <int MODE, bool STATS = false, bool XCELLS = false, bool YCELLS = false>
 __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(const Conv2dArgs a) {
-  constexpr bool VT = YCELLS || VTB;        // column tiles over the batch's images side by side (always with cell output; VTB: with fp32 output)
   constexpr int NT = MODE == 0 ? 256 : 512;            // threads
   constexpr int TH = MODE == 1 ? 16 : 8;               // output rows per workgroup
   constexpr int CT = MODE == 2 ? 2 : 1;                // 64-channel slabs per workgroup
-  constexpr int K = 3, PH = TH + 2, PW = VT ? 38 : 34, PLANE = PH * PW, NITEM = 2 * PLANE;    // VT: up to three image segments per row
+  constexpr int K = 3, PH = TH + 2, PW = YCELLS ? 38 : 34, PLANE = PH * PW, NITEM = 2 * PLANE;    // YCELLS: up to three image segments per row
   constexpr int PIT = (NITEM + NT - 1) / NT;           // patch rounds = slices, one per stage while they last
   constexpr int NW = 9 * 256, WST = 3 * 256 * CT;      // weight cells per chunk and 64-channel slab / per stage
   constexpr int WIT = (WST + NT - 1) / NT;
@@ -516,7 +515,7 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
   const int ct = bid % a.cout_tiles; bid /= a.cout_tiles;
   const int tx = bid % a.tiles_x; bid /= a.tiles_x;
   const int ty = bid % a.tiles_y; bid /= a.tiles_y;
-  const int n = VT ? 0 : bid;
+  const int n = YCELLS ? 0 : bid;
   const int oy0 = ty * TH, ox0 = tx * kTileW;
   const int iy0 = oy0 - a.pad, ix0 = ox0 - a.pad;
   const int cout0 = (ct * CT + slab) * kHsCout;
@@ -527,10 +526,10 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
   // spans up to three images (W >= 16); in the staged patch row every image segment keeps its own left / right halo cell, so
   // the lane of virtual column v reads cell (lane + 2 seg + kw) and the main loop is the one of the per-image tiling.
   const int vx0 = tx * kTileW;
-  const int n0 = VT ? vx0 / a.vw : 0, x0 = VT ? vx0 - n0 * a.vw : 0;
+  const int n0 = YCELLS ? vx0 / a.vw : 0, x0 = YCELLS ? vx0 - n0 * a.vw : 0;
   const int vl = vx0 + l31;
-  const int nl = VT ? vl / a.vw : 0, xl = VT ? vl - nl * a.vw : 0, seg = nl - n0;
-  const bool lane_valid = !VT || (nl < a.N && xl < a.W);
+  const int nl = YCELLS ? vl / a.vw : 0, xl = YCELLS ? vl - nl * a.vw : 0, seg = nl - n0;
+  const bool lane_valid = !YCELLS || (nl < a.N && xl < a.W);
   const size_t hw = (size_t)a.H * a.W;
   const int nchunks_all = a.cin_pad / kHsCC;
   const int nchunks = a.ksplit > 1 ? a.cper : nchunks_all;       // chunks THIS workgroup reduces over
@@ -541,7 +540,7 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
   constexpr uint32_t kOutside = 0xC0000000u;
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(xin), 0,
-      (int)(uint32_t)((VT ? (size_t)a.N * a.Cin : (size_t)(a.Cin - chunk0 * kHsCC)) * hw * sizeof(float)), 0x00020000);
+      (int)(uint32_t)((YCELLS ? (size_t)a.N * a.Cin : (size_t)(a.Cin - chunk0 * kHsCC)) * hw * sizeof(float)), 0x00020000);
   const uint32_t plane_bytes = (uint32_t)(hw * sizeof(float));
   // YCELLS: widths of the tile's image segments in output columns (s0 + s1 + s2 = 32; an image is at least 16 columns wide)
   const int s0 = min(kTileW, a.vw - x0), s1 = min(kTileW - s0, a.vw);
@@ -555,14 +554,14 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
     const int py = p / PW, px = p - py * PW;
     const int iy = iy0 + py;
     int ix = ix0 + px, ni = n;
-    if constexpr (VT) {        // patch column px -> (image, input column): [seg 0: x0 - 1 .. x0 + s0] [seg 1: -1 .. s1] [seg 2: -1 .. ]
+    if constexpr (YCELLS) {        // patch column px -> (image, input column): [seg 0: x0 - 1 .. x0 + s0] [seg 1: -1 .. s1] [seg 2: -1 .. ]
       const int sg = px < s0 + 2 ? 0 : (px < s0 + s1 + 4 ? 1 : 2);
       const int first = sg == 0 ? 0 : (sg == 1 ? s0 + 2 : s0 + s1 + 4);
       ix = (sg == 0 ? x0 : 0) - 1 + (px - first);
       ni = n0 + sg;
     }
     const bool ok = e < NITEM && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && ni < a.N;
-    const size_t ioff = VT ? (size_t)ni * a.Cin * hw * sizeof(float) : 0;
+    const size_t ioff = YCELLS ? (size_t)ni * a.Cin * hw * sizeof(float) : 0;
     goff[k] = !ok ? kOutside
                   : XCELLS ? (uint32_t)(ioff + hg * 8 * hw * sizeof(float) + ((size_t)iy * a.W + ix) * 16)   // cell (2 chunk + hg, hi, iy, ix)
                            : (uint32_t)(ioff + (hg * 8 * hw + (size_t)iy * a.W + ix) * sizeof(float));
@@ -667,7 +666,7 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
     *d1 = lo;
   };
 
-  const int pb_lane = khalf * 2 * PLANE + (rowpair * 2) * PW + l31 + (VT ? 2 * seg : 0);
+  const int pb_lane = khalf * 2 * PLANE + (rowpair * 2) * PW + l31 + (YCELLS ? 2 * seg : 0);
   const int wa_lane = slab * 768 + khalf * 64 + l31;
 
   // prologue: stage 0 complete in LDS; weights of stage 1 and the first slice of chunk 1 in flight
@@ -727,12 +726,12 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
   // epilogue through buffer descriptors: one instruction per access (wave-uniform channel offset in an SGPR, the
   // lane's pixel in one 32-bit VGPR); lanes outside the map carry the out-of-range offset, so their loads return 0
   // and their stores are dropped; without a residual the descriptor is empty and every load returns 0
-  const int ox = VT ? xl : ox0 + l31;
+  const int ox = YCELLS ? xl : ox0 + l31;
   const uint32_t plane_ob = (uint32_t)(a.OH * a.OW) * (uint32_t)sizeof(float);
   const size_t img = (size_t)n * a.Cout * a.OH * a.OW;
   // YCELLS: the descriptors cover the whole tensors and the lane's image rides in its offset
-  const int img_bytes = (int)(uint32_t)((VT ? (uint32_t)a.N : 1u) * (uint32_t)a.Cout * plane_ob);
-  const uint32_t img_off = VT ? (uint32_t)nl * (uint32_t)a.Cout * plane_ob : 0u;
+  const int img_bytes = (int)(uint32_t)((YCELLS ? (uint32_t)a.N : 1u) * (uint32_t)a.Cout * plane_ob);
+  const uint32_t img_off = YCELLS ? (uint32_t)nl * (uint32_t)a.Cout * plane_ob : 0u;
   float* const ybase = a.ksplit > 1 ? a.part + (size_t)kpart * a.part_stride : a.y;
   const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(ybase + img, 0, img_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -814,7 +813,7 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
   } else {
   uint32_t voff[2];
 #pragma unroll
-  for (int rr = 0; rr < 2; ++rr) voff[rr] = inside[rr] ? img_off + pix[rr] * 4u + (uint32_t)(4 * khalf) * plane_ob : kOutside;
+  for (int rr = 0; rr < 2; ++rr) voff[rr] = inside[rr] ? pix[rr] * 4u + (uint32_t)(4 * khalf) * plane_ob : kOutside;
   float rv[2][2][16];
 #pragma unroll
   for (int rr = 0; rr < 2; ++rr)
@@ -863,7 +862,7 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
       for (int w = 0; w < WPS; ++w)
 #pragma unroll
         for (int j = 0; j < 2; ++j) t += red[((((MODE == 2 ? sl * WPS + w : w) * 4 + kh2 * 2 + j) * 32) + idx32) * 2 + which];
-      const int p = (n * a.tiles_y + ty) * a.tiles_x + tx;        // (VT: n = 0 and tiles_x runs over the batch)
+      const int p = (n * a.tiles_y + ty) * a.tiles_x + tx;
       a.stats_part[((size_t)((ct * CT + sl) * kHsCout + ch) * 2 + which) * a.stats_p + p] = t;
     }
   }
@@ -1460,15 +1459,6 @@ __global__ void __launch_bounds__(256) conv2d_split_reduce_kernel(const float* _
   reinterpret_cast<f32x4*>(y)[i] = v;
 }
 
-// Column tiles over the batch's images side by side (conv2d_hs3x3_kernel: VT) for this launch?  Maps narrower than 16 columns
-// (a tile would span more than three images), single images, split reductions and tensors beyond the 32-bit whole-tensor
-// offsets keep the per-image tiling.
-static bool hs3x3_vt(const Conv2dArgs& a) {
-  static const bool vcat_on = [] { const char* e = getenv("ADX_CONV_VCAT"); return !(e != nullptr && e[0] == '0'); }();
-  return vcat_on && a.N > 1 && a.OW >= 16 && (size_t)a.N * a.Cout * a.OH * a.OW * sizeof(float) < 0xC0000000u &&
-         (size_t)a.N * a.Cin * a.H * a.W * sizeof(float) < 0xC0000000u;
-}
-
 template <int MODE>
 static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
   constexpr int NT = MODE == 0 ? 256 : 512, TH = MODE == 1 ? 16 : 8, CT = MODE == 2 ? 2 : 1;
@@ -1493,31 +1483,10 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
   const size_t cap = a.part != nullptr ? a.part_stride : 0;      // conv2d_launch_raw parks the scratch capacity here
   const int nchunks = a.cin_pad / kHsCC;
   a.ksplit = 1; a.cper = nchunks; a.part_stride = 0;
-  constexpr size_t vlds = (size_t)2 * 64 * (TH + 2) * 38 + (size_t)2 * 3 * 256 * CT * 16 + (2 * 64 * CT + 8) * sizeof(float) + 48;
-  static_assert(vlds <= (MODE == 0 ? 80 : 160) * 1024, "LDS budget");
-  // fp32-layout launches on the batch-wide column tiles (the training forward with its statistics, the data gradients, full
-  // batches of an fp32-layout inference pass): the grid loses the padded columns at every image's right edge
-  const bool vt = hs3x3_vt(a) && !a.x_cells && !a.y_cells && !a.res_cells;
-  auto vt_launch = [&](auto stats_tag) -> int {
-    constexpr bool ST = decltype(stats_tag)::value;
-    static bool vattr = false;
-    if (!vattr) {
-      ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, ST, false, false, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlds));
-      vattr = true;
-    }
-    a.vw = a.OW;
-    a.tiles_x = ceil_div(a.N * a.vw, kTileW);
-    const size_t vgrid = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y;
-    conv2d_hs3x3_kernel<MODE, ST, false, false, true><<<dim3((unsigned)vgrid), dim3(NT), vlds, s>>>(a);
-    ADX_LAUNCH_CHECK();
-    return ADX_OK;
-  };
   if (a.stats_part != nullptr) {          // training forward: statistics in the epilogue (one workgroup per tile: no split)
-    const int ntiles = vt ? a.tiles_y * ceil_div(a.N * a.OW, kTileW) : a.N * a.tiles_y * a.tiles_x;
-    ADX_REQUIRE(a.stats_p == ntiles, "conv2d_hs: statistics buffer laid out for %d tiles, launch has %d", a.stats_p, ntiles);
+    ADX_REQUIRE(a.stats_p == a.N * a.tiles_y * a.tiles_x, "conv2d_hs: statistics buffer laid out for %d tiles, launch has %d",
+                a.stats_p, a.N * a.tiles_y * a.tiles_x);
     a.part = nullptr;
-    if (vt) return vt_launch(std::true_type{});
     conv2d_hs3x3_kernel<MODE, true><<<dim3((unsigned)grid), dim3(NT), lds, s>>>(a);
     ADX_LAUNCH_CHECK();
     return ADX_OK;
@@ -1555,7 +1524,8 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
     }
     // column tiles over the images side by side (conv2d_hs3x3_kernel: YCELLS): no padded MFMA columns at the right edge of
     // every image.  Maps narrower than 16 columns (a tile would span more than three images) keep the per-image tiling.
-    a.vw = hs3x3_vt(a) ? a.OW : round_up(a.OW, kTileW);
+    static const bool vcat_on = [] { const char* e = getenv("ADX_CONV_VCAT"); return !(e != nullptr && e[0] == '0'); }();
+    a.vw = (vcat_on && a.N > 1 && a.OW >= 16) ? a.OW : round_up(a.OW, kTileW);
     a.tiles_x = ceil_div(a.N * a.vw, kTileW);
     const size_t cgrid = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y;
     ADX_REQUIRE((size_t)a.N * a.Cout * a.OH * a.OW * sizeof(float) < 0xC0000000u && (size_t)a.N * a.Cin * a.H * a.W * sizeof(float) < 0xC0000000u,
@@ -1565,7 +1535,6 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
     ADX_LAUNCH_CHECK();
     return ADX_OK;
   }
-  if (vt) return vt_launch(std::false_type{});
   conv2d_hs3x3_kernel<MODE><<<dim3((unsigned)grid), dim3(NT), lds, s>>>(a);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
@@ -1614,8 +1583,7 @@ bool conv2d_hs3x3_plain(const ConvSpec& L, int N, int H, int W) {
 int conv2d_hs_stats_tiles(const ConvSpec& L, const Conv2dArgs& a) {
   const int mode = hs3x3_mode(L, a);
   if (mode < 0) return 0;
-  const int rows = ceil_div(a.OH, mode == 1 ? 16 : 8);
-  return hs3x3_vt(a) ? rows * ceil_div(a.N * a.OW, kTileW) : a.N * rows * ceil_div(a.OW, kTileW);
+  return a.N * ceil_div(a.OH, mode == 1 ? 16 : 8) * ceil_div(a.OW, kTileW);
 }
 
 // forward weight [cout][cin][3][3] -> weight [4 cin][cout][2][2] of the 2x2 conv that is the stride-2 data gradient:
