@@ -169,7 +169,11 @@ def test_conv_non_finite_inputs_stay_loud():
                                                           (64, 128, 9, 40, 1, 1e-5, 1), (128, 64, 5, 70, 2, 20.0, 1),
                                                           (64, 128, 64, 225, 2, 1e-4, 2), (128, 256, 32, 113, 2, 1.0, 2),
                                                           (256, 512, 16, 57, 3, 1e-6, 2), (64, 64, 7, 9, 2, 1e-2, 2),
-                                                          (64, 128, 33, 70, 1, 1.0, 2)])
+                                                          (64, 128, 33, 70, 1, 1.0, 2),
+                                                          # larger batches (several units per workgroup of a split)
+                                                          (64, 64, 12, 225, 9, 1e-4, 1), (128, 128, 8, 113, 10, 1.0, 1),
+                                                          (256, 256, 5, 57, 16, 3e-7, 1), (512, 512, 4, 29, 33, 1e-3, 1),
+                                                          (64, 128, 6, 40, 7, 1e-5, 1)])
 def test_conv3x3_weight_gradient_split_fp16(cin, cout, h, w, n, dyscale, stride):
     """adx_conv2d_wgrad (3x3, stride 1 and 2: fp16 matrix cores, transposing LDS reads, dy rescaled by its measured
     range) against an fp64 evaluation; the bar is torch's own fp32 weight gradient on CPU and on the GPU, x1.5."""
