@@ -1249,7 +1249,7 @@ __global__ void conv2d_hs_pack_kernel(const float* __restrict__ w, _Float16* __r
 
 // The same for up to kHsPackJobs weight tensors in ONE launch (the training step re-lays every conv weight every step: 36
 // forward images and 29 data-gradient images, each a ~5 us launch of its own otherwise).  The job table travels in the kernel
-// arguments; a block finds its job by scanning the (wave-uniform) first-block column.
+// arguments; a block finds its job by a binary search of the (wave-uniform) first-block column.
 constexpr int kHsPackJobs = 48;
 struct HsPackTable {
   const float* w[kHsPackJobs];
@@ -1259,8 +1259,11 @@ struct HsPackTable {
   int n;
 };
 __global__ void __launch_bounds__(256) conv2d_hs_pack_many_kernel(const HsPackTable t) {
-  int j = 0;
-  while (j + 1 < t.n && blockIdx.x >= t.first[j + 1]) ++j;
+  int j = 0, jend = t.n;               // binary search of the job: six kernel-argument reads, not one per job
+  while (jend - j > 1) {
+    const int mid = (j + jend) >> 1;
+    if (blockIdx.x >= t.first[mid]) j = mid; else jend = mid;
+  }
   const int M = t.M[j], Kc = t.Kc[j], Kreal = t.Kreal[j], taps = t.taps[j], dgrad = t.dgrad[j];
   const float* __restrict__ w = t.w[j];
   _Float16* __restrict__ p = t.p[j];
