@@ -91,15 +91,30 @@ __global__ void __launch_bounds__(256) channel_sums_kernel(const float* __restri
 // The pipelined 3x3 conv leaves per-workgroup partial sums of its output and of its squares ([C][2][P] floats, conv2d_hs.hip:
 // STATS); this adds the P partials of every (channel, moment) in fp64 -- one workgroup each, fixed order -- into the same
 // sums[c][2] slots channel_sums_kernel<0> would have filled from a pass over the whole output tensor.
-__global__ void __launch_bounds__(256) stats_reduce_kernel(const float* __restrict__ part, double* __restrict__ sums, int P) {
-  const float* src = part + (size_t)blockIdx.x * P;      // blockIdx.x = 2 c + moment
+// One launch per conv: workgroup c adds both moments' partials of channel c in fp64 (fixed order: thread i of a moment's 128
+// takes partials i, i + 128, ...) and finishes the channel (what a reduce launch + a finalize launch did before)
+__device__ __forceinline__ void bn_finalize_channel(int c, double s0, double s1, const float* gamma, const float* beta, float* scale,
+                                                    float* shift, float* mean, float* rstd, float* running_mean, float* running_var,
+                                                    double count);
+__global__ void __launch_bounds__(256) stats_reduce_finalize_kernel(const float* __restrict__ part, double* __restrict__ sums, int P,
+                                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                     float* __restrict__ scale, float* __restrict__ shift,
+                                                                     float* __restrict__ mean, float* __restrict__ rstd,
+                                                                     float* running_mean, float* running_var, double count) {
+  const int c = blockIdx.x, moment = threadIdx.x >> 7, t = threadIdx.x & 127;
+  const float* src = part + (size_t)(2 * c + moment) * P;
   double s = 0.0;
-  for (int i = threadIdx.x; i < P; i += 256) s += (double)src[i];
+  for (int i = t; i < P; i += 128) s += (double)src[i];
   __shared__ double red[4];
   s = wave_sum_d(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) sums[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    const double s0 = red[0] + red[1], s1 = red[2] + red[3];
+    sums[2 * c] = s0;
+    sums[2 * c + 1] = s1;
+    bn_finalize_channel(c, s0, s1, gamma, beta, scale, shift, mean, rstd, running_mean, running_var, count);
+  }
 }
 
 // batch statistics -> scale/shift for the apply pass, saved mean/rstd, running-buffer update
@@ -109,8 +124,14 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, const float*
                                    float* running_var, int C, double count) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
-  const double m = sums[2 * c] / count;
-  double var = sums[2 * c + 1] / count - m * m;
+  bn_finalize_channel(c, sums[2 * c], sums[2 * c + 1], gamma, beta, scale, shift, mean, rstd, running_mean, running_var, count);
+}
+
+__device__ __forceinline__ void bn_finalize_channel(int c, double s0, double s1, const float* gamma, const float* beta, float* scale,
+                                                    float* shift, float* mean, float* rstd, float* running_mean, float* running_var,
+                                                    double count) {
+  const double m = s0 / count;
+  double var = s1 / count - m * m;
   if (var < 0.0) var = 0.0;
   const float r = (float)(1.0 / sqrt(var + 1e-5));
   float sc, sh;
@@ -188,10 +209,13 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
                                                             const double* __restrict__ sums, float* __restrict__ draw,
                                                             float* __restrict__ dz_out, int C, int HW, size_t total,
                                                             double count, int relu_mask, uint32_t* __restrict__ amax,
-                                                            const float* __restrict__ beta) {
+                                                            const float* __restrict__ beta, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta) {
   // grid-stride: a fixed number of workgroups, each leaving max |draw| of its share in amax[blockIdx.x] (bits:
   // monotonic for non-negative floats); the data-gradient conv reduces those partials for its dynamic range
   __shared__ uint32_t red[4];
+  if (blockIdx.x == 0 && dgamma != nullptr)          // the affine parameters' gradients are the finished sums themselves
+    for (int c = threadIdx.x; c < C; c += 256) { dbeta[c] = (float)sums[2 * c]; dgamma[c] = (float)sums[2 * c + 1]; }
   uint32_t b = 0;
   const bool small = total <= 0xFFFFFFFFull;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -233,8 +257,11 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_planes_kernel(const float* _
                                                                    const double* __restrict__ sums, float* __restrict__ draw,
                                                                    float* __restrict__ dz_out, int C, int HW, int planes,
                                                                    double count, int relu_mask, uint32_t* __restrict__ amax,
-                                                                   const float* __restrict__ beta) {
+                                                                   const float* __restrict__ beta, float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta) {
   __shared__ uint32_t red[4];
+  if (blockIdx.x == 0 && dgamma != nullptr)
+    for (int c = threadIdx.x; c < C; c += 256) { dbeta[c] = (float)sums[2 * c]; dgamma[c] = (float)sums[2 * c + 1]; }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hw4 = HW >> 2;
   uint32_t b = 0;
@@ -287,14 +314,6 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_planes_kernel(const float* _
     const uint32_t m01 = red[0] > red[1] ? red[0] : red[1], m23 = red[2] > red[3] ? red[2] : red[3];
     amax[blockIdx.x] = m01 > m23 ? m01 : m23;
   }
-}
-
-__global__ void bn_param_grad_kernel(const double* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                     int C) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  dbeta[c] = (float)sums[2 * c];
-  dgamma[c] = (float)sums[2 * c + 1];
 }
 
 // dst[n][c][2y][2x] (+)= src[n][c][y][x]; everything else of dst untouched (caller zeroes when accumulate == 0)
@@ -905,15 +924,17 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
     if (rc != ADX_OK) { tape->recs.push_back(rec); return rec.out; }
     const int HW = rec.OH * rec.OW;
     double* sums = sums_all + (size_t)(&L - r->convs.data()) * 2 * 512;
-    if (stats_p > 0) {
-      stats_reduce_kernel<<<dim3(2 * L.cout), dim3(256), 0, s>>>(stats_part, sums, stats_p);
+    float* const run_m = update_running ? const_cast<float*>(T[L.t_m]) : nullptr;
+    float* const run_v = update_running ? const_cast<float*>(T[L.t_v]) : nullptr;
+    if (stats_p > 0) {       // partial sums from the conv epilogue: reduce and finish the channel in one launch
+      stats_reduce_finalize_kernel<<<dim3(L.cout), dim3(256), 0, s>>>(stats_part, sums, stats_p, T[L.t_g], T[L.t_b], scale, shift,
+                                                                      rec.mean, rec.rstd, run_m, run_v, (double)batch * HW);
     } else {
       channel_sums_kernel<0><<<dim3(batch * L.cout), dim3(256), 0, s>>>(rec.raw, nullptr, nullptr, nullptr, nullptr, sums,
                                                                         L.cout, HW, 0, nullptr, nullptr);
+      bn_finalize_kernel<<<dim3(ceil_div(L.cout, 256)), dim3(256), 0, s>>>(sums, T[L.t_g], T[L.t_b], scale, shift, rec.mean, rec.rstd,
+                                                                           run_m, run_v, L.cout, (double)batch * HW);
     }
-    bn_finalize_kernel<<<dim3(ceil_div(L.cout, 256)), dim3(256), 0, s>>>(
-        sums, T[L.t_g], T[L.t_b], scale, shift, rec.mean, rec.rstd, update_running ? const_cast<float*>(T[L.t_m]) : nullptr,
-        update_running ? const_cast<float*>(T[L.t_v]) : nullptr, L.cout, (double)batch * HW);
     if (!apply) {
       // the caller consumes (raw, scale, shift) itself before the next conv_bn overwrites scale / shift (stream order)
     } else if (bn_planes_ok(HW, rec.raw, identity, rec.out)) {
@@ -1046,13 +1067,14 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
       const int planes = batch * L.cout;
       n_amax = (int)std::min<size_t>(kAmaxPartials, (size_t)ceil_div(planes, 4));
       bn_bwd_apply_planes_kernel<<<dim3(n_amax), dim3(256), 0, s>>>(dout, rec.out, rec.raw, rec.mean, rec.rstd, T[L.t_g], sums,
-                                                                    draw, dz_keep, L.cout, HW, planes, count, mask, amax, T[L.t_b]);
+                                                                    draw, dz_keep, L.cout, HW, planes, count, mask, amax, T[L.t_b],
+                                                                    G[L.t_g], G[L.t_b]);
     } else {
       n_amax = (int)std::min<size_t>(kAmaxPartials, (n + 255) / 256);
       bn_bwd_apply_kernel<<<dim3(n_amax), dim3(256), 0, s>>>(
-          dout, rec.out, rec.raw, rec.mean, rec.rstd, T[L.t_g], sums, draw, dz_keep, L.cout, HW, n, count, mask, amax, T[L.t_b]);
+          dout, rec.out, rec.raw, rec.mean, rec.rstd, T[L.t_g], sums, draw, dz_keep, L.cout, HW, n, count, mask, amax, T[L.t_b],
+          G[L.t_g], G[L.t_b]);
     }
-    bn_param_grad_kernel<<<dim3(ceil_div(L.cout, 256)), dim3(256), 0, s>>>(sums, G[L.t_g], G[L.t_b], L.cout);
     ADX_LAUNCH_CHECK();
     int rc2 = conv2d_wgrad(rec.x, draw, G[L.t_w], batch, L.cin, rec.H, rec.W, L.cout, L.k, L.stride, L.pad, s, amax, n_amax, false, wgrad9);
     if (rc2 != ADX_OK || !need_dx) return rc2;

@@ -425,11 +425,12 @@ int adx_unet_backward(adx_unet* u, const void* packed, void* workspace, size_t w
     if (rc != ADX_OK) return rc;
     rc = bias_grad(dtb, u->sum_c, 1, 0, dbcat, rows, u->sum_c, 1, s);
     if (rc != ADX_OK) return rc;
-    for (auto& b : u->blocks) {
-      ADX_CHECK_HIP(hipMemcpyAsync(grads[b.p_tw], dwcat + (size_t)b.tb_off * 2 * dim, sizeof(float) * (size_t)b.cout * 2 * dim,
-                                   hipMemcpyDeviceToDevice, s));
-      ADX_CHECK_HIP(hipMemcpyAsync(grads[b.p_tb], dbcat + b.tb_off, sizeof(float) * b.cout, hipMemcpyDeviceToDevice, s));
+    for (auto& b : u->blocks) {          // the blocks' slices of the concatenated gradients: one launch, not 32 copies
+      batch_copy_add(grads[b.p_tw], dwcat + (size_t)b.tb_off * 2 * dim, (size_t)b.cout * 2 * dim);
+      batch_copy_add(grads[b.p_tb], dbcat + b.tb_off, (size_t)b.cout);
     }
+    rc = batch_copy_flush(s);
+    if (rc != ADX_OK) return rc;
     adx_tconv_desc g{};
     g.kind = 0; g.taps = 1; g.stride = 1; g.pad = 0; g.c0 = u->sum_c; g.c1 = 0; g.cout = 2 * dim; g.lin = 1; g.lout = 1;
     g.groups = 0; g.eps = 1e-5f; g.w_layout = 1; g.w_flip = 0; g.exact = 1;
