@@ -203,8 +203,9 @@ def write_stamp(t: torch.Tensor) -> int:
     """A number that moves when `t` is written in place: autograd's version counter.  Inference tensors -- everything
     created under `torch.inference_mode()`, which is how the reference's `train.evaluate` runs (train.py:53) -- carry no
     counter (`._version` raises on them); they answer 0, so a memo keyed on (identity, stamp) then rests on identity alone:
-    an in-place write to an inference tensor between two forwards is NOT seen (none of the reference's callers does one;
-    `model.cache_perception = False` or `model.refresh_weights()` covers a caller that does)."""
+    an in-place write to an inference tensor between two forwards is NOT seen.  The image-feature memo therefore skips
+    inference tensors unless the caller opts in (`model.cache_perception = "identity"`, modeling/temporal.py:image_feature);
+    the weight-image memos key on parameters, which optimizers and loaders replace or write outside inference mode."""
     return 0 if t.is_inference() else t._version
 
 
@@ -214,9 +215,16 @@ def grad_buffer(p: torch.Tensor) -> torch.Tensor:
     handed out -- autograd adopts a gradient tensor nobody else holds as `.grad` without copying, so the gradient is born
     inside the bucket the collective runs on.  With a gradient already present (accumulation over several backwards)
     autograd ADDS what the node returns to `.grad`, which may be this very storage: then, and without an averager, the
-    node gets a buffer of its own."""
+    node gets a buffer of its own.
+
+    The view is LENT at most once per backward (`p._adx_grad_leased`): a parameter that feeds two nodes of one graph (the
+    model called twice before one `loss.backward()`, shared weights) reaches both nodes with `.grad is None` -- AccumulateGrad
+    has not run yet -- and two nodes writing the same storage would leave autograd summing two aliases of the second
+    gradient.  The averager clears the lease when the gradient has been accumulated (its post-accumulate hook) or reduced."""
     v = getattr(p, "_adx_grad_view", None)
-    if v is not None and p.grad is None and v.device == p.device and v.shape == p.shape:
+    if (v is not None and p.grad is None and not getattr(p, "_adx_grad_leased", False)
+            and v.device == p.device and v.shape == p.shape):
+        p._adx_grad_leased = True
         return v.detach()
     return torch.empty_like(p)
 

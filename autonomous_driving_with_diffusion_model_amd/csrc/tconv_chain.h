@@ -51,6 +51,7 @@ struct ChainArgs {
   int par_src, par_floats, par_lds;    // the chain's per-channel parameters: one block in `packed` -> one block in LDS
   int n_tb; int tb_col[4], tb_cout[4], tb_lds[4];   // time-bias slices: column in tb, channels, LDS float offset of [bt][cout_pad]
   int tab_lds;                         // where the kernel parks the stage table
+  unsigned* zero_words; int n_zero;    // words workgroup 0 clears (<= 512): the ticket words of the forward this launch opens
   int xch_lds;                         // GroupNorm partials of stages whose samples span two row tiles
   ChainStage st[kChainMaxStages];
 };

@@ -391,8 +391,8 @@ static adx_tconv_io make_io(const ConvLayer& L, const float* base, const Act& x0
 // order by the launches it is handed to, so two calls on different streams never share it).
 constexpr size_t kSplitScratchFloats = (size_t)2 << 20;
 static thread_local float* t_split_scratch = nullptr;
-static thread_local uint32_t* t_split_tickets = nullptr;     // 64 words, zero between calls (adx_tconv_io::tickets)
 constexpr size_t kTicketWords = 256;
+static thread_local uint32_t* t_split_tickets = nullptr;     // kTicketWords words (adx_tconv_io::tickets), cleared by every forward
 
 static int run_conv(const ConvLayer& L, const float* base, const Act& x0, const Act* x1, const float* tbias,
                     int64_t tb_stride, const Act* res, float* y, int64_t y_sb, int64_t y_sc, int64_t y_sl, int rows,
@@ -584,8 +584,10 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
   float* ws = (float*)workspace;
   size_t off = 0;
   auto take = [&](size_t n) { float* p = ws + off; off += align64(n); return p; };
-  // the ticket words come FIRST: their place must not depend on `rows` (they are zero between calls, whatever batch the
-  // caller's workspace was last used with)
+  // the ticket words come first: their place does not depend on `rows`.  Every forward CLEARS them before their first user
+  // runs -- nothing rests on what the caller's buffer held (uninitialised memory, a launch that never finished): where the
+  // forward opens with a chained level that launch's workgroup 0 does it (ChainArgs::zero_words, no extra node in a captured
+  // step), otherwise a 1 KB memset node goes first
   uint32_t* const split_tickets = reinterpret_cast<uint32_t*>(take(kTicketWords));
   float* te = take((size_t)rows * dim);
   float* mc = take((size_t)rows * 2 * dim);
@@ -602,6 +604,11 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
   float* const split_scratch = take(kSplitScratchFloats);
   static const bool tickets_on = [] { const char* e = getenv("ADX_TCONV_NO_TICKET"); return !(e != nullptr && e[0] == '1'); }();
   ScratchScope scratch_scope(split_scratch, tickets_on ? split_tickets : nullptr);
+  bool tickets_pending = tickets_on;      // still to be cleared by this call
+  if (tickets_pending && !(io->time_bias != nullptr && u->down_chains[0].valid)) {
+    ADX_CHECK_HIP(hipMemsetAsync(split_tickets, 0, kTicketWords * sizeof(uint32_t), s));
+    tickets_pending = false;
+  }
 
   int rc = ADX_OK;
   if (io->time_bias != nullptr) {
@@ -668,6 +675,10 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
     for (int k = 0; k < a.n_stages; ++k)
       if ((a.st[k].flags & kChOut) && dense4(*outs[(a.st[k].flags >> 12) & 1])) a.st[k].flags |= kChOutVec;
     a.batch = rows;
+    if (tickets_pending) {
+      a.zero_words = split_tickets; a.n_zero = (int)kTicketWords;
+      tickets_pending = false;
+    }
     static const bool dbg = getenv("ADX_CHAIN_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "[chain] rows %d len %d bt %d grid %d lds %zu stages %d in_vec %d\n", rows, cp.len, bt, ceil_div(rows, bt), lds, a.n_stages, a.in_vec);
     return chain_launch(a, ceil_div(rows, bt), lds, s);

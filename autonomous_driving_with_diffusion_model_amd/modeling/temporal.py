@@ -12,7 +12,8 @@ step (modeling/temporal.py:203) although in eval mode the result cannot change. 
 under no_grad the feature is cached against the *identity* of the image tensor object (weak
 reference + version counter + weight fingerprint), which makes the agents' sampling loops
 (interact.py:131-164) pay for one perception pass per scene without touching their code.  Set
-`model.cache_perception = False` for the reference-faithful per-step behaviour.
+`model.cache_perception = False` for the reference-faithful per-step behaviour.  Inference tensors carry no version
+counter, so an in-place refill cannot be seen: they are memoised only with `model.cache_perception = "identity"`.
 """
 from __future__ import annotations
 
@@ -212,6 +213,12 @@ class TemporalMapUnet(nn.Module):
         # eval mode: the forward is a plain native call in every grad mode (no_grad, inference_mode -- train.py:53 -- or grad
         # enabled, as interact.py:147-155 calls it), its result depends on (image, weights) only
         use_cache = self.cache_perception and not self.training
+        if use_cache and img.is_inference() and self.cache_perception != "identity":
+            # an inference tensor (everything made under torch.inference_mode(), train.py:53) has no version counter: a caller
+            # that refills one preallocated frame buffer in place would be handed the previous frame's feature.  Such tensors
+            # are memoised only on request (`cache_perception = "identity"`: the caller vouches that a tensor object's
+            # content never changes); by default the encoder runs, as in the reference
+            use_cache = False
         if use_cache and self._feat_cache is not None:
             ref, stamp, wkey, feat = self._feat_cache
             if ref() is img and stamp == L.write_stamp(img) and wkey == self.perception.weights_key():
@@ -245,9 +252,9 @@ class TemporalMapUnet(nn.Module):
     def _workspace(self, rows: int, device):
         nbytes = L.lib().adx_unet_workspace_bytes(self._native(), rows)
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
-            # zero-filled once: the workspace holds the ticket words of the split reductions (adx_tconv_io::tickets), which
-            # every call leaves zero again
-            self._ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+            # no initialisation needed: the ticket words of the split reductions (adx_tconv_io::tickets) at its front are
+            # cleared by every adx_unet_forward itself
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         return self._ws
 
     @torch.no_grad()

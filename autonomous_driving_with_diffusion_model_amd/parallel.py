@@ -54,7 +54,8 @@ class GradientAverager:
     primitive  "all_reduce" (one collective per bucket) or "reduce_scatter" (reduce_scatter_tensor into this rank's
                slice of the bucket + all_gather_into_tensor back, both in place: the explicit two-phase form SURVEY 8e
                prefers on a fully connected xGMI node; buckets are padded to a multiple of the world size).
-    mean       True: `.grad` holds the mean after `synchronize()` (ReduceOp.AVG: no separate division pass).
+    mean       True: `.grad` holds the mean after `synchronize()` (ReduceOp.AVG where the backend has it -- probed once --,
+               else SUM and one scaling pass).
                False: `.grad` holds the SUM and `grad_scale` = 1 / world is left to the consumer --
                `FusedAdamWEMA(grad_scale=...)` folds it into its single pass over the gradients."""
 
@@ -74,9 +75,25 @@ class GradientAverager:
         self._pending: list = []
         self._ready: List[int] = []
         self.copied_in = 0            # gradients of the last reduction that did not live in their bucket (diagnostic)
+        self.trace = False            # True: device events around every bucket's collective (see overlap_report)
+        self._trace_events: list = []
+        self._comm_stream = None
+        self._avg_ok = True
         if self.world > 1:
             for bi in range(len(self.buckets)):
                 self._ensure_bucket(bi)
+            if mean and self.params:
+                self._avg_ok = self._probe_avg(self.params[0].device)
+
+    def _probe_avg(self, device) -> bool:
+        """ReduceOp.AVG exists in RCCL / NCCL >= 2.10 and in recent gloo only: one 1-element collective at construction
+        (every rank constructs the averager) decides; without it the buckets carry the SUM and are scaled after the wait."""
+        try:
+            t = torch.ones(1, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group)
+            return bool(abs(float(t) - 1.0) < 1e-6)
+        except (RuntimeError, ValueError, NotImplementedError):
+            return False
 
     def _ensure_bucket(self, bi: int) -> torch.Tensor:
         idxs = self.buckets[bi]
@@ -92,6 +109,7 @@ class GradientAverager:
             p = self.params[i]
             v = flat[off:off + p.numel()].view(p.shape)
             p._adx_grad_view = v          # the backward nodes write here (see _lib.grad_buffer)
+            p._adx_grad_leased = False
             views.append(v)
             off += p.numel()
         self._views[bi] = views
@@ -115,6 +133,7 @@ class GradientAverager:
 
     def _make_hook(self, i: int):
         def hook(_param):
+            _param._adx_grad_leased = False        # accumulated: the bucket view may be lent again once .grad is cleared
             if self.world == 1:
                 return
             bi = self._where[i]
@@ -129,6 +148,8 @@ class GradientAverager:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        for p in self.params:
+            p._adx_grad_leased = False
 
     @torch.no_grad()
     def synchronize(self) -> None:
@@ -146,22 +167,59 @@ class GradientAverager:
         flat = self._ensure_bucket(bi)
         copied = []
         for i, v in zip(idxs, self._views[bi]):
+            self.params[i]._adx_grad_leased = False      # (the no-hook form: average() after backward)
             g = self.params[i].grad
             if g is None:
                 raise RuntimeError("a parameter has no gradient (every rank must produce every gradient)")
             if g.data_ptr() != v.data_ptr() or g.device != v.device:      # not born in the bucket: bring it in
                 v.copy_(g)
                 copied.append(i)
-        op = dist.ReduceOp.AVG if self.mean else dist.ReduceOp.SUM
-        if self.primitive == "reduce_scatter":
-            shard = flat.view(self.world, -1)[self.rank]
-            w1 = dist.reduce_scatter_tensor(shard, flat, op=op, group=self.group, async_op=True)
-            if dist.get_backend(self.group) != "nccl":
-                w1.wait()     # RCCL runs a group's collectives in issue order on its own stream; gloo's worker threads do not
-            works = [w1, dist.all_gather_into_tensor(flat, shard, group=self.group, async_op=True)]
-        else:
-            works = [dist.all_reduce(flat, op=op, group=self.group, async_op=True)]
+        op = dist.ReduceOp.AVG if (self.mean and self._avg_ok) else dist.ReduceOp.SUM
+
+        def issue():
+            if self.primitive == "reduce_scatter":
+                shard = flat.view(self.world, -1)[self.rank]
+                w1 = dist.reduce_scatter_tensor(shard, flat, op=op, group=self.group, async_op=True)
+                # The all-gather must not start before the reduce-scatter has written this rank's slice.  That order is
+                # EXPLICIT, not left to the backend's issue order: on a device backend `Work.wait()` makes the issuing (side)
+                # stream depend on the reduce-scatter and the all-gather's stream picks that dependency up when it is issued;
+                # on gloo it blocks the host until the worker thread is done.
+                w1.wait()
+                return [w1, dist.all_gather_into_tensor(flat, shard, group=self.group, async_op=True)]
+            return [dist.all_reduce(flat, op=op, group=self.group, async_op=True)]
+
+        if not flat.is_cuda:
+            return (issue(), bi, copied)
+        # Issued from a side stream that first joins the compute stream (the bucket's gradients were written there), so the
+        # compute stream -- still running the rest of backward -- is never held up by a collective; it joins in finish().
+        cur = torch.cuda.current_stream(flat.device)
+        if self._comm_stream is None or self._comm_stream.device != flat.device:
+            self._comm_stream = torch.cuda.Stream(device=flat.device)
+        ready = done = None
+        if self.trace:
+            ready = torch.cuda.Event(enable_timing=True)
+            ready.record(cur)
+        self._comm_stream.wait_stream(cur)
+        with torch.cuda.stream(self._comm_stream):
+            works = issue()
+            if self.trace:
+                works[-1].wait()
+                done = torch.cuda.Event(enable_timing=True)
+                done.record(self._comm_stream)
+                self._trace_events.append((bi, flat.numel() * flat.element_size(), ready, done))
         return (works, bi, copied)
+
+    def overlap_report(self, backward_end: "torch.cuda.Event") -> list:
+        """With `trace = True` during one backward: per bucket, when its last gradient was ready and when its collective had
+        finished, in ms RELATIVE TO THE END OF BACKWARD on the device (`backward_end` = an event recorded on the compute stream
+        right after `loss.backward()` returned; negative = before).  A collective that finishes before 0 was fully hidden
+        behind backward.  Call after `synchronize()` and a device sync."""
+        out = []
+        for bi, nbytes, ready, done in self._trace_events:
+            out.append({"bucket": bi, "mb": round(nbytes / 1e6, 1), "ready_ms": round(-ready.elapsed_time(backward_end), 3),
+                        "done_ms": round(-done.elapsed_time(backward_end), 3)})
+        self._trace_events = []
+        return out
 
     @torch.no_grad()
     def average(self, async_op: bool = False):
@@ -180,6 +238,8 @@ class GradientAverager:
         for handles, bi, copied in works:
             for h in handles:
                 h.wait()
+            if self.mean and not self._avg_ok:
+                self._flat[bi].mul_(1.0 / self.world)
             self.copied_in += len(copied)
             where = dict(zip(self.buckets[bi], self._views[bi]))
             for i in copied:

@@ -99,6 +99,18 @@ def pmc_traffic(key):
     return None
 
 
+def pmc_traffic_per_shape(key):
+    """{"64->64 @64x225": {"fetch": .., "write": ..}, ...} of the newest committed PMC passes for kernel `key` ({} if none)."""
+    try:
+        with open(pmc_traffic_file()) as f:
+            for k, v in json.load(f)["kernels"].items():
+                if k.startswith(key):
+                    return {name.split(" (")[0]: rec for name, rec in v.get("per_shape", {}).items()}
+    except Exception:
+        pass
+    return {}
+
+
 def rocprof_avg_ms(prefix):
     """Launch-weighted average duration of the kernels whose name contains `prefix` (a string, or several that must all
     occur) in the newest committed rocprofv3 --kernel-trace --stats summary of this command (profiles/r*_bench_kernel_stats.csv)."""
@@ -134,6 +146,7 @@ def conv2d_roofline(dev, reps=10):
     tot_ms = tot_fl = tot_bytes = 0.0
     count = 0
     per_shape = []
+    pmc = pmc_traffic_per_shape("conv2d_hs3x3_kernel")
     for (cin, cout, k, s, p, h, w), cnt in shapes.items():
         x = torch.randn((B, cin, h, w), device=dev)
         wt = torch.randn((cout, cin, k, k), device=dev) * (1.0 / (cin * k * k)) ** 0.5
@@ -159,8 +172,14 @@ def conv2d_roofline(dev, reps=10):
         ms /= cnt
         fl = conv_flops(B, cin, cout, k, s, p, h, w)
         byts = 4.0 * (x.numel() + y.numel() + wt.numel() + res.numel() * n2 / cnt)     # conv2 of every block also reads its residual
-        per_shape.append({"shape": f"{cin}->{cout} k{k} @{h}x{w}", "count": cnt, "ms": round(ms, 4), "ms_by_operand_layout": detail,
-                          "algorithmic_tflops": round(fl / ms / 1e9, 1), "issued_mfma_tflops": round(3 * fl / ms / 1e9, 1)})
+        rec = {"shape": f"{cin}->{cout} k{k} @{h}x{w}", "count": cnt, "ms": round(ms, 4), "ms_by_operand_layout": detail,
+               "algorithmic_tflops": round(fl / ms / 1e9, 1), "issued_mfma_tflops": round(3 * fl / ms / 1e9, 1),
+               "algorithmic_mb": round(byts / 1e6, 1)}
+        t = pmc.get(f"{cin}->{cout} @{h}x{w}")
+        if t is not None:       # HBM-side bytes of this shape from the committed PMC passes, against its algorithmic bytes
+            rec["pmc_traffic_mb"] = round((t["fetch"] + t["write"]) / 1e6, 1)
+            rec["pmc_traffic_over_algorithmic"] = round((t["fetch"] + t["write"]) / byts, 2)
+        per_shape.append(rec)
         tot_ms += ms * cnt
         tot_fl += fl * cnt
         tot_bytes += byts * cnt
@@ -357,10 +376,18 @@ def cpu_baseline(steps=5):
             "s_per_step": round(per, 3), "unet_only_steps_per_sec": round(1.0 / unet_s, 3)}
 
 
-def train_leg(dev, world, steps=5, warm=3):
-    """BASELINE configs[1]: NO_GUIDANCE training step at B=64, H=32: add_noise -> train-mode forward (batch-stat
-    BatchNorm) -> MSE -> backward -> fused nan_to_num + AdamW + EMA.  One optimizer step = one denoising step."""
+def train_leg(dev, world, use_cond="NO_GUIDANCE", steps=20, warm=3, trace_overlap=False):
+    """One training leg at B = 64 per GPU, H = 32, 3x256x900: add_noise -> train-mode forward (batch-statistics BatchNorm)
+    -> MSE -> backward -> fused nan_to_num + AdamW + EMA (train.py:221-261); one optimizer step = one denoising step.
+
+    use_cond "NO_GUIDANCE"   BASELINE configs[1] (configs/default.yaml).
+             "FREE_GUIDANCE" BASELINE configs[4]'s per-GPU workload (configs/guidance/free_guidance.yaml): the model with
+                             cond_mlp, and train.py:236-242's draw -- with probability 1 - USE_FREE_COND_PROB = 0.3 a batch
+                             trains with cond=None.  The draw is per batch AND per process (`random.random()`), so under
+                             data parallelism the ranks of one step take different branches; here it comes from a
+                             `random.Random(1000 + rank)` so that a run is reproducible."""
     import contextlib
+    import random
     from autonomous_driving_with_diffusion_model_amd import scheduler as S
     from autonomous_driving_with_diffusion_model_amd.config import create_cfg
     from autonomous_driving_with_diffusion_model_amd.modeling import build_model
@@ -368,8 +395,11 @@ def train_leg(dev, world, steps=5, warm=3):
     from autonomous_driving_with_diffusion_model_amd.parallel import DataParallel
     from autonomous_driving_with_diffusion_model_amd.utils import procedural as P
     torch.cuda.empty_cache()      # the sampling legs' workspaces go back to the driver before the 27 GB of tapes arrive
+    rank = int(os.environ.get("RANK", "0"))
+    free = use_cond == "FREE_GUIDANCE"
     cfg = create_cfg()
     cfg.MODEL.HORIZON = H
+    cfg.TRAIN.USE_COND = cfg.GUIDANCE.USE_COND = use_cond
     with contextlib.redirect_stdout(sys.stderr):
         model = build_model(cfg)
     P.load_procedural(model, 0)
@@ -380,52 +410,91 @@ def train_leg(dev, world, steps=5, warm=3):
     dp = DataParallel(model, optimizer=opt) if world > 1 else None       # buckets carry the sum, 1 / world folded into opt.step
     fwd = dp if dp is not None else model
     sch = S.DDPMScheduler(**SCHED_KW)
-    d = {k: v.to(dev) for k, v in P.synthetic_batch(B, H, image_hw=IMG, seed=7 + int(os.environ.get("RANK", "0"))).items()}
+    d = {k: v.to(dev) for k, v in P.synthetic_batch(B, H, image_hw=IMG, seed=7 + rank).items()}
+    draw = random.Random(1000 + rank)
+    branches = {"cond": 0, "cond_none": 0}
 
-    def step():
+    def step(count=True):
+        cond = None
+        if free:
+            drop = draw.random() > cfg.TRAIN.USE_FREE_COND_PROB           # train.py:237-241
+            cond = None if drop else d["target"]
+            if count:
+                branches["cond_none" if drop else "cond"] += 1
         noisy = sch.add_noise(d["trajs"], d["noise"], d["t"], zero_first=True)
-        pred = fwd(noisy, d["imgs"], d["t"])
+        pred = fwd(noisy, d["imgs"], d["t"], cond=cond)
         loss = torch.nn.functional.mse_loss(pred, d["trajs"])
         loss.backward()
+        end = None
+        if trace_overlap and dp is not None and dp.averager.trace:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()
         if dp is not None:
             dp.synchronize()
         opt.step()
         opt.zero_grad()
-        return loss
+        return loss, cond is None and free, end
 
     # the first step's loss is a known number: the CPU oracle's train-mode forward on the same inputs (rank 0's batch, seed 7;
     # tests/golden/make_bench_loss.py wrote it, tests/test_gpu_fullsize.py recomputes it on the box) -- a training leg that
-    # computes something else must not report a time
-    first = float(step().detach())
+    # computes something else must not report a time.  Every rank runs on whatever the verdict (no rank leaves the others
+    # inside a collective); rank 0 reports `parity_failed` instead of a value.
+    loss0, dropped0, _ = step(count=False)
+    first = float(loss0.detach())
     expected = None
     try:
         with open(os.path.join(ROOT, "tests", "golden", "bench_train_loss.json")) as f:
-            expected = json.load(f)["loss_fp32"]
+            expected = json.load(f)[("free_drop_loss_fp32" if dropped0 else "free_loss_fp32") if free else "loss_fp32"]
     except (OSError, KeyError, ValueError):
         pass
-    if int(os.environ.get("RANK", "0")) == 0 and expected is not None and not abs(first - expected) <= 2e-5 * max(1.0, abs(expected)):
-        raise RuntimeError(f"training leg: first-step loss {first!r} differs from the oracle's {expected!r}")
+    parity_ok = expected is None or abs(first - expected) <= 2e-5 * max(1.0, abs(expected))
     for _ in range(warm - 1):
-        step()
+        step(count=False)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        loss = step()
+        loss, _, _ = step()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt, per_rank = max_over_ranks(time.perf_counter() - t0, world, dev)
-    flops = 3 * (64 * 34.02e9) + 3 * 10.03e9      # ~3x forward (SURVEY §8d)
-    return {"workload": "configs/default.yaml train step, NO_GUIDANCE, batch 64 per GPU, horizon 32, image 3x256x900, "
-                        "fwd + bwd + fused AdamW/EMA" + (" + RCCL gradient all-reduce" if world > 1 else ""),
-            "value": round(world * steps / dt, 3), "unit": "train-steps/sec", "ms_per_step": round(1e3 * dt / steps, 2),
-            "steps": steps, "approx_tflops_per_gpu": round(flops * steps / dt / 1e12, 1), "first_step_loss": round(first, 7),
-            "first_step_loss_oracle": expected, "final_loss": round(float(loss.detach()), 5),
-            **({"per_rank_ms_per_step": [round(1e3 * t / steps, 2) for t in per_rank],
-                "gradient_buckets": {"primitive": dp.averager.primitive, "n": len(dp.averager.buckets),
-                                     "copied_in_last_step": dp.averager.copied_in}} if world > 1 else {})}
+    overlap = None
+    if trace_overlap and dp is not None:
+        # one more step with device events around every bucket's collective (outside the timed region): when a bucket's last
+        # gradient was ready and when its reduction had finished, relative to the end of backward on the device
+        dp.averager.trace = True
+        _, _, end = step(count=False)
+        torch.cuda.synchronize()
+        overlap = dp.averager.overlap_report(end)
+        dp.averager.trace = False
+    flops = 3 * (64 * 34.02e9) + 3 * 10.03e9      # ~3x forward (SURVEY 8d)
+    name = ("configs/guidance/free_guidance.yaml train step, FREE_GUIDANCE (cond=None with probability 0.3 per batch and rank)"
+            if free else "configs/default.yaml train step, NO_GUIDANCE")
+    res = {"workload": name + ", batch 64 per GPU, horizon 32, image 3x256x900, fwd + bwd + fused AdamW/EMA"
+                       + (" + RCCL gradient all-reduce" if world > 1 else ""),
+           "value": round(world * steps / dt, 3), "unit": "train-steps/sec", "ms_per_step": round(1e3 * dt / steps, 2),
+           "steps": steps, "approx_tflops_per_gpu": round(flops * steps / dt / 1e12, 1), "first_step_loss": round(first, 7),
+           "first_step_loss_oracle": expected, "final_loss": round(float(loss.detach()), 5)}
+    if free:
+        res["first_step_branch"] = "cond_none" if dropped0 else "cond"
+        res["timed_steps_by_branch_rank0"] = branches
+    if not parity_ok:
+        res["parity_failed"] = {"first_step_loss": first, "expected": expected, "tolerance": "2e-5 relative"}
+        res["value"] = res["ms_per_step"] = None
+    if world > 1:
+        res["per_rank_ms_per_step"] = [round(1e3 * t / steps, 2) for t in per_rank]
+        res["gradient_buckets"] = {"primitive": dp.averager.primitive, "n": len(dp.averager.buckets),
+                                   "copied_in_last_step": dp.averager.copied_in}
+        if overlap is not None:
+            res["gradient_buckets"]["overlap_rank0"] = overlap
+            res["gradient_buckets"]["overlap_note"] = ("per bucket, ms relative to the END of backward on the device (negative = "
+                                                       "before): ready = its last gradient written, done = its collective finished; "
+                                                       "done_ms < 0 means the reduction was hidden behind backward")
+    del model, opt, dp, fwd
+    torch.cuda.empty_cache()
+    return res
 
 
 def visible_gpu_count() -> int:
@@ -509,8 +578,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=20, help="timed optimizer steps per training leg")
     ap.add_argument("--no-deployed", action="store_true")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--short-sampling", action="store_true", help=argparse.SUPPRESS)   # tests: skip the hoisted / graph legs
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -599,14 +670,16 @@ def main():
     model.cache_perception = False          # reference-faithful: perception re-run every step
     dt, per_rank = timed(args.steps, args.warmup)
     model.cache_perception = True           # product default: one perception pass per scene
-    dt_h, per_rank_h = timed(max(args.steps, N_INFER), args.warmup)
-    steps_h = max(args.steps, N_INFER)
+    steps_h = args.steps if args.short_sampling else max(args.steps, N_INFER)
+    dt_h, per_rank_h = timed(steps_h, args.warmup)
 
     # the same hoisted loop as ONE HIP graph per 50-step tick (sampling.GraphedSampler: perception pass, 50 x (UNet +
     # scheduler step), clamp and scaling captured once, replayed bit-identically): no host work between launches
     from autonomous_driving_with_diffusion_model_amd.sampling import GraphedSampler
     gs = GraphedSampler(model, sch, cfg)
-    ticks = max(1, (max(args.steps, N_INFER) + N_INFER - 1) // N_INFER)
+    ticks = max(10, (max(args.steps, N_INFER) + N_INFER - 1) // N_INFER)     # >= 10 replays of ~25 ms: one sample is noise
+    if args.short_sampling:
+        ticks = 1
     with torch.no_grad():
         for _ in range(2):                   # capture + one replay
             gs(d["imgs"], d["target"], d["init_trajs"])
@@ -621,14 +694,19 @@ def main():
 
     del model
     torch.cuda.empty_cache()
-    train = None
+    # training legs: configs[1] (NO_GUIDANCE) on one GPU; configs[4]'s per-GPU workload (FREE_GUIDANCE incl. the cond=None
+    # draw) at every world size -- with N > 1 ranks that IS configs[4] (8 x 64 = 512 global), so it is the only one run there
+    train = train_free = None
     if not args.no_train:
         try:
-            train = train_leg(dev, world)
+            if world == 1:
+                train = train_leg(dev, world, "NO_GUIDANCE", steps=args.train_steps)
+            train_free = train_leg(dev, world, "FREE_GUIDANCE", steps=args.train_steps, trace_overlap=world > 1)
         except Exception as e:   # the headline sampling metric must survive a failure of the secondary leg
             if world > 1:
                 raise            # ... but not at the price of a hang: the other ranks are inside this leg's collectives
-            train = {"error": f"{type(e).__name__}: {e}"[:300]}
+            err = {"error": f"{type(e).__name__}: {e}"[:300]}
+            train, train_free = (train or err), (train_free or err)
 
     if rank == 0:
         res = {
@@ -662,6 +740,8 @@ def main():
             res["hoisted_graph"]["per_rank_ms_per_step"] = [round(1e3 * t / steps_g, 4) for t in per_rank_g]
         if train is not None:
             res["train"] = train
+        if train_free is not None:
+            res["train_free"] = train_free
         if not args.no_roofline:
             res["roofline"] = conv2d_roofline(dev)
             res["roofline_tconv"] = tconv_roofline(None, dev)

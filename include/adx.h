@@ -138,8 +138,8 @@ int adx_unet_num_params(const adx_unet* u);
 size_t adx_unet_packed_bytes(const adx_unet* u);
 int adx_unet_pack(adx_unet* u, const float* const* params, int32_t n_params, const float* freqs,
                   void* packed, adx_stream s);
-/* The workspace must be ZERO-FILLED by the caller once, when it is allocated: its first 256 words are the ticket words of
- * adx_tconv_io::tickets (at a place that does not depend on `rows`; the library leaves them zero after every call). */
+/* The workspace needs no initialisation.  Its first 256 words are the ticket words of adx_tconv_io::tickets (at a place
+ * that does not depend on `rows`); adx_unet_forward clears them itself at the head of every call. */
 size_t adx_unet_workspace_bytes(const adx_unet* u, int32_t rows);
 
 typedef struct adx_unet_io {

@@ -1,7 +1,10 @@
-"""First-step loss of bench.py's training leg (BASELINE configs[1]: NO_GUIDANCE, B = 64, H = 32, 3x256x900, procedural
-weights seed 0, synthetic batch seed 7 = rank 0's), computed by the CPU oracle's train-mode FORWARD (batch-statistics
-BatchNorm).  bench.py asserts its own first step against this figure; tests/test_gpu_fullsize.py recomputes it on the
-GPU box's host.  Usage: python tests/golden/make_bench_loss.py  ->  tests/golden/bench_train_loss.json"""
+"""First-step losses of bench.py's training legs (B = 64, H = 32, 3x256x900, procedural weights seed 0, synthetic batch
+seed 7 = rank 0's), computed by the CPU oracle's train-mode FORWARD (batch-statistics BatchNorm):
+  * BASELINE configs[1]: NO_GUIDANCE (`loss_fp32`);
+  * BASELINE configs[4]'s per-GPU workload: FREE_GUIDANCE, in both branches of train.py:236-242 -- the target point as
+    the condition (`free_loss_fp32`) and cond=None (`free_drop_loss_fp32`).
+bench.py compares its own first step against these figures; tests/test_gpu_fullsize.py recomputes the first on the GPU
+box's host.  Usage: python tests/golden/make_bench_loss.py  ->  tests/golden/bench_train_loss.json"""
 import json
 import os
 import sys
@@ -16,22 +19,26 @@ from autonomous_driving_with_diffusion_model_amd.utils import procedural as P  #
 from oracle import sampling as OS  # noqa: E402
 
 
-def bench_train_loss(batch=64, horizon=32, image_hw=(256, 900), seed=7, dtype=torch.float32):
-    sd = P.procedural_state_dict(((e.key, e.shape) for e in unet_entries("NO_GUIDANCE")), 0)
+def bench_train_loss(batch=64, horizon=32, image_hw=(256, 900), seed=7, dtype=torch.float32, use_cond="NO_GUIDANCE",
+                     drop_cond=False):
+    sd = P.procedural_state_dict(((e.key, e.shape) for e in unet_entries(use_cond)), 0)
     d = P.synthetic_batch(batch, horizon, image_hw=image_hw, seed=seed)
     cast = lambda t: t.to(dtype) if t.is_floating_point() else t  # noqa: E731
     sd = {k: cast(v) for k, v in sd.items()}
     with torch.no_grad():
         return OS.training_loss(sd, cast(d["imgs"]), cast(d["trajs"]), cast(d["target"]), d["t"], cast(d["noise"]),
-                                use_cond="NO_GUIDANCE").item()
+                                use_cond=use_cond, drop_cond=drop_cond).item()
 
 
 if __name__ == "__main__":
     t0 = time.time()
     l32 = bench_train_loss(dtype=torch.float32)
     l64 = bench_train_loss(dtype=torch.float64)
-    out = {"loss_fp32": l32, "loss_fp64": l64, "batch": 64, "horizon": 32, "image_hw": [256, 900], "weights_seed": 0,
-           "batch_seed": 7, "use_cond": "NO_GUIDANCE", "made_by": "tests/golden/make_bench_loss.py (CPU oracle, train-mode forward)"}
+    f32 = bench_train_loss(use_cond="FREE_GUIDANCE")
+    fd32 = bench_train_loss(use_cond="FREE_GUIDANCE", drop_cond=True)
+    out = {"loss_fp32": l32, "loss_fp64": l64, "free_loss_fp32": f32, "free_drop_loss_fp32": fd32, "batch": 64, "horizon": 32,
+           "image_hw": [256, 900], "weights_seed": 0, "batch_seed": 7, "use_cond": "NO_GUIDANCE",
+           "made_by": "tests/golden/make_bench_loss.py (CPU oracle, train-mode forward)"}
     with open(os.path.join(HERE, "bench_train_loss.json"), "w") as f:
         json.dump(out, f)
     print(out, f"{time.time() - t0:.0f} s")

@@ -336,7 +336,9 @@ def gen_train():
     H = 16
     data = P.synthetic_batch(2, H, image_hw=IMG_SMALL, seed=41)
     sch = DB.DDPMScheduler(**SCHED_KW)
-    for name in ("NO_GUIDANCE", "FREE_GUIDANCE", "CLASSIFIER_GUIDANCE"):
+    # FREE_GUIDANCE_DROP: the cond=None branch train.py:236-242 takes with probability 0.3 per batch (null embedding cond_mlp(0))
+    for name in ("NO_GUIDANCE", "FREE_GUIDANCE", "CLASSIFIER_GUIDANCE", "FREE_GUIDANCE_DROP"):
+        tag, name = name, name.replace("_DROP", "")
         m = ref_model(name, H).train()
         # TrajPredict has dropout(0.1) that is active in train mode and draws from the RNG;
         # zero it so the fixture is deterministic (the build documents this)
@@ -347,16 +349,19 @@ def gen_train():
                 mod.dropout = 0.0
         noisy = sch.add_noise(data["trajs"], data["noise"], data["t"])
         noisy[..., 0, :3] = 0
-        cond = data["target"] if name == "FREE_GUIDANCE" else None
+        cond = data["target"] if tag == "FREE_GUIDANCE" else None
         pred = m(noisy, data["imgs"], data["t"], cond=cond)
         loss = torch.nn.functional.mse_loss(pred.float(), data["trajs"].float())
         loss.backward()
+        name = tag
         put(f"train.{name}.loss", loss)
         named = dict(m.named_parameters())
         keys = ["perception.conv1.weight", "perception.layer4.2.conv2.weight", "perception.fc.weight",
                 "time_mlp.1.weight", "downs.0.0.blocks.0.block.0.weight", "downs.3.1.blocks.1.block.2.weight",
                 "mid_block1.time_mlp.1.weight", "ups.0.0.residual_conv.weight", "ups.2.3.conv.weight"]
         keys += {"NO_GUIDANCE": ["final_conv.1.weight"], "FREE_GUIDANCE": ["final_conv.1.weight", "cond_mlp.0.weight"],
+                 "FREE_GUIDANCE_DROP": ["final_conv.1.weight", "cond_mlp.0.weight", "cond_mlp.0.bias", "cond_mlp.2.weight",
+                                        "cond_mlp.2.bias"],
                  "CLASSIFIER_GUIDANCE": ["act_conv.1.weight", "state_pred.input_proj.weight",
                                          "state_pred.encoder_traj.layers.1.linear2.weight"]}[name]
         for k in keys:

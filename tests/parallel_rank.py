@@ -1,5 +1,5 @@
 """One rank of tests/test_gpu_parallel.py: the real model under parallel.DataParallel, two FREE_GUIDANCE training steps
-(train.py:221-261) on this rank's shard.  Every rank sits on cuda:0 and the collectives go through gloo -- RCCL refuses two
+(train.py:221-261) on this rank's shard; in each step ONE of the ranks takes the cond=None branch of train.py:236-242.  Every rank sits on cuda:0 and the collectives go through gloo -- RCCL refuses two
 ranks on one device, and a gpurun box has one GPU; the data path (kernels, autograd nodes, bucket views, optimizer) is
 the real one.  Usage: RANK=r WORLD_SIZE=n MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tests/parallel_rank.py OUT_DIR PRIMITIVE"""
 import os
@@ -29,11 +29,17 @@ def shard(rank, step, per_rank=2):
     return {k: v.to("cuda:0") for k, v in P.synthetic_batch(per_rank, 16, image_hw=(64, 96), seed=100 + 10 * step + rank).items()}
 
 
-def loss_of(model, d):
+def drops_cond(rank, step):
+    """train.py:236-242 draws `random.random() > USE_FREE_COND_PROB` per batch in EVERY process, so in one optimizer step some
+    ranks train with the target point and others with cond=None.  Here: step 0 -- rank 1 drops it; step 1 -- rank 0 does."""
+    return (rank + step) % 2 == 1
+
+
+def loss_of(model, d, drop=False):
     from autonomous_driving_with_diffusion_model_amd import scheduler as S
     from helpers import SCHED_KW
     noisy = S.DDPMScheduler(**SCHED_KW).add_noise(d["trajs"], d["noise"], d["t"], zero_first=True)
-    return torch.nn.functional.mse_loss(model(noisy, d["imgs"], d["t"], cond=d["target"]), d["trajs"])
+    return torch.nn.functional.mse_loss(model(noisy, d["imgs"], d["t"], cond=None if drop else d["target"]), d["trajs"])
 
 
 def main():
@@ -47,9 +53,9 @@ def main():
     dp = DataParallel(model, bucket_mb=16.0, primitive=primitive, optimizer=opt)
     res = {"grad_scale": opt.grad_scale}
     for step in range(2):
-        loss = loss_of(dp, shard(rank, step))
+        loss = loss_of(dp, shard(rank, step), drop=drops_cond(rank, step))
         loss.backward()
-        dp.synchronize()
+        dp.synchronize()      # raises when a bucket is incomplete: the cond=None rank must still produce every cond_mlp gradient
         if step == 0:
             res["grads"] = {k: (p.grad * opt.grad_scale).cpu() for k, p in model.named_parameters()}
             res["born_in_bucket"] = all(p.grad.data_ptr() == p._adx_grad_view.data_ptr() for p in model.parameters())

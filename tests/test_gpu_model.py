@@ -451,3 +451,39 @@ def test_levels_layer_by_layer_vs_oracle():
     assert len(cases) == 4, r.stdout
     for _, name, rows, H, err in cases:
         assert float(err) <= 2e-5, (name, rows, H, err)
+
+
+@pytest.mark.parametrize("use_cond,B,H,dims", [("FREE_GUIDANCE", 1, 16, None), ("NO_GUIDANCE", 64, 32, None),
+                                                ("NO_GUIDANCE", 2, 16, (64, (1, 2)))])
+def test_forward_does_not_depend_on_what_the_workspace_held(use_cond, B, H, dims):
+    """adx_unet_forward clears the ticket words of its split reductions itself (the first 256 words of the caller's
+    workspace): a workspace full of garbage -- uninitialised memory of a C-ABI caller, the debris of a launch that never
+    finished -- gives the same bits as a zero-filled one, on the path that opens with a chained level (precomputed
+    conditioning), on the path that opens with the embedding kernel, and on a model without chained first level."""
+    from autonomous_driving_with_diffusion_model_amd import _lib as L
+    if dims is None:
+        m, _ = make_model(use_cond, H)
+    else:
+        from autonomous_driving_with_diffusion_model_amd.config import create_cfg
+        from autonomous_driving_with_diffusion_model_amd.modeling import build_model
+        cfg = create_cfg()
+        cfg.MODEL.HORIZON, cfg.MODEL.DIM, cfg.MODEL.DIM_MULTS = H, dims[0], dims[1]
+        m = build_model(cfg)
+        P.load_procedural(m, 0)
+        m = m.to(DEV).eval()
+    d = {k: v.to(DEV) for k, v in P.synthetic_batch(B, H, image_hw=IMG_SMALL, seed=77).items()}
+    free = use_cond == "FREE_GUIDANCE"
+    cond = torch.cat([d["target"], torch.zeros_like(d["target"])], 0) if free else None
+    rows = 2 * B if free else B
+    x = torch.cat([d["init_trajs"]] * 2, 0) if free else d["init_trajs"]
+    ts = torch.tensor([40], dtype=torch.int64, device=DEV)
+    t = ts if free else ts.repeat(B)
+    with torch.no_grad():
+        tc = m.time_conditioning(d["imgs"], ts, cond=cond, rows=rows)
+        want_tc, want = m(x, None, None, time_cond=(tc, 0)), m(x, d["imgs"], t, cond=cond)
+        nbytes = L.lib().adx_unet_workspace_bytes(m._native(), rows)
+        for fill in (0xFF, 0x01, 0x5A):
+            m._ws = torch.full((nbytes,), fill, dtype=torch.uint8, device=DEV)
+            assert torch.equal(m(x, None, None, time_cond=(tc, 0)), want_tc), hex(fill)
+            m._ws = torch.full((nbytes,), fill, dtype=torch.uint8, device=DEV)
+            assert torch.equal(m(x, d["imgs"], t, cond=cond), want), hex(fill)

@@ -45,11 +45,13 @@ def test_two_ranks_real_model_free_guidance_train_steps(tmp_path, primitive):
     singles = []
     for r in range(world):
         m = W.build(seed=0)
-        W.loss_of(m, W.shard(r, 0)).backward()
+        W.loss_of(m, W.shard(r, 0), drop=W.drops_cond(r, 0)).backward()
         singles.append({k: p.grad.cpu() for k, p in m.named_parameters()})
         if r == 0:
             bufs0 = {k: b.clone().cpu() for k, b in m.named_buffers()}
         del m
+    # rank 1 trained step 0 with cond=None: its d(cond_mlp.0.weight) is all zero, so the mean is half of rank 0's
+    assert singles[1]["cond_mlp.0.weight"].abs().max().item() == 0.0 and singles[0]["cond_mlp.0.weight"].abs().max().item() > 0.0
     worst = 0.0
     for k, g in res[0]["grads"].items():
         assert torch.equal(g, res[1]["grads"][k]), k                  # both ranks hold the same reduced bucket
@@ -66,3 +68,34 @@ def test_two_ranks_real_model_free_guidance_train_steps(tmp_path, primitive):
     for k, b in res[0]["buffers_before_sync"].items():
         assert torch.equal(b, res[0]["buffers_after_sync"][k]) and torch.equal(b, res[1]["buffers_after_sync"][k]), k
     assert all(torch.isfinite(torch.tensor([r["loss0"], r["loss1"]])).all() for r in res)
+
+
+def test_bench_two_ranks_same_device_fullsize_free_train_leg():
+    """`bench.py --gpus 2` end to end on one GPU (ADX_BENCH_SAME_DEVICE=1: both ranks on cuda:0, gloo collectives): the
+    launcher, the sharded sampling legs and -- the point -- BASELINE configs[4]'s per-GPU workload as the training leg:
+    FREE_GUIDANCE at B = 64 per rank, H = 32, 3 x 256 x 900 under parallel.DataParallel with train.py:236-242's per-rank
+    cond=None draw.  Every gradient must have been born in its bucket (nothing copied), every rank reports its own step
+    time, the first step's loss is the oracle's, and the traced step reports when each bucket's reduction ran relative to
+    the end of backward.  The times of such a run mean nothing."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["ADX_BENCH_SAME_DEVICE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--train-steps", "3", "--short-sampling", "--no-roofline"], env=env, capture_output=True, text=True,
+                       timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = lines[0]
+    assert res["n_gpus"] == 2 and len(res["per_rank_ms_per_step"]) == 2 and res["value"] > 0
+    assert "train" not in res                      # N > 1: the training leg IS configs[4]
+    tf = res["train_free"]
+    assert "error" not in tf and "parity_failed" not in tf, tf
+    assert "FREE_GUIDANCE" in tf["workload"] and tf["value"] > 0 and len(tf["per_rank_ms_per_step"]) == 2
+    assert abs(tf["first_step_loss"] - tf["first_step_loss_oracle"]) <= 2e-5 * max(1.0, abs(tf["first_step_loss_oracle"]))
+    gb = tf["gradient_buckets"]
+    assert gb["copied_in_last_step"] == 0 and gb["n"] >= 2
+    ov = gb["overlap_rank0"]
+    assert len(ov) == gb["n"] and all(o["done_ms"] >= o["ready_ms"] for o in ov)
+    # the temporal stack's buckets are complete long before backward ends (the perception backward is two thirds of the step)
+    assert min(o["ready_ms"] for o in ov) < -5.0, ov

@@ -36,6 +36,8 @@ def _stubbed_model():
 def test_image_feature_memo_in_every_grad_mode():
     for ctx in (torch.no_grad, torch.inference_mode, torch.enable_grad):
         m, calls = _stubbed_model()
+        if ctx is torch.inference_mode:
+            m.cache_perception = "identity"      # inference tensors are memoised on request only (next test)
         with ctx():
             img = torch.randn(2, 3, 8, 8)
             f0 = m.image_feature(img)
@@ -52,6 +54,31 @@ def test_image_feature_memo_in_every_grad_mode():
             m.image_feature(img2)
             m.image_feature(img2)
         assert len(calls) >= 4
+
+
+def test_inference_tensors_are_not_memoised_by_default():
+    """An inference tensor has no version counter: a real-time agent that refills ONE preallocated frame buffer in place
+    under torch.inference_mode() must get the new frame's feature, not the memo of the previous one."""
+    m, calls = _stubbed_model()
+    with torch.inference_mode():
+        frame = torch.zeros(1, 3, 8, 8)
+        f0 = m.image_feature(frame)
+        frame.add_(1.0)                                                    # next camera frame, same buffer
+        f1 = m.image_feature(frame)
+        assert len(calls) == 2 and not torch.equal(f0, f1)
+        m.cache_perception = "identity"                                    # the caller vouches for immutability
+        m.image_feature(frame)
+        m.image_feature(frame)
+        assert len(calls) == 3
+    with torch.no_grad():                                                  # ordinary tensors: the counter sees the refill
+        m.cache_perception = True
+        frame = torch.zeros(1, 3, 8, 8)
+        m.image_feature(frame)
+        m.image_feature(frame)
+        assert len(calls) == 4
+        frame.add_(1.0)
+        m.image_feature(frame)
+        assert len(calls) == 5
 
 
 def test_memo_is_dropped_in_train_mode_and_after_weight_changes():

@@ -209,16 +209,19 @@ def test_loop_cfg1_evaluate(golden):
     close(r, golden("loop")["loop.evaluate.cfg1"], 2e-5)
 
 
-@pytest.mark.parametrize("name", ["NO_GUIDANCE", "FREE_GUIDANCE", "CLASSIFIER_GUIDANCE"])
+@pytest.mark.parametrize("name", ["NO_GUIDANCE", "FREE_GUIDANCE", "CLASSIFIER_GUIDANCE", "FREE_GUIDANCE_DROP"])
 def test_training_step(golden, name):
+    """FREE_GUIDANCE_DROP = the cond=None branch of train.py:236-242 (taken with probability 0.3 per batch)."""
     g = golden("train")
     d = P.synthetic_batch(2, 16, image_hw=IMG_SMALL, seed=41)
+    tag, name, drop = name, name.replace("_DROP", ""), name.endswith("_DROP")
     sd = oracle_sd(name)
     entries = unet_entries(name)
     for e in entries:
         if not e.is_buffer:
             sd[e.key].requires_grad_()
-    loss = S.training_loss(sd, d["imgs"], d["trajs"], d["target"], d["t"], d["noise"], use_cond=name)
+    loss = S.training_loss(sd, d["imgs"], d["trajs"], d["target"], d["t"], d["noise"], use_cond=name, drop_cond=drop)
+    name = tag
     close(loss.detach(), g[f"train.{name}.loss"], 2e-6)
     loss.backward()
     assert sum(sd[e.key].numel() for e in entries if not e.is_buffer) == int(g[f"train.{name}.n_params"])

@@ -147,6 +147,22 @@ def _inplace_worker(rank, world, port, out, primitive):
         w2 = w.detach().clone().requires_grad_()
         (2 * lin(x @ w2.t()).square().sum()).backward()
         ok = ok and torch.allclose(w.grad, w2.grad, atol=1e-4, rtol=1e-5)
+        # one parameter feeding TWO nodes of one graph (the model called twice before one backward; shared weights): both
+        # nodes run before AccumulateGrad, so both see `.grad is None` -- the bucket view may be lent to one of them only
+        avg = GradientAverager([w, *lin.parameters()], bucket_mb=1e-3, primitive=primitive, mean=mean).attach()
+        for step in range(2):
+            w.grad = None
+            lin.zero_grad(set_to_none=True)
+            x2 = torch.randn(4, 7, generator=torch.Generator().manual_seed(5 + rank))
+            (lin(_BucketBornGrad.apply(x, w)).square().sum() + 3.0 * lin(_BucketBornGrad.apply(x2, w)).square().sum()).backward()
+            w2 = w.detach().clone().requires_grad_()
+            ref_lin = lambda v: torch.nn.functional.linear(v, lin.weight.detach(), lin.bias.detach())  # noqa: E731
+            (ref_lin(x @ w2.t()).square().sum() + 3.0 * ref_lin(x2 @ w2.t()).square().sum()).backward()
+            avg.synchronize()
+            parts = [torch.zeros_like(w2.grad) for _ in range(world)]
+            dist.all_gather(parts, w2.grad)
+            ok = ok and torch.allclose(w.grad * avg.grad_scale, sum(parts) / world, atol=1e-4, rtol=1e-5)
+        avg.detach()
     out.put((rank, bool(ok)))
     dist.destroy_process_group()
 
