@@ -37,6 +37,21 @@ void set_error(const char* fmt, ...);
     }                                                                                    \
   } while (0)
 
+// Debug switches of the library: the environment is parsed ONCE, here, into this struct (api.cpp).  Every one of them is an
+// A/B or diagnostic configuration that a tracked test or tool runs (INTEGRATION.md lists them); there are no others.
+struct DebugSwitches {
+  bool conv_exact = false;     // ADX_CONV_EXACT=1   every 2-D conv (and weight gradient) on the exact-fp32 MFMA kernels
+  bool wgrad_exact = false;    // ADX_WGRAD_EXACT=1  the 2-D weight gradients only
+  bool tconv_exact = false;    // ADX_TCONV_EXACT=1  the temporal stack on the exact-fp32 MFMA kernel
+  bool unet_chain = true;      // ADX_UNET_CHAIN=0   every temporal level layer by layer (no chained launches)
+  unsigned chain_mask = ~0u;   // ADX_CHAIN_MASK=<bits>  which levels are chained (bit i: down level i, bit 8 + i: up level i)
+  bool conv_cells = true;      // ADX_CONV_CELLS=0   fp32 NCHW between all perception convs (no pre-split cell tensors)
+  int hs_mode = -1;            // ADX_HS_MODE=0|1|2  pins the tile mode of the pipelined 3x3 kernel
+  bool check_range = false;    // ADX_CHECK_RANGE=1  perception forward: fail with the first layer whose activations leave the
+                               //                    fp16 range of the split kernels instead of propagating inf (synchronises)
+};
+const DebugSwitches& debug_switches();
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // __builtin_bit_cast(T, vec[i]) on an ext_vector ELEMENT lvalue is miscompiled by this clang (ROCm 7.2: it reads element 0

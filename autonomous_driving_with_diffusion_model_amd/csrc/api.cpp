@@ -1,6 +1,7 @@
 // extern "C" surface of libadx.so (declared in include/adx.h): thin wrappers over the adx::
 // implementations plus the thread-local error string.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "tconv.h"
 
@@ -13,6 +14,23 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+const DebugSwitches& debug_switches() {
+  static const DebugSwitches sw = [] {
+    DebugSwitches d;
+    auto is = [](const char* name, char v) { const char* e = getenv(name); return e != nullptr && e[0] == v; };
+    d.conv_exact = is("ADX_CONV_EXACT", '1');
+    d.wgrad_exact = is("ADX_WGRAD_EXACT", '1');
+    d.tconv_exact = is("ADX_TCONV_EXACT", '1');
+    d.unet_chain = !is("ADX_UNET_CHAIN", '0');
+    d.conv_cells = !is("ADX_CONV_CELLS", '0');
+    d.check_range = is("ADX_CHECK_RANGE", '1');
+    if (const char* e = getenv("ADX_CHAIN_MASK")) d.chain_mask = (unsigned)strtoul(e, nullptr, 0);
+    if (const char* e = getenv("ADX_HS_MODE")) d.hs_mode = atoi(e);
+    return d;
+  }();
+  return sw;
 }
 
 int embed_forward(const adx_embed_weights* w, int dim, const int64_t* t, int t_rows, const float* cond,

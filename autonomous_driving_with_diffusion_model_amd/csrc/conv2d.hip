@@ -23,8 +23,8 @@ namespace adx {
 
 constexpr int kCoutT = 64;   // output channels per workgroup (2 MFMA row blocks)
 constexpr size_t kMaxLds = 96 * 1024;
-static int g_conv_cc = 16;    // channels per LDS chunk of the 8-row kernel (ADX_CONV_CC=8: smaller chunk, 3 workgroups/CU)
-static int g_conv_rows = 2;   // rows per wave of the 3x3 stride-1 kernel (ADX_CONV_ROWS=1 selects the 4-row tile)
+constexpr int g_conv_cc = 16;    // channels per LDS chunk of the 8-row kernel
+constexpr int g_conv_rows = 2;   // rows per wave of the 3x3 stride-1 kernel
 
 // Software pipeline (register double buffer): the global loads of chunk i+1 (input patch + weight
 // slab) are issued before the MFMAs of chunk i and written to LDS after them, so HBM/L2 latency
@@ -393,16 +393,8 @@ void conv2d_set_split_scratch(float* p, size_t floats) { t_split_scratch = p; t_
 
 int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const float* scale, const float* shift,
                       const float* res, float* y, int N, int H, int W, int relu, hipStream_t s, const uint32_t* x_amax,
-                      int x_amax_n, float* stats_part, size_t stats_floats, int* stats_p, int fmt) {
+                      int x_amax_n, float* stats_part, size_t stats_floats, int* stats_p, int fmt, const BnBwdStats* bst) {
   if (stats_p != nullptr) *stats_p = 0;
-  static bool env_read = false;
-  if (!env_read) {
-    const char* e = getenv("ADX_CONV_ROWS");
-    if (e != nullptr && e[0] == '1') g_conv_rows = 1;
-    const char* c = getenv("ADX_CONV_CC");
-    if (c != nullptr && c[0] == '8') g_conv_cc = 8;
-    env_read = true;
-  }
   Conv2dArgs a;
   a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.res = res; a.y = y; a.x_amax = x_amax; a.x_amax_n = x_amax_n;
   a.w_ds = nullptr; a.scale_ds = nullptr; a.shift_ds = nullptr; a.y_ds = nullptr;
@@ -414,6 +406,14 @@ int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const f
   a.d2s_cin = 0; a.d2s_h = 0; a.d2s_w = 0; a.stem_seg_tiles = 0; a.stem_nseg = 1;
   a.ksplit = 1; a.cper = 0; a.part = t_split_scratch; a.part_stride = t_split_floats;   // part_stride: capacity until the launch fixes it
   a.stats_part = nullptr; a.stats_p = 0;
+  a.bs_raw = a.bs_out = a.bs_mean = a.bs_rstd = a.bs_gamma = a.bs_beta = nullptr; a.bs_mask = 0;
+  if (bst != nullptr) {
+    ADX_REQUIRE(bst->raw && bst->mean && bst->rstd && bst->gamma && bst->beta && (bst->mask == 2 || (bst->mask == 1 && bst->out)),
+                "conv2d: incomplete BatchNorm-backward statistics request");
+    ADX_REQUIRE(scale == nullptr && relu == 0, "conv2d: BatchNorm-backward statistics belong to data-gradient launches");
+    a.bs_raw = bst->raw; a.bs_out = bst->out; a.bs_mean = bst->mean; a.bs_rstd = bst->rstd; a.bs_gamma = bst->gamma;
+    a.bs_beta = bst->beta; a.bs_mask = bst->mask;
+  }
   a.x_cells = (fmt & kFmtXCells) != 0; a.y_cells = (fmt & kFmtYCells) != 0; a.res_cells = (fmt & kFmtResCells) != 0 && res != nullptr;
   ADX_REQUIRE(fmt == 0 || (stats_part == nullptr && conv2d_hs3x3_plain(L, N, H, W)),
               "conv2d: the cell layout belongs to plain launches of the pipelined 3x3 kernel (%d -> %d, k%d s%d)", L.cin, L.cout, L.k, L.stride);
@@ -640,6 +640,39 @@ int adx_resnet_forward_u8(adx_resnet* r, const void* packed, void* workspace, co
   return resnet_forward_impl(r, packed, workspace, nullptr, frames_hwc, mean, stdv, batch, h, w, feature, stream);
 }
 
+// ADX_CHECK_RANGE=1 (debug): the split-fp16 kernels hold activations as fp16 hi / lo pairs, so a forward activation of
+// |x| >= 65504 becomes inf and travels on silently ("Range").  In this mode every activation tensor of
+// the perception pass is scanned right after the launch that wrote it and the call fails with the FIRST tensor that left
+// the range (fp32 tensors: |x| >= 65504 or non-finite; cell tensors: a half with an all-ones exponent).  It synchronises
+// the stream after every launch (no graph capture) and owns one device word.
+__global__ void __launch_bounds__(256) range_scan_kernel(const uint32_t* __restrict__ v, size_t words, int cells, unsigned* flag) {
+  bool bad = false;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) {
+    const uint32_t b = v[i];
+    if (cells) bad |= ((b & 0x7C00u) == 0x7C00u) | ((b & 0x7C000000u) == 0x7C000000u);
+    else bad |= (b & 0x7FFFFFFFu) >= 0x477FE000u;            // 65504.0f
+  }
+  if (bad) atomicOr(flag, 1u);
+}
+
+static int range_check(const char* what, int index, const float* t, size_t floats, bool cells, hipStream_t s) {
+  if (!debug_switches().check_range) return ADX_OK;
+  static unsigned* flag = nullptr;
+  if (flag == nullptr) ADX_CHECK_HIP(hipMalloc(&flag, sizeof(unsigned)));
+  ADX_CHECK_HIP(hipMemsetAsync(flag, 0, sizeof(unsigned), s));
+  range_scan_kernel<<<dim3(1024), dim3(256), 0, s>>>(reinterpret_cast<const uint32_t*>(t), floats, cells ? 1 : 0, flag);
+  ADX_LAUNCH_CHECK();
+  unsigned h = 0;
+  ADX_CHECK_HIP(hipMemcpyAsync(&h, flag, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  ADX_CHECK_HIP(hipStreamSynchronize(s));
+  if (h != 0) {
+    set_error("adx_resnet_forward: %s %d writes activations outside the fp16 range of the split kernels (|x| >= 65504 or "
+              "non-finite); ADX_CONV_EXACT=1 runs the pass on the exact-fp32 kernels", what, index);
+    return ADX_ERR_RANGE;
+  }
+  return ADX_OK;
+}
+
 static int resnet_forward_impl(adx_resnet* r, const void* packed, void* workspace, const float* img,
                                const uint8_t* frames_u8, const float* mean, const float* stdv, int32_t batch, int32_t h,
                                int32_t w, float* feature, adx_stream stream) {
@@ -668,11 +701,7 @@ static int resnet_forward_impl(adx_resnet* r, const void* packed, void* workspac
   const size_t nblocks = r->block_has_ds.size();
 
   struct Cursor { size_t ci; int cur, H, W; bool cells; };
-  static int fuse = -1;           // ADX_STEM_POOL=0 keeps the stem and the pool as two launches
-  if (fuse < 0) {
-    const char* e = getenv("ADX_STEM_POOL");
-    fuse = (e != nullptr && e[0] == '0') ? 0 : 1;
-  }
+  constexpr int fuse = 1;         // stem + max-pool as one launch (0: two launches, the round-1 form)
 
   // stem (+ pool) of images [n0, n0 + n)
   auto run_stem = [&](Cursor& st, int n0, int n, int nf) -> int {
@@ -698,7 +727,7 @@ static int resnet_forward_impl(adx_resnet* r, const void* packed, void* workspac
       if (rc != ADX_OK) return rc;
     }
     st = Cursor{1, 0, h2, w2, pooled_cells};
-    return ADX_OK;
+    return range_check("the stem (conv1 + bn1 + relu + maxpool), tensor", 0, pooled, (size_t)n * 64 * h2 * w2, pooled_cells, s);
   };
 
   // Activation formats (conv2d_hs.hip: XCELLS).  Where a layer's 3x3 stride-1 convs run as plain launches of the pipelined
@@ -764,8 +793,12 @@ static int resnet_forward_impl(adx_resnet* r, const void* packed, void* workspac
     }
     ADX_REQUIRE(out_cells || !(mid_cells || id_cells),
                 "adx_resnet_forward: internal error (a conv with cell-layout operands whose reader wants fp32)");
+    rc = range_check("conv1 + bn1 + relu of BasicBlock", (int)b, buf[mid] + off_out, (size_t)n * c1.cout * OH * OW, mid_cells, s);
+    if (rc != ADX_OK) return rc;
     rc = conv2d_launch(c2, base, buf[mid] + off_out, identity, dst, n, OH, OW, 1, s,
                        (mid_cells ? kFmtXCells : 0) | (out_cells ? kFmtYCells : 0) | (id_cells ? kFmtResCells : 0));
+    if (rc != ADX_OK) return rc;
+    rc = range_check("the output of BasicBlock", (int)b, dst, (size_t)n * c2.cout * OH * OW, out_cells, s);
     if (rc != ADX_OK) return rc;
     st = Cursor{ci, r->block_has_ds[b] ? cur : outb, OH, OW, out_cells};
     return ADX_OK;

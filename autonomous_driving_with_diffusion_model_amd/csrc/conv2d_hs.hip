@@ -483,12 +483,15 @@ __device__ __forceinline__ void hs_trace_id() {
 // layout costs eight 4-byte loads and ~48 VALU instructions, once per 64-channel output slab; the producer splits each
 // element once.  The products are bit-identical either way (the halves are the ones the consumer would have computed); a
 // residual read from cells (Conv2dArgs::res_cells) is hi + lo / 2^11, the tensor to 2^-23.  Inference executor only.
-template <int MODE, bool STATS = false, bool XCELLS = false, bool YCELLS = false>
+// STATS: 0 none; 1 the training forward's BatchNorm statistics of this conv's own output; 2 (data-gradient launches) the
+// BACKWARD sums of the BatchNorm in front of this conv in forward order, whose incoming gradient this launch produces
+// (Conv2dArgs::bs_*).
+template <int MODE, int STATS = 0, bool XCELLS = false, bool YCELLS = false>
 __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(const Conv2dArgs a) {
   constexpr int NT = MODE == 0 ? 256 : 512;            // threads
   constexpr int TH = MODE == 1 ? 16 : 8;               // output rows per workgroup
   constexpr int CT = MODE == 2 ? 2 : 1;                // 64-channel slabs per workgroup
-  constexpr int K = 3, PH = TH + 2, PW = YCELLS ? 38 : 34, PLANE = PH * PW, NITEM = 2 * PLANE;    // YCELLS: up to three image segments per row
+  constexpr int K = 3, PH = TH + 2, PW = 34, PLANE = PH * PW, NITEM = 2 * PLANE;
   constexpr int PIT = (NITEM + NT - 1) / NT;           // patch rounds = slices, one per stage while they last
   constexpr int NW = 9 * 256, WST = 3 * 256 * CT;      // weight cells per chunk and 64-channel slab / per stage
   constexpr int WIT = (WST + NT - 1) / NT;
@@ -498,6 +501,7 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
   u32x4* wl = patch + 2 * 4 * PLANE;                   // 2 x [slab][kw][plane][k-half][64]
   float* ss = reinterpret_cast<float*>(wl + 2 * WST);  // scale[64 CT], shift[64 CT], 8 words for the range reduction
   u32x4* dummy = reinterpret_cast<u32x4*>(ss + 2 * 64 * CT + 8);   // where idle threads of a partial round write
+  float* bsl = reinterpret_cast<float*>(dummy + 3);                 // STATS == 2: [mean | rstd | mask scale | mask shift] x 64 CT
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rowpair = MODE == 2 ? (wave & 3) : wave, slab = MODE == 2 ? (wave >> 2) : 0;
@@ -520,15 +524,18 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
   const int iy0 = oy0 - a.pad, ix0 = ox0 - a.pad;
   const int cout0 = (ct * CT + slab) * kHsCout;
   const int l31 = lane & 31, khalf = lane >> 5;
-  // YCELLS (the inference executor's launches): column tiles run over the VIRTUAL width N x vw -- the images of the batch side
-  // by side, vw = W columns each (or W rounded up to 32, which is the per-image tiling) -- so a map 225 / 113 / 57 / 29 wide
-  // pays no padded MFMA columns: 450 tiles instead of 512 per tile row at B = 64 (-12 / 12 / 11 / 9 %).  A 32-column tile then
-  // spans up to three images (W >= 16); in the staged patch row every image segment keeps its own left / right halo cell, so
-  // the lane of virtual column v reads cell (lane + 2 seg + kw) and the main loop is the one of the per-image tiling.
+  // YCELLS (the inference executor's launches): column tiles run over a VIRTUAL row -- the images of the batch side by side,
+  // vw = W + 1 columns each: the W real ones and ONE all-zero column, which is the right padding of its image and the left
+  // padding of the next one (pad = 1) -- so a map 225 / 113 / 57 / 29 wide pays one padded MFMA column per image instead of
+  // 31 / 15 / 7 / 3: 452 tiles instead of 512 per tile row at B = 64.  The staged patch row is the 34 consecutive virtual
+  // columns around the tile, whatever images they belong to, and the lane of virtual column v reads cell (lane + kw) exactly
+  // as in the per-image tiling: consecutive lanes, consecutive 16-byte cells, no bank conflict.  (Round 3 gave every image
+  // segment of a tile its own two halo cells, i.e. lanes behind an image boundary read two cells further: a 2-way conflict in
+  // nearly every 16-lane group of a tile that holds a boundary -- 25 % of the LDS cycles of the 512-channel layers.)
   const int vx0 = tx * kTileW;
-  const int n0 = YCELLS ? vx0 / a.vw : 0, x0 = YCELLS ? vx0 - n0 * a.vw : 0;
   const int vl = vx0 + l31;
-  const int nl = YCELLS ? vl / a.vw : 0, xl = YCELLS ? vl - nl * a.vw : 0, seg = nl - n0;
+  auto vdiv = [&](int v) { return (int)(((float)v + 0.5f) * a.inv_vw); };     // v / vw for 0 <= v < 2^21 (launch check)
+  const int nl = YCELLS ? vdiv(vl) : 0, xl = YCELLS ? vl - nl * a.vw : 0;
   const bool lane_valid = !YCELLS || (nl < a.N && xl < a.W);
   const size_t hw = (size_t)a.H * a.W;
   const int nchunks_all = a.cin_pad / kHsCC;
@@ -542,8 +549,6 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
       const_cast<float*>(xin), 0,
       (int)(uint32_t)((YCELLS ? (size_t)a.N * a.Cin : (size_t)(a.Cin - chunk0 * kHsCC)) * hw * sizeof(float)), 0x00020000);
   const uint32_t plane_bytes = (uint32_t)(hw * sizeof(float));
-  // YCELLS: widths of the tile's image segments in output columns (s0 + s1 + s2 = 32; an image is at least 16 columns wide)
-  const int s0 = min(kTileW, a.vw - x0), s1 = min(kTileW - s0, a.vw);
   uint32_t goff[PIT];
   int pcell[PIT];
 #pragma unroll
@@ -554,11 +559,10 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
     const int py = p / PW, px = p - py * PW;
     const int iy = iy0 + py;
     int ix = ix0 + px, ni = n;
-    if constexpr (YCELLS) {        // patch column px -> (image, input column): [seg 0: x0 - 1 .. x0 + s0] [seg 1: -1 .. s1] [seg 2: -1 .. ]
-      const int sg = px < s0 + 2 ? 0 : (px < s0 + s1 + 4 ? 1 : 2);
-      const int first = sg == 0 ? 0 : (sg == 1 ? s0 + 2 : s0 + s1 + 4);
-      ix = (sg == 0 ? x0 : 0) - 1 + (px - first);
-      ni = n0 + sg;
+    if constexpr (YCELLS) {        // patch column px = virtual column vx0 - 1 + px -> (image, input column); column W of an image is zero
+      const int v = vx0 - 1 + px;
+      ni = vdiv(v < 0 ? 0 : v);
+      ix = v - ni * a.vw;          // -1 for the column left of the first image
     }
     const bool ok = e < NITEM && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && ni < a.N;
     const size_t ioff = YCELLS ? (size_t)ni * a.Cin * hw * sizeof(float) : 0;
@@ -584,6 +588,15 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
     const int half = tid / (64 * CT), cc = tid - half * 64 * CT;
     const int c = ct * CT * kHsCout + cc;
     ssv = a.scale == nullptr ? (half == 0 ? 1.f : 0.f) : (half == 0 ? a.scale[c] : a.shift[c]);
+  }
+  float bsv = 0.f;
+  if (STATS == 2 && tid < 4 * 64 * CT) {
+    const int which = tid / (64 * CT), cc = tid - which * 64 * CT;
+    const int c = ct * CT * kHsCout + cc;
+    // the mask's affine form exactly as the forward pass applied it (resnet_train.hip: bn_affine)
+    const float mu = a.bs_mean[c], rs = a.bs_rstd[c];
+    const float sc = a.bs_gamma[c] * rs;
+    bsv = which == 0 ? mu : (which == 1 ? rs : (which == 2 ? sc : __builtin_fmaf(-mu, sc, a.bs_beta[c])));
   }
   float xs = 1.f, xs_inv = 1.f;
   if (a.x_amax != nullptr) {
@@ -666,7 +679,7 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
     *d1 = lo;
   };
 
-  const int pb_lane = khalf * 2 * PLANE + (rowpair * 2) * PW + l31 + (YCELLS ? 2 * seg : 0);
+  const int pb_lane = khalf * 2 * PLANE + (rowpair * 2) * PW + l31;
   const int wa_lane = slab * 768 + khalf * 64 + l31;
 
   // prologue: stage 0 complete in LDS; weights of stage 1 and the first slice of chunk 1 in flight
@@ -676,6 +689,7 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
   for (int k = 0; k < PIT; ++k) { load_p(0, k, 0); store_p(0, k, 0); }
   load_w(1, 1);                 // nchunks is even (>= 2): stage 1 and chunk 1 exist
   if (tid < 2 * 64 * CT) ss[tid] = ssv;
+  if (STATS == 2 && tid < 4 * 64 * CT) bsl[tid] = bsv;
   load_p(1, 0, 1);
   HS_TRACE(1);
   __syncthreads();
@@ -815,6 +829,7 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
 #pragma unroll
   for (int rr = 0; rr < 2; ++rr) voff[rr] = inside[rr] ? pix[rr] * 4u + (uint32_t)(4 * khalf) * plane_ob : kOutside;
   float rv[2][2][16];
+  if constexpr (STATS != 2) {
 #pragma unroll
   for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
@@ -824,34 +839,96 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
         const int cu = half * 32 + (r & 3) + 8 * (r >> 2);     // + 4 * khalf, which rides in voff
         rv[rr][half][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, voff[rr], cbase_o + cu * plane_ob, 0));
       }
+  }
 #ifdef ADX_HS_TRACE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   HS_TRACE(6);
 #endif
-  if (STATS) {
-    // Training forward: this workgroup's per-channel sum and sum of squares of the conv output (pixels outside the map
-    // excluded), so that the BatchNorm statistics need no pass over the output tensor.  Per (half, r) register: the two rows
-    // of the lane, then the 16 lanes of a DPP row; lanes 0 / 16 / 32 / 48 park their row's totals in LDS (the patch is dead:
-    // every wave passed the main loop's last barrier), 64 CT x 2 threads add the 2 x NW/CT rows up in a fixed order.
+  if constexpr (STATS != 0) {
+    // Per-channel partial sums of this workgroup's pixels (those outside the map excluded), so that a BatchNorm needs no pass
+    // over the tensor this launch writes.  STATS == 1 (training forward): sum and sum of squares of the conv output.  STATS
+    // == 2 (data gradient): dx = conv + residual is finished and stored HERE, and the sums are those of the BatchNorm backward
+    // of the layer dx flows into: sum dz and sum dz xhat, dz = dx where that layer's ReLU let the value through.
+    // Per (half, r) register: the two rows of the lane, then the 16 lanes of a DPP row; lanes 0 / 16 / 32 / 48 park their row's
+    // totals in LDS (the patch is dead: every wave passed the main loop's last barrier), 64 CT x 2 threads add the 2 x NW/CT
+    // rows up in a fixed order.
     float* red = reinterpret_cast<float*>(smem_raw);          // [wave][lane >> 4][32][2]
     const bool val0 = voff[0] != kOutside, val1 = voff[1] != kOutside;
+    auto park = [&](int half, int r, float sm, float sq) {
+      sm += hs_dpp<0xB1>(sm);  sq += hs_dpp<0xB1>(sq);      // quad_perm [1,0,3,2]
+      sm += hs_dpp<0x4E>(sm);  sq += hs_dpp<0x4E>(sq);      // quad_perm [2,3,0,1]
+      sm += hs_dpp<0x141>(sm); sq += hs_dpp<0x141>(sq);     // row_half_mirror
+      sm += hs_dpp<0x140>(sm); sq += hs_dpp<0x140>(sq);     // row_mirror: every lane of a row of 16 holds the row's total
+      if ((lane & 15) == 0) {
+        float* d = red + (((wave * 4 + (lane >> 4)) * 32) + half * 16 + r) * 2;
+        d[0] = sm;
+        d[1] = sq;
+      }
+    };
+    if constexpr (STATS == 1) {
 #pragma unroll
-    for (int half = 0; half < 2; ++half)
+      for (int half = 0; half < 2; ++half)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float v0 = val0 ? (accm[0][half][r] + accl[0][half][r] * (1.f / kLoScale)) * xs_inv : 0.f;
-        const float v1 = val1 ? (accm[1][half][r] + accl[1][half][r] * (1.f / kLoScale)) * xs_inv : 0.f;
-        float sm = v0 + v1, sq = v0 * v0 + v1 * v1;
-        sm += hs_dpp<0xB1>(sm);  sq += hs_dpp<0xB1>(sq);      // quad_perm [1,0,3,2]
-        sm += hs_dpp<0x4E>(sm);  sq += hs_dpp<0x4E>(sq);      // quad_perm [2,3,0,1]
-        sm += hs_dpp<0x141>(sm); sq += hs_dpp<0x141>(sq);     // row_half_mirror
-        sm += hs_dpp<0x140>(sm); sq += hs_dpp<0x140>(sq);     // row_mirror: every lane of a row of 16 holds the row's total
-        if ((lane & 15) == 0) {
-          float* d = red + (((wave * 4 + (lane >> 4)) * 32) + half * 16 + r) * 2;
-          d[0] = sm;
-          d[1] = sq;
+        for (int r = 0; r < 16; ++r) {
+          const float v0 = val0 ? (accm[0][half][r] + accl[0][half][r] * (1.f / kLoScale)) * xs_inv : 0.f;
+          const float v1 = val1 ? (accm[1][half][r] + accl[1][half][r] * (1.f / kLoScale)) * xs_inv : 0.f;
+          park(half, r, v0 + v1, v0 * v0 + v1 * v1);
+        }
+    } else {
+      // the accumulators fold into accm first (accl is dead afterwards); then one 32-channel half at a time: residual, conv
+      // output of the consumer BatchNorm (xhat, and its ReLU mask when the ReLU sits straight behind it) and, otherwise, that
+      // layer's output (the mask) are fetched together -- 96 loads in flight -- and dx is stored from the same registers
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) accm[rr][half][r] = (accm[rr][half][r] + accl[rr][half][r] * (1.f / kLoScale)) * xs_inv;
+      const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bs_raw + img), 0, img_bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(a.bs_mask == 1 ? a.bs_out + img : a.y), 0, a.bs_mask == 1 ? img_bytes : 0, 0x00020000);
+      const float* bsw = bsl + slab * 64;
+      const bool mask_out = a.bs_mask == 1;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        float rs_[2][16], rw_[2][16], ro_[2][16];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const uint32_t so = cbase_o + (uint32_t)(half * 32 + (r & 3) + 8 * (r >> 2)) * plane_ob;
+            rs_[rr][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, voff[rr], so, 0));
+            rw_[rr][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, voff[rr], so, 0));
+            ro_[rr][r] = 0.f;
+          }
+        if (mask_out) {        // wave-uniform: the 32 loads of the consumer layer's output only where its ReLU follows the residual add
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const uint32_t so = cbase_o + (uint32_t)(half * 32 + (r & 3) + 8 * (r >> 2)) * plane_ob;
+              ro_[rr][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(orsrc, voff[rr], so, 0));
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cu = half * 32 + (r & 3) + 8 * (r >> 2);
+          const int cl = cu + 4 * khalf;
+          const float mu = bsw[cl], rsd = bsw[64 * CT + cl], msc = bsw[2 * 64 * CT + cl], msh = bsw[3 * 64 * CT + cl];
+          float p[2], q[2];
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr) {
+            const float y = accm[rr][half][r] + rs_[rr][r];            // scale 1, shift 0, no ReLU: what `finish` would store
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, y), yrsrc, voff[rr], cbase_o + cu * plane_ob, 0);
+            const bool keep = (rr == 0 ? val0 : val1) &&
+                              (mask_out ? ro_[rr][r] > 0.f : __builtin_fmaf(rw_[rr][r], msc, msh) > 0.f);
+            p[rr] = keep ? y : 0.f;
+            q[rr] = p[rr] * ((rw_[rr][r] - mu) * rsd);
+          }
+          park(half, r, p[0] + p[1], q[0] + q[1]);
         }
       }
+    }
     __syncthreads();
     if (tid < 2 * 64 * CT) {
       const int which = tid & 1, chs = tid >> 1, sl = chs >> 6, ch = chs & 63;     // channel ch of slab sl
@@ -882,7 +959,9 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yrsrc, voff[rr], cbase_o + cu * plane_ob, 0);
         }
   };
-  if (a.relu) finish(std::true_type{}); else finish(std::false_type{});
+  if constexpr (STATS != 2) {
+    if (a.relu) finish(std::true_type{}); else finish(std::false_type{});
+  }
   }
   HS_TRACE(4);
 #ifdef ADX_HS_TRACE
@@ -1310,18 +1389,7 @@ int conv2d_hs_pack_many(const HsPackJob* jobs, int n, hipStream_t s) {
 }
 
 bool conv2d_hs_eligible(const ConvSpec& L) {
-  static int exact = -1;
-  if (exact < 0) {
-    const char* e = getenv("ADX_CONV_EXACT");    // ADX_CONV_EXACT=1: keep every conv on the exact-fp32 MFMA kernels
-    exact = (e != nullptr && e[0] == '1') ? 1 : 0;
-  }
-  if (exact) return false;
-  static int mode = -1;                          // debugging aid: ADX_HS_ONLY=fwd|dgrad restricts the split kernels
-  if (mode < 0) {
-    const char* e = getenv("ADX_HS_ONLY");
-    mode = e == nullptr ? 0 : (e[0] == 'f' ? 1 : 2);
-  }
-  if ((mode == 1 && L.dgrad) || (mode == 2 && !L.dgrad)) return false;
+  if (debug_switches().conv_exact) return false;     // ADX_CONV_EXACT=1: every conv on the exact-fp32 MFMA kernels
   if (hs_is_stem(L) && !L.dgrad) return true;
   if (L.cin % kHsCC != 0 || L.cin_pad != L.cin || L.cout % kHsCout != 0) return false;
   return L.k == 3 && (L.stride == 1 || L.stride == 2);
@@ -1466,13 +1534,16 @@ template <int MODE>
 static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
   constexpr int NT = MODE == 0 ? 256 : 512, TH = MODE == 1 ? 16 : 8, CT = MODE == 2 ? 2 : 1;
   constexpr size_t lds = (size_t)2 * 64 * (TH + 2) * 34 + (size_t)2 * 3 * 256 * CT * 16 + (2 * 64 * CT + 8) * sizeof(float) + 48;
-  static_assert(lds <= (MODE == 0 ? 80 : 160) * 1024, "LDS budget");
+  constexpr size_t lds_bs = lds + 4 * 64 * CT * sizeof(float);       // STATS == 2: + the consumer BatchNorm's constants
+  static_assert(lds_bs <= (MODE == 0 ? 80 : 160) * 1024, "LDS budget");
   static bool attr = false;
   if (!attr) {
-    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, false>),
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 0>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, true>),
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 1>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bs));
     attr = true;
   }
   a.tiles_x = ceil_div(a.OW, kTileW); a.tiles_y = ceil_div(a.OH, TH); a.cout_tiles = a.Cout / (kHsCout * CT);
@@ -1481,7 +1552,7 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
   ADX_REQUIRE((size_t)a.Cout * a.OH * a.OW * sizeof(float) < 0x7FFFFFFFu, "conv2d_hs: one image of the output exceeds the 32-bit byte offsets");
   // Small batches (one camera frame per tick): a 512->512 layer on one 8x29 map is 8 workgroups, each walking 96 stages
   // (83 us); with a scratch buffer the chunks are split over up to 16 workgroups per tile and a reduce launch finishes.
-  static const bool split_on = [] { const char* e = getenv("ADX_CONV_NO_KSPLIT"); return !(e != nullptr && e[0] == '1'); }();
+  constexpr bool split_on = true;
   const size_t out_floats = (size_t)a.N * a.Cout * a.OH * a.OW;
   const size_t cap = a.part != nullptr ? a.part_stride : 0;      // conv2d_launch_raw parks the scratch capacity here
   const int nchunks = a.cin_pad / kHsCC;
@@ -1490,7 +1561,8 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
     ADX_REQUIRE(a.stats_p == a.N * a.tiles_y * a.tiles_x, "conv2d_hs: statistics buffer laid out for %d tiles, launch has %d",
                 a.stats_p, a.N * a.tiles_y * a.tiles_x);
     a.part = nullptr;
-    conv2d_hs3x3_kernel<MODE, true><<<dim3((unsigned)grid), dim3(NT), lds, s>>>(a);
+    if (a.bs_raw != nullptr) conv2d_hs3x3_kernel<MODE, 2><<<dim3((unsigned)grid), dim3(NT), lds_bs, s>>>(a);
+    else conv2d_hs3x3_kernel<MODE, 1><<<dim3((unsigned)grid), dim3(NT), lds, s>>>(a);
     ADX_LAUNCH_CHECK();
     return ADX_OK;
   }
@@ -1516,25 +1588,25 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
     // the executor keeps a layer's 3x3 convs in the cell layout from the first one's output to the last one's (the stride-2
     // kernel and the average pool read cells too), so a cell operand always comes with a cell output
     ADX_REQUIRE(a.y_cells && a.x_amax == nullptr, "conv2d_hs: cell-layout operands come with a cell-layout output (and no dynamic range)");
-    constexpr size_t clds = (size_t)2 * 64 * (TH + 2) * 38 + (size_t)2 * 3 * 256 * CT * 16 + (2 * 64 * CT + 8) * sizeof(float) + 48;
-    static_assert(clds <= (MODE == 0 ? 80 : 160) * 1024, "LDS budget");
+    constexpr size_t clds = lds;
     static bool cattr = false;
     if (!cattr) {
-      const void* fns[2] = {reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, false, true, true>),
-                            reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, false, false, true>)};
+      const void* fns[2] = {reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 0, true, true>),
+                            reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 0, false, true>)};
       for (const void* f : fns) ADX_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
       cattr = true;
     }
-    // column tiles over the images side by side (conv2d_hs3x3_kernel: YCELLS): no padded MFMA columns at the right edge of
-    // every image.  Maps narrower than 16 columns (a tile would span more than three images) keep the per-image tiling.
-    static const bool vcat_on = [] { const char* e = getenv("ADX_CONV_VCAT"); return !(e != nullptr && e[0] == '0'); }();
-    a.vw = (vcat_on && a.N > 1 && a.OW >= 16) ? a.OW : round_up(a.OW, kTileW);
-    a.tiles_x = ceil_div(a.N * a.vw, kTileW);
+    // column tiles over the images side by side with one shared zero column between neighbours (conv2d_hs3x3_kernel: YCELLS):
+    // one padded MFMA column per image instead of the round-up to 32
+    a.vw = a.N > 1 ? a.OW + 1 : a.OW;
+    a.inv_vw = 1.f / (float)a.vw;
+    ADX_REQUIRE((long)a.N * a.vw < (1L << 21), "conv2d_hs: batch x width exceeds the virtual-row arithmetic");
+    a.tiles_x = ceil_div(a.N * a.vw - (a.N > 1 ? 1 : 0), kTileW);       // the last image's zero column needs no tile
     const size_t cgrid = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y;
     ADX_REQUIRE((size_t)a.N * a.Cout * a.OH * a.OW * sizeof(float) < 0xC0000000u && (size_t)a.N * a.Cin * a.H * a.W * sizeof(float) < 0xC0000000u,
                 "conv2d_hs: a cell-layout tensor exceeds the 32-bit byte offsets");
-    if (a.x_cells) conv2d_hs3x3_kernel<MODE, false, true, true><<<dim3((unsigned)cgrid), dim3(NT), clds, s>>>(a);
-    else conv2d_hs3x3_kernel<MODE, false, false, true><<<dim3((unsigned)cgrid), dim3(NT), clds, s>>>(a);
+    if (a.x_cells) conv2d_hs3x3_kernel<MODE, 0, true, true><<<dim3((unsigned)cgrid), dim3(NT), clds, s>>>(a);
+    else conv2d_hs3x3_kernel<MODE, 0, false, true><<<dim3((unsigned)cgrid), dim3(NT), clds, s>>>(a);
     ADX_LAUNCH_CHECK();
     return ADX_OK;
   }
@@ -1546,17 +1618,8 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
 // tile mode of the pipelined 3x3 stride-1 kernel for this launch, -1 when another kernel serves it
 static int hs3x3_mode(const ConvSpec& L, const Conv2dArgs& a) {
   if (!(L.k == 3 && L.stride == 1 && a.w_ds == nullptr)) return -1;
-  static int pipe = -1;
-  if (pipe < 0) {
-    const char* e = getenv("ADX_HS_PIPE");      // ADX_HS_PIPE=0: the one-stage-ahead kernel for every 3x3 conv
-    pipe = (e != nullptr && e[0] == '0') ? 0 : 1;
-  }
-  if (!(pipe && (L.cin_pad / kHsCC) % 2 == 0 && L.pad == 1)) return -1;
-  static int mode_env = -2;       // ADX_HS_MODE=0|1|2 pins the tile mode (default: by shape)
-  if (mode_env == -2) {
-    const char* e = getenv("ADX_HS_MODE");
-    mode_env = e != nullptr ? atoi(e) : -1;
-  }
+  if (!((L.cin_pad / kHsCC) % 2 == 0 && L.pad == 1)) return -1;
+  const int mode_env = debug_switches().hs_mode;       // ADX_HS_MODE=0|1|2 pins the tile mode (default: by shape)
   // The three tiles time within 3 % of each other on every ResNet-34 shape (the MFMA rate the chip sustains on
   // random data paces all of them): short K loops take the small tile (better tail balance), long ones the
   // 8-wave tiles that move fewer operand bytes per MFMA.
@@ -1569,8 +1632,7 @@ static int hs3x3_mode(const ConvSpec& L, const Conv2dArgs& a) {
 }
 
 bool conv2d_hs3x3_plain(const ConvSpec& L, int N, int H, int W) {
-  static const bool off = [] { const char* e = getenv("ADX_CONV_CELLS"); return e != nullptr && e[0] == '0'; }();   // A/B: fp32 NCHW between all layers
-  if (off || !conv2d_hs_eligible(L) || L.dgrad) return false;
+  if (!debug_switches().conv_cells || !conv2d_hs_eligible(L) || L.dgrad) return false;   // ADX_CONV_CELLS=0: fp32 NCHW between all layers
   Conv2dArgs a{};
   a.N = N; a.Cin = L.cin; a.Cout = L.cout; a.H = H; a.W = W;
   a.OH = conv_out_dim(H, L.k, L.stride, L.pad); a.OW = conv_out_dim(W, L.k, L.stride, L.pad);
@@ -1607,10 +1669,9 @@ __global__ void dgrad_s2_weights_kernel(const float* __restrict__ w, float* __re
 }
 
 bool conv2d_hs_dgrad_s2_eligible(int cin, int cout) {
-  static const bool off = [] { const char* e = getenv("ADX_S2_DGRAD_DILATE"); return e != nullptr && e[0] == '1'; }();   // A/B: the zero-dilated path
   ConvSpec probe{};
   probe.cin = cout; probe.cin_pad = cout; probe.cout = 4 * cin; probe.k = 3; probe.stride = 1; probe.dgrad = 1;
-  return !off && cin % kHsCout == 0 && cout % kHsCC == 0 && conv2d_hs_eligible(probe);
+  return cin % kHsCout == 0 && cout % kHsCC == 0 && conv2d_hs_eligible(probe);
 }
 
 int conv2d_hs_dgrad_s2(const float* w, const float* dy, float* dx, int accumulate, int N, int cin, int cout, int H, int W,

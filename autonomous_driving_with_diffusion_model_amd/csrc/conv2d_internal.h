@@ -57,9 +57,19 @@ struct Conv2dArgs {
   // (p = (image, row tile, column tile)), pixels outside the map excluded; bn statistics then need no pass over the output
   float* stats_part;
   int stats_p;
+  // conv2d_hs3x3 only (training backward, bs_raw != null): this launch is a data gradient whose output dx is the incoming
+  // gradient of a BatchNorm (the conv BEFORE it in forward order).  Its epilogue then also leaves, in stats_part, that
+  // BatchNorm's backward sums -- per channel the sum of dz and of dz * xhat over the workgroup's pixels, dz = dx * ReLU mask,
+  // xhat = (raw - mean) * rstd -- so that no pass over dx has to compute them (channel_sums_kernel<1>).  bs_mask: 1 the
+  // mask is `bs_out > 0` (ReLU after the residual add), 2 it is re-derived from the conv output: fma(raw, gamma rstd, beta -
+  // mean gamma rstd) > 0 (ReLU straight after BatchNorm).
+  const float* bs_raw; const float* bs_out; const float* bs_mean; const float* bs_rstd; const float* bs_gamma; const float* bs_beta;
+  int bs_mask;
   // conv2d_hs3x3 only (inference executor): x / y / res in the cell layout instead of fp32 NCHW (conv2d_hs.hip: XCELLS)
   int x_cells, y_cells, res_cells;
-  int vw;       // y_cells: virtual width of one image in the column tiling (W: images side by side; W rounded up to 32: per image)
+  int vw;       // y_cells: columns of one image in the virtual row the column tiles run over (W + 1: the images side by side with
+                // one shared all-zero column between neighbours; W for a single image)
+  float inv_vw; // 1 / vw
 };
 
 // activation formats of one launch of the inference executor (bits)
@@ -82,10 +92,11 @@ namespace adx {
 // one conv2d launch: y = [relu](conv(x, w) [* scale + shift] [+ res]); w = packed [tap][cin_pad][cout]
 // x_amax (optional, device): x_amax_n bit patterns whose maximum is max|x| over the whole input; the split-fp16 kernels use it to move x
 // into fp16's normal range by an exact power of two (data gradients are far below 2^-14)
+struct BnBwdStats { const float* raw; const float* out; const float* mean; const float* rstd; const float* gamma; const float* beta; int mask; };
 int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const float* scale, const float* shift,
                       const float* res, float* y, int N, int H, int W, int relu, hipStream_t s,
                       const uint32_t* x_amax = nullptr, int x_amax_n = 0, float* stats_part = nullptr, size_t stats_floats = 0,
-                      int* stats_p = nullptr, int fmt = 0);
+                      int* stats_p = nullptr, int fmt = 0, const BnBwdStats* bst = nullptr);
 // true when this launch will run the pipelined 3x3 stride-1 kernel as ONE launch (no split reduction): the launches whose
 // input / output / residual may be in the cell layout (fmt: kFmt*)
 bool conv2d_hs3x3_plain(const ConvSpec& L, int N, int H, int W);

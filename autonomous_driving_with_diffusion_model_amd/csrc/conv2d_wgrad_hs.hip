@@ -239,12 +239,7 @@ __global__ void __launch_bounds__(kWThreads) conv2d_wgrad_hs_kernel(const WgradH
 }
 
 bool conv2d_wgrad_hs_eligible(int Cin, int Cout, int k, int stride, int pad) {
-  static int exact = -1;
-  if (exact < 0) {
-    const char* e = getenv("ADX_CONV_EXACT");
-    const char* w = getenv("ADX_WGRAD_EXACT");
-    exact = ((e != nullptr && e[0] == '1') || (w != nullptr && w[0] == '1')) ? 1 : 0;
-  }
+  const bool exact = debug_switches().conv_exact || debug_switches().wgrad_exact;
   return !exact && k == 3 && (stride == 1 || stride == 2) && pad == 1 && Cin % 64 == 0 && Cout % 64 == 0;
 }
 

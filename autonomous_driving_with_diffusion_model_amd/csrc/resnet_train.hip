@@ -117,6 +117,23 @@ __global__ void __launch_bounds__(256) stats_reduce_finalize_kernel(const float*
   }
 }
 
+// the same reduction without the forward's finalisation: the partial sums are those of a BatchNorm BACKWARD (sum dz, sum dz
+// xhat), left by the data-gradient conv that produced dz's tensor (conv2d_hs.hip: STATS == 2)
+__global__ void __launch_bounds__(256) stats_reduce_kernel(const float* __restrict__ part, double* __restrict__ sums, int P) {
+  const int c = blockIdx.x, moment = threadIdx.x >> 7, t = threadIdx.x & 127;
+  const float* src = part + (size_t)(2 * c + moment) * P;
+  double s = 0.0;
+  for (int i = t; i < P; i += 128) s += (double)src[i];
+  __shared__ double red[4];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    sums[2 * c] = red[0] + red[1];
+    sums[2 * c + 1] = red[2] + red[3];
+  }
+}
+
 // batch statistics -> scale/shift for the apply pass, saved mean/rstd, running-buffer update
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift,
@@ -328,8 +345,8 @@ __global__ void __launch_bounds__(256) dilate2_kernel(const float* __restrict__ 
 }
 
 // MaxPool2d(3, 2, 1) backward without atomics.  The forward left one byte per pooled element: which of its window's 9 taps is
-// the first maximum (torch's tie rule).  maxpool_bwd_gather_kernel (one wave per input row): an input pixel lies in at most
-// 2 x 2 windows; it receives dy of those whose code points back at it.
+// the first maximum (torch's tie rule).  maxpool_bwd_gather4: an input pixel lies in at most 2 x 2 windows; it receives dy of
+// those whose code points back at it.
 
 // Training forward of the stem's tail in ONE pass over the conv output: BatchNorm apply + ReLU + MaxPool2d(3, 2, 1) + the
 // first-maximum tap of every window (one byte, for the backward).  The 944 MB post-BN stem map (B = 64,
@@ -433,55 +450,120 @@ __global__ void __launch_bounds__(256) bn_relu_pool_code_kernel(const float* __r
   }
 }
 
-__global__ void __launch_bounds__(256) maxpool_bwd_gather_kernel(const uint8_t* __restrict__ code, const float* __restrict__ dy,
-                                                                  float* __restrict__ dx, int H, int W, int OH, int OW) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int iy = blockIdx.y * 4 + wave;
-  const int pl = blockIdx.x;
-  if (iy >= H) return;
-  const uint8_t* cp = code + (size_t)pl * OH * OW;
-  const float* gp = dy + (size_t)pl * OH * OW;
-  float* dst = dx + ((size_t)pl * H + iy) * W;
+// d(pool input) of the 4 consecutive pixels 4j .. 4j+3 of input row iy: their windows lie in output columns 2j, 2j+1, 2j+2,
+// so 3 codes + 3 gradients per window row serve all four (cp / gp: the plane's codes and pooled-map gradient)
+__device__ __forceinline__ void maxpool_bwd_gather4(const uint8_t* __restrict__ cp, const float* __restrict__ gp, int iy, int j,
+                                                    int OH, int OW, float (&out)[4]) {
   // windows containing row iy: oy with 2 oy - 1 <= iy <= 2 oy + 1 (one for even rows, two for odd ones)
   const int oys[2] = {(iy + 1) >> 1, iy >> 1};
   const int noy = oys[0] == oys[1] ? 1 : 2;
-  // a lane owns 4 consecutive pixels 4j .. 4j+3: their windows lie in output columns 2j, 2j+1, 2j+2, so the lane
-  // fetches 3 codes + 3 gradients per window row once instead of up to 4 + 4 per pixel
-  for (int j = lane; 4 * j < W; j += 64) {
-    int cd[2][3];
-    float g[2][3];
+  int cd[2][3];
+  float g[2][3];
 #pragma unroll
-    for (int a2 = 0; a2 < 2; ++a2)
+  for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int oy = oys[a2], ox = 2 * j + c;
-        const bool ok = a2 < noy && oy < OH && ox < OW;
-        cd[a2][c] = ok ? cp[(size_t)oy * OW + ox] : 255;
-        g[a2][c] = ok ? gp[(size_t)oy * OW + ox] : 0.f;
-      }
-    float out[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int ix = 4 * j + q;
-      const int oxa = (ix + 1) >> 1, oxb = ix >> 1;
-      float acc = 0.f;
-#pragma unroll
-      for (int a2 = 0; a2 < 2; ++a2) {
-        const int ty = iy - (2 * oys[a2] - 1);
-#pragma unroll
-        for (int b2 = 0; b2 < 2; ++b2) {
-          const int ox = b2 == 0 ? oxa : oxb;
-          if (b2 == 1 && oxb == oxa) continue;
-          const int c = ox - 2 * j;                        // 0..2 by construction
-          const int tx = ix - (2 * ox - 1);
-          acc += cd[a2][c] == ty * 3 + tx ? g[a2][c] : 0.f;
-        }
-      }
-      out[q] = acc;
+    for (int c = 0; c < 3; ++c) {
+      const int oy = oys[a2], ox = 2 * j + c;
+      const bool ok = a2 < noy && oy < OH && ox < OW;
+      cd[a2][c] = ok ? cp[(size_t)oy * OW + ox] : 255;
+      g[a2][c] = ok ? gp[(size_t)oy * OW + ox] : 0.f;
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (4 * j + q < W) dst[4 * j + q] = out[q];
+  for (int q = 0; q < 4; ++q) {
+    const int ix = 4 * j + q;
+    const int oxa = (ix + 1) >> 1, oxb = ix >> 1;
+    float acc = 0.f;
+#pragma unroll
+    for (int a2 = 0; a2 < 2; ++a2) {
+      const int ty = iy - (2 * oys[a2] - 1);
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2) {
+        const int ox = b2 == 0 ? oxa : oxb;
+        if (b2 == 1 && oxb == oxa) continue;
+        const int c = ox - 2 * j;                        // 0..2 by construction
+        const int tx = ix - (2 * ox - 1);
+        acc += cd[a2][c] == ty * 3 + tx ? g[a2][c] : 0.f;
+      }
+    }
+    out[q] = acc;
+  }
+}
+
+// The stem's BatchNorm backward with the max-pool backward folded in: d(stem map) = the pooled map's gradient gathered
+// through the arg-max codes is formed on the fly in both passes and never written (944 MB at B = 64, 3x256x900: one
+// write and two reads less).  PASS 0 = channel_sums_kernel<1> with relu_mask 2 (one workgroup per plane, one fp64 atomic
+// pair per plane); PASS 1 = bn_bwd_apply (one wave per input row): draw = gamma rstd (dz - m1 - xhat m2), and the affine
+// parameters' gradients (the finished sums) by workgroup (0, 0).  Same arithmetic as the separate passes.
+template <int PASS>
+__global__ void __launch_bounds__(256) stem_pool_bn_bwd_kernel(const uint8_t* __restrict__ code, const float* __restrict__ dpool,
+                                                                const float* __restrict__ raw, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, double* __restrict__ sums,
+                                                                float* __restrict__ draw, int C, int H, int W, int OH, int OW,
+                                                                double count, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pl = blockIdx.x, c = pl % C;
+  if (PASS == 1 && blockIdx.x == 0 && blockIdx.y == 0 && dgamma != nullptr)
+    for (int k = threadIdx.x; k < C; k += 256) { dbeta[k] = (float)sums[2 * k]; dgamma[k] = (float)sums[2 * k + 1]; }
+  const uint8_t* cp = code + (size_t)pl * OH * OW;
+  const float* gp = dpool + (size_t)pl * OH * OW;
+  const float mu = mean[c], rs = rstd[c], ga = gamma[c];
+  float sc, sh;
+  bn_affine(ga, beta[c], mu, rs, sc, sh);
+  float m1 = 0.f, m2 = 0.f;
+  if (PASS == 1) { m1 = (float)(sums[2 * c] / count); m2 = (float)(sums[2 * c + 1] / count); }
+  double s0 = 0.0, s1 = 0.0;
+  const int row0 = PASS == 0 ? wave : blockIdx.y * 4 + wave, row_step = PASS == 0 ? 4 : H;
+  for (int iy = row0; iy < H; iy += row_step) {
+    const float* rrow = raw + ((size_t)pl * H + iy) * W;
+    float* drow = PASS == 1 ? draw + ((size_t)pl * H + iy) * W : nullptr;
+    for (int j = lane; 4 * j < W; j += 64) {
+      float dz[4];
+      maxpool_bwd_gather4(cp, gp, iy, j, OH, OW, dz);
+      // a lane's 4 pixels are 16 contiguous bytes, 4-byte aligned (rows of 450 floats start on 8-byte boundaries only)
+      typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+      const bool whole = 4 * j + 3 < W;
+      float rw4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (whole) {
+        const f32x4u t = *reinterpret_cast<const f32x4u*>(rrow + 4 * j);
+        rw4[0] = t[0]; rw4[1] = t[1]; rw4[2] = t[2]; rw4[3] = t[3];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (4 * j + q < W) rw4[q] = rrow[4 * j + q];
+      }
+      float o4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float rw = rw4[q];
+        float v = (4 * j + q < W) ? dz[q] : 0.f;
+        if (!(bn_eval(rw, sc, sh) > 0.f)) v = 0.f;          // the stem's ReLU sits straight behind its BatchNorm
+        const float xh = (rw - mu) * rs;
+        if (PASS == 0) {
+          s0 += v;
+          s1 += (double)v * (double)xh;
+        }
+        o4[q] = ga * rs * (v - m1 - xh * m2);
+      }
+      if (PASS == 1) {
+        if (whole) {
+          *reinterpret_cast<f32x4u*>(drow + 4 * j) = f32x4u{o4[0], o4[1], o4[2], o4[3]};
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (4 * j + q < W) drow[4 * j + q] = o4[q];
+        }
+      }
+    }
+  }
+  if (PASS == 0) {
+    __shared__ double red[8];
+    s0 = wave_sum_d(s0);
+    s1 = wave_sum_d(s1);
+    if (lane == 0) { red[wave * 2] = s0; red[wave * 2 + 1] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      atomicAdd(sums + 2 * c, (red[0] + red[2]) + (red[4] + red[6]));
+      atomicAdd(sums + 2 * c + 1, (red[1] + red[3]) + (red[5] + red[7]));
+    }
   }
 }
 
@@ -825,6 +907,7 @@ struct adx_resnet_tape {
   float* pool_in = nullptr; float* pool_out = nullptr; int ph = 0, pw = 0, poh = 0, pow_ = 0;
   uint8_t* pool_code = nullptr;   // first-maximum tap of every pooling window, written by the forward's fused stem tail
   float* final_map = nullptr; int fh = 0, fw_ = 0;
+  float* stats_part = nullptr;    // kStatsPartFloats floats of the forward's workspace: conv-epilogue partial sums (both passes)
   size_t fwd_floats = 0;
 };
 
@@ -908,6 +991,7 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
   float* scale = ws.take(512);
   float* shift = ws.take(512);
   float* stats_part = ws.take(kStatsPartFloats);
+  tape->stats_part = stats_part;
   int rc = ADX_OK;
   auto conv_bn = [&](const ConvSpec& L, const float* x, int H, int W, const float* identity, int relu,
                      bool apply = true) -> float* {
@@ -1051,8 +1135,13 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
   }
   // one conv+BN(+identity)(+ReLU) backward.  dout -> (dz for the identity path), d(conv input) accumulated
   // into dx (dx_has tells whether dx already holds a contribution).
+  // `sums_ready`: the record whose BatchNorm-backward sums (sum dz, sum dz xhat) the last data-gradient conv already left in
+  // its slot of sums_all -- the conv that PRODUCED that record's incoming gradient computed them in its epilogue (conv2d_hs.hip:
+  // STATS == 2), so channel_sums_kernel<1>'s pass over that gradient is not needed.  `next`: the record dx flows into (null:
+  // nobody's statistics can come from this launch -- dx is completed by a later launch, or feeds no BatchNorm).
+  const adx_resnet_tape::Rec* sums_ready = nullptr;
   auto conv_bn_bwd = [&](const adx_resnet_tape::Rec& rec, const float* dout, float* dz_keep, float* draw, float* dx,
-                         bool dx_has, bool need_dx) -> int {
+                         bool dx_has, bool need_dx, const adx_resnet_tape::Rec* next = nullptr) -> int {
     const ConvSpec& L = *rec.L;
     const int HW = rec.OH * rec.OW;
     const size_t n = (size_t)batch * L.cout * HW;
@@ -1060,8 +1149,10 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
     double* sums = sums_all + (size_t)(&L - r->convs.data()) * 2 * 512;
     // ReLU mask: straight after BN it is re-derived from the conv output (one tensor read less in both passes)
     const int mask = !rec.relu ? 0 : (rec.identity != nullptr ? 1 : 2);
-    channel_sums_kernel<1><<<dim3(batch * L.cout), dim3(256), 0, s>>>(dout, rec.out, rec.raw, rec.mean, rec.rstd, sums,
-                                                                      L.cout, HW, mask, T[L.t_g], T[L.t_b]);
+    if (sums_ready != &rec)
+      channel_sums_kernel<1><<<dim3(batch * L.cout), dim3(256), 0, s>>>(dout, rec.out, rec.raw, rec.mean, rec.rstd, sums,
+                                                                        L.cout, HW, mask, T[L.t_g], T[L.t_b]);
+    sums_ready = nullptr;
     int n_amax;
     if (bn_planes_ok(HW, dout, rec.raw, draw) && bn_planes_ok(HW, rec.out, dz_keep, nullptr)) {
       const int planes = batch * L.cout;
@@ -1082,6 +1173,21 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
     ConvSpec g{};
     g.cin = L.cout; g.cout = L.cin; g.k = L.k; g.stride = 1; g.pad = L.k - 1 - L.pad; g.cc = 16; g.cin_pad = L.cout; g.dgrad = 1;
     if (const float* pre = dgrad_img[&L - r->convs.data()]) {      // stride-1 3x3: image packed with the others at the start
+      const int next_mask = next == nullptr || !next->relu ? 0 : (next->identity != nullptr ? 1 : 2);
+      if (next_mask != 0 && tape->stats_part != nullptr) {
+        const ConvSpec& Ln = *next->L;
+        ADX_REQUIRE(Ln.cout == L.cin && next->OH == rec.H && next->OW == rec.W, "adx_resnet_backward: consumer record does not match dx");
+        const BnBwdStats bst{next->raw, next->out, next->mean, next->rstd, T[Ln.t_g], T[Ln.t_b], next_mask};
+        int stats_p = 0;
+        rc2 = conv2d_launch_raw(g, draw, pre, nullptr, nullptr, dx_has ? dx : nullptr, dx, batch, rec.OH, rec.OW, 0, s, amax, n_amax,
+                                tape->stats_part, kStatsPartFloats, &stats_p, 0, &bst);
+        if (rc2 == ADX_OK && stats_p > 0) {
+          stats_reduce_kernel<<<dim3(Ln.cout), dim3(256), 0, s>>>(tape->stats_part, sums_all + (size_t)(&Ln - r->convs.data()) * 2 * 512,
+                                                                 stats_p);
+          sums_ready = next;
+        }
+        return rc2;
+      }
       return conv2d_launch_raw(g, draw, pre, nullptr, nullptr, dx_has ? dx : nullptr, dx, batch, rec.OH, rec.OW, 0, s, amax, n_amax);
     }
     rc2 = conv2d_pack_spec(g, T[L.t_w], wimg, 1, s);
@@ -1126,7 +1232,7 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
     int k = 0;
     for (auto p : gb) if (p != g_cur && p != gb[4] && k < 4) others[k++] = p;
     float* dz2 = others[0]; float* draw = others[1]; float* do1 = others[2];
-    rc = conv_bn_bwd(c2, g_cur, dz2, draw, do1, false, true);            // -> do1 = d(o1), dz2 = masked dout
+    rc = conv_bn_bwd(c2, g_cur, dz2, draw, do1, false, true, &c1);       // -> do1 = d(o1) (c1's incoming gradient), dz2 = masked dout
     if (rc != ADX_OK) break;
     float* dx = g_cur;                                                   // d(block out) is dead now: reuse for d(block in)
     if (ds) {
@@ -1135,8 +1241,9 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
       rc = conv_bn_bwd(*dsr, dz2, nullptr, draw, dx, true, true);        // identity path through the downsample conv adds to
                                                                          // the even pixels (no clearing pass over dx)
     } else {
-      // identity gradient is dz2 itself: main path = conv(...) + res(dz2)
-      rc = conv_bn_bwd(c1, do1, nullptr, draw, dz2, true, true);
+      // identity gradient is dz2 itself: main path = conv(...) + res(dz2).  The result is the incoming gradient of the block
+      // before this one (its conv2, ReLU after the residual add); block 0's flows into the max-pool instead
+      rc = conv_bn_bwd(c1, do1, nullptr, draw, dz2, true, true, b > 0 ? &tape->recs[ri - 1] : nullptr);
       dx = dz2;
     }
     g_cur = dx;
@@ -1144,18 +1251,26 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
   if (rc != ADX_OK) return rc;
   // maxpool, then the stem (no data gradient: the image needs none)
   {
-    float* dstem = nullptr;
-    for (auto p : gb) if (p != g_cur && p != gb[4]) { dstem = p; break; }
-    const size_t nin = (size_t)batch * 64 * tape->ph * tape->pw;
-    (void)nin;
+    // the max-pool backward is folded into the stem's two BatchNorm-backward passes (stem_pool_bn_bwd_kernel): d(stem map)
+    // is gathered through the forward's arg-max codes on the fly and never written
     const uint8_t* code = tape->pool_code;     // written by the forward's fused stem tail
-    ADX_REQUIRE(code != nullptr && dstem != gb[4] && g_cur != gb[4], "adx_resnet_backward: scratch buffer clash");
-    maxpool_bwd_gather_kernel<<<dim3(batch * 64, ceil_div(tape->ph, 4)), dim3(256), 0, s>>>(code, g_cur, dstem, tape->ph, tape->pw,
-                                                                                        tape->poh, tape->pow_);
-    ADX_LAUNCH_CHECK();
     float* draw = nullptr;
-    for (auto p : gb) if (p != g_cur && p != gb[4] && p != dstem) { draw = p; break; }
-    rc = conv_bn_bwd(tape->recs[0], dstem, nullptr, draw, nullptr, false, false);
+    for (auto p : gb) if (p != g_cur && p != gb[4]) { draw = p; break; }
+    ADX_REQUIRE(code != nullptr && draw != nullptr && g_cur != gb[4], "adx_resnet_backward: scratch buffer clash");
+    const adx_resnet_tape::Rec& st = tape->recs[0];
+    const ConvSpec& L = *st.L;
+    ADX_REQUIRE(st.relu && st.identity == nullptr && L.cout == 64 && st.OH == tape->ph && st.OW == tape->pw,
+                "adx_resnet_backward: the stem record does not match the pooled map");
+    double* sums = sums_all + (size_t)(&L - r->convs.data()) * 2 * 512;
+    const double count = (double)batch * st.OH * st.OW;
+    stem_pool_bn_bwd_kernel<0><<<dim3(batch * 64), dim3(256), 0, s>>>(code, g_cur, st.raw, st.mean, st.rstd, T[L.t_g], T[L.t_b], sums,
+                                                                      nullptr, 64, tape->ph, tape->pw, tape->poh, tape->pow_, count,
+                                                                      nullptr, nullptr);
+    stem_pool_bn_bwd_kernel<1><<<dim3(batch * 64, ceil_div(tape->ph, 4)), dim3(256), 0, s>>>(
+        code, g_cur, st.raw, st.mean, st.rstd, T[L.t_g], T[L.t_b], sums, draw, 64, tape->ph, tape->pw, tape->poh, tape->pow_, count,
+        G[L.t_g], G[L.t_b]);
+    ADX_LAUNCH_CHECK();
+    rc = conv2d_wgrad(st.x, draw, G[L.t_w], batch, L.cin, st.H, st.W, L.cout, L.k, L.stride, L.pad, s, nullptr, 0, false, wgrad9);
   }
   return rc;
 }

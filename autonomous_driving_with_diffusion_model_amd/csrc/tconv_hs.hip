@@ -61,6 +61,10 @@ struct HsArgs {
   // an XCD's L2, 18 us per layer.)
   unsigned* tickets;
   size_t part_bytes;
+  // K-split kernel: taps [tap0, tap0 + ntap) are the ones that reach a real input position from some output position; the others
+  // multiply the zero row only and are not walked (a k5 conv on 2 positions -- the deepest level at horizon 16: three of five
+  // taps, 40 % of the weight stream and of the MFMAs gone; every tap is live from 3 positions on)
+  int tap0, ntap;
 };
 
 __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
@@ -329,11 +333,11 @@ __device__ __forceinline__ void tconv_hs_body(const HsArgs& ha, const int bid) {
   for (int c0 = cbeg; c0 < cend; c0 += a.ck) {
     const int ckc = min(a.ck, cend - c0);
     const int ncbc = ckc >> 4;
-    const int nblk = a.taps * ncbc;
+    const int nblk = ha.ntap * ncbc;
     const int nbw = nblk > wave ? (nblk - wave + NW - 1) / NW : 0;   // K-steps of this wave in this chunk
     const int cb0 = c0 >> 4;
-    // this wave's K-steps: i = wave, wave + NW, ...  (tap, 16-channel block) = (i / ncbc, i % ncbc)
-    int ltap = 0, lcb = wave;
+    // this wave's K-steps: i = wave, wave + NW, ...  (tap, 16-channel block) = (tap0 + i / ncbc, i % ncbc)
+    int ltap = ha.tap0, lcb = wave;
     while (lcb >= ncbc) { lcb -= ncbc; ++ltap; }
     auto issue = [&](u32x4 (&dst)[NF][2]) {
       const int tp = min(ltap, a.taps - 1);  // past-the-end slots re-read a valid block and are never used
@@ -355,7 +359,7 @@ __device__ __forceinline__ void tconv_hs_body(const HsArgs& ha, const int bid) {
     __syncthreads();
     ADX_TSTAMP(1);
     // ---- K loop over this wave's steps, PF-deep weight ring, activation fragments fetched one step ahead -------
-    int ctap = 0, ccb = wave;
+    int ctap = ha.tap0, ccb = wave;
     while (ccb >= ncbc) { ccb -= ncbc; ++ctap; }
     u32x4 ah, al;
     const bool kind0 = a.kind == 0;
@@ -814,11 +818,7 @@ static int ilog2_exact_hs(int v) {
 constexpr size_t kMaxHsLds = 144 * 1024;
 
 bool tconv_hs_supported(const adx_tconv_desc* d) {
-  static const bool force_exact = [] {
-    const char* e = getenv("ADX_TCONV_EXACT");
-    return e != nullptr && e[0] == '1';
-  }();
-  if (force_exact || d->exact != 0) return false;
+  if (debug_switches().tconv_exact || d->exact != 0) return false;
   if ((d->lin_valid > 0 && d->lin_valid != d->lin) || (d->lout_valid > 0 && d->lout_valid != d->lout)) return false;
   if (d->lout > 32 || ilog2_exact_hs(d->lout) < 0 || ilog2_exact_hs(d->lin) < 0) return false;   // 32 rows per tile = whole samples
   if (32 % d->lout != 0) return false;
@@ -848,10 +848,7 @@ static bool hsd_geometry(const adx_tconv_desc* d, int* nsteps, int* kcells, int*
   return true;
 }
 
-static bool hsd_enabled() {
-  static const bool on = [] { const char* e = getenv("ADX_TCONV_NO_DIRECT"); return !(e != nullptr && e[0] == '1'); }();
-  return on;
-}
+static bool hsd_enabled() { return true; }
 
 size_t tconv_hs_packed_floats(const adx_tconv_desc* d) {
   const int cin_pad = round_up(d->c0 + d->c1, 16);
@@ -1002,6 +999,11 @@ static int hs_prepare(const adx_tconv_desc* d, const adx_tconv_io* io, HsTile* t
             (d->c1 == 0 || dense_src(io->x1, io->x1_sb, io->x1_sc, io->x1_sl));
   ha.pitch16 = t.pitch16;
   ha.nrows = t.nrows;
+  ha.tap0 = 0; ha.ntap = d->taps;
+  if (d->kind == 0) {      // ip = l stride + tap - pad lies in [0, lin) for some l in [0, lout)
+    const int lo = std::max(0, d->pad - (d->lout - 1) * d->stride), hi = std::min(d->taps - 1, d->pad + d->lin - 1);
+    if (hi >= lo) { ha.tap0 = lo; ha.ntap = hi - lo + 1; }
+  }
   ha.vec_stage = a.dense && t.bt * (d->lin / 4) * (t.ck / 8) >= 256;
   const int n_gn = a.cg * d->lout;
   ha.fast_epi = d->lout >= 2 && (d->groups == 0 || (n_gn >= 64 && n_gn <= 256)) && (d->lout >= 4 || d->cout % 2 == 0);
@@ -1036,10 +1038,9 @@ static int hs_plan(const adx_tconv_desc* d, const adx_tconv_io* io, HsPlan* p) {
   p->grid = grid; p->base_grid = grid; p->reduce = false;
   // a grid that fits the chip one workgroup per CU must not be packed two per CU (the dispatcher does that with
   // 128 workgroups on 256 CUs): the two would share one CU's L2->L1 fill rate, which is what bounds the K loop
-  static const size_t min_lds = [] { const char* e = getenv("ADX_TCONV_MIN_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();   // measured: no gain, off by default
-  if (grid <= 256 && t.lds_bytes < min_lds) t.lds_bytes = min_lds;
+  // (forcing that through the LDS size was measured: no gain)
   // tiny batches: split the input channels over up to 16 workgroups per (row tile, slab) + one reduce launch
-  static const bool split_on = [] { const char* e = getenv("ADX_TCONV_NO_KSPLIT"); return !(e != nullptr && e[0] == '1'); }();
+  constexpr bool split_on = true;
   const TConvArgs& a = ha.t;
   // Measured at 2 rows, H = 16 (tools/bench_tconv.py, SCRATCH=1 vs 0): 512->512 x5 15.1 -> 10.9 us, 1024->256 x5 20.2 -> 9.6,
   // 1024->256 x1 13.4 -> 8.8; but 512->128 x5 9.4 -> 10.5, 512->128 x1 5.7 -> 9.9, 256->256 x3 7.1 -> 8.5: the second launch
@@ -1049,7 +1050,7 @@ static int hs_plan(const adx_tconv_desc* d, const adx_tconv_io* io, HsPlan* p) {
   // Round 3: with the ticket reduction the second launch is gone, and a grid of 33..128 workgroups (the 512-channel layers at
   // UNet batch 128: 128 workgroups on 256 CUs, each streaming a 655 KB weight slab through one CU's L1) takes a split in TWO:
   // 341 -> 332 us per forward at 128 rows (tools/chain_time.py); in four: 395 us (the partial tiles' round trip).
-  static const int split_grid = [] { const char* e = getenv("ADX_TCONV_KSPLIT_GRID"); return e ? atoi(e) : 128; }();
+  constexpr int split_grid = 128;
   if (split_on && worth && io->scratch != nullptr && ha.fast_epi && grid <= split_grid && a.ncb >= 8 &&
       (grid <= 32 || io->tickets != nullptr)) {
     int S = grid <= 32 ? 16 : 2;
@@ -1119,7 +1120,7 @@ extern "C" int adx_debug_tconv_trace(unsigned long long* host_dst, int n) {
 // otherwise two launches.  Same results either way.
 int tconv_hs_forward_pair(const adx_tconv_desc* da, const adx_tconv_io* ioa, const adx_tconv_desc* db,
                           const adx_tconv_io* iob, hipStream_t s) {
-  static const bool pair_on = [] { const char* e = getenv("ADX_TCONV_NO_PAIR"); return !(e != nullptr && e[0] == '1'); }();
+  constexpr bool pair_on = true;
   HsTile ta, tb;
   HsArgs ha, hb;
   HsdPair pr;
@@ -1133,7 +1134,7 @@ int tconv_hs_forward_pair(const adx_tconv_desc* da, const adx_tconv_io* ioa, con
       return hsd_launch_pair(pr, ga + gb, la > lb ? la : lb, s);
     }
     // `a` on the K-split kernel (one launch: unsplit, or split with ticket words) beside a short-K `b`
-    static const bool mixed_on = [] { const char* e = getenv("ADX_TCONV_NO_MIXED"); return !(e != nullptr && e[0] == '1'); }();
+    constexpr bool mixed_on = true;
     HsPlan p;
     if (mixed_on && !a_short && b_short && hs_plan(da, ioa, &p) == ADX_OK && !p.reduce) {
       HsMixed mx;

@@ -79,10 +79,7 @@ struct Builder {
 constexpr int kChainMaxChannels = 128;     // all channels of a layer in one workgroup: every workgroup streams every weight
 
 // ADX_UNET_CHAIN=0 turns the chains off (every level layer by layer: the A/B)
-static bool chains_enabled() {
-  static const bool on = [] { const char* e = getenv("ADX_UNET_CHAIN"); return !(e != nullptr && e[0] == '0'); }();
-  return on;
-}
+static bool chains_enabled() { return debug_switches().unet_chain; }
 
 static int ilog2_floor(int v) { int l = 0; while ((2 << l) <= v) ++l; return l; }
 
@@ -184,12 +181,12 @@ static void plan_chain(ChainPlan* cp, const ResBlock& b0, const ResBlock& b1, co
   cp->valid = false;
   cp->st.clear();
   // ADX_CHAIN_MASK: bit i = down level i, bit 8 + i = up level i (diagnostic: which levels are chained; default all)
-  static const unsigned mask = [] { const char* e = getenv("ADX_CHAIN_MASK"); return e ? (unsigned)strtoul(e, nullptr, 0) : ~0u; }();
+  const unsigned mask = debug_switches().chain_mask;
   if (((mask >> (up_level ? 8 + level : level)) & 1u) == 0) return;
   if (!chains_enabled() || !b0.has_r || b1.has_r) return;      // block 0 changes the channel count (R = 1x1 conv), block 1 keeps it
   if (b0.cout > kChainMaxChannels || b1.cout != b0.cout) return;
   const ConvLayer* all[] = {&b0.a, &b0.b, &b0.r, &b1.a, &b1.b, tail, h0, h1};
-  static const int max_steps = [] { const char* e = getenv("ADX_CHAIN_MAX_STEPS"); return e ? atoi(e) : 48; }();
+  constexpr int max_steps = 48;
   for (const ConvLayer* L : all) {
     if (L == nullptr) continue;
     if (!chain_layer_ok(&L->d)) return;
@@ -602,7 +599,7 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
     ~ScratchScope() { t_split_scratch = nullptr; t_split_tickets = nullptr; }
   };
   float* const split_scratch = take(kSplitScratchFloats);
-  static const bool tickets_on = [] { const char* e = getenv("ADX_TCONV_NO_TICKET"); return !(e != nullptr && e[0] == '1'); }();
+  constexpr bool tickets_on = true;
   ScratchScope scratch_scope(split_scratch, tickets_on ? split_tickets : nullptr);
   bool tickets_pending = tickets_on;      // still to be cleared by this call
   if (tickets_pending && !(io->time_bias != nullptr && u->down_chains[0].valid)) {
@@ -649,7 +646,7 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
   };
 
   // one launch for a whole level (tconv_chain.hip) where the plan allows it
-  static const int chain_rows = [] { const char* e = getenv("ADX_CHAIN_ROWS"); return e ? atoi(e) : 0; }();   // 16 / 32: A/B
+  constexpr int chain_rows = 0;     // 16 / 32 pin the rows per workgroup (measured: the rule below wins)
   auto run_chain = [&](const ChainPlan& cp, const Act& in0, const Act* in1, const Act& o0, const Act* o1) -> int {
     // samples per workgroup: as many as keep its rows (bt x the chain's longest length) within 32 where that still gives
     // the chip ~a hundred workgroups, else the fewest that fill a 16-row tile (more, smaller workgroups)
@@ -679,8 +676,6 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
       a.zero_words = split_tickets; a.n_zero = (int)kTicketWords;
       tickets_pending = false;
     }
-    static const bool dbg = getenv("ADX_CHAIN_DEBUG") != nullptr;
-    if (dbg) fprintf(stderr, "[chain] rows %d len %d bt %d grid %d lds %zu stages %d in_vec %d\n", rows, cp.len, bt, ceil_div(rows, bt), lds, a.n_stages, a.in_vec);
     return chain_launch(a, ceil_div(rows, bt), lds, s);
   };
 

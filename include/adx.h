@@ -25,6 +25,7 @@ extern "C" {
 #define ADX_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define ADX_ERR_HIP (-2)       /* a HIP runtime call failed */
 #define ADX_ERR_STATE (-3)     /* object used before it was initialised */
+#define ADX_ERR_RANGE (-4)     /* ADX_CHECK_RANGE=1 only: an activation left the fp16 range of the split kernels */
 
 typedef void* adx_stream;      /* hipStream_t */
 

@@ -66,6 +66,7 @@ def time_mlp(sd: SD, t: torch.Tensor, dim: int) -> torch.Tensor:
 
 def cond_mlp(sd: SD, cond: torch.Tensor) -> torch.Tensor:
     """modeling/temporal.py:88-92."""
+    cond = cond.to(sd["cond_mlp.0.weight"].dtype)       # no-op in fp32 (the zeros of cond=None are fp32: lets tests run in fp64)
     h = F.mish(F.linear(cond, sd["cond_mlp.0.weight"], sd["cond_mlp.0.bias"]))
     return F.linear(h, sd["cond_mlp.2.weight"], sd["cond_mlp.2.bias"])
 

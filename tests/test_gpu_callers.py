@@ -86,7 +86,10 @@ def test_train_evaluate_body_under_inference_mode_vs_golden(golden, cache):
 
 
 def test_inference_tensor_memo_follows_the_image_object():
-    """The perception memo under inference_mode: same image object -> one encoder pass, another object -> a new one."""
+    """The perception memo under inference_mode.  Inference tensors carry no version counter, so by default they are NOT
+    memoised (an in-place refill of a frame buffer could not be seen): the encoder runs at every forward, as in the
+    reference.  With `cache_perception = "identity"` the caller vouches for immutability: same image object -> one encoder
+    pass, another object -> a new one."""
     from autonomous_driving_with_diffusion_model_amd.config import create_cfg
     from autonomous_driving_with_diffusion_model_amd.modeling import build_model
     m = build_model(create_cfg())
@@ -99,6 +102,13 @@ def test_inference_tensor_memo_follows_the_image_object():
     with torch.inference_mode():
         img = d["imgs"].to(DEV)
         x, t = d["trajs"].to(DEV), d["t"].to(DEV)
+        y0 = m(x, img, t)
+        img.mul_(0.5)                                   # the next frame written into the same buffer
+        y_refilled = m(x, img, t)
+        assert len(calls) == 2 and not torch.equal(y0, y_refilled)
+        img.mul_(2.0)
+        calls.clear()
+        m.cache_perception = "identity"
         y0 = m(x, img, t)
         y1 = m(x, img, t)
         assert len(calls) == 1 and torch.equal(y0, y1)

@@ -1,6 +1,8 @@
 """GPU parity, model level: ResNet-34, whole TemporalMapUnet forwards and the callers' sampling loops
 through the drop-in Python surface, against (a) the golden vectors produced by the real reference and
 (b) the CPU oracle on the same seeded inputs.  north_star tolerance: fp32 trajectories within 1e-4."""
+import os
+
 import pytest
 import torch
 
@@ -487,3 +489,35 @@ def test_forward_does_not_depend_on_what_the_workspace_held(use_cond, B, H, dims
             assert torch.equal(m(x, None, None, time_cond=(tc, 0)), want_tc), hex(fill)
             m._ws = torch.full((nbytes,), fill, dtype=torch.uint8, device=DEV)
             assert torch.equal(m(x, d["imgs"], t, cond=cond), want), hex(fill)
+
+
+def test_check_range_mode_names_the_first_layer_that_leaves_the_fp16_range():
+    """ADX_CHECK_RANGE=1 (read once per process, so a process of its own): the split-fp16 perception kernels turn a forward
+    activation of |x| >= 65504 into inf and carry it on; in this mode the pass fails with the first tensor that left the range
+    instead.  Procedural weights pass; the same model with one BatchNorm scale multiplied by 1e6 fails and names the block."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, "tests")
+from test_gpu_model import make_model, P, IMG_SMALL, DEV
+from autonomous_driving_with_diffusion_model_amd._lib import AdxError
+m, _ = make_model("NO_GUIDANCE", 16)
+img = P.synthetic_batch(2, 16, image_hw=IMG_SMALL, seed=3)["imgs"].to(DEV)
+with torch.no_grad():
+    f = m.perception(img)
+    assert bool(torch.isfinite(f).all())
+    m.perception.layer2[1].bn1.weight.mul_(1e6)
+    m.refresh_weights()
+    try:
+        m.perception(img)
+    except AdxError as e:
+        assert "BasicBlock 4" in str(e) and "65504" in str(e), str(e)
+        print("RANGE_OK")
+    else:
+        raise SystemExit("no range error")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, ADX_CHECK_RANGE="1"), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "RANGE_OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])

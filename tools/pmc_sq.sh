@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for shape in "512 8 29" "64 64 225"; do
+for shape in "512 8 29" "256 16 57" "64 64 225"; do
 tag=$(echo $shape | tr ' ' '_')
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM --output-format csv -d gpurun_out/pmcA_$tag -- python3 tools/pmc_one.py $shape > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_INST_LEVEL_VMEM SQ_VMEM_TA_ADDR_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_WAIT_ANY --output-format csv -d gpurun_out/pmcB_$tag -- python3 tools/pmc_one.py $shape > /dev/null 2>&1

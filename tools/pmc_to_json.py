@@ -49,7 +49,7 @@ def main():
     for (cin, cout, k, s, p, h, w), cnt in shapes.items():
         mode = 0 if cin < 256 else (1 if h > 8 else 2)       # conv2d_hs_launch's tile-mode rule
         th, ct, nt = (16 if mode == 1 else 8), (2 if mode == 2 else 1), (256 if mode == 0 else 512)
-        wgs = ((h + th - 1) // th) * ((bench.B * w + 31) // 32) * (cout // (64 * ct))   # column tiles over the images side by side
+        wgs = ((h + th - 1) // th) * ((bench.B * (w + 1) - 1 + 31) // 32) * (cout // (64 * ct))   # column tiles over the images side by side, one shared zero column between neighbours
         grids[wgs * nt] = (f"{cin}->{cout} @{h}x{w} (tile mode {mode})", cnt)
     per_shape, tf, tw, n = {}, 0.0, 0.0, 0
     for g, (label, cnt) in grids.items():
