@@ -507,7 +507,7 @@ img = P.synthetic_batch(2, 16, image_hw=IMG_SMALL, seed=3)["imgs"].to(DEV)
 with torch.no_grad():
     f = m.perception(img)
     assert bool(torch.isfinite(f).all())
-    m.perception.layer2[1].bn1.weight.mul_(1e6)
+    dict(m.named_parameters())["perception.layer2.1.bn1.weight"].mul_(1e6)
     m.refresh_weights()
     try:
         m.perception(img)
