@@ -45,6 +45,7 @@ struct DebugSwitches {
   bool tconv_exact = false;    // ADX_TCONV_EXACT=1  the temporal stack on the exact-fp32 MFMA kernel
   bool unet_chain = true;      // ADX_UNET_CHAIN=0   every temporal level layer by layer (no chained launches)
   unsigned chain_mask = ~0u;   // ADX_CHAIN_MASK=<bits>  which levels are chained (bit i: down level i, bit 8 + i: up level i)
+  bool unet_pipe = true;       // ADX_UNET_PIPE=0    the deepest level's layer run as launches, not as one pipeline launch (tconv_pipe.hip)
   bool conv_cells = true;      // ADX_CONV_CELLS=0   fp32 NCHW between all perception convs (no pre-split cell tensors)
   int hs_mode = -1;            // ADX_HS_MODE=0|1|2  pins the tile mode of the pipelined 3x3 kernel
   bool check_range = false;    // ADX_CHECK_RANGE=1  perception forward: fail with the first layer whose activations leave the

@@ -24,6 +24,7 @@ const DebugSwitches& debug_switches() {
     d.wgrad_exact = is("ADX_WGRAD_EXACT", '1');
     d.tconv_exact = is("ADX_TCONV_EXACT", '1');
     d.unet_chain = !is("ADX_UNET_CHAIN", '0');
+    d.unet_pipe = !is("ADX_UNET_PIPE", '0');
     d.conv_cells = !is("ADX_CONV_CELLS", '0');
     d.check_range = is("ADX_CHECK_RANGE", '1');
     if (const char* e = getenv("ADX_CHAIN_MASK")) d.chain_mask = (unsigned)strtoul(e, nullptr, 0);

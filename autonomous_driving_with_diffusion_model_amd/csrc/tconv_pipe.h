@@ -1,0 +1,49 @@
+// Cooperative pipeline of same-shaped temporal layers (tconv_pipe.hip): argument block shared with the UNet executor.
+#pragma once
+#include "tconv.h"
+
+namespace adx {
+
+constexpr int kPipeMaxStages = 8;      // conv stages + the finisher
+constexpr int kPipeCh = 16;            // output channels per workgroup (one 16 x 16 MFMA tile)
+constexpr int kPipeRows = 16;          // MFMA rows: (sample, position) pairs of the whole batch
+constexpr size_t kPipeMaxLds = 150 * 1024;
+
+// How the INPUT of a stage is formed.  Stage 0 reads a finished activation; every later stage (and the finisher) reads the
+// records of the stage before it -- raw conv sums + bias, [rows x L][C] -- and applies that conv's GroupNorm + Mish and the
+// block's addend itself (a ResidualTemporalMapBlockConcat, modeling/temporal.py:46-55: h = block0(x) + time bias;
+// y = block1(h) + residual).
+struct PipeStage {
+  const float* w;          // this conv's weight image in the pipeline layout (pipe_pack); unused by the finisher
+  const float* bias;       // this conv's bias [C]
+  const float* in;         // stage 0: finished activation [rows][C][L]; later stages: null
+  const float* gamma;      // GroupNorm affine of the conv whose records are read (stages >= 1)
+  const float* beta;
+  const float* add;        // addend of the formed input, by add_kind
+  int64_t add_stride;      // add_kind 1: floats between the time-bias rows of two samples
+  float* pub;              // where rank 0 writes the formed input (pub_kind)
+  float* pub2;             // optional second copy as [rows x L][C] (a later stage's residual), or null
+  int add_early;           // add_kind 2 only: the residual was written by an EARLIER launch (requested before the wait)
+  int add_kind;            // 0 none; 1 time bias add[sample * add_stride + c]; 2 residual [rows][C][L]; 3 residual [rows x L][C]
+  int pub_kind;            // 0 not written; 1 as [rows][C][L] (a skip / the run's output); 2 as [rows x L][C] (a later residual)
+};
+
+struct PipeArgs {
+  PipeStage st[kPipeMaxStages];
+  int n_conv;              // conv stages; the launch has n_conv * P + 1 workgroups, the last one is the finisher (stage n_conv)
+  int C, L, rows, P;       // channels (in = out), positions per sample, samples, workgroups per stage = C / 16
+  int groups, taps, pad, tap0, ntap;   // GroupNorm groups; conv taps and padding; live taps [tap0, tap0 + ntap)
+  float eps;
+  float* records;          // [n_conv][P][16 rows][16 channels]
+  unsigned* counters;      // n_conv arrival counters, 16 words apart, zero on entry (the executor's ticket words)
+};
+
+// live taps of a stride-1 conv on L positions, and whether a layer run of this shape fits the kernel (weights of one workgroup
+// in LDS, the whole batch in one 16-row tile)
+void pipe_live_taps(int taps, int pad, int L, int* tap0, int* ntap);
+bool pipe_shape_ok(int C, int L, int rows, int taps, int pad, int groups);
+size_t pipe_packed_floats(int C, int taps, int pad, int L);
+int pipe_pack(const float* w, float* packed, int C, int taps, int pad, int L, hipStream_t s);
+int pipe_launch(const PipeArgs& a, hipStream_t s);
+
+}  // namespace adx

@@ -334,6 +334,31 @@ static int build(adx_unet* u) {
     plan_chain(&u->up_chains[i], b0, b1, &u->ups[i], last ? &u->head0 : nullptr, last ? &u->head1 : nullptr, true, i);
     if (u->up_chains[i].valid) give_images(u->up_chains[i]);
   }
+  // the pipeline run (tconv_pipe.hip): the last level's block 0 second conv, block 1 and both mid blocks when they are seven
+  // convs of ONE shape whose per-workgroup weight share fits the LDS (three live taps at 512 channels: MODEL.HORIZON = 16)
+  {
+    ResBlock& b0 = u->blocks[2 * (n - 1)];
+    ResBlock& b1 = u->blocks[2 * (n - 1) + 1];
+    ResBlock& m1 = u->blocks[2 * n];
+    ResBlock& m2 = u->blocks[2 * n + 1];
+    ConvLayer* run[7] = {&b0.b, &b1.a, &b1.b, &m1.a, &m1.b, &m2.a, &m2.b};
+    const adx_tconv_desc& d0 = b0.b.d;
+    bool ok = debug_switches().unet_pipe && !u->down_chains[n - 1].valid && b0.has_r && !b1.has_r && !m1.has_r && !m2.has_r &&
+              d0.lin == b0.len;
+    for (ConvLayer* L : run) {
+      const adx_tconv_desc& d = L->d;
+      ok = ok && d.kind == 0 && d.stride == 1 && d.c1 == 0 && d.c0 == d0.cout && d.cout == d0.cout && d.taps == d0.taps &&
+           d.pad == d0.pad && d.lin == d0.lin && d.lout == d0.lin && d.groups == d0.groups && d.groups > 0 && d.eps == d0.eps &&
+           d.w_layout == 0 && d.w_flip == 0;
+    }
+    ok = ok && pipe_shape_ok(d0.cout, d0.lin, 1, d0.taps, d0.pad, d0.groups) && (d0.cout / d0.groups) % 4 == 0;
+    u->pipe_ok = ok;
+    if (ok)
+      for (ConvLayer* L : run) {
+        L->piped = true;
+        L->o_pw = B.take(pipe_packed_floats(d0.cout, d0.taps, d0.pad, d0.lin));
+      }
+  }
   u->packed_floats = B.off;
   // validate every layer's geometry now so that forward() cannot fail on shape grounds (any layer one of the three
   // temporal kernels covers: tconv_check)
@@ -361,6 +386,7 @@ static int pack_layer(const ConvLayer& L, const float* const* P, float* base, hi
   int rc = tconv_pack(&L.d, P[L.p_w], base + L.o_w, s);
   if (rc == ADX_OK && L.chained)       // chain image; `rider` = the block's 1x1 residual conv, stored behind this conv's steps
     rc = chain_pack(&L.d, P[L.p_w], rider != nullptr ? &rider->d : nullptr, rider != nullptr ? P[rider->p_w] : nullptr, base + L.o_cw, s);
+  if (rc == ADX_OK && L.piped) rc = pipe_pack(P[L.p_w], base + L.o_pw, L.d.cout, L.d.taps, L.d.pad, L.d.lin, s);
   if (rc == ADX_OK && L.p_b >= 0) rc = copy_f(base + L.o_b, P[L.p_b], L.d.cout, s);
   if (rc == ADX_OK && L.p_g >= 0) rc = copy_f(base + L.o_g, P[L.p_g], L.d.cout, s);
   if (rc == ADX_OK && L.p_be >= 0) rc = copy_f(base + L.o_be, P[L.p_be], L.d.cout, s);
@@ -681,6 +707,7 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
 
   size_t bi = 0;
   const int n = u->n_levels;
+  bool pipe_done = false;
   for (int i = 0; i < n; ++i) {
     const ResBlock& B0 = u->blocks[bi++];
     const ResBlock& B1 = u->blocks[bi++];
@@ -698,6 +725,64 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
       if (rc != ADX_OK) return rc;
       continue;
     }
+    if (i == n - 1 && u->pipe_ok && tickets_on && split_scratch != nullptr &&
+        pipe_shape_ok(B0.cout, B0.len, rows, B0.b.d.taps, B0.b.d.pad, B0.b.d.groups)) {
+      // Small batch: block 0's second conv, block 1 and both mid blocks -- seven same-shaped convs -- as ONE pipeline launch
+      // (tconv_pipe.hip).  Block 0's first conv + 1x1 residual conv stay the pair / mixed launch they were.
+      const int C = B0.cout, Lp = B0.len;
+      float* h = next_buf();
+      float* rb = next_buf();
+      {
+        const adx_tconv_io io_a = make_io(B0.a, base, cur, nullptr, tb + B0.tb_off, u->sum_c, nullptr, h, (int64_t)C * Lp, Lp, 1, rows);
+        const adx_tconv_io io_r = make_io(B0.r, base, cur, nullptr, nullptr, 0, nullptr, rb, (int64_t)C * Lp, Lp, 1, rows);
+        rc = tconv_hs_forward_pair(&B0.a.d, &io_a, &B0.r.d, &io_r, s);
+        if (rc != ADX_OK) return rc;
+      }
+      const ResBlock& M1 = u->blocks[bi];
+      const ResBlock& M2 = u->blocks[bi + 1];
+      float* out = next_buf();
+      const ConvLayer* run[7] = {&B0.b, &B1.a, &B1.b, &M1.a, &M1.b, &M2.a, &M2.b};
+      PipeArgs pa;
+      memset(&pa, 0, sizeof(pa));
+      pa.n_conv = 7; pa.C = C; pa.L = Lp; pa.rows = rows; pa.P = C / kPipeCh;
+      pa.groups = B0.b.d.groups; pa.taps = B0.b.d.taps; pa.pad = B0.b.d.pad; pa.eps = B0.b.d.eps;
+      pipe_live_taps(pa.taps, pa.pad, Lp, &pa.tap0, &pa.ntap);
+      // scratch of this call: records of the seven stages, then the two block outputs only later residuals read
+      const size_t rec_floats = (size_t)7 * pa.P * kPipeRows * kPipeCh;
+      pa.records = split_scratch;
+      float* ya = split_scratch + align64(rec_floats);
+      float* yb = ya + align64((size_t)rows * Lp * C);
+      float* yc = yb + align64((size_t)rows * Lp * C);
+      pa.counters = split_tickets + 128;                          // words 128, 144, ... 224: a 64-byte line per stage (the split
+                                                                  // reductions' tickets stay below 128), cleared at the head of this forward
+      for (int k = 0; k < 7; ++k) {
+        pa.st[k].w = base + run[k]->o_pw;
+        pa.st[k].bias = base + run[k]->o_b;
+      }
+      for (int k = 1; k <= 7; ++k) {                               // stage k forms its input from conv k - 1's records
+        pa.st[k].gamma = base + run[k - 1]->o_g;
+        pa.st[k].beta = base + run[k - 1]->o_be;
+      }
+      pa.st[0].in = h;                                             // h0 = block0(x) + time bias, finished by the launch above
+      // conv 0 = B0.b: y0 = act + R(x);       conv 1 = B1.a: h1 = act + tb(B1);   conv 2 = B1.b: y2 = act + y0 (the level's output, the skip)
+      // conv 3 = M1.a: h3 = act + tb(M1);     conv 4 = M1.b: y4 = act + y2;      conv 5 = M2.a: h5 = act + tb(M2);  conv 6 = M2.b: y6 = act + y4
+      auto resid = [&](int k, const float* p, int kind) { pa.st[k].add = p; pa.st[k].add_kind = kind; };
+      auto tbias = [&](int k, const ResBlock& Bk) { pa.st[k].add = tb + Bk.tb_off; pa.st[k].add_stride = u->sum_c; pa.st[k].add_kind = 1; };
+      auto publish = [&](int k, float* p, int kind) { pa.st[k].pub = p; pa.st[k].pub_kind = kind; };
+      resid(1, rb, 2);       publish(1, ya, 2);        pa.st[1].add_early = 1;      // R(x): finished by the launch above
+      tbias(2, B1);
+      resid(3, ya, 3);       publish(3, skips[i], 1);  pa.st[3].pub2 = yc;          // the level's output: the skip, and y4's residual
+      tbias(4, M1);
+      resid(5, yc, 3);       publish(5, yb, 2);
+      tbias(6, M2);
+      resid(7, yb, 3);       publish(7, out, 1);
+      rc = pipe_launch(pa, s);
+      if (rc != ADX_OK) return rc;
+      cur = dense(out, C, Lp);
+      bi += 2;                // the mid blocks ran inside the pipeline
+      pipe_done = true;
+      continue;
+    }
     float* y0 = next_buf();
     rc = run_block(B0, cur, nullptr, y0);
     if (rc != ADX_OK) return rc;
@@ -713,7 +798,7 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
       cur = dense(y, dn.d.cout, dn.d.lout);
     }
   }
-  for (int k = 0; k < 2; ++k) {  // mid_block1, mid_block2
+  for (int k = 0; k < 2 && !pipe_done; ++k) {  // mid_block1, mid_block2
     const ResBlock& B = u->blocks[bi++];
     float* y = next_buf();
     rc = run_block(B, cur, nullptr, y);

@@ -4,6 +4,7 @@
 
 #include "tconv.h"
 #include "tconv_chain.h"
+#include "tconv_pipe.h"
 
 namespace adx {
 
@@ -16,6 +17,8 @@ struct ConvLayer {
   size_t o_w = 0, o_b = 0, o_g = 0, o_be = 0;       // float offsets into the packed buffer
   size_t o_cw = 0;                                  // weight image in the chain kernel's layout (layers of a chain only)
   bool chained = false;
+  size_t o_pw = 0;                                  // weight image in the pipeline kernel's layout (tconv_pipe.hip)
+  bool piped = false;
 };
 
 struct ResBlock {
@@ -61,5 +64,8 @@ struct adx_unet {
   size_t packed_floats = 0;
   bool packed_once = false;
   std::vector<adx::ChainPlan> down_chains, up_chains;   // per level; !valid: the level runs layer by layer
+  // the deepest level's same-shaped layer run (block 0's second conv, block 1, both mid blocks: seven convs) as ONE pipeline
+  // launch at small batches (tconv_pipe.hip); pipe_ok: the configuration qualifies (decided once, at creation)
+  bool pipe_ok = false;
 };
 

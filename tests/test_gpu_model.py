@@ -446,13 +446,43 @@ def test_levels_layer_by_layer_vs_oracle():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "chain_worker.py")], env=dict(os.environ, ADX_UNET_CHAIN="0"),
-                       capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-3000:]
-    cases = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("CASE")]
-    assert len(cases) == 4, r.stdout
-    for _, name, rows, H, err in cases:
-        assert float(err) <= 2e-5, (name, rows, H, err)
+    # ADX_UNET_PIPE=0: the deepest level's seven same-shaped convs as launches instead of the one pipeline launch the small
+    # batches at H = 16 take by default (csrc/tconv_pipe.hip); the worker's (2, 16) and (5, 16) cases cross that switch
+    for switch in ("ADX_UNET_CHAIN", "ADX_UNET_PIPE"):
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "chain_worker.py")], env=dict(os.environ, **{switch: "0"}),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        cases = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("CASE")]
+        assert len(cases) == 4, r.stdout
+        for _, name, rows, H, err in cases:
+            assert float(err) <= 2e-5, (switch, name, rows, H, err)
+
+
+@pytest.mark.parametrize("use_cond,rows", [("NO_GUIDANCE", 1), ("FREE_GUIDANCE", 2), ("NO_GUIDANCE", 3), ("FREE_GUIDANCE", 8),
+                                           ("CLASSIFIER_GUIDANCE", 4), ("NO_GUIDANCE", 9)])
+def test_pipeline_launch_of_the_deepest_level_vs_oracle(use_cond, rows):
+    """csrc/tconv_pipe.hip: at MODEL.HORIZON = 16 (two positions at the deepest level) and up to 8 rows, block 0's second conv,
+    block 1 and both mid blocks -- seven Conv1d(512, 512, 5) + GroupNorm + Mish -- run as ONE launch: 7 x 32 workgroups that
+    hand raw conv sums on through memory, the consumer applying GroupNorm / Mish / time bias / residual.  Whole forwards against
+    the oracle for every row count the tile holds (9 rows: back on the launch chain), twice each (a second call must not
+    depend on the first one's counters), modeling/temporal.py:197-245."""
+    m, _ = make_model(use_cond, 16)
+    d = P.synthetic_batch(rows, 16, image_hw=(32, 32), seed=90 + rows)
+    feat = P._uniform("pipe.feat", 90 + rows, (rows, 64), -3.0, 3.0)
+    m.perception.forward = lambda img, f=feat: f.to(DEV)
+    cond = d["target"] if use_cond == "FREE_GUIDANCE" else None
+    kw = dict(cond=cond.to(DEV)) if cond is not None else {}
+    if use_cond == "CLASSIFIER_GUIDANCE":
+        kw["return_action_and_time_only"] = True
+    want = U.unet_forward(oracle_sd(use_cond), d["trajs"], None, d["t"], cond, use_cond=use_cond, img_feature=feat)
+    outs = []
+    with torch.no_grad():
+        for _ in range(2):
+            y = m(d["trajs"].to(DEV), d["imgs"].to(DEV), d["t"].to(DEV), **kw)
+            outs.append((y[0] if isinstance(y, tuple) else y).cpu())
+    assert torch.equal(outs[0], outs[1])
+    w = want if want.shape[-1] == outs[0].shape[-1] else want[..., -outs[0].shape[-1]:]
+    close(outs[0], w, 2e-5)
 
 
 @pytest.mark.parametrize("use_cond,B,H,dims", [("FREE_GUIDANCE", 1, 16, None), ("NO_GUIDANCE", 64, 32, None),
