@@ -319,8 +319,9 @@ def deployed_leg(dev):
             "tick_ms_graph": round(1e3 * out["graph"], 3), "tick_ms_eager": round(1e3 * out["eager"], 3),
             "denoising_steps_per_sec": round(N_INFER / out["graph"], 1), "us_per_step": round(1e6 * per_step, 1),
             "hbm_frac_weights_once_per_step": round(wbytes / per_step / 1e9 / PEAK_HBM_GBS, 4), **cls,
-            "note": "bound by the chain of ~40 dependent launches per step (3 chained levels + 28 per-layer + 9 reduce launches; a wave "
-                    "retires an instruction per ~8-12 clocks at this occupancy), not by HBM: DESIGN.md sections 3 and 8"}
+            "note": "bound by the chain of ~24 dependent launches per step (3 chained levels, the pipeline launch of the deepest level's "
+                    "seven convs, ~20 per-layer launches; a wave retires an instruction per ~8-12 clocks at this occupancy, a hand-off "
+                    "between workgroups costs ~4 us), not by HBM: DESIGN.md sections 3 and 8"}
 
 
 def cpu_model_name():
