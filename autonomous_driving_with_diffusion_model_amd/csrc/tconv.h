@@ -38,6 +38,7 @@ int tconv_generic_forward(const adx_tconv_desc* d, const adx_tconv_io* io, hipSt
 // supported and the descriptor does not ask for the exact-fp32 kernel
 bool tconv_hs_supported(const adx_tconv_desc* d);
 size_t tconv_hs_packed_floats(const adx_tconv_desc* d);
+bool tconv_hs_kernel_image(const adx_tconv_desc* d);     // tconv_pack writes the K-split kernel's weight image for this layer
 int tconv_hs_pack(const adx_tconv_desc* d, const float* w, float* packed, hipStream_t s);
 int tconv_hs_forward(const adx_tconv_desc* d, const adx_tconv_io* io, hipStream_t s);
 // two independent convolutions, in one launch where both run on the short-K kernel

@@ -850,6 +850,12 @@ static bool hsd_geometry(const adx_tconv_desc* d, int* nsteps, int* kcells, int*
 
 static bool hsd_enabled() { return true; }
 
+// true when tconv_pack leaves this layer's weights in the K-split kernel's image ([cout / 32][tap x cin / 16][plane][lane][8 halfs])
+bool tconv_hs_kernel_image(const adx_tconv_desc* d) {
+  int ns, kc, lg;
+  return tconv_hs_supported(d) && !(hsd_enabled() && hsd_geometry(d, &ns, &kc, &lg));
+}
+
 size_t tconv_hs_packed_floats(const adx_tconv_desc* d) {
   const int cin_pad = round_up(d->c0 + d->c1, 16);
   size_t f = (size_t)round_up(d->cout, 32) * d->taps * cin_pad;     // 2 halfs = 4 bytes per (padded) weight

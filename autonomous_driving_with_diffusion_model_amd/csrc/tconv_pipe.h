@@ -44,6 +44,8 @@ void pipe_live_taps(int taps, int pad, int L, int* tap0, int* ntap);
 bool pipe_shape_ok(int C, int L, int rows, int taps, int pad, int groups);
 size_t pipe_packed_floats(int C, int taps, int pad, int L);
 int pipe_pack(const float* w, float* packed, int C, int taps, int pad, int L, hipStream_t s);
+// the same image made from the layer's K-split image (tconv_hs.hip), which the executor holds anyway
+int pipe_repack_from_hs(const float* hs_image, float* packed, int C, int taps, int pad, int L, hipStream_t s);
 int pipe_launch(const PipeArgs& a, hipStream_t s);
 
 }  // namespace adx

@@ -103,6 +103,34 @@ __global__ void __launch_bounds__(256) pipe_pack_kernel(const float* __restrict_
   packed[idx] = plane == 0 ? hi : (_Float16)((v - (float)hi) * kPipeLoScale);
 }
 
+// the same image from the K-split kernel's image of the layer (tconv_hs.hip: [cout / 32][tap x cin / 16][plane][64 lanes][8 halfs],
+// lane (n & 31, half of the 16-channel block), which every piped layer has anyway): a pure permutation of 16-byte cells, so the
+// pipeline's images can be made where they are first needed (the inference forward) instead of at every weight update
+__global__ void __launch_bounds__(256) pipe_repack_kernel(const u32x4* __restrict__ hs, u32x4* __restrict__ packed, int C, int taps,
+                                                           int tap0, int steps, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;            // one 16-byte cell: (rank, step, plane, lane)
+  if (idx >= total) return;
+  const int lane = idx & 63, plane = (idx >> 6) & 1;
+  const size_t blk = idx >> 7;
+  const int k = blk % steps, rank = blk / steps;
+  const int c32n = C / 32, ti = k / c32n, c32 = k - ti * c32n;
+  const int n = rank * kPipeCh + (lane & 15), cin = c32 * 32 + (lane >> 4) * 8;
+  const int ncb = C / 16, nkb = taps * ncb;
+  const int kb = (tap0 + ti) * ncb + (cin >> 4), ln = (((cin >> 3) & 1) << 5) | (n & 31);
+  packed[idx] = hs[((size_t)(n >> 5) * nkb + kb) * 128 + plane * 64 + ln];
+}
+
+int pipe_repack_from_hs(const float* hs_image, float* packed, int C, int taps, int pad, int L, hipStream_t s) {
+  int t0, nt;
+  pipe_live_taps(taps, pad, L, &t0, &nt);
+  const int steps = nt * (C / 32);
+  const size_t total = (size_t)(C / kPipeCh) * steps * 2 * 64;
+  pipe_repack_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
+      reinterpret_cast<const u32x4*>(hs_image), reinterpret_cast<u32x4*>(packed), C, taps, t0, steps, total);
+  ADX_LAUNCH_CHECK();
+  return ADX_OK;
+}
+
 int pipe_pack(const float* w, float* packed, int C, int taps, int pad, int L, hipStream_t s) {
   int t0, nt;
   pipe_live_taps(taps, pad, L, &t0, &nt);

@@ -351,7 +351,8 @@ static int build(adx_unet* u) {
            d.pad == d0.pad && d.lin == d0.lin && d.lout == d0.lin && d.groups == d0.groups && d.groups > 0 && d.eps == d0.eps &&
            d.w_layout == 0 && d.w_flip == 0;
     }
-    ok = ok && pipe_shape_ok(d0.cout, d0.lin, 1, d0.taps, d0.pad, d0.groups) && (d0.cout / d0.groups) % 4 == 0;
+    ok = ok && pipe_shape_ok(d0.cout, d0.lin, 1, d0.taps, d0.pad, d0.groups) && (d0.cout / d0.groups) % 4 == 0 &&
+         tconv_hs_kernel_image(&d0);      // the pipeline's images are re-laid from the K-split kernel's (not with ADX_TCONV_EXACT=1)
     u->pipe_ok = ok;
     if (ok)
       for (ConvLayer* L : run) {
@@ -386,7 +387,6 @@ static int pack_layer(const ConvLayer& L, const float* const* P, float* base, hi
   int rc = tconv_pack(&L.d, P[L.p_w], base + L.o_w, s);
   if (rc == ADX_OK && L.chained)       // chain image; `rider` = the block's 1x1 residual conv, stored behind this conv's steps
     rc = chain_pack(&L.d, P[L.p_w], rider != nullptr ? &rider->d : nullptr, rider != nullptr ? P[rider->p_w] : nullptr, base + L.o_cw, s);
-  if (rc == ADX_OK && L.piped) rc = pipe_pack(P[L.p_w], base + L.o_pw, L.d.cout, L.d.taps, L.d.pad, L.d.lin, s);
   if (rc == ADX_OK && L.p_b >= 0) rc = copy_f(base + L.o_b, P[L.p_b], L.d.cout, s);
   if (rc == ADX_OK && L.p_g >= 0) rc = copy_f(base + L.o_g, P[L.p_g], L.d.cout, s);
   if (rc == ADX_OK && L.p_be >= 0) rc = copy_f(base + L.o_be, P[L.p_be], L.d.cout, s);
@@ -559,7 +559,7 @@ int adx_unet_pack(adx_unet* u, const float* const* P, int32_t n_params, const fl
     const int rf = batch_copy_flush(s);            // always drain the queue, also after an error
     if (rc == ADX_OK) rc = rf;
   }
-  if (rc == ADX_OK) u->packed_once = true;
+  if (rc == ADX_OK) { u->packed_once = true; u->pipe_stale = true; }
   return rc;
 }
 
@@ -753,6 +753,15 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
       float* ya = split_scratch + align64(rec_floats);
       float* yb = ya + align64((size_t)rows * Lp * C);
       float* yc = yb + align64((size_t)rows * Lp * C);
+      if (u->pipe_stale) {
+        // made here, from the K-split images adx_unet_pack wrote, and not at every weight update: training never needs them
+        for (const ConvLayer* Lk : run) {
+          ADX_REQUIRE(tconv_hs_kernel_image(&Lk->d), "adx_unet_forward: piped layer without a K-split weight image");
+          rc = pipe_repack_from_hs(base + Lk->o_w, const_cast<float*>(base) + Lk->o_pw, C, Lk->d.taps, Lk->d.pad, Lp, s);
+          if (rc != ADX_OK) return rc;
+        }
+        u->pipe_stale = false;
+      }
       pa.counters = split_tickets + 128;                          // words 128, 144, ... 224: a 64-byte line per stage (the split
                                                                   // reductions' tickets stay below 128), cleared at the head of this forward
       for (int k = 0; k < 7; ++k) {
