@@ -231,3 +231,22 @@ def test_interact_generate_traj_through_the_shim_vs_golden(golden, reference_nam
     got2 = agent.generate_traj(d["imgs"] * 0.25, target)
     assert not torch.equal(got, got2)
     assert torch.equal(agent.generate_traj(d["imgs"].clone(), target), got)
+
+
+def test_pipeline_launch_completes_with_the_gpu_shared_between_processes(tmp_path):
+    """csrc/tconv_pipe.hip is a launch of 225 workgroups in which later stages spin on earlier ones -- without a cooperative launch.
+    Three processes sample on this one GPU at once (one scene, H = 16: every step of every process issues that launch), so the
+    pipeline's workgroups are not all resident together; every tick of every process must still complete and reproduce the
+    bits of that process's first, eagerly launched tick, and the processes must agree with each other."""
+    import subprocess
+    procs, outs = [], []
+    for i in range(3):
+        outs.append(str(tmp_path / f"w{i}.pt"))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "pipe_contention_worker.py"), outs[-1], "40"],
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=900)[0] for p in procs]
+    for p, lg in zip(procs, logs):
+        assert p.returncode == 0, lg[-3000:]
+    res = [torch.load(o) for o in outs]
+    assert all(r["all_equal"] and r["finite"] for r in res), [(r["all_equal"], r["finite"]) for r in res]
+    assert torch.equal(res[0]["first"], res[1]["first"]) and torch.equal(res[0]["first"], res[2]["first"])
