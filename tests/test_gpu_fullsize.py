@@ -111,33 +111,37 @@ def test_cfg4_b64_fullsize_classifier_guidance_vs_oracle(full, n_steps):
     close_traj(got, want, 1e-4)
 
 
-@pytest.mark.parametrize("Bt", [16, 64])
-def test_cfg2_train_step_fullsize_vs_oracle_autograd(full, Bt):
+@pytest.mark.parametrize("use_cond,Bt", [("NO_GUIDANCE", 16), ("NO_GUIDANCE", 64), ("FREE_GUIDANCE-drop", 16)])
+def test_cfg2_train_step_fullsize_vs_oracle_autograd(full, use_cond, Bt):
     """BASELINE configs[1] (NO_GUIDANCE train step, H = 32, full image): loss, and the relative L2 error of EVERY parameter's
     gradient tensor (not its norm) against torch autograd through the oracle, in fp64 and in fp32 -- at B = 16 and, since round
     4, at the full B = 64 (the grids conv2d_wgrad_hs, the data-gradient convs with their BatchNorm-backward epilogue statistics and
     the plane passes actually run at; the oracle's autograd through a ResNet-34 on 64 full-size images takes ~2 minutes and
-    ~200 GB on the box's host, which has them)."""
+    ~200 GB on the box's host, which has them).  FREE_GUIDANCE-drop: BASELINE configs[4]'s model in the cond=None branch of
+    train.py:236-242 (every cond_mlp gradient present; d(cond_mlp.0.weight) exactly zero on both sides)."""
     from autonomous_driving_with_diffusion_model_amd import scheduler as S
-    m, _ = _model("NO_GUIDANCE")
+    use_cond, _, drop = use_cond.partition("-")
+    m, _ = _model(use_cond)
     m.train()
     d = {k: v[:Bt] for k, v in full.d.items()}
     sch = S.DDPMScheduler(**SCHED_KW)
     dd = {k: v.to(DEV) for k, v in d.items()}
     noisy = sch.add_noise(dd["trajs"], dd["noise"], dd["t"], zero_first=True)
-    loss = F.mse_loss(m(noisy, dd["imgs"], dd["t"]), dd["trajs"])
+    cond = dd["target"] if (use_cond == "FREE_GUIDANCE" and not drop) else None
+    loss = F.mse_loss(m(noisy, dd["imgs"], dd["t"], cond=cond), dd["trajs"])
     loss.backward()
     got = {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
     del m
     torch.cuda.empty_cache()
-    pkeys = [e.key for e in unet_entries("NO_GUIDANCE") if not e.is_buffer]
+    pkeys = [e.key for e in unet_entries(use_cond) if not e.is_buffer]
+    assert set(got) == set(pkeys)
 
     def oracle_grads(dtype):
         sd = {k: (v.to(dtype).requires_grad_(k in pkeys) if v.is_floating_point() else v)
-              for k, v in oracle_sd("NO_GUIDANCE").items()}
+              for k, v in oracle_sd(use_cond).items()}
         cast = lambda t: t.to(dtype) if t.is_floating_point() else t  # noqa: E731
         ls = OS.training_loss(sd, cast(d["imgs"]), cast(d["trajs"]), cast(d["target"]), d["t"], cast(d["noise"]),
-                              use_cond="NO_GUIDANCE")
+                              use_cond=use_cond, drop_cond=bool(drop))
         ls.backward()
         return ls.item(), {k: sd[k].grad for k in pkeys}
 
@@ -150,12 +154,14 @@ def test_cfg2_train_step_fullsize_vs_oracle_autograd(full, Bt):
     assert abs(loss.item() - loss64) <= 2e-5 * max(1.0, abs(loss64))
     rel = lambda a, b: ((a.double() - b).norm() / (b.norm() + 1e-300)).item()  # noqa: E731
     rows = sorted(((rel(got[k], g64[k]), rel(g32[k], g64[k]), k) for k in pkeys), reverse=True)
-    _record(f"cfg2_train_b{Bt}", {"loss": loss.item(), "loss_fp64": loss64, "loss_fp32": loss32,
+    _record(f"train_{use_cond}{'_drop' if drop else ''}_b{Bt}", {"loss": loss.item(), "loss_fp64": loss64, "loss_fp32": loss32,
                                "worst (e_hip, e_oracle_fp32, tensor)": rows[:8],
                                "median_e_hip": rows[len(rows) // 2][0],
                                "median_e_oracle_fp32": sorted(r[1] for r in rows)[len(rows) // 2]})
     for e_hip, e_ref, k in rows:
         assert e_hip <= 3 * e_ref + 1e-3, (k, e_hip, e_ref)
+    if drop:
+        assert got["cond_mlp.0.weight"].abs().max().item() == 0.0 and g64["cond_mlp.0.weight"].abs().max().item() == 0.0
 
 
 def test_cfg2_train_step_b64_fullsize_loss_vs_oracle_and_split_vs_exact(tmp_path):
