@@ -142,13 +142,14 @@ def from_cells(cells: torch.Tensor, shape) -> torch.Tensor:
 
 
 def conv2d_cells(x: torch.Tensor, packed: torch.Tensor, cin: int, cout: int, n: int, h: int, w: int, *, x_cells: bool,
-                 scale=None, shift=None, res=None, res_cells: bool = False, relu: bool = False) -> torch.Tensor:
+                 scale=None, shift=None, res=None, res_cells: bool = False, relu: bool = False,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """3x3 stride-1 pad-1 conv with a cell-layout output (and optionally cell-layout input / residual); returns the
     output cells (uint8, fp32 byte size).  Only for launches adx_conv2d_cells_supported accepts."""
     d = L.Conv2dDesc(cin, cout, 3, 1, 1)
     if not L.lib().adx_conv2d_cells_supported(C.byref(d), n, h, w):
         raise ValueError(f"conv2d_cells: {cin}->{cout} at {n}x{h}x{w} is not a plain launch of the pipelined 3x3 kernel")
-    y = torch.empty(n * cout * h * w * 4, dtype=torch.uint8, device=x.device)
+    y = out if out is not None else torch.empty(n * cout * h * w * 4, dtype=torch.uint8, device=x.device)
     fmt = (1 if x_cells else 0) | 2 | (4 if (res is not None and res_cells) else 0)
     L.check(L.lib().adx_conv2d_forward_cells(C.byref(d), x.data_ptr(), packed.data_ptr(), L.ptr(scale), L.ptr(shift), L.ptr(res),
                                              y.data_ptr(), n, h, w, int(relu), fmt, L.stream_ptr(x.device)),
