@@ -222,11 +222,19 @@ def conv2d_roofline(dev, reps=10):
     avg_ms = tot_ms / count
     equiv = tot_fl / count / avg_ms / 1e9      # algorithmic TFLOP/s
     achieved = 3.0 * equiv                     # fp16 MFMA TFLOP/s issued
+    sus = sustained_mfma(dev)
     return {"kernel": "conv2d_hs3x3_kernel<0|1|2> (ResNet-34 3x3 stride-1 convs, B=64, 3x256x900; fp32-grade result "
                       "from fp16 hi/lo split operands, 3 MFMA products per multiply-add)",
             "bound": "mfma", "achieved": round(equiv, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(equiv / PEAK_F16_TFLOPS, 4),
             "achieved_issued": round(achieved, 1), "frac_issued": round(achieved / PEAK_F16_TFLOPS, 4),
+            # measured in this run, same box, same clocks: the ceiling the power limit leaves under `peak`
+            "sustained": {"mfma_fp16_tflops_random_operands": sus["random"], "mfma_fp16_tflops_zero_operands": sus["zero"],
+                          "frac_of_peak": round(sus["random"] / PEAK_F16_TFLOPS, 4),
+                          "achieved_issued_over_sustained": round(achieved / sus["random"], 4),
+                          "note": "adx_probe_mfma_fp16: the kernel's inner loop alone (8 LDS operand reads per 12 v_mfma_f32_32x32x16_f16, two "
+                                  "4-wave workgroups per CU, no global memory) -- the fp16 MFMA rate this chip sustains at its power limit; `peak` "
+                                  "is the datasheet figure at the boost clock.  A 3-product launch cannot exceed sustained / 3 algorithmic."},
             "achieved_note": "achieved / frac (the contract figures, SURVEY 8d) = ALGORITHMIC conv flops (2*M*N*K) per launch / "
                              "HIP-event launch time, against the dense fp16 MFMA peak; achieved_issued / frac_issued = the fp16 "
                              "MFMA flops the kernel actually issues (3 x algorithmic: hi*hi + hi*lo + lo*hi) / the same time",
@@ -247,6 +255,28 @@ def conv2d_roofline(dev, reps=10):
             "mfma_gflop_per_launch": round(3 * tot_fl / count / 1e9, 2),
             "algorithmic_mb_per_launch": round(tot_bytes / count / 1e6, 2),
             "hbm_gbs_at_algorithmic_bytes": round(tot_bytes / count / avg_ms / 1e6, 1), "per_shape": per_shape}
+
+
+def sustained_mfma(dev):
+    """What the matrix pipe of THIS chip sustains (adx_probe_mfma_fp16: the 3x3 kernel's inner loop -- 8 LDS operand reads per 12
+    v_mfma_f32_32x32x16_f16 -- with no global traffic, staging or epilogue, two 4-wave workgroups per CU like the kernel), on random
+    and on all-zero operands.  The datasheet peak assumes the boost clock; under matrix load the shader clock settles at the
+    power limit, and how far depends on how much the operands toggle."""
+    import ctypes as C
+    from autonomous_driving_with_diffusion_model_amd import _lib as L
+    out = torch.empty(512 * 256, dtype=torch.float32, device=dev)
+    fl = C.c_double(0.0)
+    res = {}
+    for name in ("random", "zero"):
+        if name == "random":      # fp16 values of both signs in [0.125, 1): every mantissa bit toggles
+            ops_ = ((torch.rand(4096 * 8, device=dev) * 0.875 + 0.125) * (torch.randint(0, 2, (4096 * 8,), device=dev) * 2 - 1)).half()
+        else:
+            ops_ = torch.zeros(4096 * 8, dtype=torch.float16, device=dev)
+        fn = lambda: L.check(L.lib().adx_probe_mfma_fp16(ops_.data_ptr(), out.data_ptr(), 512, 4000, C.byref(fl),  # noqa: E731
+                                                         L.stream_ptr(dev)), "adx_probe_mfma_fp16")
+        ms = time_events(fn, 3, warm=1)
+        res[name] = round(fl.value / ms / 1e9, 1)
+    return res
 
 
 def tconv_roofline(model, dev, reps=20):

@@ -389,6 +389,13 @@ int adx_image_normalize(const uint8_t* frame_hwc, float* out_nchw, int32_t n, in
 int adx_image_augment(uint8_t* frames_hwc, uint8_t* scratch, int32_t n, int32_t h, int32_t w, const float* plan,
                       const uint64_t* seeds, const int32_t* ranges, const float* blur_sigma, int32_t any_blur, adx_stream s);
 
+/* Measurement probe (bench.py's `roofline.sustained`; no reference counterpart): `workgroups` x 4 waves run `iters` trips of
+ * the 3x3 convolution's inner loop -- 8 LDS operand reads per 12 v_mfma_f32_32x32x16_f16 -- on the 64 KB of fp16 operand cells
+ * at `operands` (device memory), with no global traffic, staging or epilogue: the fp16 MFMA rate the chip sustains at its
+ * power limit.  out: workgroups * 256 floats (a checksum, so that nothing is optimised away); *flops (host, optional)
+ * receives the MFMA flops of the launch. */
+int adx_probe_mfma_fp16(const void* operands, float* out, int32_t workgroups, int32_t iters, double* flops, adx_stream s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -200,3 +200,23 @@ def test_other_weight_gradients(cin, cout, k, stride, pad, h, w):
     ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, k, k), dy.double(), stride=stride, padding=pad)
     dw = _ops().conv2d_weight_grad(x.to(DEV), dy.to(DEV), k, stride=stride, pad=pad)
     assert ((dw.double().cpu() - ref).abs().max() / ref.abs().max()).item() < 5e-6
+
+
+def test_mfma_probe_counts_its_flops_and_is_deterministic():
+    """adx_probe_mfma_fp16 (bench.py's `roofline.sustained`): the checksum of a launch is a pure function of the operand cells (the
+    loop is really executed, on the operands given), zero operands give zero, and the reported flops are workgroups x 4 waves x
+    iters x 12 MFMAs x 2 x 32 x 32 x 16."""
+    import ctypes as C
+    from autonomous_driving_with_diffusion_model_amd import _lib as L
+    g = torch.Generator().manual_seed(5)
+    cells = ((torch.rand(4096 * 8, generator=g) * 0.875 + 0.125) * 0.01).half().to(DEV)
+    out = [torch.empty(8 * 256, device=DEV) for _ in range(2)]
+    fl = C.c_double(0.0)
+    for o in out:
+        L.check(L.lib().adx_probe_mfma_fp16(cells.data_ptr(), o.data_ptr(), 8, 64, C.byref(fl), L.stream_ptr(torch.device(DEV))))
+    torch.cuda.synchronize()
+    assert fl.value == 8 * 4 * 64 * 12 * 2 * 32 * 32 * 16
+    assert torch.equal(out[0], out[1]) and out[0].abs().max().item() > 0 and torch.isfinite(out[0]).all()
+    z = torch.zeros(4096 * 8, dtype=torch.float16, device=DEV)
+    L.check(L.lib().adx_probe_mfma_fp16(z.data_ptr(), out[0].data_ptr(), 8, 64, None, L.stream_ptr(torch.device(DEV))))
+    assert out[0].abs().max().item() == 0.0
