@@ -1,5 +1,6 @@
-"""The reference-faithful sampling leg alone (3 warm-up + 20 timed steps), for kernel-level profiling."""
+"""The reference-faithful sampling leg alone (3 warm-up + 20 timed steps; STEPS=<n> runs n), for kernel-level profiling."""
 import contextlib
+import os
 import sys
 import time
 
@@ -30,7 +31,8 @@ ts = list(sch.timesteps)
 trajs = d["init_trajs"].clone()
 trajs[:, 0, :3] = 0
 with torch.no_grad():
-    for i in range(23):
+    n_steps = int(os.environ.get("STEPS", "23"))
+    for i in range(n_steps):
         if i == 3:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -38,4 +40,4 @@ with torch.no_grad():
         out = model(torch.cat([trajs, trajs], 0), d["imgs"], t.reshape(-1), cond=cond)
         trajs = sch.step(out, t, trajs, cfg_scale=bench.FREE_SCALE, zero_first=True).prev_sample
 torch.cuda.synchronize()
-print(f"{(time.perf_counter() - t0) / 20 * 1e3:.3f} ms per faithful step")
+print(f"{(time.perf_counter() - t0) / (n_steps - 3) * 1e3:.3f} ms per faithful step")
