@@ -149,6 +149,10 @@ int conv2d_hs_launch_block_s2(const ConvSpec& c1, const ConvSpec& ds, const floa
 bool conv2d_wgrad_hs_eligible(int Cin, int Cout, int k, int stride, int pad);
 int conv2d_wgrad_hs(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, int stride,
                     const uint32_t* dy_amax, int dy_amax_n, hipStream_t s);
+// conv2d_wgrad_stem_hs.hip: the stem's (7x7 stride 2, 3 -> 64) weight gradient on the fp16 matrix cores; dw must be zero on entry
+bool conv2d_wgrad_stem_hs_eligible(int Cin, int Cout, int k, int stride, int pad);
+int conv2d_wgrad_stem_hs(const float* x, const float* dy, float* dw, int N, int H, int W, const uint32_t* dy_amax, int dy_amax_n,
+                         hipStream_t s);
 inline int conv_out_dim(int h, int k, int s, int p) { return (h + 2 * p - k) / s + 1; }
 int maxpool_launch(const float* x, float* y, int planes, int H, int W, int OH, int OW, hipStream_t s);
 int avgpool_fc_launch(const float* x, const float* fw, const float* fb, float* out, int batch, int C, int HW, int out_dim,

@@ -500,8 +500,10 @@ __global__ void __launch_bounds__(256) stem_pool_bn_bwd_kernel(const uint8_t* __
                                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, double* __restrict__ sums,
                                                                 float* __restrict__ draw, int C, int H, int W, int OH, int OW,
-                                                                double count, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                                double count, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                uint32_t* __restrict__ amax = nullptr, int n_amax = 0) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t mx = 0;        // PASS 1: max |draw| of this workgroup (bit pattern), for the split-fp16 weight gradient's range
   const int pl = blockIdx.x, c = pl % C;
   if (PASS == 1 && blockIdx.x == 0 && blockIdx.y == 0 && dgamma != nullptr)
     for (int k = threadIdx.x; k < C; k += 256) { dbeta[k] = (float)sums[2 * k]; dgamma[k] = (float)sums[2 * k + 1]; }
@@ -543,6 +545,10 @@ __global__ void __launch_bounds__(256) stem_pool_bn_bwd_kernel(const uint8_t* __
           s1 += (double)v * (double)xh;
         }
         o4[q] = ga * rs * (v - m1 - xh * m2);
+        if (PASS == 1 && 4 * j + q < W) {
+          const uint32_t ob = f2u(o4[q]) & 0x7FFFFFFFu;
+          mx = ob > mx ? ob : mx;
+        }
       }
       if (PASS == 1) {
         if (whole) {
@@ -553,6 +559,15 @@ __global__ void __launch_bounds__(256) stem_pool_bn_bwd_kernel(const uint8_t* __
         }
       }
     }
+  }
+  if (PASS == 1 && amax != nullptr) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const uint32_t o = (uint32_t)__shfl_xor((int)mx, off, 64);
+      mx = o > mx ? o : mx;
+    }
+    // one slot per (plane, row band) modulo the table: the slots were cleared by the caller
+    if (lane == 0 && mx != 0) atomicMax(amax + (blockIdx.x * gridDim.y + blockIdx.y) % n_amax, mx);
   }
   if (PASS == 0) {
     __shared__ double red[8];
@@ -781,6 +796,9 @@ int conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int
   }
   if (conv2d_wgrad_hs_eligible(Cin, Cout, k, stride, pad))
     return conv2d_wgrad_hs(x, dy, dw, N, Cin, H, W, Cout, stride, dy_amax, dy_amax_n, s);
+  // the stem: split-fp16 kernel when the gradient's range is known (it is far below fp16's), the exact-fp32 kernel otherwise
+  if (dy_amax != nullptr && conv2d_wgrad_stem_hs_eligible(Cin, Cout, k, stride, pad))
+    return conv2d_wgrad_stem_hs(x, dy, dw, N, H, W, dy_amax, dy_amax_n, s);
   WgradArgs2 a;
   a.x = x; a.dy = dy; a.dw = dw;
   a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.pad = pad;
@@ -1266,11 +1284,16 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
     stem_pool_bn_bwd_kernel<0><<<dim3(batch * 64), dim3(256), 0, s>>>(code, g_cur, st.raw, st.mean, st.rstd, T[L.t_g], T[L.t_b], sums,
                                                                       nullptr, 64, tape->ph, tape->pw, tape->poh, tape->pow_, count,
                                                                       nullptr, nullptr);
+    // the apply pass also leaves max |draw| (atomic maxima over a cleared table): the stem's weight gradient runs on the fp16
+    // matrix cores like the others and needs the gradient's range
+    const bool stem_hs = conv2d_wgrad_stem_hs_eligible(L.cin, L.cout, L.k, L.stride, L.pad);
+    if (stem_hs) ADX_CHECK_HIP(hipMemsetAsync(amax, 0, sizeof(uint32_t) * kAmaxPartials, s));
     stem_pool_bn_bwd_kernel<1><<<dim3(batch * 64, ceil_div(tape->ph, 4)), dim3(256), 0, s>>>(
         code, g_cur, st.raw, st.mean, st.rstd, T[L.t_g], T[L.t_b], sums, draw, 64, tape->ph, tape->pw, tape->poh, tape->pow_, count,
-        G[L.t_g], G[L.t_b]);
+        G[L.t_g], G[L.t_b], stem_hs ? amax : nullptr, (int)kAmaxPartials);
     ADX_LAUNCH_CHECK();
-    rc = conv2d_wgrad(st.x, draw, G[L.t_w], batch, L.cin, st.H, st.W, L.cout, L.k, L.stride, L.pad, s, nullptr, 0, false, wgrad9);
+    rc = conv2d_wgrad(st.x, draw, G[L.t_w], batch, L.cin, st.H, st.W, L.cout, L.k, L.stride, L.pad, s, stem_hs ? amax : nullptr,
+                      stem_hs ? (int)kAmaxPartials : 0, false, wgrad9);
   }
   return rc;
 }

@@ -220,3 +220,27 @@ def test_mfma_probe_counts_its_flops_and_is_deterministic():
     z = torch.zeros(4096 * 8, dtype=torch.float16, device=DEV)
     L.check(L.lib().adx_probe_mfma_fp16(z.data_ptr(), out[0].data_ptr(), 8, 64, None, L.stream_ptr(torch.device(DEV))))
     assert out[0].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("h,w,n,dyscale", [(64, 96, 2, 1e-4), (70, 131, 3, 1.0), (32, 48, 1, 1e-2), (33, 250, 2, 3e-7),
+                                           (256, 900, 2, 1e-6), (130, 450, 5, 1e-3)])
+def test_stem_weight_gradient_split_fp16(h, w, n, dyscale):
+    """The stem's 7x7 stride-2 weight gradient on the fp16 matrix cores (csrc/conv2d_wgrad_stem_hs.hip: output pixels as the
+    reduction axis, stride and tap shift resolved while staging, dy rescaled by its measured range) against an fp64 evaluation;
+    the bar is torch's own fp32 weight gradient on CPU and on the GPU, x1.5 -- odd sizes, several segments and row chunks,
+    gradients far below fp16's range.  ADX_WGRAD_EXACT=1 keeps the exact-fp32 kernel (test_other_weight_gradients runs both
+    through estimate_range)."""
+    g = torch.Generator().manual_seed(h + w)
+    x = torch.randn(n, 3, h, w, generator=g)
+    oh, ow = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+    dy = torch.randn(n, 64, oh, ow, generator=g) * dyscale
+    ref = torch.nn.grad.conv2d_weight(x.double(), (64, 3, 7, 7), dy.double(), stride=2, padding=3)
+    f32 = torch.nn.grad.conv2d_weight(x, (64, 3, 7, 7), dy, stride=2, padding=3)
+    g32 = torch.nn.grad.conv2d_weight(x.to(DEV), (64, 3, 7, 7), dy.to(DEV), stride=2, padding=3).cpu()
+    dw = _ops().conv2d_weight_grad(x.to(DEV), dy.to(DEV), 7, stride=2, pad=3)
+    den = ref.abs().max().item()
+    err = lambda t: (t.double().cpu() - ref).abs().max().item() / den  # noqa: E731
+    assert err(dw) <= BAR * max(err(f32), err(g32)) + 2e-7, (err(dw), err(f32), err(g32))
+    # without a range estimate the exact-fp32 kernel answers: both paths stay alive
+    dwx = _ops().conv2d_weight_grad(x.to(DEV), dy.to(DEV), 7, stride=2, pad=3, estimate_range=False)
+    assert err(dwx) < 5e-6
