@@ -26,6 +26,7 @@
 #include <mutex>
 
 #include "tconv_internal.h"
+#include "tconv_pack.h"
 
 namespace adx {
 
@@ -206,25 +207,7 @@ __global__ void __launch_bounds__(64 * NW) tconv_kernel(const TConvArgs a) {
 }
 
 // weight image: [cout_pad/16][nkb][64 lanes][4]; element j of lane l in block (tap, cb) is
-// W[n = 16*tile + (l & 15)][ci = 16*cb + 4*j + (l >> 4)][tap]  (B operand of 16x16x4, k = l >> 4)
-__global__ void tconv_pack_kernel(const float* __restrict__ w, float* __restrict__ packed, int layout, int flip,
-                                  int taps, int cin, int cout, int ncb, int nkb, size_t total) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int j = idx & 3;
-  const int lane = (idx >> 2) & 63;
-  const size_t blk = idx >> 8;
-  const int kb = blk % nkb;
-  const int t16 = blk / nkb;
-  const int tap = kb / ncb, cb = kb - tap * ncb;
-  const int n = t16 * 16 + (lane & 15);
-  const int ci = cb * 16 + 4 * j + (lane >> 4);
-  float v = 0.f;
-  const int ts = flip ? taps - 1 - tap : tap;
-  if (n < cout && ci < cin)
-    v = layout == 0 ? w[((size_t)n * cin + ci) * taps + ts] : w[((size_t)ci * cout + n) * taps + ts];
-  packed[idx] = v;
-}
+// W[n = 16*tile + (l & 15)][ci = 16*cb + 4*j + (l >> 4)][tap]  (B operand of 16x16x4, k = l >> 4): tconv_pack.hip, kPackExact
 
 constexpr size_t kMaxTconvLds = 132 * 1024;
 
@@ -418,10 +401,11 @@ int tconv_pack(const adx_tconv_desc* d, const float* w, float* packed, hipStream
   const int cin = d->c0 + d->c1;
   const int ncb = round_up(cin, 16) / 16;
   const size_t total = tconv_packed_floats(d);
-  tconv_pack_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
-      w, packed, d->kind == 1 ? 1 - d->w_layout : d->w_layout, d->w_flip, d->taps, cin, d->cout, ncb, d->taps * ncb, total);
-  ADX_LAUNCH_CHECK();
-  return ADX_OK;
+  PackJob j{};
+  j.w = w; j.out = packed; j.total = (uint32_t)total; j.kind = kPackExact;
+  j.layout = d->kind == 1 ? 1 - d->w_layout : d->w_layout; j.flip = d->w_flip; j.taps = d->taps; j.cin = cin; j.cout = d->cout;
+  j.a = ncb; j.b = d->taps * ncb;
+  return pack_submit(j, s);
 }
 
 template <int MF, int NF>

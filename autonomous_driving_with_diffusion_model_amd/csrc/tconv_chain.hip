@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "tconv_chain.h"
+#include "tconv_pack.h"
 
 namespace adx {
 
@@ -416,29 +417,7 @@ extern "C" int adx_debug_chain_trace_clear() {
 // ncell, ci = 8 (kc % ncell) + j], split into hi / lo planes; ncell = padded input channels / 8, a multiple of 4, so a step
 // never straddles taps).  A stage with a 1x1 residual conv stores that conv's steps behind the main reduction's inside
 // every tile (`tile_steps` = both, `step0` = where this conv's steps begin).
-__global__ void chain_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ packed, int layout, int flip, int taps,
-                                  int cin, int cout, int ncell, int nsteps, int tile_steps, int step0, size_t total) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int j = idx & 7;
-  const int ln = (idx >> 3) & 63;
-  const size_t blk = idx >> 9;
-  const int step = blk % nsteps;
-  const int t16 = blk / nsteps;
-  const int kc = 4 * step + (ln >> 4);
-  const int tap = kc / ncell, ci = 8 * (kc - tap * ncell) + j;
-  const int n = t16 * 16 + (ln & 15);
-  float v = 0.f;
-  if (tap < taps && n < cout && ci < cin) {
-    const int ts = flip ? taps - 1 - tap : tap;
-    v = layout == 0 ? w[((size_t)n * cin + ci) * taps + ts] : w[((size_t)ci * cout + n) * taps + ts];
-  }
-  const _Float16 hi = (_Float16)v;
-  const _Float16 lo = (_Float16)((v - (float)hi) * kChLoScale);
-  _Float16* dst = packed + ((size_t)t16 * tile_steps + step0 + step) * 1024 + ln * 8 + j;
-  dst[0] = hi;
-  dst[512] = lo;
-}
+// (tconv_pack.hip, kPackCell)
 
 static int ilog2_exact_ch(int v) {
   int l = 0;
@@ -469,20 +448,19 @@ size_t chain_packed_floats(const adx_tconv_desc* d) {
 int chain_pack(const adx_tconv_desc* d, const float* w, const adx_tconv_desc* r, const float* rw, float* packed, hipStream_t s) {
   const int ns = chain_steps(d), nr = r != nullptr ? chain_steps(r) : 0;
   const int tiles = round_up(d->cout, 16) / 16;
-  {
-    const size_t total = (size_t)tiles * ns * 512;
-    chain_pack_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
-        w, reinterpret_cast<_Float16*>(packed), d->kind == 1 ? 1 - d->w_layout : d->w_layout, d->w_flip, d->taps,
-        d->c0 + d->c1, d->cout, chain_cin_pad(d) / 8, ns, ns + nr, 0, total);
+  PackJob j{};
+  j.w = w; j.out = packed; j.total = (uint32_t)((size_t)tiles * ns * 512); j.kind = kPackCell;
+  j.layout = d->kind == 1 ? 1 - d->w_layout : d->w_layout; j.flip = d->w_flip; j.taps = d->taps; j.cin = d->c0 + d->c1;
+  j.cout = d->cout; j.a = chain_cin_pad(d) / 8; j.b = ns; j.tile_steps = ns + nr; j.step0 = 0;
+  int rc = pack_submit(j, s);
+  if (rc == ADX_OK && r != nullptr) {
+    PackJob q{};
+    q.w = rw; q.out = packed; q.total = (uint32_t)((size_t)tiles * nr * 512); q.kind = kPackCell;
+    q.layout = r->w_layout; q.flip = r->w_flip; q.taps = r->taps; q.cin = r->c0 + r->c1; q.cout = r->cout;
+    q.a = chain_cin_pad(r) / 8; q.b = nr; q.tile_steps = ns + nr; q.step0 = ns;
+    rc = pack_submit(q, s);
   }
-  if (r != nullptr) {
-    const size_t total = (size_t)tiles * nr * 512;
-    chain_pack_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
-        rw, reinterpret_cast<_Float16*>(packed), r->w_layout, r->w_flip, r->taps, r->c0 + r->c1, r->cout,
-        chain_cin_pad(r) / 8, nr, ns + nr, ns, total);
-  }
-  ADX_LAUNCH_CHECK();
-  return ADX_OK;
+  return rc;
 }
 
 int chain_launch(const ChainArgs& ca, int grid, size_t lds_bytes, hipStream_t s) {

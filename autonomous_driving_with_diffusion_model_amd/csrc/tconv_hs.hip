@@ -28,6 +28,7 @@
 
 #define ADX_TCONV_TRACE_TU
 #include "tconv_internal.h"
+#include "tconv_pack.h"
 
 namespace adx {
 
@@ -760,54 +761,9 @@ __global__ void __launch_bounds__(64 * NW) tconv_hs_mixed_kernel(const HsMixed p
 
 // weight image of the short-K variant: [cout_pad32 / 16][nsteps][2 planes][64 lanes][8 halfs]; element j of lane ln at
 // `step` is W[n = 16 tile + (ln & 15)][flattened cell kc = 4 step + (ln >> 4): tap = kc / ncell, ci = 8 (kc % ncell) + j]
-__global__ void tconv_hsd_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ packed, int layout, int flip,
-                                      int taps, int cin, int cout, int ncell, int nsteps, size_t total) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int j = idx & 7;
-  const int ln = (idx >> 3) & 63;
-  const size_t blk = idx >> 9;
-  const int step = blk % nsteps;
-  const int t16 = blk / nsteps;
-  const int kc = 4 * step + (ln >> 4);
-  const int tap = kc / ncell, ci = 8 * (kc - tap * ncell) + j;
-  const int n = t16 * 16 + (ln & 15);
-  float v = 0.f;
-  if (tap < taps && n < cout && ci < cin) {
-    const int ts = flip ? taps - 1 - tap : tap;
-    v = layout == 0 ? w[((size_t)n * cin + ci) * taps + ts] : w[((size_t)ci * cout + n) * taps + ts];
-  }
-  const _Float16 hi = (_Float16)v;
-  const _Float16 lo = (_Float16)((v - (float)hi) * kLoScale);
-  _Float16* dst = packed + blk * 1024 + ln * 8 + j;
-  dst[0] = hi;
-  dst[512] = lo;
-}
-
-// weight image [cout_pad32 / 32][nkb][2 planes][64 lanes][8 halfs]; element j of lane ln in K-step (tap, cb) is
-// W[n = 32 tile + (ln & 31)][ci = 16 cb + 8 (ln >> 5) + j][tap]  (B operand of 32x32x16)
-__global__ void tconv_hs_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ packed, int layout, int flip,
-                                     int taps, int cin, int cout, int ncb, int nkb, size_t total) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;   // one (tile, K-step, lane, j) per thread, both planes
-  if (idx >= total) return;
-  const int j = idx & 7;
-  const int ln = (idx >> 3) & 63;
-  const size_t blk = idx >> 9;
-  const int kb = blk % nkb;
-  const int t32 = blk / nkb;
-  const int tap = kb / ncb, cb = kb - tap * ncb;
-  const int n = t32 * 32 + (ln & 31);
-  const int ci = cb * 16 + 8 * (ln >> 5) + j;
-  float v = 0.f;
-  const int ts = flip ? taps - 1 - tap : tap;
-  if (n < cout && ci < cin)
-    v = layout == 0 ? w[((size_t)n * cin + ci) * taps + ts] : w[((size_t)ci * cout + n) * taps + ts];
-  const _Float16 hi = (_Float16)v;
-  const _Float16 lo = (_Float16)((v - (float)hi) * kLoScale);
-  _Float16* dst = packed + blk * 1024 + ln * 8 + j;
-  dst[0] = hi;
-  dst[512] = lo;
-}
+// (tconv_pack.hip, kPackCell); weight image of the K-split kernel: [cout_pad32 / 32][nkb][2 planes][64 lanes][8 halfs]; element j
+// of lane ln in K-step (tap, cb) is W[n = 32 tile + (ln & 31)][ci = 16 cb + 8 (ln >> 5) + j][tap]  (B operand of 32x32x16;
+// kPackHs)
 
 static int ilog2_exact_hs(int v) {
   int l = 0;
@@ -869,22 +825,22 @@ int tconv_hs_pack(const adx_tconv_desc* d, const float* w, float* packed, hipStr
     int ns, kc, lg;
     if (hsd_enabled() && hsd_geometry(d, &ns, &kc, &lg)) {
       const size_t total = (size_t)(round_up(d->cout, 32) / 16) * ns * 512;
-      tconv_hsd_pack_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
-          w, reinterpret_cast<_Float16*>(packed), d->kind == 1 ? 1 - d->w_layout : d->w_layout, d->w_flip, d->taps,
-          d->c0 + d->c1, d->cout, 1 << lg, ns, total);
-      ADX_LAUNCH_CHECK();
-      return ADX_OK;
+      PackJob j{};
+      j.w = w; j.out = packed; j.total = (uint32_t)total; j.kind = kPackCell;
+      j.layout = d->kind == 1 ? 1 - d->w_layout : d->w_layout; j.flip = d->w_flip; j.taps = d->taps; j.cin = d->c0 + d->c1;
+      j.cout = d->cout; j.a = 1 << lg; j.b = ns; j.tile_steps = ns; j.step0 = 0;
+      return pack_submit(j, s);
     }
   }
   const int cin = d->c0 + d->c1;
   const int ncb = round_up(cin, 16) / 16;
   const int nkb = d->taps * ncb;
   const size_t total = (size_t)(round_up(d->cout, 32) / 32) * nkb * 512;
-  tconv_hs_pack_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
-      w, reinterpret_cast<_Float16*>(packed), d->kind == 1 ? 1 - d->w_layout : d->w_layout, d->w_flip, d->taps, cin,
-      d->cout, ncb, nkb, total);
-  ADX_LAUNCH_CHECK();
-  return ADX_OK;
+  PackJob j{};
+  j.w = w; j.out = packed; j.total = (uint32_t)total; j.kind = kPackHs;
+  j.layout = d->kind == 1 ? 1 - d->w_layout : d->w_layout; j.flip = d->w_flip; j.taps = d->taps; j.cin = cin; j.cout = d->cout;
+  j.a = ncb; j.b = nkb;
+  return pack_submit(j, s);
 }
 
 struct HsTile {

@@ -16,6 +16,7 @@
 
 #include "batch_ops.h"
 #include "unet_internal.h"
+#include "tconv_pack.h"
 
 namespace adx {
 
@@ -515,6 +516,7 @@ int adx_unet_pack(adx_unet* u, const float* const* P, int32_t n_params, const fl
   float* base = (float*)packed;
   const int dim = u->cfg.dim;
   int rc = ADX_OK;
+  pack_queue_open();        // every weight image of the stack in one table-driven launch (tconv_pack.h), flushed below
   for (auto& b : u->blocks) {
     if (rc == ADX_OK) rc = pack_layer(b.a, P, base, s);
     if (rc == ADX_OK) rc = pack_layer(b.b, P, base, s, (b.has_r && b.b.chained) ? &b.r : nullptr);
@@ -544,6 +546,10 @@ int adx_unet_pack(adx_unet* u, const float* const* P, int32_t n_params, const fl
     }
   if (rc == ADX_OK) rc = batch_copy_flush(s);      // the fused Linear below is packed from the concatenated copy
   if (rc == ADX_OK) rc = tconv_pack(&u->tlin.d, base + u->o_tlin_raw, base + u->tlin.o_w, s);
+  {
+    const int rp = pack_flush(s);                  // behind the copies above (the fused Linear reads one); always closes the queue
+    if (rc == ADX_OK) rc = rp;
+  }
   if (rc == ADX_OK) rc = copy_f(base + u->o_freqs, freqs, dim / 2, s);
   if (rc == ADX_OK) rc = copy_f(base + u->o_t1w, P[u->p_t1w], (size_t)4 * dim * dim, s);
   if (rc == ADX_OK) rc = copy_f(base + u->o_t1b, P[u->p_t1b], 4 * dim, s);

@@ -11,9 +11,11 @@
 // inputs, skips) are accumulated through the conv epilogue's `res` input, so no extra passes.
 #include <algorithm>
 #include <unordered_map>
+#include <vector>
 
 #include "batch_ops.h"
 #include "unet_internal.h"
+#include "tconv_pack.h"
 
 namespace adx {
 
@@ -105,9 +107,15 @@ size_t adx_unet_train_workspace_bytes(const adx_unet* u, int32_t rows) {
   f += align64t((size_t)rows * u->sum_c) * 2 + align64t((size_t)rows * 2 * u->cfg.dim) * 2 + align64t((size_t)rows * u->cfg.dim) * 2;
   f += n_conv * align64t((size_t)rows * 8 * 2);                       // GN stats
   f += align64t((size_t)u->sum_c * 2 * u->cfg.dim) + 2 * align64t(tconv_packed_floats(&u->blocks[u->blocks.size() / 2].a.d) * 2);
-  size_t maxw = 0;                                                      // dgrad weight image scratch
-  for (auto& b : u->blocks) maxw = std::max(maxw, tconv_packed_floats(&b.a.d));
-  f += align64t(maxw * 2);
+  // data-gradient weight images: one slot per conv (they are all re-laid in ONE launch before the backward loop); a gradient's
+  // image has the roles of c0 + c1 and cout swapped, which the padded sizes bound by the forward image's x 2
+  size_t wall = 0;
+  auto img = [&](const adx_tconv_desc& d) { wall += align64t(tconv_packed_floats(&d) * 2); };
+  for (auto& b : u->blocks) { img(b.a.d); img(b.b.d); if (b.has_r) img(b.r.d); }
+  for (auto& l : u->downs) img(l.d);
+  for (auto& l : u->ups) img(l.d);
+  img(u->head0.d); img(u->head1.d);
+  f += wall + align64t((size_t)u->sum_c * 2 * u->cfg.dim * 2);
   return f * sizeof(float);
 }
 
@@ -274,10 +282,46 @@ int adx_unet_backward(adx_unet* u, const void* packed, void* workspace, size_t w
   float* dtb = ws.take((size_t)rows * u->sum_c);
   float* dc_buf = ws.take(amax);
   float* cat_buf = ws.take(amax);
-  size_t maxw = 0;
-  for (auto& b : u->blocks) maxw = std::max(maxw, tconv_packed_floats(&b.a.d));
-  float* wscratch = ws.take(maxw);
-  ADX_REQUIRE(ws.ok, "adx_unet_backward: workspace of %zu bytes too small", workspace_bytes);
+  // the data-gradient conv of a launch: the same conv with the channel roles swapped, on the exact-fp32 kernel
+  auto dgrad_desc = [](const adx_tconv_desc& d) {
+    adx_tconv_desc g{};
+    g.groups = 0; g.eps = d.eps; g.c0 = d.cout; g.c1 = 0; g.cout = d.c0 + d.c1; g.lin = d.lout; g.lout = d.lin; g.taps = d.taps;
+    g.lin_valid = d.lout_valid; g.lout_valid = d.lin_valid;
+    g.exact = 1;   // gradients span many binades (1e-9 .. 1): keep them off the fp16 operand path
+    if (d.kind == 0 && d.stride == 1) {
+      g.kind = 0; g.stride = 1; g.pad = d.taps - 1 - d.pad; g.w_layout = 1; g.w_flip = 1;
+    } else if (d.kind == 0) {       // strided conv -> transposed conv with the conv's own weight
+      g.kind = 1; g.stride = d.stride; g.pad = d.pad; g.w_layout = 0; g.w_flip = 0;
+    } else {                        // transposed conv -> strided conv with the transposed conv's own weight
+      g.kind = 0; g.stride = d.stride; g.pad = d.pad; g.w_layout = 0; g.w_flip = 0;
+    }
+    return g;
+  };
+  // every data-gradient weight image in its own slot, all of them re-laid by ONE launch here (they were ~55 launches inside the
+  // loop, each in front of the conv that reads it)
+  std::vector<float*> gimg(tape->ops.size(), nullptr);
+  adx_tconv_desc g_tlin{};
+  g_tlin.kind = 0; g_tlin.taps = 1; g_tlin.stride = 1; g_tlin.pad = 0; g_tlin.c0 = u->sum_c; g_tlin.c1 = 0; g_tlin.cout = 2 * dim;
+  g_tlin.lin = 1; g_tlin.lout = 1; g_tlin.groups = 0; g_tlin.eps = 1e-5f; g_tlin.w_layout = 1; g_tlin.w_flip = 0; g_tlin.exact = 1;
+  float* tlin_img = nullptr;
+  {
+    pack_queue_open();
+    int rq = ADX_OK;
+    for (size_t oi = 0; oi < tape->ops.size() && rq == ADX_OK; ++oi) {
+      const TapeOp& op = tape->ops[oi];
+      if (!op.need_dx) continue;
+      const adx_tconv_desc g = dgrad_desc(op.L->d);
+      gimg[oi] = ws.take(tconv_packed_floats(&g));
+      if (!ws.ok) break;
+      rq = tconv_pack(&g, params[op.L->p_w], gimg[oi], s);
+    }
+    tlin_img = ws.take(tconv_packed_floats(&g_tlin));
+    if (ws.ok && rq == ADX_OK) rq = tconv_pack(&g_tlin, base + u->o_tlin_raw, tlin_img, s);
+    const int rf = pack_flush(s);
+    ADX_REQUIRE(ws.ok, "adx_unet_backward: workspace of %zu bytes too small", workspace_bytes);
+    if (rq != ADX_OK) return rq;
+    if (rf != ADX_OK) return rf;
+  }
 
   // every small gradient tensor that is accumulated atomically (conv weights, GroupNorm affine, conv bias) is zeroed
   // here in a handful of launches instead of one memset each inside the loop
@@ -367,23 +411,11 @@ int adx_unet_backward(adx_unet* u, const void* packed, void* workspace, size_t w
     }
     // ---- data gradient
     if (!op.need_dx) continue;
-    adx_tconv_desc g{};
-    g.groups = 0; g.eps = d.eps; g.c0 = d.cout; g.c1 = 0; g.cout = cin; g.lin = d.lout; g.lout = d.lin; g.taps = d.taps;
-    g.lin_valid = d.lout_valid; g.lout_valid = d.lin_valid;
-    g.exact = 1;   // gradients span many binades (1e-9 .. 1): keep them off the fp16 operand path
-    if (d.kind == 0 && d.stride == 1) {
-      g.kind = 0; g.stride = 1; g.pad = d.taps - 1 - d.pad; g.w_layout = 1; g.w_flip = 1;
-    } else if (d.kind == 0) {       // strided conv -> transposed conv with the conv's own weight
-      g.kind = 1; g.stride = d.stride; g.pad = d.pad; g.w_layout = 0; g.w_flip = 0;
-    } else {                        // transposed conv -> strided conv with the transposed conv's own weight
-      g.kind = 0; g.stride = d.stride; g.pad = d.pad; g.w_layout = 0; g.w_flip = 0;
-    }
-    rc = tconv_pack(&g, params[L.p_w], wscratch, s);
-    if (rc != ADX_OK) break;
+    const adx_tconv_desc g = dgrad_desc(d);        // its weight image was re-laid before the loop
     adx_tconv_io gio;
     memset(&gio, 0, sizeof(gio));
     gio.x0 = dc; gio.x0_sb = (int64_t)d.cout * d.lout; gio.x0_sc = d.lout; gio.x0_sl = 1;
-    gio.packed_w = wscratch;
+    gio.packed_w = gimg[oi];
     gio.batch = rows;
     const int64_t xsb = (int64_t)cin * d.lin;
     if (!op.has_x1) {
@@ -431,15 +463,11 @@ int adx_unet_backward(adx_unet* u, const void* packed, void* workspace, size_t w
     }
     rc = batch_copy_flush(s);
     if (rc != ADX_OK) return rc;
-    adx_tconv_desc g{};
-    g.kind = 0; g.taps = 1; g.stride = 1; g.pad = 0; g.c0 = u->sum_c; g.c1 = 0; g.cout = 2 * dim; g.lin = 1; g.lout = 1;
-    g.groups = 0; g.eps = 1e-5f; g.w_layout = 1; g.w_flip = 0; g.exact = 1;
-    rc = tconv_pack(&g, base + u->o_tlin_raw, wscratch, s);
-    if (rc != ADX_OK) return rc;
+    const adx_tconv_desc g = g_tlin;               // image re-laid before the loop, with the others
     adx_tconv_io gio;
     memset(&gio, 0, sizeof(gio));
     gio.x0 = dtb; gio.x0_sb = u->sum_c; gio.x0_sc = 1; gio.x0_sl = 0;
-    gio.packed_w = wscratch;
+    gio.packed_w = tlin_img;
     gio.y = dmc; gio.y_sb = 2 * dim; gio.y_sc = 1; gio.y_sl = 0;
     gio.batch = rows;
     rc = tconv_forward(&g, &gio, s);
