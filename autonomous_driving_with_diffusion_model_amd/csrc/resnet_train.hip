@@ -501,10 +501,43 @@ __global__ void __launch_bounds__(256) stem_pool_bn_bwd_kernel(const uint8_t* __
                                                                 const float* __restrict__ beta, double* __restrict__ sums,
                                                                 float* __restrict__ draw, int C, int H, int W, int OH, int OW,
                                                                 double count, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                uint32_t* __restrict__ amax = nullptr, int n_amax = 0) {
+                                                                uint32_t* __restrict__ amax = nullptr, int n_amax = 0,
+                                                                const float* __restrict__ pooled = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t mx = 0;        // PASS 1: max |draw| of this workgroup (bit pattern), for the split-fp16 weight gradient's range
   const int pl = blockIdx.x, c = pl % C;
+  if (PASS == 0 && pooled != nullptr && fabsf(gamma[c]) >= 1e-12f) {
+    // The sums from the POOLED tensors alone (472 MB instead of the 944 MB conv output + codes + gathers): d(stem map) is the
+    // pooled gradient scattered to each window's arg-max position, so sum dz = sum over the windows whose maximum passed the ReLU
+    // of their gradient, and sum dz xhat = the same sum weighted with xhat AT the arg-max -- which the pooled value itself gives
+    // back: pooled = gamma xhat + beta there (> 0).  (gamma ~ 0 would lose xhat: such a channel takes the pass below.)
+    const float ga = gamma[c], be = beta[c], inv = 1.f / ga;
+    const size_t n = (size_t)OH * OW;
+    const float* gp = dpool + (size_t)pl * n;
+    const float* pp = pooled + (size_t)pl * n;
+    double s0 = 0.0, s1 = 0.0;
+    if ((n & 3) == 0 && (((size_t)gp | (size_t)pp) & 15) == 0) {
+      for (size_t i = threadIdx.x; 4 * i < n; i += 256) {
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(gp + 4 * i), a4 = *reinterpret_cast<const f32x4*>(pp + 4 * i);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (a4[q] > 0.f) { s0 += g4[q]; s1 += (double)g4[q] * (double)((a4[q] - be) * inv); }
+      }
+    } else {
+      for (size_t i = threadIdx.x; i < n; i += 256)
+        if (pp[i] > 0.f) { s0 += gp[i]; s1 += (double)gp[i] * (double)((pp[i] - be) * inv); }
+    }
+    __shared__ double redp[8];
+    s0 = wave_sum_d(s0);
+    s1 = wave_sum_d(s1);
+    if (lane == 0) { redp[wave * 2] = s0; redp[wave * 2 + 1] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      atomicAdd(sums + 2 * c, (redp[0] + redp[2]) + (redp[4] + redp[6]));
+      atomicAdd(sums + 2 * c + 1, (redp[1] + redp[3]) + (redp[5] + redp[7]));
+    }
+    return;
+  }
   if (PASS == 1 && blockIdx.x == 0 && blockIdx.y == 0 && dgamma != nullptr)
     for (int k = threadIdx.x; k < C; k += 256) { dbeta[k] = (float)sums[2 * k]; dgamma[k] = (float)sums[2 * k + 1]; }
   const uint8_t* cp = code + (size_t)pl * OH * OW;
@@ -1283,7 +1316,7 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
     const double count = (double)batch * st.OH * st.OW;
     stem_pool_bn_bwd_kernel<0><<<dim3(batch * 64), dim3(256), 0, s>>>(code, g_cur, st.raw, st.mean, st.rstd, T[L.t_g], T[L.t_b], sums,
                                                                       nullptr, 64, tape->ph, tape->pw, tape->poh, tape->pow_, count,
-                                                                      nullptr, nullptr);
+                                                                      nullptr, nullptr, nullptr, 0, tape->pool_out);
     // the apply pass also leaves max |draw| (atomic maxima over a cleared table): the stem's weight gradient runs on the fp16
     // matrix cores like the others and needs the gradient's range
     const bool stem_hs = conv2d_wgrad_stem_hs_eligible(L.cin, L.cout, L.k, L.stride, L.pad);
