@@ -531,12 +531,6 @@ int adx_conv2d_forward_cells(const adx_conv2d_desc* d, const void* x, const floa
                            (hipStream_t)stream, nullptr, 0, nullptr, 0, nullptr, fmt);
 }
 
-// conv1 3x3 stride 2 on the split-fp16 kernel + a 1x1 stride-2 downsample of the same shape: one fused launch
-static bool resnet_fuses_ds(const ConvSpec& c1, const ConvSpec& ds) {
-  return conv2d_hs_eligible(c1) && c1.k == 3 && c1.stride == 2 && c1.pad == 1 && ds.k == 1 && ds.stride == 2 && ds.pad == 0 &&
-         ds.cin == c1.cin && ds.cout == c1.cout;
-}
-
 int adx_resnet_create(int32_t out_dim, adx_resnet** out) {
   ADX_REQUIRE(out != nullptr && out_dim >= 1 && out_dim <= 4096, "adx_resnet_create: bad argument");
   adx_resnet* r = new adx_resnet();

@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
   if (tid < 2 * kHsCout) {
     const int c = cout0 + (tid & (kHsCout - 1));
     ss[tid] = a.scale == nullptr ? (tid < kHsCout ? 1.f : 0.f) : (tid < kHsCout ? a.scale[c] : a.shift[c]);
-    if (DS) ss[2 * kHsCout + tid] = tid < kHsCout ? a.scale_ds[c] : a.shift_ds[c];
+    if (DS) ss[2 * kHsCout + tid] = a.scale_ds == nullptr ? (tid < kHsCout ? 1.f : 0.f) : (tid < kHsCout ? a.scale_ds[c] : a.shift_ds[c]);
   }
 
   // optional dynamic range: scale x so that max|x| lands in [2^14, 2^15), undone exactly in the epilogue
@@ -1487,14 +1487,15 @@ int conv2d_hs_stem_pool(const ConvSpec& L, const float* x, const float* w, const
 
 int conv2d_hs_launch_block_s2(const ConvSpec& c1, const ConvSpec& ds, const float* x, const float* w1, const float* scale1,
                               const float* shift1, float* y1, const float* wd, const float* scaled, const float* shiftd,
-                              float* yd, int N, int H, int W, hipStream_t s, int x_cells, int y_cells) {
-  ADX_REQUIRE(x && w1 && scale1 && shift1 && y1 && wd && scaled && shiftd && yd, "conv2d_hs block launch: null pointer");
+                              float* yd, int N, int H, int W, hipStream_t s, int x_cells, int y_cells, int relu) {
+  ADX_REQUIRE(x && w1 && y1 && wd && yd && (scale1 != nullptr) == (shift1 != nullptr) && (scaled != nullptr) == (shiftd != nullptr),
+              "conv2d_hs block launch: null pointer");
   Conv2dArgs a{};
   a.x = x; a.w = w1; a.scale = scale1; a.shift = shift1; a.res = nullptr; a.y = y1; a.x_amax = nullptr; a.x_amax_n = 0;
   a.w_ds = wd; a.scale_ds = scaled; a.shift_ds = shiftd; a.y_ds = yd;
   a.N = N; a.Cin = c1.cin; a.H = H; a.W = W; a.Cout = c1.cout;
   a.OH = conv_out_dim(H, 3, 2, 1); a.OW = conv_out_dim(W, 3, 2, 1);
-  a.KH = 3; a.KW = 3; a.stride = 2; a.pad = 1; a.relu = 1;
+  a.KH = 3; a.KW = 3; a.stride = 2; a.pad = 1; a.relu = relu;
   a.cin_pad = c1.cin_pad; a.cc = c1.cc;
   a.x_cells = x_cells;
   a.y_cells = y_cells;

@@ -142,9 +142,15 @@ int conv2d_hs_stem_pool(const ConvSpec& L, const float* x, const float* w, const
                         const float* mean = nullptr, const float* stdv = nullptr, int y_cells = 0);      // y_cells: pooled as a cell tensor
 // conv1 (3x3 stride 2, +BN+ReLU) and the block's downsample (1x1 stride 2, +BN) in one pass over x; both must be
 // conv2d_hs_eligible (the downsample's weights packed with conv2d_hs_pack_ds)
+// scale / shift pairs may be null (identity: the training forward wants both raw conv outputs); relu applies to conv1 only
 int conv2d_hs_launch_block_s2(const ConvSpec& c1, const ConvSpec& ds, const float* x, const float* w1, const float* scale1,
                               const float* shift1, float* y1, const float* wd, const float* scaled, const float* shiftd,
-                              float* yd, int N, int H, int W, hipStream_t s, int x_cells = 0, int y_cells = 0);   // x / both outputs in the cell layout
+                              float* yd, int N, int H, int W, hipStream_t s, int x_cells = 0, int y_cells = 0, int relu = 1);   // x / both outputs in the cell layout
+// conv1 3x3 stride 2 on the split-fp16 kernel + a 1x1 stride-2 downsample of the same shape: one fused launch (conv2d.hip)
+inline bool resnet_fuses_ds(const ConvSpec& c1, const ConvSpec& ds) {
+  return conv2d_hs_eligible(c1) && c1.k == 3 && c1.stride == 2 && c1.pad == 1 && ds.k == 1 && ds.stride == 2 && ds.pad == 0 &&
+         ds.cin == c1.cin && ds.cout == c1.cout;
+}
 // conv2d_wgrad_hs.hip: weight gradient of the 3x3 convs on the fp16 matrix cores; dw must be zero on entry
 bool conv2d_wgrad_hs_eligible(int Cin, int Cout, int k, int stride, int pad);
 int conv2d_wgrad_hs(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, int stride,

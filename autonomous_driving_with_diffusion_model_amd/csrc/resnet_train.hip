@@ -1020,7 +1020,8 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
   {
     std::vector<HsPackJob> jobs;
     for (const ConvSpec& L : r->convs) {
-      if (conv2d_hs_pack_batchable(L, 0)) {
+      // (a downsample conv that rides on its block's stride-2 conv1 -- one fused launch below -- takes that kernel's image)
+      if (conv2d_hs_pack_batchable(L, 0) || (L.fuse_with >= 0 && resnet_fuses_ds(r->convs[L.fuse_with], L))) {
         jobs.push_back(HsPackJob{T[L.t_w], base + L.o_w, L.cout, L.cin_pad, L.cin, L.k * L.k, 0});
       } else {
         int rc = conv2d_pack_spec(L, T[L.t_w], base + L.o_w, 0, s);
@@ -1045,17 +1046,20 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
   tape->stats_part = stats_part;
   int rc = ADX_OK;
   auto conv_bn = [&](const ConvSpec& L, const float* x, int H, int W, const float* identity, int relu,
-                     bool apply = true) -> float* {
+                     bool apply = true, float* raw_done = nullptr) -> float* {
     adx_resnet_tape::Rec rec;
     rec.L = &L; rec.x = x; rec.H = H; rec.W = W; rec.relu = relu; rec.identity = identity;
     rec.OH = conv_out_dim(H, L.k, L.stride, L.pad); rec.OW = conv_out_dim(W, L.k, L.stride, L.pad);
     const size_t n = (size_t)batch * L.cout * rec.OH * rec.OW;
     // apply == false (the stem): the post-BN map is never formed, so it gets no storage either (0.94 GB at B = 64)
-    rec.raw = ws.take(n); rec.out = apply ? ws.take(n) : nullptr; rec.mean = ws.take(L.cout); rec.rstd = ws.take(L.cout);
+    // raw_done: the conv output already sits there (the fused stride-2 launch of a downsample block)
+    rec.raw = raw_done != nullptr ? raw_done : ws.take(n);
+    rec.out = apply ? ws.take(n) : nullptr; rec.mean = ws.take(L.cout); rec.rstd = ws.take(L.cout);
     if (!ws.ok || rc != ADX_OK) { tape->recs.push_back(rec); return rec.out; }
     int stats_p = 0;     // > 0: the conv's own epilogue left per-workgroup partial sums (the 3x3 stride-1 layers)
-    rc = conv2d_launch_raw(L, x, base + L.o_w, nullptr, nullptr, nullptr, rec.raw, batch, H, W, 0, s, nullptr, 0, stats_part,
-                           kStatsPartFloats, &stats_p);
+    if (raw_done == nullptr)
+      rc = conv2d_launch_raw(L, x, base + L.o_w, nullptr, nullptr, nullptr, rec.raw, batch, H, W, 0, s, nullptr, 0, stats_part,
+                             kStatsPartFloats, &stats_p);
     if (rc != ADX_OK) { tape->recs.push_back(rec); return rec.out; }
     const int HW = rec.OH * rec.OW;
     double* sums = sums_all + (size_t)(&L - r->convs.data()) * 2 * 512;
@@ -1103,10 +1107,25 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
   for (size_t b = 0; b < r->block_has_ds.size(); ++b) {
     const ConvSpec& c1 = r->convs[ci++];
     const ConvSpec& c2 = r->convs[ci++];
-    float* o1 = conv_bn(c1, cur, H, W, nullptr, 1);
     const int OH = conv_out_dim(H, 3, c1.stride, 1), OW = conv_out_dim(W, 3, c1.stride, 1);
+    float* o1;
     const float* identity = cur;
-    if (r->block_has_ds[b]) identity = conv_bn(r->convs[ci++], cur, H, W, nullptr, 0);
+    if (r->block_has_ds[b] && resnet_fuses_ds(c1, r->convs[ci])) {
+      // conv1 (3x3 stride 2) and the downsample (1x1 stride 2) read the same pixels: ONE launch leaves both raw outputs (the
+      // downsample alone was a launch of the exact-fp32 1x1 kernel: 0.12 ms x 3 per step)
+      const ConvSpec& ds = r->convs[ci++];
+      const size_t n = (size_t)batch * c1.cout * OH * OW;
+      float* raw1 = ws.take(n);
+      float* rawd = ws.take(n);
+      if (ws.ok && rc == ADX_OK)
+        rc = conv2d_hs_launch_block_s2(c1, ds, cur, base + c1.o_w, nullptr, nullptr, raw1, base + ds.o_w, nullptr, nullptr, rawd,
+                                       batch, H, W, s, 0, 0, 0);
+      o1 = conv_bn(c1, cur, H, W, nullptr, 1, true, raw1);
+      identity = conv_bn(ds, cur, H, W, nullptr, 0, true, rawd);
+    } else {
+      o1 = conv_bn(c1, cur, H, W, nullptr, 1);
+      if (r->block_has_ds[b]) identity = conv_bn(r->convs[ci++], cur, H, W, nullptr, 0);
+    }
     cur = conv_bn(c2, o1, OH, OW, identity, 1);
     H = OH; W = OW;
   }
