@@ -353,13 +353,11 @@ __global__ void __launch_bounds__(256) dilate2_kernel(const float* __restrict__ 
 // 3x256x900) is then never written nor re-read: bn_apply (read + write), maxpool (read) and a separate arg-max pass of the
 // backward (read) collapse into one read.  Same values as the separate passes: v = relu(fma(raw, scale, shift)) as bn_apply forms it,
 // the maximum with torch's NaN rule as maxpool_kernel, the code = the first tap that attains the maximum (torch's tie rule).
-__global__ void __launch_bounds__(256) bn_relu_pool_code_kernel(const float* __restrict__ raw, const float* __restrict__ scale,
-                                                                 const float* __restrict__ shift, float* __restrict__ pooled,
-                                                                 uint8_t* __restrict__ code, int C, int H, int W, int OH, int OW) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int oy = blockIdx.y * 4 + wave;
-  const int pl = blockIdx.x;
-  if (oy >= OH) return;
+constexpr int kPoolRowsPerWave = 4;       // pooled rows a wave produces one after the other (fewer, longer workgroups)
+__device__ __forceinline__ void bn_relu_pool_code_row(const float* __restrict__ raw, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, float* __restrict__ pooled,
+                                                      uint8_t* __restrict__ code, int C, int H, int W, int OH, int OW, int pl, int oy,
+                                                      int lane) {
   const float sc = scale[pl % C], sh = shift[pl % C];
   const float* src = raw + (size_t)pl * H * W;
   float* dst = pooled + ((size_t)pl * OH + oy) * OW;
@@ -450,6 +448,16 @@ __global__ void __launch_bounds__(256) bn_relu_pool_code_kernel(const float* __r
   }
 }
 
+__global__ void __launch_bounds__(256) bn_relu_pool_code_kernel(const float* __restrict__ raw, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, float* __restrict__ pooled,
+                                                                 uint8_t* __restrict__ code, int C, int H, int W, int OH, int OW) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int rr = 0; rr < kPoolRowsPerWave; ++rr) {
+    const int oy = (blockIdx.y * kPoolRowsPerWave + rr) * 4 + wave;
+    if (oy < OH) bn_relu_pool_code_row(raw, scale, shift, pooled, code, C, H, W, OH, OW, blockIdx.x, oy, lane);
+  }
+}
+
 // d(pool input) of the 4 consecutive pixels 4j .. 4j+3 of input row iy: their windows lie in output columns 2j, 2j+1, 2j+2,
 // so 3 codes + 3 gradients per window row serve all four (cp / gp: the plane's codes and pooled-map gradient)
 __device__ __forceinline__ void maxpool_bwd_gather4(const uint8_t* __restrict__ cp, const float* __restrict__ gp, int iy, int j,
@@ -494,6 +502,7 @@ __device__ __forceinline__ void maxpool_bwd_gather4(const uint8_t* __restrict__ 
 // write and two reads less).  PASS 0 = channel_sums_kernel<1> with relu_mask 2 (one workgroup per plane, one fp64 atomic
 // pair per plane); PASS 1 = bn_bwd_apply (one wave per input row): draw = gamma rstd (dz - m1 - xhat m2), and the affine
 // parameters' gradients (the finished sums) by workgroup (0, 0).  Same arithmetic as the separate passes.
+constexpr int kStemBwdRows = 4;
 template <int PASS>
 __global__ void __launch_bounds__(256) stem_pool_bn_bwd_kernel(const uint8_t* __restrict__ code, const float* __restrict__ dpool,
                                                                 const float* __restrict__ raw, const float* __restrict__ mean,
@@ -548,8 +557,10 @@ __global__ void __launch_bounds__(256) stem_pool_bn_bwd_kernel(const uint8_t* __
   float m1 = 0.f, m2 = 0.f;
   if (PASS == 1) { m1 = (float)(sums[2 * c] / count); m2 = (float)(sums[2 * c + 1] / count); }
   double s0 = 0.0, s1 = 0.0;
-  const int row0 = PASS == 0 ? wave : blockIdx.y * 4 + wave, row_step = PASS == 0 ? 4 : H;
-  for (int iy = row0; iy < H; iy += row_step) {
+  // PASS 1: a wave applies kStemBwdRows input rows one after the other (rows 4 apart: the workgroup's waves stay on neighbouring rows)
+  const int row0 = PASS == 0 ? wave : blockIdx.y * 4 * kStemBwdRows + wave;
+  const int row_end = PASS == 0 ? H : min(H, (int)(blockIdx.y + 1) * 4 * kStemBwdRows);
+  for (int iy = row0; iy < row_end; iy += 4) {
     const float* rrow = raw + ((size_t)pl * H + iy) * W;
     float* drow = PASS == 1 ? draw + ((size_t)pl * H + iy) * W : nullptr;
     for (int j = lane; 4 * j < W; j += 64) {
@@ -1097,7 +1108,7 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
   float* pooled = ws.take((size_t)batch * 64 * h2 * w2);
   uint8_t* pcode = reinterpret_cast<uint8_t*>(ws.take(((size_t)batch * 64 * h2 * w2 + 3) / 4));
   if (ws.ok && rc == ADX_OK) {
-    bn_relu_pool_code_kernel<<<dim3(batch * 64, ceil_div(h2, 4)), dim3(256), 0, s>>>(tape->recs[0].raw, scale, shift, pooled, pcode,
+    bn_relu_pool_code_kernel<<<dim3(batch * 64, ceil_div(h2, 4 * kPoolRowsPerWave)), dim3(256), 0, s>>>(tape->recs[0].raw, scale, shift, pooled, pcode,
                                                                                  64, h1, w1, h2, w2);
   }
   tape->pool_in = stem; tape->pool_out = pooled; tape->ph = h1; tape->pw = w1; tape->poh = h2; tape->pow_ = w2;
@@ -1340,7 +1351,7 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
     // matrix cores like the others and needs the gradient's range
     const bool stem_hs = conv2d_wgrad_stem_hs_eligible(L.cin, L.cout, L.k, L.stride, L.pad);
     if (stem_hs) ADX_CHECK_HIP(hipMemsetAsync(amax, 0, sizeof(uint32_t) * kAmaxPartials, s));
-    stem_pool_bn_bwd_kernel<1><<<dim3(batch * 64, ceil_div(tape->ph, 4)), dim3(256), 0, s>>>(
+    stem_pool_bn_bwd_kernel<1><<<dim3(batch * 64, ceil_div(tape->ph, 4 * kStemBwdRows)), dim3(256), 0, s>>>(
         code, g_cur, st.raw, st.mean, st.rstd, T[L.t_g], T[L.t_b], sums, draw, 64, tape->ph, tape->pw, tape->poh, tape->pow_, count,
         G[L.t_g], G[L.t_b], stem_hs ? amax : nullptr, (int)kAmaxPartials);
     ADX_LAUNCH_CHECK();
