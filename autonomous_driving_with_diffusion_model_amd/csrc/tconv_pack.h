@@ -28,5 +28,15 @@ struct PackJob {
 void pack_queue_open();
 int pack_submit(const PackJob& job, hipStream_t s);
 int pack_flush(hipStream_t s);       // closes the queue
+void pack_queue_abandon();           // closes the queue and drops what it holds
+
+// Scope of an open queue: whatever path leaves the scope without pack_flush (an early error return) closes the queue, so that a
+// later stand-alone pack is never silently parked in a queue nobody flushes.
+struct PackQueueScope {
+  PackQueueScope() { pack_queue_open(); }
+  ~PackQueueScope() { pack_queue_abandon(); }
+  PackQueueScope(const PackQueueScope&) = delete;
+  PackQueueScope& operator=(const PackQueueScope&) = delete;
+};
 
 }  // namespace adx

@@ -115,6 +115,11 @@ int pack_submit(const PackJob& job, hipStream_t s) {
   return launch_jobs(&job, 1, s);
 }
 
+void pack_queue_abandon() {
+  g_open = false;
+  g_jobs.clear();
+}
+
 int pack_flush(hipStream_t s) {
   g_open = false;
   const int rc = g_jobs.empty() ? ADX_OK : launch_jobs(g_jobs.data(), (int)g_jobs.size(), s);

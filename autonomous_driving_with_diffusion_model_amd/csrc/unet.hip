@@ -516,7 +516,7 @@ int adx_unet_pack(adx_unet* u, const float* const* P, int32_t n_params, const fl
   float* base = (float*)packed;
   const int dim = u->cfg.dim;
   int rc = ADX_OK;
-  pack_queue_open();        // every weight image of the stack in one table-driven launch (tconv_pack.h), flushed below
+  PackQueueScope pack_scope;   // every weight image of the stack in one table-driven launch (tconv_pack.h), flushed below
   for (auto& b : u->blocks) {
     if (rc == ADX_OK) rc = pack_layer(b.a, P, base, s);
     if (rc == ADX_OK) rc = pack_layer(b.b, P, base, s, (b.has_r && b.b.chained) ? &b.r : nullptr);

@@ -305,7 +305,7 @@ int adx_unet_backward(adx_unet* u, const void* packed, void* workspace, size_t w
   g_tlin.lin = 1; g_tlin.lout = 1; g_tlin.groups = 0; g_tlin.eps = 1e-5f; g_tlin.w_layout = 1; g_tlin.w_flip = 0; g_tlin.exact = 1;
   float* tlin_img = nullptr;
   {
-    pack_queue_open();
+    PackQueueScope pack_scope;
     int rq = ADX_OK;
     for (size_t oi = 0; oi < tape->ops.size() && rq == ADX_OK; ++oi) {
       const TapeOp& op = tape->ops[oi];
