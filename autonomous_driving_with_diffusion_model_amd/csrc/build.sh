@@ -7,7 +7,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 OUT=${ADX_OUT:-../libadx.so}
-SRCS="api.cpp batch_ops.hip tconv.hip tconv_hs.hip tconv_generic.hip tconv_pack.hip tconv_chain.hip tconv_pipe.hip embed.hip sched.hip augment.hip unet.hip conv2d.hip conv2d_hs.hip conv2d_wgrad_hs.hip conv2d_wgrad_stem_hs.hip trajpred.hip tbwd.hip unet_train.hip resnet_train.hip optim.hip probe.hip"
+SRCS="api.cpp batch_ops.hip tconv.hip tconv_hs.hip tconv_generic.hip tconv_pack.hip tconv_chain.hip tconv_pipe.hip embed.hip sched.hip augment.hip unet.hip conv2d.hip conv2d_hs.hip conv2d_hs16.hip conv2d_wgrad_hs.hip conv2d_wgrad_stem_hs.hip trajpred.hip tbwd.hip unet_train.hip resnet_train.hip optim.hip probe.hip"
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function $*"
 HDRS=$(ls *.h ../../include/adx.h | LC_ALL=C sort)
 SRC_HASH=$(cat $(ls *.hip *.cpp *.h ../../include/adx.h build.sh | LC_ALL=C sort) | sha256sum | cut -c1-32)

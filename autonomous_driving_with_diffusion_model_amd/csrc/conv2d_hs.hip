@@ -29,29 +29,9 @@
 
 #include "adx_common.h"
 #include "conv2d_internal.h"
+#include "conv2d_hs_common.h"
 
 namespace adx {
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-
-constexpr int kHsCout = 64;          // output channels per workgroup
-constexpr int kHsCC = 16;            // channels per chunk = K of one MFMA
-constexpr float kLoScale = 2048.f;   // 2^11
-
-__device__ __forceinline__ void split8(const float* v, float xs, u32x4& hi, u32x4& lo) {
-  f16x8 h, l;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float x = v[j] * xs;     // xs is a power of two: exact
-    const _Float16 hj = (_Float16)x;
-    h[j] = hj;
-    l[j] = (_Float16)((x - (float)hj) * kLoScale);
-  }
-  hi = __builtin_bit_cast(u32x4, h);
-  lo = __builtin_bit_cast(u32x4, l);
-}
 
 template <int CTRL>
 __device__ __forceinline__ float hs_dpp(float v) {
@@ -721,9 +701,9 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
         for (int r = 0; r < 2; ++r)
 #pragma unroll
           for (int m = 0; m < 2; ++m) {
-            accm[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][m], B[0][r], accm[r][m], 0, 0, 0);
-            accl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][m], B[1][r], accl[r][m], 0, 0, 0);
-            accl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][m], B[0][r], accl[r][m], 0, 0, 0);
+            accm[r][m] = hs_mfma(A[0][m], B[0][r], accm[r][m]);
+            accl[r][m] = hs_mfma(A[0][m], B[1][r], accl[r][m]);
+            accl[r][m] = hs_mfma(A[1][m], B[0][r], accl[r][m]);
           }
         if (kw == 0) {
           // what arrived during the previous stage goes to LDS under this stage's remaining MFMAs:
@@ -1589,6 +1569,7 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
     // the executor keeps a layer's 3x3 convs in the cell layout from the first one's output to the last one's (the stride-2
     // kernel and the average pool read cells too), so a cell operand always comes with a cell output
     ADX_REQUIRE(a.y_cells && a.x_amax == nullptr, "conv2d_hs: cell-layout operands come with a cell-layout output (and no dynamic range)");
+    if (conv2d_hs3x3q_eligible(a)) return conv2d_hs3x3q_launch(a, s);      // the 16x16x32 kernel (conv2d_hs16.hip) where its tile rules hold
     constexpr size_t clds = lds;
     static bool cattr = false;
     if (!cattr) {

@@ -1,0 +1,295 @@
+// The 3x3 stride-1 perception convolution on v_mfma_f32_16x16x32_f16 (round 5).
+//
+// Same arithmetic as conv2d_hs3x3_kernel (conv2d_hs.hip: fp32-grade results from fp16 hi / lo split operands, three matrix
+// products per multiply-add, two fp32 accumulators), same operand tensors (cell-layout activations, the [cout/64][cin/16][tap]
+// split weight image of conv2d_hs_pack), another matrix instruction.  Why: at this chip's power limit the 16x16x32 shape
+// sustains 14 % more flops than the 32x32x16 shape at the same LDS reads per flop (tools/micro/mfma_rate.hip: 1642 vs 1436
+// TFLOP/s on random operands; MI355X_MICROARCH.md, DVFS give-back item 7: half the accumulator traffic per flop), and a
+// timing-only build of the 32x32x16 kernel with every MFMA issued as two 16x16x32 on the same registers ran 7 / 6 / 10 / 13 %
+// faster on the 64 / 128 / 256 / 512-channel layers (profiles/README.md, round 5).
+//
+// What changes with K = 32 per instruction:
+//  * a lane's fragment is still ONE 16-byte cell (8 channels of a pixel / of an output channel's tap), but a wave's 64 lanes are
+//    16 rows x 4 k-groups, so a K-step covers 32 input channels: the patch of a chunk is [k-group 0..3][plane][pixels] cells and a
+//    stage is ONE TAP of a 32-channel chunk (48 MFMAs per wave), weights double-buffered per tap (16 KB), the patch per chunk
+//    (43 KB, fetched in three rounds spread over the chunk's nine stages);
+//  * wave tile = 64 channels x 64 pixels (2 rows x 32 columns) as 4 x 4 blocks of 16 x 16: 16 fragment reads per 48 MFMAs, the
+//    reads-per-flop of the 32x32x16 kernel; workgroup = 8 waves = 8 rows x 32 columns x 128 channels (MODE 2's tile);
+//  * accumulator lane = (pixel l & 15, channels 4 (l >> 4) .. + 3): four v_permlane16_swap per pair of pixel blocks leave every
+//    lane with one whole cell of 8 channels, then affine / residual / ReLU / split / two 16-byte stores as before.
+// The weight image is the one conv2d_hs_pack writes for every kernel of this family (a layer's packed weights must not depend on
+// the batch size that picks the kernel): a stage's 1024 cells are four contiguous 4 KB runs of it.
+// Scope: the inference executor's plain cell-layout launches (x, y and the residual as cell tensors, virtual-row column tiles)
+// with Cout % 128 == 0 and Cin % 64 == 0 -- 23 of the 29 stride-1 convs of ResNet-34; everything else stays on conv2d_hs3x3_kernel.
+#include "adx_common.h"
+#include "conv2d_internal.h"
+#include "conv2d_hs_common.h"
+
+namespace adx {
+
+namespace {
+
+constexpr int kQNT = 512;                  // threads
+constexpr int kQTH = 8;                    // output rows per workgroup
+constexpr int kQPW = 34;                   // patch columns
+constexpr int kQPlane = (kQTH + 2) * kQPW; // 340 staged pixels
+constexpr int kQPlaneP = 344;              // pitch of one [k-group][plane] image: 2 * pitch is a multiple of 16 cells, so the four
+                                           // k-groups of a fragment read start on the same bank phase (conflict-free ds_read_b128)
+constexpr int kQPairs = 4 * kQPlane;       // (k-group, pixel) cell pairs of a 32-channel chunk
+constexpr int kQPit = (kQPairs + kQNT - 1) / kQNT;   // 3 rounds
+constexpr int kQWst = 1024;                // weight cells of a stage: [slab][16-channel half][plane][k-half][64]
+constexpr size_t kQLds = (size_t)2 * 8 * kQPlaneP * 16 + (size_t)2 * kQWst * 16 + 256 * sizeof(float) + 2 * 16;
+
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+// hi + lo / 2^11 of four channels held as two packed fp16 pairs per plane
+__device__ __forceinline__ void half4(uint32_t h0, uint32_t h1, uint32_t l0, uint32_t l1, float* out) {
+  const float inv = 1.f / kLoScale;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(out[0]) : "v"(l0), "s"(inv), "v"(h0));
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(out[1]) : "v"(l0), "s"(inv), "v"(h0));
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(out[2]) : "v"(l1), "s"(inv), "v"(h1));
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(out[3]) : "v"(l1), "s"(inv), "v"(h1));
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs a) {
+  constexpr int NT = kQNT, PW = kQPW, PLANE = kQPlane, PP = kQPlaneP, PIT = kQPit, WST = kQWst;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32x4* patch = reinterpret_cast<u32x4*>(smem_raw);          // 2 x [k-group][plane][PP]
+  u32x4* wl = patch + 2 * 8 * PP;                             // 2 x [slab][16-channel half][plane][k-half][64]
+  float* ss = reinterpret_cast<float*>(wl + 2 * WST);         // scale[128], shift[128]
+  u32x4* dummy = reinterpret_cast<u32x4*>(ss + 256);          // where the idle threads of the last patch round write
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rowpair = wave & 3, slab = wave >> 2;
+  const int j = lane & 15, kq = lane >> 4;
+  int bid = blockIdx.x;
+  {   // consecutive ids go to different XCDs: give each XCD one contiguous eighth of the tile space (shared halos and slabs meet in one L2)
+    const int per = gridDim.x >> 3;
+    if (bid < per * 8) bid = (bid & 7) * per + (bid >> 3);
+  }
+  const int ct = bid % a.cout_tiles; bid /= a.cout_tiles;
+  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+  const int ty = bid;
+  const int oy0 = ty * kQTH, vx0 = tx * 32;
+  auto vdiv = [&](int v) { return (int)(((float)v + 0.5f) * a.inv_vw); };     // v / vw for 0 <= v < 2^21 (launch check)
+  const size_t hw = (size_t)a.H * a.W;
+  const int nch16 = a.cin_pad / 16, nch32 = a.cin_pad / 32, nstages = nch32 * 9;
+  constexpr uint32_t kOutside = 0xC0000000u;
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x), 0, (int)(uint32_t)((size_t)a.N * a.Cin * hw * sizeof(float)), 0x00020000);
+  const uint32_t plane_bytes = (uint32_t)(hw * sizeof(float));
+  uint32_t goff[PIT];
+  int pcell[PIT];
+#pragma unroll
+  for (int k = 0; k < PIT; ++k) {
+    const int e = tid + NT * k;
+    const int g = e / PLANE, p = e - g * PLANE;                // k-group, staged pixel
+    const int py = p / PW, px = p - py * PW;
+    const int iy = oy0 - 1 + py;
+    const int v = vx0 - 1 + px;                                // virtual column: image v / vw, column v % vw (column W of an image is zero)
+    const int ni = vdiv(v < 0 ? 0 : v);
+    const int ix = v - ni * a.vw;
+    const bool ok = e < kQPairs && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && ni < a.N;
+    goff[k] = !ok ? kOutside : (uint32_t)((size_t)ni * a.Cin * hw * sizeof(float) + (size_t)g * 8 * hw * sizeof(float) + ((size_t)iy * a.W + ix) * 16);
+    pcell[k] = e < kQPairs ? g * 2 * PP + p : -1;
+  }
+  // this thread's two weight cells of a stage: cell e of the LDS image is cell wsrc_off[k] + (18 chunk + tap) * 256 of the packed image
+  const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.w);
+  int wsrc_off[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int e = tid + NT * k;
+    const int sl = e >> 9, half16 = (e >> 8) & 1, within = e & 255;
+    wsrc_off[k] = (((ct * 2 + sl) * nch16 + half16) * 9) * 256 + within;
+  }
+  float ssv = 0.f;
+  if (tid < 256) {
+    const int c = ct * 128 + (tid & 127);
+    ssv = a.scale == nullptr ? (tid < 128 ? 1.f : 0.f) : (tid < 128 ? a.scale[c] : a.shift[c]);
+  }
+
+  f32x4 accm[4][4], accl[4][4];            // [channel block][pixel block]: hi*hi sums, cross-term sums (scaled by 2^11)
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { accm[cb][pb][i] = 0.f; accl[cb][pb][i] = 0.f; }
+
+  u32x4 wv[2][2], pvh[2], pvl[2];          // register sets: weights of stage s in wv[s & 1]; the patch round fetched at stage s in pv*[s & 1]
+  auto load_w = [&](int stage, int set) {
+    const int chunk = stage / 9, tap = stage - chunk * 9;
+    const u32x4* ws = wsrc + (size_t)(chunk * 18 + tap) * 256;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) wv[set][k] = ws[wsrc_off[k]];
+  };
+  auto store_w = [&](int set, int buf) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) wl[buf * WST + tid + NT * k] = wv[set][k];
+  };
+  auto load_p = [&](int chunk, int k, int set) {
+    const uint32_t cbase = (uint32_t)chunk * 32u * plane_bytes;
+    pvh[set] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, goff[k], cbase, 0);
+    pvl[set] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, goff[k], cbase + 4 * plane_bytes, 0);
+  };
+  auto store_p = [&](int set, int k, int buf) {
+    u32x4* pd = patch + buf * 8 * PP + pcell[k];
+    u32x4* d0 = (k < PIT - 1 || pcell[k] >= 0) ? pd : dummy;
+    u32x4* d1 = (k < PIT - 1 || pcell[k] >= 0) ? pd + PP : dummy + 1;
+    *d0 = pvh[set];
+    *d1 = pvl[set];
+  };
+
+  // fragment bases: B (pixels) of lane (j, kq): patch cell kq * 2 PP + (2 rowpair + kh + row) * PW + 16 colhalf + j + kw, + PP for lo;
+  // A (channels) of lane (j, kq): weight cell slab * 512 + (kq >> 1) * 256 + plane * 128 + (kq & 1) * 64 + 16 cb + j
+  const int pb_lane = kq * 2 * PP + (rowpair * 2) * PW + j;
+  const int wa_lane = slab * 512 + (kq >> 1) * 256 + (kq & 1) * 64 + j;
+
+  // prologue: stage 0 complete in LDS, the weights of stage 1 in flight
+  load_w(0, 0);
+  store_w(0, 0);
+#pragma unroll
+  for (int k = 0; k < PIT; ++k) { load_p(0, k, 0); store_p(0, k, 0); }
+  load_w(1, 1);
+  if (tid < 256) ss[tid] = ssv;
+  __syncthreads();
+
+  for (int cp = 0; cp < nch32; cp += 2) {
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+      const int s = 9 * cp + i;                   // global stage; s & 1 == i & 1 because 9 cp is even
+      const int cpar = i / 9, t = i % 9, kh = t / 3, kw = t % 3;
+      const u32x4* pb0 = patch + cpar * 8 * PP + pb_lane + kh * PW + kw;
+      const u32x4* wa0 = wl + (i & 1) * WST + wa_lane;
+      // fetch two stages ahead: the weights of stage s + 2, and at a kernel row's first tap one round of the NEXT chunk's patch
+      // (past the end the last stage / chunk is fetched again; its copy in the idle buffers is never read)
+      load_w(s + 2 < nstages ? s + 2 : nstages - 1, i & 1);
+      if (kw == 0) load_p(cp + cpar + 1 < nch32 ? cp + cpar + 1 : nch32 - 1, kh, i & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      f16x8 A[2][4], B[2][4];
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) A[pl][cb] = __builtin_bit_cast(f16x8, wa0[pl * 128 + cb * 16]);
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) B[pl][pb] = __builtin_bit_cast(f16x8, pb0[pl * PP + (pb >> 1) * PW + (pb & 1) * 16]);
+      }
+#pragma unroll
+      for (int pb = 0; pb < 4; ++pb) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+          accm[cb][pb] = mfma16(A[0][cb], B[0][pb], accm[cb][pb]);
+          accl[cb][pb] = mfma16(A[0][cb], B[1][pb], accl[cb][pb]);
+        }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) accl[cb][pb] = mfma16(A[1][cb], B[0][pb], accl[cb][pb]);
+        if (pb == 0) {
+          // what arrived during the previous stage goes to LDS under this stage's remaining MFMAs
+          store_w((i + 1) & 1, (i + 1) & 1);
+          if (kw == 1) store_p((i + 1) & 1, kh, (cpar + 1) & 1);
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: one cell (8 channels of a pixel, hi + lo) per lane and (channel block, row) ----
+  // Accumulator lane (j, kq) holds channels 16 cb + 4 kq + i of pixel (row pb >> 1, column 16 (pb & 1) + j).  After the swaps of
+  // a row's two pixel blocks lane (j, rw = kq) holds the cell of channels 16 cb + 8 (rw >> 1) .. + 7 at column 16 (rw & 1) + j.
+  const int rw = kq;
+  const int vcol = vx0 + 16 * (rw & 1) + j;
+  const int nl = vdiv(vcol), xl = vcol - nl * a.vw;
+  const bool col_valid = nl < a.N && xl < a.W;
+  const uint32_t plane_ob = (uint32_t)(a.OH * a.OW) * (uint32_t)sizeof(float);
+  const uint32_t cplane = (uint32_t)(a.OH * a.OW) * 16u;
+  const uint32_t img_bytes = (uint32_t)a.N * (uint32_t)a.Cout * plane_ob;
+  const uint32_t img_off = (uint32_t)nl * (uint32_t)a.Cout * plane_ob;
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)img_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.res != nullptr ? a.res : a.y), 0, a.res != nullptr ? (int)img_bytes : 0, 0x00020000);
+  const int cout0 = ct * 128 + slab * 64;
+  const uint32_t cell0 = (uint32_t)(cout0 >> 3) * 2u * cplane;            // hi plane of this wave's first cell group
+  uint32_t vcell[2];
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const int oy = oy0 + rowpair * 2 + rr;
+    vcell[rr] = (col_valid && oy < a.OH) ? img_off + (uint32_t)(oy * a.OW + xl) * 16u + (uint32_t)(rw >> 1) * 2u * cplane : kOutside;
+  }
+  // the residual cells of the whole tile first (one exposed latency): cell group 2 cb + (rw >> 1) of the wave's 64 channels
+  u32x4 rh[4][2], rl[4][2];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const uint32_t so = cell0 + (uint32_t)(2 * cb) * 2u * cplane;
+      rh[cb][rr] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, vcell[rr], so, 0);
+      rl[cb][rr] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, vcell[rr], so + cplane, 0);
+    }
+  const float* sc = ss + slab * 64;
+  const float* sh = ss + 128 + slab * 64;
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      float x[4], y[4];                           // pixel blocks 2 rr (columns 0-15) and 2 rr + 1 (columns 16-31): channels 16 cb + 4 kq + i
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int cl = cb * 16 + 4 * kq + i;
+        x[i] = (accm[cb][2 * rr][i] + accl[cb][2 * rr][i] * (1.f / kLoScale)) * sc[cl] + sh[cl];
+        y[i] = (accm[cb][2 * rr + 1][i] + accl[cb][2 * rr + 1][i] * (1.f / kLoScale)) * sc[cl] + sh[cl];
+      }
+      float o[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        // rows of 16 lanes: x's odd rows <-> y's even rows.  Afterwards x = channels + 0..3 and y = channels + 4..7 of the lane's cell
+        const auto sw = __builtin_amdgcn_permlane16_swap(f2u(x[i]), f2u(y[i]), false, false);
+        o[i] = u2f(sw[0]);
+        o[4 + i] = u2f(sw[1]);
+      }
+      float r8[8];
+      half4(rh[cb][rr][0], rh[cb][rr][1], rl[cb][rr][0], rl[cb][rr][1], r8);
+      half4(rh[cb][rr][2], rh[cb][rr][3], rl[cb][rr][2], rl[cb][rr][3], r8 + 4);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float tsum = o[i] + r8[i];
+        o[i] = a.relu ? __builtin_fmaxf(tsum, 0.f) : tsum;
+      }
+      u32x4 hi, lo;
+      split8(o, 1.f, hi, lo);
+      const uint32_t so = cell0 + (uint32_t)(2 * cb) * 2u * cplane;
+      __builtin_amdgcn_raw_buffer_store_b128(hi, yrsrc, vcell[rr], so, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(lo, yrsrc, vcell[rr], so + cplane, 0);
+      // a VALU write to the data registers of a 16-byte buffer store with an SGPR offset in the next issue slot can reach the
+      // store (conv2d_hs.hip: cells_store32); keep both operands alive across one wait state
+      asm volatile("s_nop 0" ::"v"(hi), "v"(lo));
+    }
+}
+
+bool conv2d_hs3x3q_eligible(const Conv2dArgs& a) {
+  const int pin = debug_switches().hs_mode;            // ADX_HS_MODE=0|1|2 pins a tile mode of the 32x32x16 kernel
+  return pin < 0 && a.x_cells && a.y_cells && (a.res == nullptr || a.res_cells) && a.x_amax == nullptr && a.stats_part == nullptr &&
+         a.Cout % 128 == 0 && a.cin_pad % 64 == 0 && a.cin_pad == a.Cin && a.pad == 1 && a.stride == 1 && a.KH == 3 && a.KW == 3 &&
+         a.H == a.OH && a.W == a.OW;
+}
+
+int conv2d_hs3x3q_launch(Conv2dArgs a, hipStream_t s) {
+  ADX_REQUIRE(conv2d_hs3x3q_eligible(a), "conv2d_hs3x3q: launch outside the kernel's rules");
+  ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3q_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQLds));
+  a.vw = a.N > 1 ? a.OW + 1 : a.OW;
+  a.inv_vw = 1.f / (float)a.vw;
+  ADX_REQUIRE((long)a.N * a.vw < (1L << 21), "conv2d_hs: batch x width exceeds the virtual-row arithmetic");
+  a.tiles_x = ceil_div(a.N * a.vw - (a.N > 1 ? 1 : 0), 32);       // the last image's zero column needs no tile
+  a.tiles_y = ceil_div(a.OH, kQTH);
+  a.cout_tiles = a.Cout / 128;
+  const size_t grid = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y;
+  ADX_REQUIRE(grid < (1u << 31), "conv2d_hs: grid too large");
+  ADX_REQUIRE((size_t)a.N * a.Cout * a.OH * a.OW * sizeof(float) < 0xC0000000u && (size_t)a.N * a.Cin * a.H * a.W * sizeof(float) < 0xC0000000u,
+              "conv2d_hs: a cell-layout tensor exceeds the 32-bit byte offsets");
+  conv2d_hs3x3q_kernel<<<dim3((unsigned)grid), dim3(kQNT), kQLds, s>>>(a);
+  ADX_LAUNCH_CHECK();
+  return ADX_OK;
+}
+
+}  // namespace adx

@@ -121,6 +121,10 @@ struct HsPackJob { const float* w; void* packed; int cout, cin_pad, cin, taps, d
 bool conv2d_hs_pack_batchable(const ConvSpec& consumer, int dgrad);
 int conv2d_hs_pack_many(const HsPackJob* jobs, int n, hipStream_t s);
 int conv2d_hs_launch(const ConvSpec& L, Conv2dArgs a, hipStream_t s);
+// conv2d_hs16.hip: the same convolution on v_mfma_f32_16x16x32_f16 for the inference executor's plain cell-layout launches with
+// Cout % 128 == 0 and Cin % 64 == 0 (same packed weights, same cell tensors; ADX_HS_MODE=0|1|2 keeps every launch on the 32x32x16 kernel)
+bool conv2d_hs3x3q_eligible(const Conv2dArgs& a);
+int conv2d_hs3x3q_launch(Conv2dArgs a, hipStream_t s);
 // partial-sum slots (workgroups per 64-channel slab) the pipelined 3x3 stride-1 kernel would fill for this launch, 0 if another
 // kernel serves it
 int conv2d_hs_stats_tiles(const ConvSpec& L, const Conv2dArgs& a);

@@ -46,6 +46,8 @@ size_t pipe_packed_floats(int C, int taps, int pad, int L);
 int pipe_pack(const float* w, float* packed, int C, int taps, int pad, int L, hipStream_t s);
 // the same image made from the layer's K-split image (tconv_hs.hip), which the executor holds anyway
 int pipe_repack_from_hs(const float* hs_image, float* packed, int C, int taps, int pad, int L, hipStream_t s);
+// the same for n <= 8 layers of one shape, one launch
+int pipe_repack_from_hs_many(const float* const* hs_images, float* const* packed, int n, int C, int taps, int pad, int L, hipStream_t s);
 int pipe_launch(const PipeArgs& a, hipStream_t s);
 
 }  // namespace adx

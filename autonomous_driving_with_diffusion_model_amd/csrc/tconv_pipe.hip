@@ -106,10 +106,13 @@ __global__ void __launch_bounds__(256) pipe_pack_kernel(const float* __restrict_
 // the same image from the K-split kernel's image of the layer (tconv_hs.hip: [cout / 32][tap x cin / 16][plane][64 lanes][8 halfs],
 // lane (n & 31, half of the 16-channel block), which every piped layer has anyway): a pure permutation of 16-byte cells, so the
 // pipeline's images can be made where they are first needed (the inference forward) instead of at every weight update
-__global__ void __launch_bounds__(256) pipe_repack_kernel(const u32x4* __restrict__ hs, u32x4* __restrict__ packed, int C, int taps,
-                                                           int tap0, int steps, size_t total) {
+struct PipeRepackJobs { const u32x4* hs[8]; u32x4* packed[8]; };
+
+__global__ void __launch_bounds__(256) pipe_repack_kernel(const PipeRepackJobs jobs, int C, int taps, int tap0, int steps, size_t total) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;            // one 16-byte cell: (rank, step, plane, lane)
   if (idx >= total) return;
+  const u32x4* __restrict__ hs = jobs.hs[blockIdx.y];
+  u32x4* __restrict__ packed = jobs.packed[blockIdx.y];
   const int lane = idx & 63, plane = (idx >> 6) & 1;
   const size_t blk = idx >> 7;
   const int k = blk % steps, rank = blk / steps;
@@ -120,15 +123,26 @@ __global__ void __launch_bounds__(256) pipe_repack_kernel(const u32x4* __restric
   packed[idx] = hs[((size_t)(n >> 5) * nkb + kb) * 128 + plane * 64 + ln];
 }
 
-int pipe_repack_from_hs(const float* hs_image, float* packed, int C, int taps, int pad, int L, hipStream_t s) {
+// n <= 8 layers of one shape in ONE launch (adx_unet_pack: the pipeline run's images are part of the packed buffer's contents,
+// made whenever the K-split images they are re-laid from are made)
+int pipe_repack_from_hs_many(const float* const* hs_images, float* const* packed, int n, int C, int taps, int pad, int L, hipStream_t s) {
+  ADX_REQUIRE(n >= 1 && n <= 8, "pipe_repack_from_hs_many: %d layers (1..8)", n);
   int t0, nt;
   pipe_live_taps(taps, pad, L, &t0, &nt);
   const int steps = nt * (C / 32);
   const size_t total = (size_t)(C / kPipeCh) * steps * 2 * 64;
-  pipe_repack_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
-      reinterpret_cast<const u32x4*>(hs_image), reinterpret_cast<u32x4*>(packed), C, taps, t0, steps, total);
+  PipeRepackJobs jobs;
+  for (int i = 0; i < 8; ++i) {
+    jobs.hs[i] = reinterpret_cast<const u32x4*>(hs_images[i < n ? i : 0]);
+    jobs.packed[i] = reinterpret_cast<u32x4*>(packed[i < n ? i : 0]);
+  }
+  pipe_repack_kernel<<<dim3((unsigned)((total + 255) / 256), (unsigned)n), dim3(256), 0, s>>>(jobs, C, taps, t0, steps, total);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
+}
+
+int pipe_repack_from_hs(const float* hs_image, float* packed, int C, int taps, int pad, int L, hipStream_t s) {
+  return pipe_repack_from_hs_many(&hs_image, &packed, 1, C, taps, pad, L, s);
 }
 
 int pipe_pack(const float* w, float* packed, int C, int taps, int pad, int L, hipStream_t s) {

@@ -550,6 +550,26 @@ int adx_unet_pack(adx_unet* u, const float* const* P, int32_t n_params, const fl
     const int rp = pack_flush(s);                  // behind the copies above (the fused Linear reads one); always closes the queue
     if (rc == ADX_OK) rc = rp;
   }
+  if (rc == ADX_OK && u->pipe_ok) {
+    // the pipeline run's seven images (tconv_pipe.hip), re-laid from the K-split images the flush above wrote: one launch.  They are
+    // part of THIS packed buffer's contents like every other image -- a forward never writes `packed`, and a caller may keep
+    // several packed buffers (live and EMA weights) on one handle
+    const int n = u->cfg.n_mults;
+    ResBlock& b0 = u->blocks[2 * (n - 1)];
+    ResBlock& b1 = u->blocks[2 * (n - 1) + 1];
+    ResBlock& m1 = u->blocks[2 * n];
+    ResBlock& m2 = u->blocks[2 * n + 1];
+    const ConvLayer* run[7] = {&b0.b, &b1.a, &b1.b, &m1.a, &m1.b, &m2.a, &m2.b};
+    const float* src[7];
+    float* dst[7];
+    for (int k = 0; k < 7; ++k) {
+      ADX_REQUIRE(run[k]->piped && tconv_hs_kernel_image(&run[k]->d), "adx_unet_pack: piped layer without a K-split weight image");
+      src[k] = base + run[k]->o_w;
+      dst[k] = base + run[k]->o_pw;
+    }
+    const adx_tconv_desc& d0 = b0.b.d;
+    rc = pipe_repack_from_hs_many(src, dst, 7, d0.cout, d0.taps, d0.pad, d0.lin, s);
+  }
   if (rc == ADX_OK) rc = copy_f(base + u->o_freqs, freqs, dim / 2, s);
   if (rc == ADX_OK) rc = copy_f(base + u->o_t1w, P[u->p_t1w], (size_t)4 * dim * dim, s);
   if (rc == ADX_OK) rc = copy_f(base + u->o_t1b, P[u->p_t1b], 4 * dim, s);
@@ -565,7 +585,7 @@ int adx_unet_pack(adx_unet* u, const float* const* P, int32_t n_params, const fl
     const int rf = batch_copy_flush(s);            // always drain the queue, also after an error
     if (rc == ADX_OK) rc = rf;
   }
-  if (rc == ADX_OK) { u->packed_once = true; u->pipe_stale = true; }
+  if (rc == ADX_OK) u->packed_once = true;
   return rc;
 }
 
@@ -759,15 +779,6 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
       float* ya = split_scratch + align64(rec_floats);
       float* yb = ya + align64((size_t)rows * Lp * C);
       float* yc = yb + align64((size_t)rows * Lp * C);
-      if (u->pipe_stale) {
-        // made here, from the K-split images adx_unet_pack wrote, and not at every weight update: training never needs them
-        for (const ConvLayer* Lk : run) {
-          ADX_REQUIRE(tconv_hs_kernel_image(&Lk->d), "adx_unet_forward: piped layer without a K-split weight image");
-          rc = pipe_repack_from_hs(base + Lk->o_w, const_cast<float*>(base) + Lk->o_pw, C, Lk->d.taps, Lk->d.pad, Lp, s);
-          if (rc != ADX_OK) return rc;
-        }
-        u->pipe_stale = false;
-      }
       pa.counters = split_tickets + 128;                          // words 128, 144, ... 224: a 64-byte line per stage (the split
                                                                   // reductions' tickets stay below 128), cleared at the head of this forward
       for (int k = 0; k < 7; ++k) {

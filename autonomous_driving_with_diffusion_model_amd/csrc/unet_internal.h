@@ -67,6 +67,5 @@ struct adx_unet {
   // the deepest level's same-shaped layer run (block 0's second conv, block 1, both mid blocks: seven convs) as ONE pipeline
   // launch at small batches (tconv_pipe.hip); pipe_ok: the configuration qualifies (decided once, at creation)
   bool pipe_ok = false;
-  bool pipe_stale = true;     // the pipeline's weight images are older than the last adx_unet_pack (made on first use, not per update)
 };
 
