@@ -124,6 +124,7 @@ _SIGS = {
     "adx_adamw_ema_step_scaled": (i32, [vp, vp, vp, i32, f32, f32, f32, f32, f32, i32, f32, i32, i32, f32, vp]),
     "adx_image_normalize": (i32, [vp, vp, i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), vp]),
     "adx_probe_mfma_fp16": (i32, [vp, vp, i32, i32, C.POINTER(C.c_double), vp]),
+    "adx_probe_mfma_fp16_16x16x32": (i32, [vp, vp, i32, i32, C.POINTER(C.c_double), vp]),
     "adx_image_augment": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp]),
     "adx_ddim_step": (i32, [C.POINTER(StepCoef), vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "adx_ddpm_step": (i32, [C.POINTER(StepCoef), vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),

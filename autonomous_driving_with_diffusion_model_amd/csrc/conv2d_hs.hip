@@ -298,9 +298,9 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
         for (int r = 0; r < ROWS; ++r)
 #pragma unroll
           for (int m = 0; m < 2; ++m) {
-            accm[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.A[0][m], f.B[0][r], accm[r][m], 0, 0, 0);
-            accl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.A[0][m], f.B[1][r], accl[r][m], 0, 0, 0);
-            accl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.A[1][m], f.B[0][r], accl[r][m], 0, 0, 0);
+            accm[r][m] = hs_mfma(f.A[0][m], f.B[0][r], accm[r][m]);
+            accl[r][m] = hs_mfma(f.A[0][m], f.B[1][r], accl[r][m]);
+            accl[r][m] = hs_mfma(f.A[1][m], f.B[0][r], accl[r][m]);
           }
         if (DS && kh == 1 && kw == 1) {   // x[2 oy][2 ox]: the 1x1 stride-2 conv's only tap
           f16x8 D[2][2];
@@ -312,9 +312,9 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_kernel(const Conv2dArgs a) {
           for (int r = 0; r < ROWS; ++r)
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-              adm[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(D[0][m], f.B[0][r], adm[r][m], 0, 0, 0);
-              adl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(D[0][m], f.B[1][r], adl[r][m], 0, 0, 0);
-              adl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(D[1][m], f.B[0][r], adl[r][m], 0, 0, 0);
+              adm[r][m] = hs_mfma(D[0][m], f.B[0][r], adm[r][m]);
+              adl[r][m] = hs_mfma(D[0][m], f.B[1][r], adl[r][m]);
+              adl[r][m] = hs_mfma(D[1][m], f.B[0][r], adl[r][m]);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1151,9 +1151,9 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_stem_kernel(const Conv2dArgs
         for (int r = 0; r < NR; ++r)
 #pragma unroll
           for (int m = 0; m < 2; ++m) {
-            accm[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.A[0][m], f.B[0][r], accm[r][m], 0, 0, 0);
-            accl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.A[0][m], f.B[1][r], accl[r][m], 0, 0, 0);
-            accl[r][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.A[1][m], f.B[0][r], accl[r][m], 0, 0, 0);
+            accm[r][m] = hs_mfma(f.A[0][m], f.B[0][r], accm[r][m]);
+            accl[r][m] = hs_mfma(f.A[0][m], f.B[1][r], accl[r][m]);
+            accl[r][m] = hs_mfma(f.A[1][m], f.B[0][r], accl[r][m]);
           }
       };
       if (POOL) {

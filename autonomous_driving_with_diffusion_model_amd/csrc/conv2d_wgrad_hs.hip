@@ -23,12 +23,11 @@
 
 #include "adx_common.h"
 #include "conv2d_internal.h"
+#include "conv2d_hs_common.h"
 
 namespace adx {
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) h4 lds_h4;
 
@@ -188,9 +187,9 @@ __global__ void __launch_bounds__(kWThreads) conv2d_wgrad_hs_kernel(const WgradH
           for (int kw = 0; kw < 3; ++kw) {
             const f16x8 Bhi = tr_pair<256 * S>(Bb + ks * 1024 * S + kw * 64);
             const f16x8 Blo = tr_pair<256 * S>(Bb + B_PLANE + ks * 1024 * S + kw * 64);
-            am[kw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi, Bhi, am[kw], 0, 0, 0);
-            al[kw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi, Blo, al[kw], 0, 0, 0);
-            al[kw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo, Bhi, al[kw], 0, 0, 0);
+            am[kw] = hs_mfma(Ahi, Bhi, am[kw]);
+            al[kw] = hs_mfma(Ahi, Blo, al[kw]);
+            al[kw] = hs_mfma(Alo, Bhi, al[kw]);
           }
         }
       }

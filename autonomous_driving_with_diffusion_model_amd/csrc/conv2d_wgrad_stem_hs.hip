@@ -20,14 +20,12 @@
 
 #include "adx_common.h"
 #include "conv2d_internal.h"
+#include "conv2d_hs_common.h"
 
 namespace adx {
 
 namespace {
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct WgradStemArgs {
   const float* x;        // [N][3][H][W]
@@ -243,9 +241,9 @@ __global__ void __launch_bounds__(kNT) conv2d_wgrad_stem_hs_kernel(const WgradSt
         for (int m = 0; m < 2; ++m) {
           const f16x8 Ahi = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(Ab + m * 32 * kPitch + ks * 32));
           const f16x8 Alo = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(Ab + kAPlane + m * 32 * kPitch + ks * 32));
-          am[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi, Bhi, am[m], 0, 0, 0);
-          al[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi, Blo, al[m], 0, 0, 0);
-          al[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo, Bhi, al[m], 0, 0, 0);
+          am[m] = hs_mfma(Ahi, Bhi, am[m]);
+          al[m] = hs_mfma(Ahi, Blo, al[m]);
+          al[m] = hs_mfma(Alo, Bhi, al[m]);
         }
       }
     };

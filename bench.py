@@ -112,8 +112,8 @@ def pmc_traffic_per_shape(key):
 
 
 def rocprof_avg_ms(prefix):
-    """Launch-weighted average duration of the kernels whose name contains `prefix` (a string, or several that must all
-    occur) in the newest committed rocprofv3 --kernel-trace --stats summary of this command (profiles/r*_bench_kernel_stats.csv)."""
+    """Launch-weighted average duration of the kernels whose name contains `prefix` (a string, several that must all
+    occur, or a predicate on the name) in the newest committed rocprofv3 --kernel-trace --stats summary of this command (profiles/r*_bench_kernel_stats.csv)."""
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")))
@@ -122,7 +122,7 @@ def rocprof_avg_ms(prefix):
     calls = tot = 0
     with open(files[-1]) as f:
         for row in csv.DictReader(f):
-            if all(part in row["Name"] for part in ([prefix] if isinstance(prefix, str) else prefix)):
+            if prefix(row["Name"]) if callable(prefix) else all(part in row["Name"] for part in ([prefix] if isinstance(prefix, str) else prefix)):
                 calls += int(row["Calls"])
                 tot += int(row["TotalDurationNs"])
     return round(tot / calls / 1e6, 4) if calls else None
@@ -223,24 +223,29 @@ def conv2d_roofline(dev, reps=10):
     equiv = tot_fl / count / avg_ms / 1e9      # algorithmic TFLOP/s
     achieved = 3.0 * equiv                     # fp16 MFMA TFLOP/s issued
     sus = sustained_mfma(dev)
-    return {"kernel": "conv2d_hs3x3_kernel<0|1|2> (ResNet-34 3x3 stride-1 convs, B=64, 3x256x900; fp32-grade result "
-                      "from fp16 hi/lo split operands, 3 MFMA products per multiply-add)",
+    return {"kernel": "conv2d_hs3x3q_kernel (16x16x32 MFMA: 128 / 256 / 512-channel layers) + conv2d_hs3x3_kernel<0> (32x32x16: 64-channel "
+                      "layers) -- the ResNet-34 3x3 stride-1 convs, B=64, 3x256x900; fp32-grade result from fp16 hi/lo split operands, "
+                      "3 MFMA products per multiply-add",
             "bound": "mfma", "achieved": round(equiv, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(equiv / PEAK_F16_TFLOPS, 4),
             "achieved_issued": round(achieved, 1), "frac_issued": round(achieved / PEAK_F16_TFLOPS, 4),
             # measured in this run, same box, same clocks: the ceiling the power limit leaves under `peak`
+            "method": "in_order",
             "sustained": {"mfma_fp16_tflops_random_operands": sus["random"], "mfma_fp16_tflops_zero_operands": sus["zero"],
+                          "by_mfma_shape_random_operands": {"32x32x16": sus["random_32x32x16"], "16x16x32": sus["random_16x16x32"]},
                           "frac_of_peak": round(sus["random"] / PEAK_F16_TFLOPS, 4),
                           "achieved_issued_over_sustained": round(achieved / sus["random"], 4),
-                          "note": "adx_probe_mfma_fp16: the kernel's inner loop alone (8 LDS operand reads per 12 v_mfma_f32_32x32x16_f16, two "
-                                  "4-wave workgroups per CU, no global memory) -- the fp16 MFMA rate this chip sustains at its power limit; `peak` "
-                                  "is the datasheet figure at the boost clock.  A 3-product launch cannot exceed sustained / 3 algorithmic."},
+                          "note": "adx_probe_mfma_fp16 / adx_probe_mfma_fp16_16x16x32: the 3x3 kernels' inner loops alone (8 LDS operand reads per "
+                                  "12 v_mfma_f32_32x32x16_f16, resp. 16 reads per 48 v_mfma_f32_16x16x32_f16: the same flops and reads per trip; "
+                                  "two 4-wave workgroups per CU, no global memory) -- the fp16 MFMA rate this chip sustains at its power limit, "
+                                  "the BETTER of the two shapes; `peak` is the datasheet figure at the boost clock.  A 3-product launch "
+                                  "cannot exceed sustained / 3 algorithmic."},
             "achieved_note": "achieved / frac (the contract figures, SURVEY 8d) = ALGORITHMIC conv flops (2*M*N*K) per launch / "
                              "HIP-event launch time, against the dense fp16 MFMA peak; achieved_issued / frac_issued = the fp16 "
                              "MFMA flops the kernel actually issues (3 x algorithmic: hi*hi + hi*lo + lo*hi) / the same time",
             # the inference instantiations (cell tensors in and out: "<MODE, false, true, true>"); the same summary also holds the
             # training leg's fp32-layout launches of this kernel
-            "avg_launch_ms_rocprof": rocprof_avg_ms(["conv2d_hs3x3_kernel", "true, true>("]),
+            "avg_launch_ms_rocprof": rocprof_avg_ms(lambda n: "conv2d_hs3x3q_kernel" in n or ("conv2d_hs3x3_kernel" in n and "true, true>(" in n)),
             "fp32_mfma_peak_tflops": PEAK_F32_TFLOPS, "frac_of_fp32_mfma_peak": round(equiv / PEAK_F32_TFLOPS, 3),
             "traffic": pmc_traffic("conv2d_hs3x3_kernel"),
             "traffic_note": "bytes/launch, 2 x FETCH_SIZE (gfx950 correction, calibrated: tools/micro/fetch_calib.hip) + WRITE_SIZE from profiles/" + os.path.basename(pmc_traffic_file() or "(none)") + " (separate rocprofv3 --pmc passes)",
@@ -267,15 +272,17 @@ def sustained_mfma(dev):
     out = torch.empty(512 * 256, dtype=torch.float32, device=dev)
     fl = C.c_double(0.0)
     res = {}
+    probes = {"32x32x16": L.lib().adx_probe_mfma_fp16, "16x16x32": L.lib().adx_probe_mfma_fp16_16x16x32}
     for name in ("random", "zero"):
         if name == "random":      # fp16 values of both signs in [0.125, 1): every mantissa bit toggles
             ops_ = ((torch.rand(4096 * 8, device=dev) * 0.875 + 0.125) * (torch.randint(0, 2, (4096 * 8,), device=dev) * 2 - 1)).half()
         else:
             ops_ = torch.zeros(4096 * 8, dtype=torch.float16, device=dev)
-        fn = lambda: L.check(L.lib().adx_probe_mfma_fp16(ops_.data_ptr(), out.data_ptr(), 512, 4000, C.byref(fl),  # noqa: E731
-                                                         L.stream_ptr(dev)), "adx_probe_mfma_fp16")
-        ms = time_events(fn, 3, warm=1)
-        res[name] = round(fl.value / ms / 1e9, 1)
+        for shape, probe in probes.items():
+            fn = lambda: L.check(probe(ops_.data_ptr(), out.data_ptr(), 512, 4000, C.byref(fl), L.stream_ptr(dev)), "adx_probe_mfma_fp16")  # noqa: E731
+            ms = time_events(fn, 3, warm=1)
+            res[f"{name}_{shape}"] = round(fl.value / ms / 1e9, 1)
+        res[name] = max(res[f"{name}_32x32x16"], res[f"{name}_16x16x32"])
     return res
 
 

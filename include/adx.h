@@ -395,6 +395,9 @@ int adx_image_augment(uint8_t* frames_hwc, uint8_t* scratch, int32_t n, int32_t 
  * power limit.  out: workgroups * 256 floats (a checksum, so that nothing is optimised away); *flops (host, optional)
  * receives the MFMA flops of the launch. */
 int adx_probe_mfma_fp16(const void* operands, float* out, int32_t workgroups, int32_t iters, double* flops, adx_stream s);
+/* The same probe on v_mfma_f32_16x16x32_f16 (the loop of csrc/conv2d_hs16.hip: 16 operand reads per 48 MFMAs -- the same flops and
+ * LDS reads per trip).  At the power limit the two shapes sustain different clocks; `roofline.sustained` reports both. */
+int adx_probe_mfma_fp16_16x16x32(const void* operands, float* out, int32_t workgroups, int32_t iters, double* flops, adx_stream s);
 
 #ifdef __cplusplus
 }

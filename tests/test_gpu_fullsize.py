@@ -163,7 +163,7 @@ def test_cfg2_train_step_fullsize_vs_oracle_autograd(full, use_cond, Bt):
     # Truth = the oracle in fp64.  A BatchNorm bias gradient in layer1 is a sum of 16 x 64 x 225 signed terms that
     # cancels to ~1e-3 of its absolute mass, so ANY fp32 evaluation -- torch's CPU autograd included -- sits ~1e-2 from
     # the fp64 value on those tensors; the bar is therefore relative to the error the oracle itself makes in fp32:
-    # e_hip <= 3 * e_fp32_oracle + 1e-3 per tensor (the bar of test_perception_train_mode_vs_oracle_autograd).
+    # e_hip <= 3 * e_fp32_oracle + 1e-3 per encoder tensor (the bar of test_perception_train_mode_vs_oracle_autograd).
     loss64, g64 = oracle_grads(torch.float64)
     loss32, g32 = oracle_grads(torch.float32)
     assert abs(loss.item() - loss64) <= 2e-5 * max(1.0, abs(loss64))
@@ -173,8 +173,12 @@ def test_cfg2_train_step_fullsize_vs_oracle_autograd(full, use_cond, Bt):
                                "worst (e_hip, e_oracle_fp32, tensor)": rows[:8],
                                "median_e_hip": rows[len(rows) // 2][0],
                                "median_e_oracle_fp32": sorted(r[1] for r in rows)[len(rows) // 2]})
+    # the absolute slack belongs to the tensors behind a BatchNorm backward (the encoder's convs and BatchNorm affines: sums that
+    # cancel to ~1e-3 of their mass); the temporal stack and perception.fc carry none of that and are held to 1e-5 (measured median
+    # 3.8e-7): a temporal kernel wrong by 0.1 % on every tensor fails here
     for e_hip, e_ref, k in rows:
-        assert e_hip <= 3 * e_ref + 1e-3, (k, e_hip, e_ref)
+        slack = 1e-3 if (k.startswith("perception.") and not k.startswith("perception.fc.")) else 1e-5
+        assert e_hip <= 3 * e_ref + slack, (k, e_hip, e_ref, slack)
     if drop:
         assert got["cond_mlp.0.weight"].abs().max().item() == 0.0 and g64["cond_mlp.0.weight"].abs().max().item() == 0.0
 
