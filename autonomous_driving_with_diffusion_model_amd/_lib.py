@@ -99,6 +99,9 @@ _SIGS = {
     "adx_resnet_train_workspace_bytes": (C.c_size_t, [vp, i32, i32, i32]),
     "adx_resnet_forward_train": (i32, [vp, C.POINTER(vp), i32, vp, vp, C.c_size_t, vp, i32, i32, i32, vp, vp, i32, vp]),
     "adx_resnet_backward": (i32, [vp, C.POINTER(vp), C.POINTER(vp), i32, vp, C.c_size_t, vp, vp, vp]),
+    "adx_resnet_backward_groups": (i32, [vp]),
+    "adx_resnet_tensor_group": (i32, [vp, i32]),
+    "adx_resnet_backward_events": (i32, [vp, C.POINTER(vp), C.POINTER(vp), i32, vp, C.c_size_t, vp, vp, C.POINTER(vp), i32, vp]),
     "adx_conv2d_packed_bytes": (C.c_size_t, [C.POINTER(Conv2dDesc)]),
     "adx_conv2d_pack": (i32, [C.POINTER(Conv2dDesc), vp, vp, vp]),
     "adx_conv2d_forward": (i32, [C.POINTER(Conv2dDesc), vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),

@@ -1150,11 +1150,43 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
 
 // d_feature [batch][out_dim] -> one gradient per tensor slot of adx_resnet_pack's list (conv weight, bn gamma,
 // bn beta written; running-stat slots untouched/NULL allowed), fc weight/bias included.
+int32_t adx_resnet_backward_groups(const adx_resnet* r) { return r ? (int32_t)r->block_has_ds.size() + 2 : 0; }
+
+int32_t adx_resnet_tensor_group(const adx_resnet* r, int32_t tensor) {
+  if (r == nullptr || tensor < 0 || tensor >= r->n_tensors) return -1;
+  const int nb = (int)r->block_has_ds.size();
+  if (tensor == r->t_fcw || tensor == r->t_fcb) return 0;
+  // convs: stem, then per block conv1, conv2, [downsample]
+  size_t ci = 0;
+  auto owns = [&](const adx::ConvSpec& L) { return tensor == L.t_w || tensor == L.t_g || tensor == L.t_b; };
+  if (owns(r->convs[ci++])) return nb + 1;
+  for (int b = 0; b < nb; ++b) {
+    const int ncv = r->block_has_ds[b] ? 3 : 2;
+    for (int k = 0; k < ncv; ++k)
+      if (owns(r->convs[ci++])) return 1 + (nb - 1 - b);
+  }
+  return -1;      // running statistics: no gradient
+}
+
 int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, int32_t n_tensors, void* workspace,
                         size_t workspace_bytes, adx_resnet_tape* tape, const float* d_feature, adx_stream stream) {
+  return adx_resnet_backward_events(r, T, G, n_tensors, workspace, workspace_bytes, tape, d_feature, nullptr, 0, stream);
+}
+
+int adx_resnet_backward_events(adx_resnet* r, const float* const* T, float* const* G, int32_t n_tensors, void* workspace,
+                               size_t workspace_bytes, adx_resnet_tape* tape, const float* d_feature, void* const* events,
+                               int32_t n_events, adx_stream stream) {
   ADX_REQUIRE(r && T && G && workspace && tape && d_feature, "adx_resnet_backward: null argument");
   ADX_REQUIRE(n_tensors == r->n_tensors && !tape->recs.empty(), "adx_resnet_backward: bad tape / tensor count");
+  ADX_REQUIRE(events == nullptr || n_events == adx_resnet_backward_groups(r), "adx_resnet_backward_events: %d events, the backward has %d groups",
+              n_events, adx_resnet_backward_groups(r));
   hipStream_t s = (hipStream_t)stream;
+  // group g's event is recorded behind the last launch that writes a gradient of group g (adx_resnet_tensor_group): a
+  // reduction of those gradients can start on another stream while the layers below are still being differentiated
+  auto mark = [&](int group) -> int {
+    if (events != nullptr && events[group] != nullptr) ADX_CHECK_HIP(hipEventRecord((hipEvent_t)events[group], s));
+    return ADX_OK;
+  };
   const int batch = tape->batch;
   Bump2 ws{(float*)workspace, tape->fwd_floats, workspace_bytes / sizeof(float)};
   const size_t n_convs = r->convs.size();
@@ -1213,6 +1245,7 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
     avgpool_fc_bwd_kernel<<<dim3(batch * (512 / kPoolSlice)), dim3(256), 0, s>>>(tape->final_map, T[r->t_fcw], d_feature, g_cur, G[r->t_fcw],
                                                             G[r->t_fcb], 512, HW, r->out_dim);
     ADX_LAUNCH_CHECK();
+    if (int rm = mark(0)) return rm;
   }
   // one conv+BN(+identity)(+ReLU) backward.  dout -> (dz for the identity path), d(conv input) accumulated
   // into dx (dx_has tells whether dx already holds a contribution).
@@ -1328,6 +1361,7 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
       dx = dz2;
     }
     g_cur = dx;
+    if (rc == ADX_OK) rc = mark(1 + (int)(r->block_has_ds.size() - 1 - b));
   }
   if (rc != ADX_OK) return rc;
   // maxpool, then the stem (no data gradient: the image needs none)
@@ -1357,6 +1391,7 @@ int adx_resnet_backward(adx_resnet* r, const float* const* T, float* const* G, i
     ADX_LAUNCH_CHECK();
     rc = conv2d_wgrad(st.x, draw, G[L.t_w], batch, L.cin, st.H, st.W, L.cout, L.k, L.stride, L.pad, s, stem_hs ? amax : nullptr,
                       stem_hs ? (int)kAmaxPartials : 0, false, wgrad9);
+    if (rc == ADX_OK) rc = mark((int)r->block_has_ds.size() + 1);
   }
   return rc;
 }

@@ -65,10 +65,25 @@ class _PerceptionTrainFn(torch.autograd.Function):
         garr = (L.vp * len(slots))()
         for i, t in enumerate(slots):
             garr[i] = None if t is None else t.data_ptr()
+        # Completion events, one per group of layers in the order the backward produces their gradients (fc, the BasicBlocks
+        # from layer4 down, the stem): a parameter carries the event of its group until its gradient has been consumed
+        # (`_adx_grad_event`), so that parallel.GradientAverager can start a bucket's reduction when ITS gradients exist instead
+        # of when this whole call -- 85 of the model's 149 MB of gradients -- has run (train.py:176-178, 251: what DDP's reducer
+        # does per parameter while accelerator.backward(loss) runs).
+        events = module._backward_events(g.device)
+        earr, n_ev = None, 0
+        if events is not None:
+            n_ev = len(events)
+            earr = (L.vp * n_ev)(*[ev.cuda_event for ev in events])
         try:
-            L.check(L.lib().adx_resnet_backward(module._native(), L.ptr_array(ctx.ts), garr, len(slots), ctx.ws.data_ptr(),
-                                                ctx.nbytes, ctx.tape.handle, g.data_ptr(), L.stream_ptr(g.device)),
-                    "adx_resnet_backward")
+            L.check(L.lib().adx_resnet_backward_events(module._native(), L.ptr_array(ctx.ts), garr, len(slots), ctx.ws.data_ptr(),
+                                                       ctx.nbytes, ctx.tape.handle, g.data_ptr(), earr, n_ev, L.stream_ptr(g.device)),
+                    "adx_resnet_backward_events")
+            if events is not None:
+                for i, e in enumerate(entries):
+                    grp = module._tensor_groups[i]
+                    if not e.is_buffer and grp >= 0:
+                        named[e.key]._adx_grad_event = (grp, events[grp])
         finally:
             ctx.tape.release()
             ctx.ws = None            # 27 GB of taped activations at B = 64: free them with the tape
@@ -101,6 +116,25 @@ class PerceptionResNet34(nn.Module):
                 L.lib().adx_resnet_destroy(self._handle)
         except Exception:
             pass
+
+    def _backward_events(self, device):
+        """One timing-enabled event per gradient group of adx_resnet_backward_events (created once per device; each is recorded
+        once here so that its native handle exists -- torch creates it lazily), or None where torch does not expose the handle."""
+        cached = getattr(self, "_bwd_events", None)
+        if cached is not None and cached[0] == device:
+            return cached[1]
+        h = self._native()
+        n = L.lib().adx_resnet_backward_groups(h)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+        st = torch.cuda.current_stream(device)
+        for ev in evs:
+            ev.record(st)
+        if not all(getattr(ev, "cuda_event", 0) for ev in evs):
+            evs = None
+        n_f32 = sum(1 for e in self._entries if e.dtype == "f32")
+        self._tensor_groups = [L.lib().adx_resnet_tensor_group(h, i) for i in range(n_f32)]
+        self._bwd_events = (device, evs)
+        return evs
 
     def _tensors(self):
         # the tensor OBJECTS are looked up once (walking the module tree twice per call was a visible part of an eagerly

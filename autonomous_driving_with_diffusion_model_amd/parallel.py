@@ -74,6 +74,8 @@ class GradientAverager:
         self._hooks: list = []
         self._pending: list = []
         self._ready: List[int] = []
+        self._seen_tagged: List[bool] = []       # per bucket: a gradient with a completion event has been accumulated ...
+        self._untagged_late: List[bool] = []     # ... and one without an event after it (then no event covers the bucket)
         self.copied_in = 0            # gradients of the last reduction that did not live in their bucket (diagnostic)
         self.trace = False            # True: device events around every bucket's collective (see overlap_report)
         self._trace_events: list = []
@@ -126,6 +128,8 @@ class GradientAverager:
             for i in idxs:
                 self._where[i] = bi
         self._ready = [0] * len(self.buckets)
+        self._seen_tagged = [False] * len(self.buckets)
+        self._untagged_late = [False] * len(self.buckets)
         self._pending = []
         for i, p in enumerate(self.params):
             self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
@@ -137,6 +141,10 @@ class GradientAverager:
             if self.world == 1:
                 return
             bi = self._where[i]
+            if getattr(_param, "_adx_grad_event", None) is not None:
+                self._seen_tagged[bi] = True
+            elif self._seen_tagged[bi]:
+                self._untagged_late[bi] = True       # an untagged gradient behind a tagged one: no event covers it
             self._ready[bi] += 1
             if self._ready[bi] == len(self.buckets[bi]):
                 self._ready[bi] = 0
@@ -196,10 +204,27 @@ class GradientAverager:
         if self._comm_stream is None or self._comm_stream.device != flat.device:
             self._comm_stream = torch.cuda.Stream(device=flat.device)
         ready = done = None
-        if self.trace:
-            ready = torch.cuda.Event(enable_timing=True)
-            ready.record(cur)
-        self._comm_stream.wait_stream(cur)
+        # When every gradient of the bucket carries the completion event of the launch that wrote it (the perception backward
+        # is ONE native call whose layer groups finish one after the other: modeling/perception.py), the side stream waits for
+        # the LAST of those events -- the bucket is reduced while the compute stream is still differentiating the layers below.
+        # Otherwise it joins everything queued on the compute stream so far (the temporal stack's per-layer nodes).
+        tagged = [t for t in (getattr(self.params[i], "_adx_grad_event", None) for i in idxs) if t is not None]
+        for i in idxs:
+            self.params[i]._adx_grad_event = None            # an event belongs to the backward that recorded it
+        # gradients of the bucket without an event are covered by the last event as long as they were accumulated BEFORE the
+        # first tagged one (their kernels precede it on the compute stream); _make_hook keeps that book per bucket
+        late = self._untagged_late[bi] if bi < len(self._untagged_late) else True
+        if bi < len(self._untagged_late):
+            self._untagged_late[bi] = self._seen_tagged[bi] = False
+        last = max(tagged, key=lambda t: t[0]) if tagged and not late else None
+        if last is not None:
+            self._comm_stream.wait_event(last[1])
+            ready = last[1] if self.trace else None
+        else:
+            if self.trace:
+                ready = torch.cuda.Event(enable_timing=True)
+                ready.record(cur)
+            self._comm_stream.wait_stream(cur)
         with torch.cuda.stream(self._comm_stream):
             works = issue()
             if self.trace:

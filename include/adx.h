@@ -264,6 +264,17 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* tensors, int32_t
 int adx_resnet_backward(adx_resnet* r, const float* const* tensors, float* const* grads, int32_t n_tensors,
                         void* workspace, size_t workspace_bytes, adx_resnet_tape* tape, const float* d_feature,
                         adx_stream s);
+/* The same with completion events: `events` = adx_resnet_backward_groups(r) hipEvent_t handles (or NULL entries); event g is
+ * recorded on `s` behind the last launch that writes a gradient of group g.  Groups in the order the backward produces them:
+ * 0 = fc, 1 .. n_blocks = the BasicBlocks from layer4's last to layer1's first, n_blocks + 1 = the stem (conv1 + bn1).
+ * adx_resnet_tensor_group(r, i) = the group of tensor slot i (-1: a running statistic).  This is what lets a gradient reduction
+ * of the upper layers start while the lower layers are still being differentiated -- what DistributedDataParallel's reducer
+ * does per parameter while accelerator.backward(loss) runs (train.py:176-178, 251). */
+int32_t adx_resnet_backward_groups(const adx_resnet* r);
+int32_t adx_resnet_tensor_group(const adx_resnet* r, int32_t tensor);
+int adx_resnet_backward_events(adx_resnet* r, const float* const* tensors, float* const* grads, int32_t n_tensors,
+                               void* workspace, size_t workspace_bytes, adx_resnet_tape* tape, const float* d_feature,
+                               void* const* events, int32_t n_events, adx_stream s);
 
 /* ------------------------------------------------------------------------------------
  * Classifier guidance: TrajPredict state head (modeling/helpers.py:22-59; hidden 64, 4 heads,

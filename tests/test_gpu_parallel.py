@@ -99,3 +99,7 @@ def test_bench_two_ranks_same_device_fullsize_free_train_leg():
     assert len(ov) == gb["n"] and all(o["done_ms"] >= o["ready_ms"] for o in ov)
     # the temporal stack's buckets are complete long before backward ends (the perception backward is two thirds of the step)
     assert min(o["ready_ms"] for o in ov) < -5.0, ov
+    # round 5: the perception backward hands out a completion event per layer group (adx_resnet_backward_events), so every bucket
+    # but the last (layer3's lower blocks ... the stem) is ready -- and its reduction launched -- while the layers below it
+    # are still being differentiated; before, all 85 MB of perception gradients became "ready" together at the end of backward
+    assert all(o["ready_ms"] < -3.0 for o in ov[:-1]), ov
