@@ -1,5 +1,6 @@
 // Shared device/host helpers for libadx (gfx950 only: wave64, fp32 MFMA).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -48,10 +49,22 @@ struct DebugSwitches {
   bool unet_pipe = true;       // ADX_UNET_PIPE=0    the deepest level's layer run as launches, not as one pipeline launch (tconv_pipe.hip)
   bool conv_cells = true;      // ADX_CONV_CELLS=0   fp32 NCHW between all perception convs (no pre-split cell tensors)
   int hs_mode = -1;            // ADX_HS_MODE=0|1|2  pins the tile mode of the pipelined 3x3 kernel
+  bool wgrad_deterministic = false;   // ADX_WGRAD_DETERMINISTIC=1  the 3x3 weight gradients (conv2d_wgrad_hs) reduce per-workgroup partial
+                               //                    sums in index order instead of with float atomics: bit-reproducible, one more pass
   bool check_range = false;    // ADX_CHECK_RANGE=1  perception forward: fail with the first layer whose activations leave the
                                //                    fp16 range of the split kernels instead of propagating inf (synchronises)
 };
 const DebugSwitches& debug_switches();
+
+// "once per device" for per-device state such as hipFuncSetAttribute(MaxDynamicSharedMemorySize): a process-wide flag would
+// leave a second GPU of the same process without the attribute (one process per GPU is the deployment, but not a rule).
+// True the first time the calling thread's current device meets this flag (devices folded modulo 64).
+inline bool first_on_device(std::atomic<uint64_t>& done) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  return (done.fetch_or(bit, std::memory_order_relaxed) & bit) == 0;
+}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

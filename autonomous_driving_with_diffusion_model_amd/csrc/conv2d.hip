@@ -439,15 +439,14 @@ int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const f
   ADX_REQUIRE(lds <= kMaxLds, "conv2d: LDS %zu bytes too large", lds);
   const size_t grid = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y * N;
   ADX_REQUIRE(grid < (1u << 31), "conv2d: grid too large");
-  static bool attr_set = false;  // dynamic LDS above 64 KB must be opted into once per kernel
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_set{0};  // dynamic LDS above 64 KB must be opted into once per kernel
+  if (first_on_device(attr_set)) {
     const void* fns[6] = {reinterpret_cast<const void*>(&conv2d_kernel<1, 3, 1>), reinterpret_cast<const void*>(&conv2d_kernel<2, 3, 1>),
                           reinterpret_cast<const void*>(&conv2d_kernel<2, 1, 1>), reinterpret_cast<const void*>(&conv2d_kernel<2, 7, 1>),
                           reinterpret_cast<const void*>(&conv2d_kernel<1, 1, 1>), reinterpret_cast<const void*>(&conv2d_kernel<1, 3, 2>)};
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_kernel<1, 3, 2, 8>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
     for (const void* f : fns) ADX_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
-    attr_set = true;
   }
   const dim3 g((unsigned)grid), blk(256);
   if (L.stride == 1 && L.k == 3 && rows == 2 && cch == 8) conv2d_kernel<1, 3, 2, 8><<<g, blk, lds, s>>>(a);

@@ -1402,11 +1402,10 @@ static int hs_launch_t(Conv2dArgs a, hipStream_t s) {
   constexpr size_t lds = (size_t)PBUF * 64 * PH * PW + (size_t)2 * K * 256 * 16 + (DS ? 256 * 16 : 0) +
                          (DS ? 4 : 2) * kHsCout * sizeof(float) + 16;
   static_assert(lds <= 80 * 1024, "two workgroups per CU need <= 80 KB each");
-  static bool attr = false;
-  if (!attr) {
+  static std::atomic<uint64_t> attr{0};
+  if (first_on_device(attr)) {
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs_kernel<STRIDE, K, ROWS, PBUF, DS, XCELLS, YCELLS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr = true;
   }
   a.tiles_x = ceil_div(a.OW, kTileW); a.tiles_y = ceil_div(a.OH, TH); a.cout_tiles = a.Cout / kHsCout;
   const size_t grid = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y * a.N;
@@ -1423,11 +1422,10 @@ static int hs_stem_launch(Conv2dArgs a, hipStream_t s) {
   constexpr size_t lds = (size_t)kStemSteps * 4096 + (size_t)PBUF * 4 * 3 * PH * kStemPP + 2 * kHsCout * sizeof(float) +
                          (POOL ? (4 * 64 + 2) * sizeof(float) : 0);     // parked columns + the dummy words of the other lanes
   static_assert(lds <= 80 * 1024, "two workgroups per CU need <= 80 KB each");
-  static bool attr = false;
-  if (!attr) {
+  static std::atomic<uint64_t> attr{0};
+  if (first_on_device(attr)) {
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs_stem_kernel<POOL, U8>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr = true;
   }
   a.tiles_x = ceil_div(a.OW, kTileW); a.cout_tiles = 1;
   a.tiles_y = POOL ? ceil_div((a.OH - 1) / 2 + 1, 4) : ceil_div(a.OH, 8);
@@ -1517,15 +1515,14 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
   constexpr size_t lds = (size_t)2 * 64 * (TH + 2) * 34 + (size_t)2 * 3 * 256 * CT * 16 + (2 * 64 * CT + 8) * sizeof(float) + 48;
   constexpr size_t lds_bs = lds + 4 * 64 * CT * sizeof(float);       // STATS == 2: + the consumer BatchNorm's constants
   static_assert(lds_bs <= (MODE == 0 ? 80 : 160) * 1024, "LDS budget");
-  static bool attr = false;
-  if (!attr) {
+  static std::atomic<uint64_t> attr{0};
+  if (first_on_device(attr)) {
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 0>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 1>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 2>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bs));
-    attr = true;
   }
   a.tiles_x = ceil_div(a.OW, kTileW); a.tiles_y = ceil_div(a.OH, TH); a.cout_tiles = a.Cout / (kHsCout * CT);
   const size_t grid = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y * a.N;
@@ -1571,12 +1568,11 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
     ADX_REQUIRE(a.y_cells && a.x_amax == nullptr, "conv2d_hs: cell-layout operands come with a cell-layout output (and no dynamic range)");
     if (conv2d_hs3x3q_eligible(a)) return conv2d_hs3x3q_launch(a, s);      // the 16x16x32 kernel (conv2d_hs16.hip) where its tile rules hold
     constexpr size_t clds = lds;
-    static bool cattr = false;
-    if (!cattr) {
+    static std::atomic<uint64_t> cattr{0};
+    if (first_on_device(cattr)) {
       const void* fns[2] = {reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 0, true, true>),
                             reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 0, false, true>)};
       for (const void* f : fns) ADX_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
-      cattr = true;
     }
     // column tiles over the images side by side with one shared zero column between neighbours (conv2d_hs3x3_kernel: YCELLS):
     // one padded MFMA column per image instead of the round-up to 32

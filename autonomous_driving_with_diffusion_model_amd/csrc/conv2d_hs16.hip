@@ -276,7 +276,9 @@ bool conv2d_hs3x3q_eligible(const Conv2dArgs& a) {
 
 int conv2d_hs3x3q_launch(Conv2dArgs a, hipStream_t s) {
   ADX_REQUIRE(conv2d_hs3x3q_eligible(a), "conv2d_hs3x3q: launch outside the kernel's rules");
-  ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3q_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQLds));
+  static std::atomic<uint64_t> attr{0};
+  if (first_on_device(attr))
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3q_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQLds));
   a.vw = a.N > 1 ? a.OW + 1 : a.OW;
   a.inv_vw = 1.f / (float)a.vw;
   ADX_REQUIRE((long)a.N * a.vw < (1L << 21), "conv2d_hs: batch x width exceeds the virtual-row arithmetic");

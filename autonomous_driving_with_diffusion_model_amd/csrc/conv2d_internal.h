@@ -159,6 +159,10 @@ inline bool resnet_fuses_ds(const ConvSpec& c1, const ConvSpec& ds) {
 bool conv2d_wgrad_hs_eligible(int Cin, int Cout, int k, int stride, int pad);
 int conv2d_wgrad_hs(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, int stride,
                     const uint32_t* dy_amax, int dy_amax_n, hipStream_t s);
+// ADX_WGRAD_DETERMINISTIC=1: scratch for the per-split copies of dw that conv2d_wgrad_hs reduces in index order (lent by the calling
+// thread's executor until cleared; conv2d_wgrad_partials_floats() = what to lend, 0 when the switch is off)
+void conv2d_wgrad_set_partials(float* p, size_t floats);
+size_t conv2d_wgrad_partials_floats();
 // conv2d_wgrad_stem_hs.hip: the stem's (7x7 stride 2, 3 -> 64) weight gradient on the fp16 matrix cores; dw must be zero on entry
 bool conv2d_wgrad_stem_hs_eligible(int Cin, int Cout, int k, int stride, int pad);
 int conv2d_wgrad_stem_hs(const float* x, const float* dy, float* dw, int N, int H, int W, const uint32_t* dy_amax, int dy_amax_n,

@@ -39,6 +39,8 @@ struct WgradHsArgs {
   int dy_amax_n;
   int N, Cin, Cout, H, W, OH, OW;
   int segs, units, units_per_wg, n_ci_tiles, n_co_tiles;
+  float* part;           // deterministic mode: [splits][Cout][Cin][9] partial sums (split s of a tile writes its own copy), else null
+  size_t part_stride;    // Cout * Cin * 9
 };
 
 constexpr float kWLo = 2048.f;
@@ -231,11 +233,35 @@ __global__ void __launch_bounds__(kWThreads) conv2d_wgrad_hs_kernel(const WgradH
     __syncthreads();
     for (int idx = tid; idx < 32 * 576; idx += kWThreads) {
       const int co_l = idx / 576, rem = idx - co_l * 576;
-      atomicAdd(a.dw + ((size_t)(co0 + pb * 32 + co_l) * a.Cin + ci0) * 9 + rem, tbuf[idx]);
+      const size_t at = ((size_t)(co0 + pb * 32 + co_l) * a.Cin + ci0) * 9 + rem;
+      if (a.part != nullptr) a.part[(size_t)split * a.part_stride + at] = tbuf[idx];      // reduced in index order by wgrad_parts_reduce_kernel
+      else atomicAdd(a.dw + at, tbuf[idx]);
     }
     __syncthreads();
   }
 }
+
+// deterministic mode: dw[i] += part[0][i] + part[1][i] + ... in index order (four elements per thread, eight loads in flight)
+__global__ void __launch_bounds__(256) wgrad_parts_reduce_kernel(const float* __restrict__ part, size_t stride, int nparts,
+                                                                 float* __restrict__ dw, size_t total4) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  f32x4 v = reinterpret_cast<const f32x4*>(part)[i];
+  for (int p0 = 1; p0 < nparts; p0 += 8) {
+    f32x4 t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = reinterpret_cast<const f32x4*>(part + (size_t)(p0 + j < nparts ? p0 + j : 0) * stride)[i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (p0 + j < nparts) v += t[j];
+  }
+  reinterpret_cast<f32x4*>(dw)[i] += v;
+}
+
+static thread_local float* t_wgrad_parts = nullptr;
+static thread_local size_t t_wgrad_parts_floats = 0;
+void conv2d_wgrad_set_partials(float* p, size_t floats) { t_wgrad_parts = p; t_wgrad_parts_floats = p != nullptr ? floats : 0; }
+size_t conv2d_wgrad_partials_floats() { return debug_switches().wgrad_deterministic ? (size_t)256 * 64 * 64 * 9 : 0; }
 
 bool conv2d_wgrad_hs_eligible(int Cin, int Cout, int k, int stride, int pad) {
   const bool exact = debug_switches().conv_exact || debug_switches().wgrad_exact;
@@ -248,11 +274,10 @@ static int wgrad_hs_launch(WgradHsArgs a, hipStream_t s) {
   constexpr size_t lds = (size_t)2 * (2 * 2 * NPX * 64) + (size_t)NSLOT * (2 * 2 * (S * NPX + 2) * 64) + 64;
   constexpr size_t need = std::max(lds, (size_t)32 * 576 * sizeof(float));
   static_assert(need <= 160 * 1024, "LDS budget");
-  static bool attr = false;
-  if (!attr) {
+  static std::atomic<uint64_t> attr{0};
+  if (first_on_device(attr)) {
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad_hs_kernel<NPX, S>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
-    attr = true;
   }
   a.segs = ceil_div(a.OW, NPX);
   a.units = a.N * a.segs;
@@ -261,8 +286,24 @@ static int wgrad_hs_launch(WgradHsArgs a, hipStream_t s) {
   if (splits > a.units) splits = a.units;
   a.units_per_wg = ceil_div(a.units, splits);
   splits = ceil_div(a.units, a.units_per_wg);
+  a.part = nullptr; a.part_stride = 0;
+  if (debug_switches().wgrad_deterministic) {
+    // ADX_WGRAD_DETERMINISTIC=1: every (tile, split) workgroup leaves its 64 x 64 x 9 block in a copy of dw of its split, and one
+    // more launch adds the copies up in index order (splits * Cout * Cin * 9 <= 256 * 64 * 64 * 9 floats: tiles * splits <= 256)
+    a.part_stride = (size_t)a.Cout * a.Cin * 9;
+    ADX_REQUIRE(t_wgrad_parts != nullptr && (size_t)splits * a.part_stride <= t_wgrad_parts_floats && (a.part_stride & 3) == 0 &&
+                    (reinterpret_cast<uintptr_t>(a.dw) & 15) == 0 && (reinterpret_cast<uintptr_t>(t_wgrad_parts) & 15) == 0,
+                "conv2d_wgrad_hs: ADX_WGRAD_DETERMINISTIC=1 needs the partial-sum scratch (%zu floats; the caller lent %zu)",
+                (size_t)splits * a.part_stride, t_wgrad_parts_floats);
+    a.part = t_wgrad_parts;
+  }
   conv2d_wgrad_hs_kernel<NPX, S><<<dim3((unsigned)(tiles * splits)), dim3(kWThreads), need, s>>>(a);
   ADX_LAUNCH_CHECK();
+  if (a.part != nullptr) {
+    const size_t total4 = a.part_stride / 4;
+    wgrad_parts_reduce_kernel<<<dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s>>>(a.part, a.part_stride, splits, a.dw, total4);
+    ADX_LAUNCH_CHECK();
+  }
   return ADX_OK;
 }
 

@@ -501,7 +501,8 @@ __device__ __forceinline__ void maxpool_bwd_gather4(const uint8_t* __restrict__ 
 // through the arg-max codes is formed on the fly in both passes and never written (944 MB at B = 64, 3x256x900: one
 // write and two reads less).  PASS 0 = channel_sums_kernel<1> with relu_mask 2 (one workgroup per plane, one fp64 atomic
 // pair per plane); PASS 1 = bn_bwd_apply (one wave per input row): draw = gamma rstd (dz - m1 - xhat m2), and the affine
-// parameters' gradients (the finished sums) by workgroup (0, 0).  Same arithmetic as the separate passes.
+// parameters' gradients (the finished sums) by workgroup (0, 0).  Same arithmetic as the separate passes, except PASS 0's
+// shortcut through the pooled tensors (below), which is gated to channels where it is accurate.
 constexpr int kStemBwdRows = 4;
 template <int PASS>
 __global__ void __launch_bounds__(256) stem_pool_bn_bwd_kernel(const uint8_t* __restrict__ code, const float* __restrict__ dpool,
@@ -515,7 +516,9 @@ __global__ void __launch_bounds__(256) stem_pool_bn_bwd_kernel(const uint8_t* __
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t mx = 0;        // PASS 1: max |draw| of this workgroup (bit pattern), for the split-fp16 weight gradient's range
   const int pl = blockIdx.x, c = pl % C;
-  if (PASS == 0 && pooled != nullptr && fabsf(gamma[c]) >= 1e-12f) {
+  // (the shortcut recovers xhat as (pooled - beta) / gamma, whose rounding error is eps |beta| / |gamma|: only where |gamma| is
+  // at least 2^-6 of |beta| -- eps * 64 on xhat -- otherwise the channel takes the exact gather pass below)
+  if (PASS == 0 && pooled != nullptr && fabsf(gamma[c]) >= 1e-12f && fabsf(gamma[c]) * 64.f >= fabsf(beta[c])) {
     // The sums from the POOLED tensors alone (472 MB instead of the 944 MB conv output + codes + gathers): d(stem map) is the
     // pooled gradient scattered to each window's arg-max position, so sum dz = sum over the windows whose maximum passed the ReLU
     // of their gradient, and sum dz xhat = the same sum weighted with xhat AT the arg-max -- which the pooled value itself gives
@@ -870,14 +873,13 @@ int conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int
     const size_t red = (size_t)ng * 1024;
     return sizeof(float) * std::max(stage, red);
   };
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_set{0};
+  if (first_on_device(attr_set)) {
     const void* fns[4] = {reinterpret_cast<const void*>(&conv2d_wgrad_kernel<1, 3, 9, 32>),
                           reinterpret_cast<const void*>(&conv2d_wgrad_kernel<2, 3, 9, 16>),
                           reinterpret_cast<const void*>(&conv2d_wgrad_kernel<2, 1, 1, 32>),
                           reinterpret_cast<const void*>(&conv2d_wgrad_kernel<2, 7, 5, 3>)};
     for (const void* f : fns) ADX_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
   }
   if (stride == 1 && k == 3) conv2d_wgrad_kernel<1, 3, 9, 32><<<grid, blk, lds_bytes(32, 9), s>>>(a);
   else if (stride == 2 && k == 3) conv2d_wgrad_kernel<2, 3, 9, 16><<<grid, blk, lds_bytes(16, 9), s>>>(a);
@@ -916,7 +918,9 @@ __global__ void __launch_bounds__(256) amax_partials_kernel(const float* __restr
 
 extern "C" {
 
-size_t adx_conv2d_wgrad_scratch_bytes(void) { return adx::kAmaxPartials * sizeof(uint32_t); }
+size_t adx_conv2d_wgrad_scratch_bytes(void) {
+  return adx::kAmaxPartials * sizeof(uint32_t) + adx::conv2d_wgrad_partials_floats() * sizeof(float);     // [range partials | ADX_WGRAD_DETERMINISTIC's copies]
+}
 
 int adx_conv2d_wgrad(const adx_conv2d_desc* d, const float* x, const float* dy, float* dw, int32_t n, int32_t h,
                      int32_t w, void* scratch, adx_stream stream) {
@@ -932,6 +936,11 @@ int adx_conv2d_wgrad(const adx_conv2d_desc* d, const float* x, const float* dy, 
     amax_partials_kernel<<<dim3(n_amax), dim3(256), 0, s>>>(dy, total, amax);
     ADX_LAUNCH_CHECK();
   }
+  struct PartsScope {
+    ~PartsScope() { conv2d_wgrad_set_partials(nullptr, 0); }
+  } parts_scope;
+  if (amax != nullptr && conv2d_wgrad_partials_floats() > 0)
+    conv2d_wgrad_set_partials(reinterpret_cast<float*>(amax + kAmaxPartials), conv2d_wgrad_partials_floats());
   return conv2d_wgrad(x, dy, dw, n, d->cin, h, w, d->cout, d->k, d->stride, d->pad, s, amax, n_amax);
 }
 
@@ -1012,7 +1021,7 @@ size_t adx_resnet_train_workspace_bytes(const adx_resnet* r, int32_t batch, int3
     conv(c2, OH, OW);
     H = OH; W = OW;
   }
-  f += al64(r->convs.size() * 2 * 512 * 2) + al64(kAmaxPartials) + al64((size_t)512 * 256 * 9) + 5 * al64(big) + 2 * al64(wmax) + wall;   // backward: sums, amax, 3x3 image of a 1x1 gradient, 5 gradient buffers, dgrad weights (one scratch pair + a slot per stride-1 3x3 conv)
+  f += al64(r->convs.size() * 2 * 512 * 2) + al64(kAmaxPartials) + al64((size_t)512 * 256 * 9) + al64(conv2d_wgrad_partials_floats()) + 5 * al64(big) + 2 * al64(wmax) + wall;   // backward: sums, amax, 3x3 image of a 1x1 gradient, 5 gradient buffers, dgrad weights (one scratch pair + a slot per stride-1 3x3 conv)
   return (f + 1024) * sizeof(float);
 }
 
@@ -1199,6 +1208,10 @@ int adx_resnet_backward_events(adx_resnet* r, const float* const* T, float* cons
   }
   uint32_t* amax = reinterpret_cast<uint32_t*>(ws.take(kAmaxPartials));   // per-workgroup max |draw| of the conv being differentiated
   float* wgrad9 = ws.take((size_t)512 * 256 * 9);     // 3x3 image of the largest 1x1 downsample gradient (conv2d_wgrad)
+  struct PartsScope {
+    ~PartsScope() { conv2d_wgrad_set_partials(nullptr, 0); }
+  } parts_scope;
+  if (const size_t pf = conv2d_wgrad_partials_floats()) conv2d_wgrad_set_partials(ws.take(pf), pf);     // ADX_WGRAD_DETERMINISTIC=1
   size_t big = 0, wmax = 0;
   for (auto& rec : tape->recs) {
     big = std::max(big, (size_t)batch * rec.L->cout * rec.OH * rec.OW);

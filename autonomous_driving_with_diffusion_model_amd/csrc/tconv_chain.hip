@@ -464,11 +464,10 @@ int chain_pack(const adx_tconv_desc* d, const float* w, const adx_tconv_desc* r,
 }
 
 int chain_launch(const ChainArgs& ca, int grid, size_t lds_bytes, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_set{0};
+  if (first_on_device(attr_set)) {
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_chain_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainMaxLds));
-    attr_set = true;
   }
   ADX_REQUIRE(lds_bytes <= kChainMaxLds, "tconv_chain: %zu bytes of LDS exceed %zu", lds_bytes, kChainMaxLds);
   tconv_chain_kernel<<<dim3(grid), dim3(kChNT), lds_bytes, s>>>(ca);

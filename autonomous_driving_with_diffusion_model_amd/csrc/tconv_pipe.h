@@ -36,7 +36,15 @@ struct PipeArgs {
   float eps;
   float* records;          // [n_conv][P][16 rows][16 channels]
   unsigned* counters;      // n_conv arrival counters, 16 words apart, zero on entry (the executor's ticket words)
+  unsigned* fault;         // host-visible word (pipe_fault_word) a timed-out stage sets; null: the NaN output is the only signal
 };
+
+// A spin that times out turns the run's output into NaN AND sets a word of pinned host memory that the next adx_unet_forward /
+// adx_unet_time_conditioning of the process reads (no synchronisation: the word is written through to the host) and reports as
+// ADX_ERR_STATE.  pipe_fault_word(): the device-side address of that word (allocated on first use; null if that failed);
+// pipe_fault_take(): its value, cleared.
+unsigned* pipe_fault_word();
+unsigned pipe_fault_take();
 
 // live taps of a stride-1 conv on L positions, and whether a layer run of this shape fits the kernel (weights of one workgroup
 // in LDS, the whole batch in one 16-row tile)

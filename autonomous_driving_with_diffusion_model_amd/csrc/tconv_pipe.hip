@@ -293,6 +293,7 @@ __global__ void __launch_bounds__(kPipeNT) tconv_pipe_kernel(const PipeArgs a) {
     // turn; the finisher makes the failure LOUD instead of leaving whatever the output buffer held: the run's output becomes NaN.
     if (!conv && S.pub != nullptr)
       for (int q = tid; q < M * C; q += kPipeNT) S.pub[q] = __builtin_nanf("");
+    if (tid == 0 && a.fault != nullptr) __hip_atomic_store(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
   PIPE_STAMP(3);
@@ -486,17 +487,48 @@ __global__ void __launch_bounds__(kPipeNT) tconv_pipe_kernel(const PipeArgs a) {
   PIPE_STAMP(9);
 }
 
+static unsigned* g_fault_host = nullptr;      // pinned, mapped: the kernel's store lands in host memory
+static unsigned* g_fault_dev = nullptr;
+static std::atomic<int> g_fault_state{0};     // 0 not tried, 1 being allocated, 2 ready, 3 failed
+
+unsigned* pipe_fault_word() {
+  int st = g_fault_state.load(std::memory_order_acquire);
+  if (st == 0) {
+    int expect = 0;
+    if (g_fault_state.compare_exchange_strong(expect, 1)) {
+      void* h = nullptr;
+      void* d = nullptr;
+      bool ok = hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess;
+      if (ok) {
+        g_fault_host = (unsigned*)h;
+        g_fault_dev = (unsigned*)d;
+        *g_fault_host = 0;
+      }
+      g_fault_state.store(ok ? 2 : 3, std::memory_order_release);
+    }
+    while ((st = g_fault_state.load(std::memory_order_acquire)) == 1) {}
+  }
+  return st == 2 ? g_fault_dev : nullptr;
+}
+
+unsigned pipe_fault_take() {
+  if (g_fault_state.load(std::memory_order_acquire) != 2) return 0;
+  volatile unsigned* p = g_fault_host;
+  const unsigned v = *p;
+  if (v != 0) *p = 0;
+  return v;
+}
+
 int pipe_launch(const PipeArgs& a, hipStream_t s) {
   ADX_REQUIRE(a.n_conv >= 1 && a.n_conv < kPipeMaxStages && a.P == a.C / kPipeCh && a.records && a.counters,
               "tconv_pipe: bad argument block");
   ADX_REQUIRE(pipe_shape_ok(a.C, a.L, a.rows, a.taps, a.pad, a.groups), "tconv_pipe: shape outside the kernel's rules");
   ADX_REQUIRE((a.C / a.groups) % 4 == 0, "tconv_pipe: GroupNorm group width must be a multiple of 4");
   const size_t lds = pipe_lds_bytes(a.C, a.rows * a.L, a.ntap);
-  static bool attr = false;
-  if (!attr) {
+  static std::atomic<uint64_t> attr{0};
+  if (first_on_device(attr)) {
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_pipe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)kPipeMaxLds));
-    attr = true;
   }
   tconv_pipe_kernel<<<dim3((unsigned)(a.n_conv * a.P + 1)), dim3(kPipeNT), lds, s>>>(a);
   ADX_LAUNCH_CHECK();

@@ -618,6 +618,11 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
     return ADX_ERR_STATE;
   }
   ADX_REQUIRE(io->x && io->out, "adx_unet_forward: null tensor");
+  if (pipe_fault_take() != 0) {
+    set_error("adx_unet_forward: a stage of an earlier pipeline launch (tconv_pipe) timed out waiting for its producers; that run's "
+              "output was set to NaN");
+    return ADX_ERR_STATE;
+  }
   const int rows = io->rows, dim = u->cfg.dim, H = u->cfg.horizon, D = u->cfg.transition_dim;
   ADX_REQUIRE(rows >= 1, "adx_unet_forward: rows must be >= 1");
   if (io->time_bias == nullptr) {
@@ -779,6 +784,7 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
       float* ya = split_scratch + align64(rec_floats);
       float* yb = ya + align64((size_t)rows * Lp * C);
       float* yc = yb + align64((size_t)rows * Lp * C);
+      pa.fault = pipe_fault_word();
       pa.counters = split_tickets + 128;                          // words 128, 144, ... 224: a 64-byte line per stage (the split
                                                                   // reductions' tickets stay below 128), cleared at the head of this forward
       for (int k = 0; k < 7; ++k) {

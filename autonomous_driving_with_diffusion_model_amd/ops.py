@@ -4,6 +4,7 @@ native executors (adx_unet_forward / adx_resnet_forward)."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -166,7 +167,7 @@ def conv2d_weight_grad(x: torch.Tensor, dy: torch.Tensor, k: int, *, stride: int
     d = L.Conv2dDesc(cin, cout, k, stride, pad)
     dw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=x.device)
     scratch = None
-    if estimate_range:
+    if estimate_range or os.environ.get("ADX_WGRAD_DETERMINISTIC") == "1":     # the deterministic mode's per-split copies ride in the scratch
         scratch = torch.empty(L.lib().adx_conv2d_wgrad_scratch_bytes(), dtype=torch.uint8, device=x.device)
     L.check(L.lib().adx_conv2d_wgrad(C.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, h, w, L.ptr(scratch),
                                      L.stream_ptr(x.device)), "adx_conv2d_wgrad")

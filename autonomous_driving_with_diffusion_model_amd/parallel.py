@@ -88,14 +88,25 @@ class GradientAverager:
                 self._avg_ok = self._probe_avg(self.params[0].device)
 
     def _probe_avg(self, device) -> bool:
-        """ReduceOp.AVG exists in RCCL / NCCL >= 2.10 and in recent gloo only: one 1-element collective at construction
-        (every rank constructs the averager) decides; without it the buckets carry the SUM and are scaled after the wait."""
+        """ReduceOp.AVG exists in RCCL / NCCL >= 2.10 (every ROCm build torch ships with) and not in gloo: decided from the backend's
+        name, without a trial collective (a collective that raises can leave an RCCL communicator in an error state, and a
+        transient failure would silently turn every step into SUM + one more pass).  Only an unknown backend is probed, and the
+        fallback is logged."""
+        backend = str(dist.get_backend(self.group)).lower()
+        if "nccl" in backend:
+            return True
+        if "gloo" in backend:
+            return False
         try:
             t = torch.ones(1, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group)
-            return bool(abs(float(t) - 1.0) < 1e-6)
+            ok = bool(abs(float(t) - 1.0) < 1e-6)
         except (RuntimeError, ValueError, NotImplementedError):
-            return False
+            ok = False
+        if not ok:
+            import warnings
+            warnings.warn(f"GradientAverager: backend {backend!r} has no ReduceOp.AVG; buckets carry the SUM and are scaled after the wait")
+        return ok
 
     def _ensure_bucket(self, bi: int) -> torch.Tensor:
         idxs = self.buckets[bi]

@@ -283,3 +283,29 @@ def test_stem_weight_gradient_split_fp16(h, w, n, dyscale):
     # without a range estimate the exact-fp32 kernel answers: both paths stay alive
     dwx = _ops().conv2d_weight_grad(x.to(DEV), dy.to(DEV), 7, stride=2, pad=3, estimate_range=False)
     assert err(dwx) < 5e-6
+
+
+@split_only
+def test_weight_gradient_deterministic_mode_is_bit_reproducible(tmp_path):
+    """ADX_WGRAD_DETERMINISTIC=1 (csrc/conv2d_wgrad_hs.hip): every (tile, split) workgroup leaves its block in a copy of dw of its
+    split and one more launch adds the copies up in index order, instead of float atomics whose arrival order moves the last
+    bits from run to run.  At the full batch of a training step, every 3x3 shape: three runs bit-equal in a process with the
+    switch, and equal to the atomic path of this process up to the order of the sums."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import wgrad_det_worker as W
+    out = str(tmp_path / "det.pt")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "wgrad_det_worker.py"), out, "64"],
+                       env=dict(os.environ, ADX_WGRAD_DETERMINISTIC="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    det = torch.load(out)
+    for shape in W.SHAPES:
+        equal, dw_det = det[shape]
+        assert equal, shape
+        cin, cout, s, h, w = shape
+        x, dy = W.inputs(cin, cout, s, h, w, 64, DEV)
+        dw = _ops().conv2d_weight_grad(x, dy, 3, stride=s, pad=1).cpu()
+        err = (dw - dw_det).abs().max().item()
+        assert err <= 2e-6 * dw.abs().max().item(), (shape, err)
