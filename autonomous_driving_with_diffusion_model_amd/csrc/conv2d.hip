@@ -573,7 +573,13 @@ int adx_resnet_create(int32_t out_dim, adx_resnet** out) {
   return ADX_OK;
 }
 
-void adx_resnet_destroy(adx_resnet* r) { delete r; }
+void adx_resnet_destroy(adx_resnet* r) {
+  if (r == nullptr) return;
+  for (auto& st : r->side) if (st != nullptr) (void)hipStreamDestroy(st);
+  if (r->ev_fork != nullptr) (void)hipEventDestroy(r->ev_fork);
+  for (auto& ev : r->ev_join) if (ev != nullptr) (void)hipEventDestroy(ev);
+  delete r;
+}
 int adx_resnet_num_tensors(const adx_resnet* r) { return r ? r->n_tensors : 0; }
 size_t adx_resnet_packed_bytes(const adx_resnet* r) { return r ? r->packed_floats * sizeof(float) : 0; }
 
@@ -697,7 +703,7 @@ static int resnet_forward_impl(adx_resnet* r, const void* packed, void* workspac
   constexpr int fuse = 1;         // stem + max-pool as one launch (0: two launches, the round-1 form)
 
   // stem (+ pool) of images [n0, n0 + n)
-  auto run_stem = [&](Cursor& st, int n0, int n, int nf) -> int {
+  auto run_stem = [&](Cursor& st, int n0, int n, int nf, hipStream_t s) -> int {
     const ConvSpec& c0 = r->convs[0];
     const float* im = img != nullptr ? img + (size_t)n0 * 3 * h * w : nullptr;
     const uint8_t* fr = frames_u8 != nullptr ? frames_u8 + (size_t)n0 * 3 * h * w : nullptr;
@@ -705,7 +711,7 @@ static int resnet_forward_impl(adx_resnet* r, const void* packed, void* workspac
     bool pooled_cells = false;
     int rc;
     if ((fuse || frames_u8 != nullptr) && conv2d_hs_eligible(c0)) {
-      scratch_scope.set(stem, (size_t)batch * 64 * h1 * w1);     // the unpooled stem map is never written on this path
+      // (the unpooled stem map is never written on this path: its region is the split-reduction scratch of this sub-batch's convs)
       // the pooled map's readers are layer1's first block: conv1 (input) and conv2 (residual); cells if both read cells
       pooled_cells = nblocks > 0 && !r->block_has_ds[0] && r->convs[1].stride == 1 && conv2d_hs3x3_plain(r->convs[1], nf, h2, w2) &&
                      conv2d_hs3x3_plain(r->convs[2], nf, h2, w2);
@@ -729,7 +735,7 @@ static int resnet_forward_impl(adx_resnet* r, const void* packed, void* workspac
   // the average pool reads them.  What stays fp32 NCHW: all of a layer whose launches split their reduction (small batches)
   // -- and the pooled stem map then.
   // One BasicBlock for images [n0, n0 + n); nf = the batch the format decisions are made for.
-  auto run_block = [&](size_t b, Cursor& st, int n0, int n, int nf) -> int {
+  auto run_block = [&](size_t b, Cursor& st, int n0, int n, int nf, hipStream_t s) -> int {
     size_t ci = st.ci;
     const int cur = st.cur, H = st.H, W = st.W;
     const bool cur_cells = st.cells;
@@ -737,7 +743,10 @@ static int resnet_forward_impl(adx_resnet* r, const void* packed, void* workspac
     const ConvSpec& c2 = r->convs[ci++];
     const int mid = (cur + 1) % 3, outb = (cur + 2) % 3;
     const int OH = conv_out(H, 3, c1.stride, 1), OW = conv_out(W, 3, c1.stride, 1);
-    const size_t off_in = (size_t)n0 * c1.cin * H * W, off_out = (size_t)n0 * c1.cout * OH * OW;
+    // a sub-batch owns the SAME region of every rotating buffer at every layer (its first image's slot of the largest map, the
+    // pooled one; the images of a layer are packed from there): sub-batches run on streams of their own and are at different
+    // layers at the same time, so a region that moved with the layer's per-image size would overlap another sub-batch's
+    const size_t off_in = (size_t)n0 * 64 * h2 * w2, off_out = off_in;
     const float* xin = buf[cur] + off_in;
     const float* identity = xin;
     bool id_cells = cur_cells, mid_cells = false;
@@ -801,14 +810,73 @@ static int resnet_forward_impl(adx_resnet* r, const void* packed, void* workspac
   // Infinity Cache when the next launch reads it, was measured: layer1's convs already find most of their input there at
   // B = 64 -- inside a pass they take 0.20 ms where the same launch repeated on fixed buffers takes 0.25 -- and the chunked
   // stem launch has too few workgroups: +-1 % end to end for 2..4 chunks, -13 % for 8.  Not kept.)
-  Cursor st{};
-  int rc = run_stem(st, 0, batch, batch);
-  if (rc != ADX_OK) return rc;
-  for (size_t b = 0; b < nblocks; ++b) {
-    rc = run_block(b, st, 0, batch, batch);
-    if (rc != ADX_OK) return rc;
+  // Sub-batches on streams of their own (round 5).  A launch of the pipelined 3x3 kernels is one workgroup per CU and tile, and at
+  // B = 64 the tile counts are 1.8 (256 channels) / 3.6 (128) / 0.94 (512) times the 256 CUs: the last round of every launch leaves
+  // 6-10 % of the chip idle and the next launch cannot start before it ends.  Two half batches are two independent chains of
+  // launches: while one's last workgroups run, the other's fill the idle CUs (a second workgroup of these kernels does not fit
+  // a CU, so the co-scheduled kernel gets exactly the idle ones).  Same kernels, same per-image arithmetic: the features are bit
+  // for bit those of the single-stream pass wherever the tile modes agree.  Weights are read once per sub-batch instead of once.
+  constexpr int kMaxSub = adx_resnet::kMaxSub;
+  int nsub = 1;
+  if (batch >= 32 && !debug_switches().check_range && fuse && conv2d_hs_eligible(r->convs[0])) {
+    nsub = std::min(debug_switches().resnet_streams, kMaxSub);
+    while (nsub > 1 && batch / nsub < 16) --nsub;
   }
-  return avgpool_fc_launch(buf[st.cur], base + r->o_fcw, base + r->o_fcb, feature, batch, 512, st.H * st.W, r->out_dim, s, st.cells);
+  if (nsub > 1) {
+    // not inside a stream capture: a replayed graph with the forked branches measured 2 % SLOWER per tick than the single chain
+    // (profiles/README.md, round 5), and streams are not created while capturing
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) nsub = 1;
+  }
+  if (nsub > 1) {
+    int dev = 0;
+    ADX_CHECK_HIP(hipGetDevice(&dev));
+    if (r->side_device != dev || r->side[nsub - 2] == nullptr) {
+      {
+        if (r->side_device != dev) {
+          for (auto& st : r->side) if (st != nullptr) { (void)hipStreamDestroy(st); st = nullptr; }
+          r->side_device = dev;
+        }
+        if (r->ev_fork == nullptr) ADX_CHECK_HIP(hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming));
+        for (int k = 0; k < nsub - 1; ++k) {
+          if (r->side[k] == nullptr) ADX_CHECK_HIP(hipStreamCreateWithFlags(&r->side[k], hipStreamNonBlocking));
+          if (r->ev_join[k] == nullptr) ADX_CHECK_HIP(hipEventCreateWithFlags(&r->ev_join[k], hipEventDisableTiming));
+        }
+      }
+    }
+  }
+  hipStream_t streams[kMaxSub];
+  int n0s[kMaxSub], ns[kMaxSub];
+  Cursor st[kMaxSub]{};
+  for (int k = 0, at = 0; k < nsub; ++k) {
+    streams[k] = k == 0 ? s : r->side[k - 1];
+    n0s[k] = at;
+    ns[k] = batch / nsub + (k < batch % nsub ? 1 : 0);
+    at += ns[k];
+  }
+  const size_t scratch_per = ((size_t)batch * 64 * h1 * w1 / nsub) & ~(size_t)63;
+  // (only where the fused stem + pool launch leaves the stem map's region unwritten; each sub-batch gets its own slice)
+  const bool stem_free = (fuse || frames_u8 != nullptr) && conv2d_hs_eligible(r->convs[0]);
+  auto lend = [&](int k) { if (stem_free) scratch_scope.set(stem + (size_t)k * scratch_per, scratch_per); };
+  if (nsub > 1) {
+    ADX_CHECK_HIP(hipEventRecord(r->ev_fork, s));
+    for (int k = 1; k < nsub; ++k) ADX_CHECK_HIP(hipStreamWaitEvent(streams[k], r->ev_fork, 0));
+  }
+  int rc = ADX_OK;
+  // launches are issued layer by layer, alternating between the sub-batches, so that every stream's queue has work early
+  for (int k = 0; k < nsub && rc == ADX_OK; ++k) { lend(k); rc = run_stem(st[k], n0s[k], ns[k], ns[k], streams[k]); }
+  for (size_t b = 0; b < nblocks && rc == ADX_OK; ++b)
+    for (int k = 0; k < nsub && rc == ADX_OK; ++k) { lend(k); rc = run_block(b, st[k], n0s[k], ns[k], ns[k], streams[k]); }
+  for (int k = 0; k < nsub && rc == ADX_OK; ++k) {
+    const size_t off = (size_t)n0s[k] * 64 * h2 * w2;          // the sub-batch's region (run_block)
+    rc = avgpool_fc_launch(buf[st[k].cur] + off, base + r->o_fcw, base + r->o_fcb, feature + (size_t)n0s[k] * r->out_dim, ns[k], 512,
+                           st[k].H * st[k].W, r->out_dim, streams[k], st[k].cells);
+  }
+  // join even after an error: a side stream must not be left forked from a capturing stream
+  for (int k = 1; k < nsub; ++k) {
+    if (hipEventRecord(r->ev_join[k - 1], streams[k]) == hipSuccess) (void)hipStreamWaitEvent(s, r->ev_join[k - 1], 0);
+  }
+  return rc;
 }
 
 }  // extern "C"

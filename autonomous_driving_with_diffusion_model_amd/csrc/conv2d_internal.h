@@ -85,6 +85,12 @@ struct adx_resnet {
   int t_fcw = 0, t_fcb = 0, n_tensors = 0;
   size_t o_fcw = 0, o_fcb = 0, packed_floats = 0;
   bool packed_once = false;
+  // side streams of the inference executor (conv2d.hip: sub-batches of a large batch run on streams of their own so that one
+  // sub-batch's launches fill the CUs another's last round of workgroups leaves idle); created on first use, per device
+  static constexpr int kMaxSub = 4;
+  hipStream_t side[kMaxSub - 1] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[kMaxSub - 1] = {nullptr, nullptr, nullptr};
+  int side_device = -1;
 };
 
 namespace adx {

@@ -95,6 +95,33 @@ def test_perception_cell_layout_vs_fp32_layout_and_oracle(tmp_path):
             close(cells[key], R.resnet34_forward(sd, "perception.", img), 2e-4, rtol=1e-5)
 
 
+def test_perception_sub_batch_streams_match_the_single_stream_pass(tmp_path):
+    """csrc/conv2d.hip (round 5): at B >= 32 the inference perception pass runs as two sub-batches on streams of their own (one
+    sub-batch's launches fill the CUs the other's last round of workgroups leaves idle).  Same kernels and per-image arithmetic,
+    so the features equal the single-stream pass (ADX_RESNET_STREAMS=1, a process of its own) up to the tile-mode decisions that
+    depend on the launch's batch -- including uneven halves whose layers make DIFFERENT layout decisions (33 = 17 + 16 at 97x131:
+    one half in cells, the other splitting its reductions) and are at different layers at the same time (each sub-batch owns a
+    fixed region of every rotating buffer)."""
+    import os
+    import subprocess
+    import sys
+    import streams_worker as W
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "one_stream.pt")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "streams_worker.py"), out],
+                       env=dict(os.environ, ADX_RESNET_STREAMS="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    one = torch.load(out)
+    two = W.features()
+    for key, runs in two.items():
+        ref = one[key][0]
+        scale = max(1.0, ref.abs().max().item())
+        for f in runs:
+            assert torch.equal(f, runs[0]), key                      # run to run: bit-equal
+            err = (f - ref).abs().max().item()
+            assert err <= 2e-6 * scale, (key, err, scale)
+
+
 @pytest.mark.parametrize("H", [16, 32])
 def test_unet_forward_vs_golden(golden, H):
     g = golden("unet")
