@@ -51,6 +51,7 @@ struct DebugSwitches {
   int hs_mode = -1;            // ADX_HS_MODE=0|1|2  pins the tile mode of the pipelined 3x3 kernel
   bool wgrad_deterministic = false;   // ADX_WGRAD_DETERMINISTIC=1  the 3x3 weight gradients (conv2d_wgrad_hs) reduce per-workgroup partial
                                //                    sums in index order instead of with float atomics: bit-reproducible, one more pass
+  bool hs_dma = true;          // ADX_HS_DMA=0       conv2d_hs3x3q stages its operands through registers instead of with LDS-DMA loads (conv2d_hs16.hip)
   int resnet_streams = 2;      // ADX_RESNET_STREAMS=1..4  sub-batches of an inference perception pass at B >= 32, each on a stream of its own
   bool check_range = false;    // ADX_CHECK_RANGE=1  perception forward: fail with the first layer whose activations leave the
                                //                    fp16 range of the split kernels instead of propagating inf (synchronises)

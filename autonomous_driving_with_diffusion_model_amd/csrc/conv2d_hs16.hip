@@ -39,6 +39,13 @@ constexpr int kQPairs = 4 * kQPlane;       // (k-group, pixel) cell pairs of a 3
 constexpr int kQPit = (kQPairs + kQNT - 1) / kQNT;   // 3 rounds
 constexpr int kQWst = 1024;                // weight cells of a stage: [slab][16-channel half][plane][k-half][64]
 constexpr size_t kQLds = (size_t)2 * 8 * kQPlaneP * 16 + (size_t)2 * kQWst * 16 + 256 * sizeof(float) + 2 * 16;
+// DMA variant (buffer_load / global_load ... lds: the staged cells go from memory to LDS without passing through registers): a wave's
+// 64 lanes write 64 CONSECUTIVE cells, so the patch image is [plane][k-group][pitch] with the cell pairs of a chunk numbered
+// linearly over (k-group, pixel); pitch 352 = 22 x 16 cells keeps the four k-groups of a fragment read on one bank phase
+constexpr int kQPlaneD = 352;
+constexpr int kQPairsD = 4 * kQPlaneD;     // 1408 = 22 waves of 64: whole waves only
+constexpr size_t kQLdsD = (size_t)2 * 8 * kQPlaneD * 16 + (size_t)2 * kQWst * 16 + 256 * sizeof(float) + 2 * 16;
+typedef __attribute__((address_space(3))) void lds_void;
 
 __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
@@ -53,8 +60,12 @@ __device__ __forceinline__ void half4(uint32_t h0, uint32_t h1, uint32_t l0, uin
 
 }  // namespace
 
+template <bool DMA>
 __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs a) {
-  constexpr int NT = kQNT, PW = kQPW, PLANE = kQPlane, PP = kQPlaneP, PIT = kQPit, WST = kQWst;
+  constexpr int NT = kQNT, PW = kQPW, PLANE = DMA ? kQPlaneD : kQPlane, PP = DMA ? kQPlaneD : kQPlaneP, PIT = kQPit, WST = kQWst;
+  constexpr int NPAIRS = DMA ? kQPairsD : kQPairs;
+  // cell strides of the patch image: [k-group][plane][PP], or (DMA) [plane][k-group][PP]
+  constexpr int GST = DMA ? PP : 2 * PP, PLST = DMA ? 4 * PP : PP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32x4* patch = reinterpret_cast<u32x4*>(smem_raw);          // 2 x [k-group][plane][PP]
   u32x4* wl = patch + 2 * 8 * PP;                             // 2 x [slab][16-channel half][plane][k-half][64]
@@ -85,15 +96,15 @@ __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs
 #pragma unroll
   for (int k = 0; k < PIT; ++k) {
     const int e = tid + NT * k;
-    const int g = e / PLANE, p = e - g * PLANE;                // k-group, staged pixel
+    const int g = e / PLANE, p = e - g * PLANE;                // k-group, staged pixel (DMA: p >= 340 is padding of the pitch)
     const int py = p / PW, px = p - py * PW;
     const int iy = oy0 - 1 + py;
     const int v = vx0 - 1 + px;                                // virtual column: image v / vw, column v % vw (column W of an image is zero)
     const int ni = vdiv(v < 0 ? 0 : v);
     const int ix = v - ni * a.vw;
-    const bool ok = e < kQPairs && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && ni < a.N;
+    const bool ok = e < NPAIRS && p < kQPlane && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && ni < a.N;
     goff[k] = !ok ? kOutside : (uint32_t)((size_t)ni * a.Cin * hw * sizeof(float) + (size_t)g * 8 * hw * sizeof(float) + ((size_t)iy * a.W + ix) * 16);
-    pcell[k] = e < kQPairs ? g * 2 * PP + p : -1;
+    pcell[k] = e < NPAIRS ? g * GST + p : -1;
   }
   // this thread's two weight cells of a stage: cell e of the LDS image is cell wsrc_off[k] + (18 chunk + tap) * 256 of the packed image
   const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.w);
@@ -119,32 +130,49 @@ __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs
       for (int i = 0; i < 4; ++i) { accm[cb][pb][i] = 0.f; accl[cb][pb][i] = 0.f; }
 
   u32x4 wv[2][2], pvh[2], pvl[2];          // register sets: weights of stage s in wv[s & 1]; the patch round fetched at stage s in pv*[s & 1]
-  auto load_w = [&](int stage, int set) {
+  // DMA: the wave's first cell of round k (a wave-uniform LDS address goes into M0; lane l lands l cells further)
+  const int wcell = __builtin_amdgcn_readfirstlane(tid & ~63);
+  auto load_w = [&](int stage, int set) {           // DMA: `set` is the LDS weight buffer
     const int chunk = stage / 9, tap = stage - chunk * 9;
     const u32x4* ws = wsrc + (size_t)(chunk * 18 + tap) * 256;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) wv[set][k] = ws[wsrc_off[k]];
+    for (int k = 0; k < 2; ++k) {
+      if constexpr (DMA) __builtin_amdgcn_global_load_lds(ws + wsrc_off[k], (lds_void*)(wl + set * WST + wcell + NT * k), 16, 0, 0);
+      else wv[set][k] = ws[wsrc_off[k]];
+    }
   };
   auto store_w = [&](int set, int buf) {
+    if constexpr (!DMA) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k) wl[buf * WST + tid + NT * k] = wv[set][k];
+      for (int k = 0; k < 2; ++k) wl[buf * WST + tid + NT * k] = wv[set][k];
+    }
   };
-  auto load_p = [&](int chunk, int k, int set) {
+  auto load_p = [&](int chunk, int k, int set) {    // DMA: `set` is the LDS patch buffer
     const uint32_t cbase = (uint32_t)chunk * 32u * plane_bytes;
-    pvh[set] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, goff[k], cbase, 0);
-    pvl[set] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, goff[k], cbase + 4 * plane_bytes, 0);
+    if constexpr (DMA) {
+      if (k < PIT - 1 || wcell + NT * k < NPAIRS) {      // whole waves: 1408 = 22 x 64
+        u32x4* d = patch + set * 8 * PP + wcell + NT * k;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)d, 16, goff[k], cbase, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(d + PLST), 16, goff[k], cbase + 4 * plane_bytes, 0, 0);
+      }
+    } else {
+      pvh[set] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, goff[k], cbase, 0);
+      pvl[set] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, goff[k], cbase + 4 * plane_bytes, 0);
+    }
   };
   auto store_p = [&](int set, int k, int buf) {
-    u32x4* pd = patch + buf * 8 * PP + pcell[k];
-    u32x4* d0 = (k < PIT - 1 || pcell[k] >= 0) ? pd : dummy;
-    u32x4* d1 = (k < PIT - 1 || pcell[k] >= 0) ? pd + PP : dummy + 1;
-    *d0 = pvh[set];
-    *d1 = pvl[set];
+    if constexpr (!DMA) {
+      u32x4* pd = patch + buf * 8 * PP + pcell[k];
+      u32x4* d0 = (k < PIT - 1 || pcell[k] >= 0) ? pd : dummy;
+      u32x4* d1 = (k < PIT - 1 || pcell[k] >= 0) ? pd + PP : dummy + 1;
+      *d0 = pvh[set];
+      *d1 = pvl[set];
+    }
   };
 
   // fragment bases: B (pixels) of lane (j, kq): patch cell kq * 2 PP + (2 rowpair + kh + row) * PW + 16 colhalf + j + kw, + PP for lo;
   // A (channels) of lane (j, kq): weight cell slab * 512 + (kq >> 1) * 256 + plane * 128 + (kq & 1) * 64 + 16 cb + j
-  const int pb_lane = kq * 2 * PP + (rowpair * 2) * PW + j;
+  const int pb_lane = kq * GST + (rowpair * 2) * PW + j;
   const int wa_lane = slab * 512 + (kq >> 1) * 256 + (kq & 1) * 64 + j;
 
   // prologue: stage 0 complete in LDS, the weights of stage 1 in flight
@@ -152,8 +180,9 @@ __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs
   store_w(0, 0);
 #pragma unroll
   for (int k = 0; k < PIT; ++k) { load_p(0, k, 0); store_p(0, k, 0); }
-  load_w(1, 1);
+  if constexpr (!DMA) load_w(1, 1);
   if (tid < 256) ss[tid] = ssv;
+  if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int cp = 0; cp < nch32; cp += 2) {
@@ -163,10 +192,17 @@ __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs
       const int cpar = i / 9, t = i % 9, kh = t / 3, kw = t % 3;
       const u32x4* pb0 = patch + cpar * 8 * PP + pb_lane + kh * PW + kw;
       const u32x4* wa0 = wl + (i & 1) * WST + wa_lane;
-      // fetch two stages ahead: the weights of stage s + 2, and at a kernel row's first tap one round of the NEXT chunk's patch
-      // (past the end the last stage / chunk is fetched again; its copy in the idle buffers is never read)
-      load_w(s + 2 < nstages ? s + 2 : nstages - 1, i & 1);
-      if (kw == 0) load_p(cp + cpar + 1 < nch32 ? cp + cpar + 1 : nch32 - 1, kh, i & 1);
+      if constexpr (DMA) {
+        // one stage ahead, straight into LDS: the weights of stage s + 1 into the buffer stage s - 1 read (every wave is past that
+        // stage's barrier), and at a kernel row's first tap one round of the NEXT chunk's patch into the idle patch buffer
+        load_w(s + 1 < nstages ? s + 1 : nstages - 1, (i + 1) & 1);
+        if (kw == 0) load_p(cp + cpar + 1 < nch32 ? cp + cpar + 1 : nch32 - 1, kh, (cpar + 1) & 1);
+      } else {
+        // fetch two stages ahead: the weights of stage s + 2, and at a kernel row's first tap one round of the NEXT chunk's patch
+        // (past the end the last stage / chunk is fetched again; its copy in the idle buffers is never read)
+        load_w(s + 2 < nstages ? s + 2 : nstages - 1, i & 1);
+        if (kw == 0) load_p(cp + cpar + 1 < nch32 ? cp + cpar + 1 : nch32 - 1, kh, i & 1);
+      }
       __builtin_amdgcn_sched_barrier(0);
       f16x8 A[2][4], B[2][4];
 #pragma unroll
@@ -174,7 +210,7 @@ __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) A[pl][cb] = __builtin_bit_cast(f16x8, wa0[pl * 128 + cb * 16]);
 #pragma unroll
-        for (int pb = 0; pb < 4; ++pb) B[pl][pb] = __builtin_bit_cast(f16x8, pb0[pl * PP + (pb >> 1) * PW + (pb & 1) * 16]);
+        for (int pb = 0; pb < 4; ++pb) B[pl][pb] = __builtin_bit_cast(f16x8, pb0[pl * PLST + (pb >> 1) * PW + (pb & 1) * 16]);
       }
 #pragma unroll
       for (int pb = 0; pb < 4; ++pb) {
@@ -191,6 +227,7 @@ __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs
           if (kw == 1) store_p((i + 1) & 1, kh, (cpar + 1) & 1);
         }
       }
+      if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this stage's transfers have landed (issued a stage of MFMAs ago)
       __syncthreads();
     }
   }
@@ -277,8 +314,10 @@ bool conv2d_hs3x3q_eligible(const Conv2dArgs& a) {
 int conv2d_hs3x3q_launch(Conv2dArgs a, hipStream_t s) {
   ADX_REQUIRE(conv2d_hs3x3q_eligible(a), "conv2d_hs3x3q: launch outside the kernel's rules");
   static std::atomic<uint64_t> attr{0};
-  if (first_on_device(attr))
-    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3q_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQLds));
+  if (first_on_device(attr)) {
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3q_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQLds));
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3q_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQLdsD));
+  }
   a.vw = a.N > 1 ? a.OW + 1 : a.OW;
   a.inv_vw = 1.f / (float)a.vw;
   ADX_REQUIRE((long)a.N * a.vw < (1L << 21), "conv2d_hs: batch x width exceeds the virtual-row arithmetic");
@@ -289,7 +328,8 @@ int conv2d_hs3x3q_launch(Conv2dArgs a, hipStream_t s) {
   ADX_REQUIRE(grid < (1u << 31), "conv2d_hs: grid too large");
   ADX_REQUIRE((size_t)a.N * a.Cout * a.OH * a.OW * sizeof(float) < 0xC0000000u && (size_t)a.N * a.Cin * a.H * a.W * sizeof(float) < 0xC0000000u,
               "conv2d_hs: a cell-layout tensor exceeds the 32-bit byte offsets");
-  conv2d_hs3x3q_kernel<<<dim3((unsigned)grid), dim3(kQNT), kQLds, s>>>(a);
+  if (debug_switches().hs_dma) conv2d_hs3x3q_kernel<true><<<dim3((unsigned)grid), dim3(kQNT), kQLdsD, s>>>(a);
+  else conv2d_hs3x3q_kernel<false><<<dim3((unsigned)grid), dim3(kQNT), kQLds, s>>>(a);
   ADX_LAUNCH_CHECK();
   return ADX_OK;
 }
