@@ -185,6 +185,9 @@ __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs
   if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  // (The compiler places each stage's barrier in the MIDDLE of the stage's MFMAs -- legal: the fragments are in registers -- so a
+  // wave reads the next stage's fragments while its SIMD partner still multiplies.  Pinning the barrier to the stage's end, or
+  // staggering waves 4-7 by half a stage against waves 0-3, measured 1-3 % slower: profiles/README.md, round 5.)
   for (int cp = 0; cp < nch32; cp += 2) {
 #pragma unroll
     for (int i = 0; i < 18; ++i) {
@@ -212,21 +215,25 @@ __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs
 #pragma unroll
         for (int pb = 0; pb < 4; ++pb) B[pl][pb] = __builtin_bit_cast(f16x8, pb0[pl * PLST + (pb >> 1) * PW + (pb & 1) * 16]);
       }
+      auto row_mfmas = [&](int rr) {             // the 24 MFMAs of one of the wave's two output rows (pixel blocks 2 rr, 2 rr + 1)
 #pragma unroll
-      for (int pb = 0; pb < 4; ++pb) {
+        for (int pb = 2 * rr; pb < 2 * rr + 2; ++pb) {
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-          accm[cb][pb] = mfma16(A[0][cb], B[0][pb], accm[cb][pb]);
-          accl[cb][pb] = mfma16(A[0][cb], B[1][pb], accl[cb][pb]);
+          for (int cb = 0; cb < 4; ++cb) {
+            accm[cb][pb] = mfma16(A[0][cb], B[0][pb], accm[cb][pb]);
+            accl[cb][pb] = mfma16(A[0][cb], B[1][pb], accl[cb][pb]);
+          }
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb) accl[cb][pb] = mfma16(A[1][cb], B[0][pb], accl[cb][pb]);
+          if (pb == 0) {
+            // what arrived during the previous stage goes to LDS under this stage's remaining MFMAs
+            store_w((i + 1) & 1, (i + 1) & 1);
+            if (kw == 1) store_p((i + 1) & 1, kh, (cpar + 1) & 1);
+          }
         }
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) accl[cb][pb] = mfma16(A[1][cb], B[0][pb], accl[cb][pb]);
-        if (pb == 0) {
-          // what arrived during the previous stage goes to LDS under this stage's remaining MFMAs
-          store_w((i + 1) & 1, (i + 1) & 1);
-          if (kw == 1) store_p((i + 1) & 1, kh, (cpar + 1) & 1);
-        }
-      }
+      };
+      row_mfmas(0);
+      row_mfmas(1);
       if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this stage's transfers have landed (issued a stage of MFMAs ago)
       __syncthreads();
     }
