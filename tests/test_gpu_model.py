@@ -122,6 +122,43 @@ def test_perception_sub_batch_streams_match_the_single_stream_pass(tmp_path):
             assert err <= 2e-6 * scale, (key, err, scale)
 
 
+def test_perception_pass_stream_runs_ahead_only_of_work_it_does_not_depend_on():
+    """modeling/perception.py: eval passes of >= 16 images run on a stream of their own; a pass on the SAME, unwritten image tensor
+    does not wait for what the caller queued since the previous pass (the reference-faithful loop's previous step).  It must still
+    see (a) an in-place write to the image (version counter), (b) a new image object at the same address, (c) changed weights;
+    and its result must be ordered in front of the caller's next use."""
+    m, _ = make_model("NO_GUIDANCE", 16)
+    p = m.perception
+    img = P.synthetic_batch(20, 16, image_hw=(64, 96), seed=3)["imgs"].to(DEV)
+    with torch.no_grad():
+        p.run_ahead = False
+        ref1 = p(img).clone()
+        ref2 = p(img * 0.5 + 0.1).clone()
+        p.run_ahead = True
+        busy = torch.randn(4096, 4096, device=DEV)
+        a = p(img)
+        for _ in range(6):                      # the caller's stream is busy when the second pass is issued
+            busy = busy @ busy.t() * 1e-4
+        b = p(img)                              # same object, same version: runs ahead of the matmuls
+        assert torch.equal(a, ref1) and torch.equal(b, ref1)
+        for _ in range(6):
+            busy = busy @ busy.t() * 1e-4
+        img.mul_(0.5).add_(0.1)                 # queued BEHIND the matmuls on the caller's stream: the pass must wait for it
+        c = p(img)
+        assert torch.equal(c, ref2)
+        img2 = img.clone()
+        d = p(img2)                             # another object
+        assert torch.equal(d, ref2)
+        w0 = p.conv1.weight.detach().clone()
+        p.conv1.weight.mul_(1.5)                # weights re-laid on the caller's stream
+        e = p(img2)
+        assert not torch.equal(e, ref2)
+        p.conv1.weight.copy_(w0)
+        assert torch.equal(p(img2), ref2)
+        torch.cuda.synchronize()
+        assert torch.isfinite(busy).all()
+
+
 @pytest.mark.parametrize("H", [16, 32])
 def test_unet_forward_vs_golden(golden, H):
     g = golden("unet")

@@ -41,16 +41,20 @@ def main():
             shapes[c] = shapes.get(c, 0) + 1
     def lookup(table, grid):
         for kname, grids_ in table.items():
-            if "conv2d_hs3x3_kernel" in kname and grid in grids_:
+            if "conv2d_hs3x3" in kname and grid in grids_:       # conv2d_hs3x3_kernel<...> and conv2d_hs3x3q_kernel<...>
                 return grids_[grid]
         raise KeyError(grid)
 
     grids = {}
     for (cin, cout, k, s, p, h, w), cnt in shapes.items():
-        mode = 0 if cin < 256 else (1 if h > 8 else 2)       # conv2d_hs_launch's tile-mode rule
-        th, ct, nt = (16 if mode == 1 else 8), (2 if mode == 2 else 1), (256 if mode == 0 else 512)
-        wgs = ((h + th - 1) // th) * ((bench.B * (w + 1) - 1 + 31) // 32) * (cout // (64 * ct))   # column tiles over the images side by side, one shared zero column between neighbours
-        grids[wgs * nt] = (f"{cin}->{cout} @{h}x{w} (tile mode {mode})", cnt)
+        cols = (bench.B * (w + 1) - 1 + 31) // 32          # column tiles over the images side by side, one shared zero column between neighbours
+        if cout % 128 == 0 and cin % 64 == 0:              # conv2d_hs3x3q_eligible: the 16x16x32 kernel, 8 rows x 32 columns x 128 channels, 512 threads
+            wgs, nt, label = ((h + 7) // 8) * cols * (cout // 128), 512, "16x16x32 kernel"
+        else:
+            mode = 0 if cin < 256 else (1 if h > 8 else 2)       # conv2d_hs_launch's tile-mode rule
+            th, ct, nt = (16 if mode == 1 else 8), (2 if mode == 2 else 1), (256 if mode == 0 else 512)
+            wgs, label = ((h + th - 1) // th) * cols * (cout // (64 * ct)), f"tile mode {mode}"
+        grids[wgs * nt] = (f"{cin}->{cout} @{h}x{w} ({label})", cnt)
     per_shape, tf, tw, n = {}, 0.0, 0.0, 0
     for g, (label, cnt) in grids.items():
         fv, wv = lookup(fetch, g), lookup(write, g)
@@ -59,7 +63,7 @@ def main():
         tf += f_ * cnt
         tw += w_ * cnt
         n += cnt
-    res["kernels"]["conv2d_hs3x3_kernel<0|1|2>"] = {"per_shape": per_shape, "fetch": tf / n, "write": tw / n,
+    res["kernels"]["conv2d_hs3x3_kernel<0|1|2> + conv2d_hs3x3q_kernel"] = {"per_shape": per_shape, "fetch": tf / n, "write": tw / n,
                                                          "traffic": (tf + tw) / n}
     tname = next(k for k in fetch if "tconv_hs_kernel<2" in k)
     fv = [v for g in fetch[tname].values() for v in g]
