@@ -250,6 +250,10 @@ def conv2d_roofline(dev, reps=10):
             "traffic": pmc_traffic("conv2d_hs3x3_kernel"),
             "traffic_note": "bytes/launch, 2 x FETCH_SIZE (gfx950 correction, calibrated: tools/micro/fetch_calib.hip) + WRITE_SIZE from profiles/" + os.path.basename(pmc_traffic_file() or "(none)") + " (separate rocprofv3 --pmc passes)",
             "avg_launch_ms": round(avg_ms, 4), "launches_per_step": count,
+            "avg_launch_ms_rocprof_note": "launch-weighted average of the same kernels in the committed rocprofv3 summary of this command run with "
+                                          "ADX_RESNET_STREAMS=1 ADX_PERCEPTION_AHEAD=0 (one chain of launches: a kernel that shares the chip with "
+                                          "another sub-batch's has no duration of its own); that run's mix = faithful steps at B = 64 + this "
+                                          "probe's chains and fixed-buffer repetitions",
             "avg_launch_ms_note": "HIP events around each layer's launches issued in the executor's order on its rotating buffers (every "
                                   "launch reads what the one before it wrote, as inside the timed region); avg_launch_ms_alone = the same "
                                   "launches repeated on fixed buffers (what rounds 1-3 reported: their 236 MB operands fall out of the 256 MB "
@@ -745,6 +749,13 @@ def main():
         barrier()
         return max_over_ranks(time.perf_counter() - t0, world, dev)
 
+    # the perception pass alone (HIP events on the caller's stream around 8 back-to-back passes on the tick's image tensor), as the
+    # product runs it: two sub-batches on streams of their own (csrc/conv2d.hip), on the pass stream (modeling/perception.py)
+    pass_ms = None
+    if rank == 0 and not args.no_roofline:
+        with torch.no_grad():
+            model.perception(d["imgs"])
+            pass_ms = round(time_events(lambda: model.perception(d["imgs"]), 8, warm=1), 4)
     model.cache_perception = False          # reference-faithful: perception re-run every step
     dt, per_rank = timed(args.steps, args.warmup)
     model.cache_perception = True           # product default: one perception pass per scene
@@ -825,6 +836,18 @@ def main():
             res["train_free"] = train_free
         if not args.no_roofline:
             res["roofline"] = conv2d_roofline(dev)
+            if pass_ms is not None:
+                conv_gf = sum(conv_flops(B, *c) for c in resnet_conv_table(*IMG)) / 1e9
+                s1_ms = res["roofline"]["avg_launch_ms"] * res["roofline"]["launches_per_step"]
+                res["roofline"]["perception_pass"] = {
+                    "ms": pass_ms, "algorithmic_tflops_all_convs": round(conv_gf / pass_ms, 1),
+                    "frac_all_convs": round(conv_gf / pass_ms / PEAK_F16_TFLOPS, 4),
+                    "sum_of_stride1_launches_in_order_ms": round(s1_ms, 3),
+                    "note": "the whole ResNet-34 pass at B = 64 as the timed region runs it -- two sub-batches of 32 on streams of their own, so "
+                            "that one's launches fill the CUs the other's last round of workgroups leaves idle (ADX_RESNET_STREAMS=1: one "
+                            "chain) -- against the sum of its 29 stride-1 launches timed one after the other at B = 64 (`avg_launch_ms` x 29; "
+                            "the pass also holds the stem + pool, three stride-2 launches and the pooling + fc).  `frac` / `avg_launch_ms` stay "
+                            "per-launch figures on ONE stream: a launch that shares the chip has no duration of its own"}
             res["roofline_tconv"] = tconv_roofline(None, dev)
         if world == 1 and not args.no_deployed:
             try:

@@ -12,10 +12,10 @@ for d in sorted(glob.glob("gpurun_out/pmc[AB]_*")):
     if not f: print(d, "no csv"); continue
     acc = {}
     for r in csv.DictReader(open(f[0])):
-        if "conv2d_hs3x3_kernel" in r["Kernel_Name"]:
+        if "conv2d_hs3x3" in r["Kernel_Name"]:          # conv2d_hs3x3_kernel<...> (64 channels) and conv2d_hs3x3q_kernel<...>
             acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     res[d.split("/")[-1]] = {k: round(sum(v[1:]) / max(1, len(v) - 1)) for k, v in acc.items()}
     print(d, res[d.split("/")[-1]])
 import json
-json.dump({"source": "bash tools/pmc_sq.sh: rocprofv3 --kernel-trace --pmc <8 counters> -- python3 tools/pmc_one.py <cin> <h> <w> (B = 64, one 3x3 stride-1 conv with BN + residual + ReLU, per launch, averaged over 4 launches); pmcA / pmcB = the two counter sets", "kernel": "conv2d_hs3x3_kernel", "counters": res}, open("gpurun_out/" + __import__("os").environ.get("R", "r02") + "_sq_counters.json", "w"), indent=1)
+json.dump({"source": "bash tools/pmc_sq.sh: rocprofv3 --kernel-trace --pmc <8 counters> -- python3 tools/pmc_one.py <cin> <h> <w> (B = 64, one 3x3 stride-1 conv with BN + residual + ReLU, per launch, averaged over 4 launches); pmcA / pmcB = the two counter sets", "kernel": "conv2d_hs3x3q_kernel<true> (512, 256 channels), conv2d_hs3x3_kernel<0, 0, true, true> (64 channels)", "counters": res}, open("gpurun_out/" + __import__("os").environ.get("R", "r02") + "_sq_counters.json", "w"), indent=1)
 PY

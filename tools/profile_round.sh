@@ -1,10 +1,15 @@
 # Round profile (run on the GPU box through gpurun): kernel stats of the whole bench, PMC traffic of the two roofline
 # kernels (separate --pmc passes, --kernel-trace only), the per-layer timeline of the temporal stack, the kernel make-up of
 # the two deployed ticks (B = 1: classifier-free and classifier guidance), the default bench.
-R=${R:-r03}
-rm -rf gpurun_out/${R}_stats gpurun_out/${R}_pmc_fetch gpurun_out/${R}_pmc_write gpurun_out/${R}_tconv_trace
+R=${R:-r05}
+rm -rf gpurun_out/${R}_stats gpurun_out/${R}_stats2 gpurun_out/${R}_pmc_fetch gpurun_out/${R}_pmc_write gpurun_out/${R}_tconv_trace
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-deployed > gpurun_out/${R}_bench_under_rocprof.json 2> gpurun_out/${R}_bench_under_rocprof.err
+# kernel stats of the bench: ONE stream for the perception pass (ADX_RESNET_STREAMS=1 ADX_PERCEPTION_AHEAD=0), so that a kernel's
+# duration in the summary is its own (bench.py's roofline.avg_launch_ms_rocprof); then the same command as the product runs it
+# (two sub-batch streams + the pass stream: concurrent kernels share the chip and their durations overlap)
+ADX_RESNET_STREAMS=1 ADX_PERCEPTION_AHEAD=0 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-deployed > gpurun_out/${R}_bench_under_rocprof.json 2> gpurun_out/${R}_bench_under_rocprof.err
+rm -rf gpurun_out/${R}_stats2
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_stats2 -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-deployed --no-train > gpurun_out/${R}_bench_under_rocprof_two_streams.json 2> gpurun_out/${R}_bench_under_rocprof_two_streams.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${R}_pmc_fetch -- python3 tools/pmc_kernels.py > gpurun_out/${R}_pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${R}_pmc_write -- python3 tools/pmc_kernels.py > gpurun_out/${R}_pmc_write.log 2>&1
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${R}_tconv_trace -- python3 tools/bench_tconv.py > gpurun_out/${R}_tconv_layers_hostclock.log 2>&1
