@@ -66,6 +66,42 @@ def test_host_side_validation_without_gpu(built):
         assert lib.adx_unet_create(ctypes.byref(cfg), ctypes.byref(h)) == -1, bad
 
 
+def test_resnet_backward_groups_map_every_gradient_to_the_event_of_its_layer_group(built):
+    """adx_resnet_backward_events (csrc/resnet_train.hip) records one completion event per layer group in the order the backward
+    produces the gradients -- fc, the 16 BasicBlocks from layer4's last to layer1's first, the stem -- and
+    adx_resnet_tensor_group tells which event covers which tensor slot of the state_dict order.  Host-side bookkeeping: checked
+    against the parameter names without a GPU."""
+    from autonomous_driving_with_diffusion_model_amd.modeling.spec import resnet34_entries
+    lib = built.lib()
+    h = built.vp()
+    assert lib.adx_resnet_create(64, ctypes.byref(h)) == 0
+    try:
+        n = lib.adx_resnet_backward_groups(h)
+        assert n == 18
+        entries = [e for e in resnet34_entries("", 64) if e.dtype == "f32"]
+        assert len(entries) == lib.adx_resnet_num_tensors(h)
+        blocks = [f"layer{li}.{b}." for li, nb in zip((1, 2, 3, 4), (3, 4, 6, 3)) for b in range(nb)]
+        seen = set()
+        for i, e in enumerate(entries):
+            g = lib.adx_resnet_tensor_group(h, i)
+            if e.is_buffer:
+                assert g == -1, e.key                       # running statistics: no gradient
+                continue
+            if e.key.startswith("fc."):
+                want = 0
+            elif e.key.startswith(("conv1.", "bn1.")):
+                want = n - 1
+            else:
+                b = next(j for j, pre in enumerate(blocks) if e.key.startswith(pre))
+                want = 1 + (len(blocks) - 1 - b)            # the backward visits the blocks in reverse
+            assert g == want, (e.key, g, want)
+            seen.add(g)
+        assert seen == set(range(n))
+        assert lib.adx_resnet_tensor_group(h, -1) == -1 and lib.adx_resnet_tensor_group(h, len(entries)) == -1
+    finally:
+        lib.adx_resnet_destroy(h)
+
+
 def test_cell_layout_host_side(built):
     """The cell layout of csrc/conv2d_hs.hip on the host: ops.to_cells / from_cells (pure torch) place the 8 channels of a
     pixel as one 16-byte cell per plane, per image [C / 8][hi, lo][H][W], and lose at most 2^-22 of the value (values far below
