@@ -466,8 +466,12 @@ __device__ __forceinline__ void hs_trace_id() {
 // STATS: 0 none; 1 the training forward's BatchNorm statistics of this conv's own output; 2 (data-gradient launches) the
 // BACKWARD sums of the BatchNorm in front of this conv in forward order, whose incoming gradient this launch produces
 // (Conv2dArgs::bs_*).
-template <int MODE, int STATS = 0, bool XCELLS = false, bool YCELLS = false>
+// VR: the column tiles run over the virtual row of the whole batch (below) although the OUTPUT is fp32 NCHW -- the training
+// forward and data-gradient launches (round 5): a map 225 / 113 / 57 / 29 columns wide pays one padded MFMA column per image
+// instead of the round-up to 32, like the cell launches; YCELLS implies it.
+template <int MODE, int STATS = 0, bool XCELLS = false, bool YCELLS = false, bool VR = false>
 __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(const Conv2dArgs a) {
+  constexpr bool VROW = YCELLS || VR;
   constexpr int NT = MODE == 0 ? 256 : 512;            // threads
   constexpr int TH = MODE == 1 ? 16 : 8;               // output rows per workgroup
   constexpr int CT = MODE == 2 ? 2 : 1;                // 64-channel slabs per workgroup
@@ -499,7 +503,7 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
   const int ct = bid % a.cout_tiles; bid /= a.cout_tiles;
   const int tx = bid % a.tiles_x; bid /= a.tiles_x;
   const int ty = bid % a.tiles_y; bid /= a.tiles_y;
-  const int n = YCELLS ? 0 : bid;
+  const int n = VROW ? 0 : bid;
   const int oy0 = ty * TH, ox0 = tx * kTileW;
   const int iy0 = oy0 - a.pad, ix0 = ox0 - a.pad;
   const int cout0 = (ct * CT + slab) * kHsCout;
@@ -515,8 +519,8 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
   const int vx0 = tx * kTileW;
   const int vl = vx0 + l31;
   auto vdiv = [&](int v) { return (int)(((float)v + 0.5f) * a.inv_vw); };     // v / vw for 0 <= v < 2^21 (launch check)
-  const int nl = YCELLS ? vdiv(vl) : 0, xl = YCELLS ? vl - nl * a.vw : 0;
-  const bool lane_valid = !YCELLS || (nl < a.N && xl < a.W);
+  const int nl = VROW ? vdiv(vl) : 0, xl = VROW ? vl - nl * a.vw : 0;
+  const bool lane_valid = !VROW || (nl < a.N && xl < a.W);
   const size_t hw = (size_t)a.H * a.W;
   const int nchunks_all = a.cin_pad / kHsCC;
   const int nchunks = a.ksplit > 1 ? a.cper : nchunks_all;       // chunks THIS workgroup reduces over
@@ -527,7 +531,7 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
   constexpr uint32_t kOutside = 0xC0000000u;
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(xin), 0,
-      (int)(uint32_t)((YCELLS ? (size_t)a.N * a.Cin : (size_t)(a.Cin - chunk0 * kHsCC)) * hw * sizeof(float)), 0x00020000);
+      (int)(uint32_t)((VROW ? (size_t)a.N * a.Cin : (size_t)(a.Cin - chunk0 * kHsCC)) * hw * sizeof(float)), 0x00020000);
   const uint32_t plane_bytes = (uint32_t)(hw * sizeof(float));
   uint32_t goff[PIT];
   int pcell[PIT];
@@ -539,13 +543,13 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
     const int py = p / PW, px = p - py * PW;
     const int iy = iy0 + py;
     int ix = ix0 + px, ni = n;
-    if constexpr (YCELLS) {        // patch column px = virtual column vx0 - 1 + px -> (image, input column); column W of an image is zero
+    if constexpr (VROW) {          // patch column px = virtual column vx0 - 1 + px -> (image, input column); column W of an image is zero
       const int v = vx0 - 1 + px;
       ni = vdiv(v < 0 ? 0 : v);
       ix = v - ni * a.vw;          // -1 for the column left of the first image
     }
     const bool ok = e < NITEM && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && ni < a.N;
-    const size_t ioff = YCELLS ? (size_t)ni * a.Cin * hw * sizeof(float) : 0;
+    const size_t ioff = VROW ? (size_t)ni * a.Cin * hw * sizeof(float) : 0;
     goff[k] = !ok ? kOutside
                   : XCELLS ? (uint32_t)(ioff + hg * 8 * hw * sizeof(float) + ((size_t)iy * a.W + ix) * 16)   // cell (2 chunk + hg, hi, iy, ix)
                            : (uint32_t)(ioff + (hg * 8 * hw + (size_t)iy * a.W + ix) * sizeof(float));
@@ -720,12 +724,12 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
   // epilogue through buffer descriptors: one instruction per access (wave-uniform channel offset in an SGPR, the
   // lane's pixel in one 32-bit VGPR); lanes outside the map carry the out-of-range offset, so their loads return 0
   // and their stores are dropped; without a residual the descriptor is empty and every load returns 0
-  const int ox = YCELLS ? xl : ox0 + l31;
+  const int ox = VROW ? xl : ox0 + l31;
   const uint32_t plane_ob = (uint32_t)(a.OH * a.OW) * (uint32_t)sizeof(float);
   const size_t img = (size_t)n * a.Cout * a.OH * a.OW;
   // YCELLS: the descriptors cover the whole tensors and the lane's image rides in its offset
-  const int img_bytes = (int)(uint32_t)((YCELLS ? (uint32_t)a.N : 1u) * (uint32_t)a.Cout * plane_ob);
-  const uint32_t img_off = YCELLS ? (uint32_t)nl * (uint32_t)a.Cout * plane_ob : 0u;
+  const int img_bytes = (int)(uint32_t)((VROW ? (uint32_t)a.N : 1u) * (uint32_t)a.Cout * plane_ob);
+  const uint32_t img_off = VROW ? (uint32_t)nl * (uint32_t)a.Cout * plane_ob : 0u;
   float* const ybase = a.ksplit > 1 ? a.part + (size_t)kpart * a.part_stride : a.y;
   const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(ybase + img, 0, img_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -807,7 +811,7 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
   } else {
   uint32_t voff[2];
 #pragma unroll
-  for (int rr = 0; rr < 2; ++rr) voff[rr] = inside[rr] ? pix[rr] * 4u + (uint32_t)(4 * khalf) * plane_ob : kOutside;
+  for (int rr = 0; rr < 2; ++rr) voff[rr] = inside[rr] ? img_off + pix[rr] * 4u + (uint32_t)(4 * khalf) * plane_ob : kOutside;
   float rv[2][2][16];
   if constexpr (STATS != 2) {
 #pragma unroll
@@ -1509,6 +1513,13 @@ __global__ void __launch_bounds__(256) conv2d_split_reduce_kernel(const float* _
   reinterpret_cast<f32x4*>(y)[i] = v;
 }
 
+// fp32-layout launches of a whole batch tile the virtual row too (conv2d_hs3x3_kernel: VR) -- training forward / data gradient
+static bool hs_vrow_ok(const Conv2dArgs& a) {
+  return debug_switches().conv_vrow && a.N > 1 && (long)a.N * (a.OW + 1) < (1L << 21) &&
+         (size_t)a.N * a.Cout * a.OH * a.OW * sizeof(float) < 0xC0000000u && (size_t)a.N * a.Cin * a.H * a.W * sizeof(float) < 0xC0000000u;
+}
+static int hs_vrow_tiles_x(const Conv2dArgs& a) { return ceil_div(a.N * (a.OW + 1) - 1, kTileW); }
+
 template <int MODE>
 static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
   constexpr int NT = MODE == 0 ? 256 : 512, TH = MODE == 1 ? 16 : 8, CT = MODE == 2 ? 2 : 1;
@@ -1523,6 +1534,12 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 2>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bs));
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 0, false, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 1, false, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 2, false, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bs));
   }
   a.tiles_x = ceil_div(a.OW, kTileW); a.tiles_y = ceil_div(a.OH, TH); a.cout_tiles = a.Cout / (kHsCout * CT);
   const size_t grid = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y * a.N;
@@ -1535,12 +1552,26 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
   const size_t cap = a.part != nullptr ? a.part_stride : 0;      // conv2d_launch_raw parks the scratch capacity here
   const int nchunks = a.cin_pad / kHsCC;
   a.ksplit = 1; a.cper = nchunks; a.part_stride = 0;
+  const bool fp32_layout = !(a.x_cells || a.y_cells || a.res_cells);
+  const bool vrow = fp32_layout && hs_vrow_ok(a);
+  auto set_vrow = [&]() -> size_t {           // column tiles over the images side by side (one shared zero column between neighbours)
+    a.vw = a.OW + 1;
+    a.inv_vw = 1.f / (float)a.vw;
+    a.tiles_x = hs_vrow_tiles_x(a);
+    return (size_t)a.cout_tiles * a.tiles_x * a.tiles_y;
+  };
   if (a.stats_part != nullptr) {          // training forward: statistics in the epilogue (one workgroup per tile: no split)
-    ADX_REQUIRE(a.stats_p == a.N * a.tiles_y * a.tiles_x, "conv2d_hs: statistics buffer laid out for %d tiles, launch has %d",
-                a.stats_p, a.N * a.tiles_y * a.tiles_x);
+    const size_t sgrid = vrow ? set_vrow() : grid;
+    const int slots = vrow ? a.tiles_y * a.tiles_x : a.N * a.tiles_y * a.tiles_x;
+    ADX_REQUIRE(a.stats_p == slots, "conv2d_hs: statistics buffer laid out for %d tiles, launch has %d", a.stats_p, slots);
     a.part = nullptr;
-    if (a.bs_raw != nullptr) conv2d_hs3x3_kernel<MODE, 2><<<dim3((unsigned)grid), dim3(NT), lds_bs, s>>>(a);
-    else conv2d_hs3x3_kernel<MODE, 1><<<dim3((unsigned)grid), dim3(NT), lds, s>>>(a);
+    if (vrow) {
+      if (a.bs_raw != nullptr) conv2d_hs3x3_kernel<MODE, 2, false, false, true><<<dim3((unsigned)sgrid), dim3(NT), lds_bs, s>>>(a);
+      else conv2d_hs3x3_kernel<MODE, 1, false, false, true><<<dim3((unsigned)sgrid), dim3(NT), lds, s>>>(a);
+    } else {
+      if (a.bs_raw != nullptr) conv2d_hs3x3_kernel<MODE, 2><<<dim3((unsigned)sgrid), dim3(NT), lds_bs, s>>>(a);
+      else conv2d_hs3x3_kernel<MODE, 1><<<dim3((unsigned)sgrid), dim3(NT), lds, s>>>(a);
+    }
     ADX_LAUNCH_CHECK();
     return ADX_OK;
   }
@@ -1588,7 +1619,12 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
     ADX_LAUNCH_CHECK();
     return ADX_OK;
   }
-  conv2d_hs3x3_kernel<MODE><<<dim3((unsigned)grid), dim3(NT), lds, s>>>(a);
+  if (vrow) {
+    const size_t vgrid = set_vrow();
+    conv2d_hs3x3_kernel<MODE, 0, false, false, true><<<dim3((unsigned)vgrid), dim3(NT), lds, s>>>(a);
+  } else {
+    conv2d_hs3x3_kernel<MODE><<<dim3((unsigned)grid), dim3(NT), lds, s>>>(a);
+  }
   ADX_LAUNCH_CHECK();
   return ADX_OK;
 }
@@ -1626,6 +1662,8 @@ bool conv2d_hs3x3_plain(const ConvSpec& L, int N, int H, int W) {
 int conv2d_hs_stats_tiles(const ConvSpec& L, const Conv2dArgs& a) {
   const int mode = hs3x3_mode(L, a);
   if (mode < 0) return 0;
+  const bool fp32_layout = !(a.x_cells || a.y_cells || a.res_cells);
+  if (fp32_layout && hs_vrow_ok(a)) return ceil_div(a.OH, mode == 1 ? 16 : 8) * hs_vrow_tiles_x(a);
   return a.N * ceil_div(a.OH, mode == 1 ? 16 : 8) * ceil_div(a.OW, kTileW);
 }
 

