@@ -212,6 +212,11 @@ size_t adx_resnet_packed_bytes(const adx_resnet* r);
  * (conv weight, bn weight, bn bias, bn running_mean, bn running_var, ..., fc weight, fc bias) */
 int adx_resnet_pack(adx_resnet* r, const float* const* tensors, int32_t n, void* packed, adx_stream s);
 size_t adx_resnet_workspace_bytes(const adx_resnet* r, int32_t batch, int32_t h, int32_t w);
+/* Stream semantics: everything the call enqueues is ordered behind `s`'s earlier work and in front of its later work.  At
+ * batch >= 32 (outside a stream capture) the pass runs as two sub-batches: one on `s`, one on a side stream the HANDLE owns
+ * (created on first use, destroyed with the handle; forked from `s` and joined into `s` by events inside the call) -- one
+ * sub-batch's launches fill the CUs the other's last round of workgroups leaves idle.  Same kernels and per-image arithmetic;
+ * ADX_RESNET_STREAMS=1 keeps one chain.  A handle must not be driven from two host threads at once. */
 int adx_resnet_forward(adx_resnet* r, const void* packed, void* workspace, const float* img /* NCHW */,
                        int32_t batch, int32_t h, int32_t w, float* feature /* [batch][out_dim] */, adx_stream s);
 /* The same with the agents' image front-end folded into the stem's staging load: frames_hwc = uint8 camera frames
