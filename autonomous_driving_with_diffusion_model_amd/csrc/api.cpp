@@ -32,6 +32,7 @@ const DebugSwitches& debug_switches() {
     d.wgrad_deterministic = is("ADX_WGRAD_DETERMINISTIC", '1');
     if (const char* e = getenv("ADX_CHAIN_MASK")) d.chain_mask = (unsigned)strtoul(e, nullptr, 0);
     if (const char* e = getenv("ADX_HS_MODE")) d.hs_mode = atoi(e);
+    if (const char* e = getenv("ADX_RESNET_SPLIT_FROM")) d.resnet_split_from = atoi(e) < 0 ? -1 : atoi(e);
     if (const char* e = getenv("ADX_RESNET_STREAMS")) d.resnet_streams = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
     return d;
   }();

@@ -858,14 +858,32 @@ static int resnet_forward_impl(adx_resnet* r, const void* packed, void* workspac
   // (only where the fused stem + pool launch leaves the stem map's region unwritten; each sub-batch gets its own slice)
   const bool stem_free = (fuse || frames_u8 != nullptr) && conv2d_hs_eligible(r->convs[0]);
   auto lend = [&](int k) { if (stem_free) scratch_scope.set(stem + (size_t)k * scratch_per, scratch_per); };
+  int rc = ADX_OK;
+  // The stem and the first layer (the blocks in front of the first downsample block) run as ONE chain on the whole batch, the fork
+  // comes behind them: their launches are thousands of two-per-CU workgroups whose last round hardly matters, and split they
+  // only stream their operands twice (-1.6 % per faithful step, profiles/README.md).  The hand-off format does not depend on the
+  // batch: a downsample block's fused stride-2 launch reads cells or fp32 as it finds them.  ADX_RESNET_SPLIT_FROM=<block> overrides.
+  size_t first_split = 0;
+  if (nsub > 1) {
+    while (first_split < nblocks && !r->block_has_ds[first_split]) ++first_split;
+    if (first_split == nblocks) first_split = 0;       // no downsample block at all: nothing to hand over to
+    if (debug_switches().resnet_split_from >= 0) first_split = std::min((size_t)debug_switches().resnet_split_from, nblocks);
+    if (first_split > 0 && !(first_split < nblocks && r->block_has_ds[first_split])) first_split = 0;
+  }
+  if (first_split > 0) {
+    Cursor whole{};
+    lend(0);
+    rc = run_stem(whole, 0, batch, batch, s);
+    for (size_t b = 0; b < first_split && rc == ADX_OK; ++b) rc = run_block(b, whole, 0, batch, batch, s);
+    for (int k = 0; k < nsub; ++k) st[k] = whole;
+  }
   if (nsub > 1) {
     ADX_CHECK_HIP(hipEventRecord(r->ev_fork, s));
     for (int k = 1; k < nsub; ++k) ADX_CHECK_HIP(hipStreamWaitEvent(streams[k], r->ev_fork, 0));
   }
-  int rc = ADX_OK;
   // launches are issued layer by layer, alternating between the sub-batches, so that every stream's queue has work early
-  for (int k = 0; k < nsub && rc == ADX_OK; ++k) { lend(k); rc = run_stem(st[k], n0s[k], ns[k], ns[k], streams[k]); }
-  for (size_t b = 0; b < nblocks && rc == ADX_OK; ++b)
+  for (int k = 0; k < nsub && rc == ADX_OK && first_split == 0; ++k) { lend(k); rc = run_stem(st[k], n0s[k], ns[k], ns[k], streams[k]); }
+  for (size_t b = first_split; b < nblocks && rc == ADX_OK; ++b)
     for (int k = 0; k < nsub && rc == ADX_OK; ++k) { lend(k); rc = run_block(b, st[k], n0s[k], ns[k], ns[k], streams[k]); }
   for (int k = 0; k < nsub && rc == ADX_OK; ++k) {
     const size_t off = (size_t)n0s[k] * 64 * h2 * w2;          // the sub-batch's region (run_block)
