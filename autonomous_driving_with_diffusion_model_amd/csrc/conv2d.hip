@@ -862,13 +862,13 @@ static int resnet_forward_impl(adx_resnet* r, const void* packed, void* workspac
   // The stem and the first layer (the blocks in front of the first downsample block) run as ONE chain on the whole batch, the fork
   // comes behind them: their launches are thousands of two-per-CU workgroups whose last round hardly matters, and split they
   // only stream their operands twice (-1.6 % per faithful step, profiles/README.md).  The hand-off format does not depend on the
-  // batch: a downsample block's fused stride-2 launch reads cells or fp32 as it finds them.  ADX_RESNET_SPLIT_FROM=<block> overrides.
+  // batch: a downsample block's fused stride-2 launch reads cells or fp32 as it finds them.  ADX_RESNET_SPLIT_FROM=<block> shortens it.
   size_t first_split = 0;
   if (nsub > 1) {
     while (first_split < nblocks && !r->block_has_ds[first_split]) ++first_split;
-    if (first_split == nblocks) first_split = 0;       // no downsample block at all: nothing to hand over to
-    if (debug_switches().resnet_split_from >= 0) first_split = std::min((size_t)debug_switches().resnet_split_from, nblocks);
-    if (first_split > 0 && !(first_split < nblocks && r->block_has_ds[first_split])) first_split = 0;
+    // (only blocks of the FIRST layer: their maps have the pooled map's per-image size, so the whole-batch tensors they leave are
+    // laid out exactly like the sub-batches' regions; the override can only shorten the prefix)
+    if (debug_switches().resnet_split_from >= 0) first_split = std::min((size_t)debug_switches().resnet_split_from, first_split);
   }
   if (first_split > 0) {
     Cursor whole{};

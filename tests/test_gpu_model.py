@@ -112,14 +112,19 @@ def test_perception_sub_batch_streams_match_the_single_stream_pass(tmp_path):
                        env=dict(os.environ, ADX_RESNET_STREAMS="1"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     one = torch.load(out)
-    two = W.features()
-    for key, runs in two.items():
-        ref = one[key][0]
-        scale = max(1.0, ref.abs().max().item())
-        for f in runs:
-            assert torch.equal(f, runs[0]), key                      # run to run: bit-equal
-            err = (f - ref).abs().max().item()
-            assert err <= 2e-6 * scale, (key, err, scale)
+    # ... and with the stem and layer1 per sub-batch as well (ADX_RESNET_SPLIT_FROM=0; by default they stay one chain on the whole batch)
+    out0 = str(tmp_path / "split_everything.pt")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "streams_worker.py"), out0],
+                       env=dict(os.environ, ADX_RESNET_SPLIT_FROM="0"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    for name, two in (("default", W.features()), ("split from the stem", torch.load(out0))):
+        for key, runs in two.items():
+            ref = one[key][0]
+            scale = max(1.0, ref.abs().max().item())
+            for f in runs:
+                assert torch.equal(f, runs[0]), (name, key)              # run to run: bit-equal
+                err = (f - ref).abs().max().item()
+                assert err <= 2e-6 * scale, (name, key, err, scale)
 
 
 def test_perception_pass_stream_runs_ahead_only_of_work_it_does_not_depend_on():
