@@ -1,5 +1,5 @@
 """Per-step wall time of the training step (B=64, H=32, 3x256x900), printed per step."""
-import sys, time, contextlib
+import os, sys, time, contextlib
 import torch
 sys.path.insert(0, ".")
 import bench
@@ -17,6 +17,19 @@ model = model.to(dev).train()
 opt = FusedAdamWEMA(model.parameters(), lr=1e-4, warmup_steps=1000)
 sch = S.DDPMScheduler(**bench.SCHED_KW)
 d = {k: v.to(dev) for k, v in P.synthetic_batch(bench.B, bench.H, image_hw=bench.IMG, seed=7).items()}
+NOSYNC = os.environ.get("NOSYNC") == "1"      # the step as bench.py's training leg runs it: no host synchronisation inside
+if NOSYNC:
+    for rep in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(8):
+            noisy = sch.add_noise(d["trajs"], d["noise"], d["t"], zero_first=True)
+            pred = model(noisy, d["imgs"], d["t"])
+            loss = torch.nn.functional.mse_loss(pred, d["trajs"])
+            loss.backward()
+            opt.step(); opt.zero_grad()
+        torch.cuda.synchronize()
+        print(f"8 steps without synchronisation: {1e3 * (time.perf_counter() - t0) / 8:.2f} ms per step")
+    sys.exit(0)
 for i in range(8):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     noisy = sch.add_noise(d["trajs"], d["noise"], d["t"], zero_first=True)
