@@ -415,7 +415,10 @@ int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const f
     a.bs_beta = bst->beta; a.bs_mask = bst->mask;
   }
   a.x_cells = (fmt & kFmtXCells) != 0; a.y_cells = (fmt & kFmtYCells) != 0; a.res_cells = (fmt & kFmtResCells) != 0 && res != nullptr;
-  ADX_REQUIRE(fmt == 0 || (stats_part == nullptr && conv2d_hs3x3_plain(L, N, H, W)),
+  // cells: plain launches of the pipelined 3x3 kernel (the inference executor), or the INPUT of a training-forward launch
+  const bool train_cells = fmt == kFmtXCells && stats_part != nullptr && stats_p != nullptr && bst == nullptr && x_amax == nullptr &&
+                           conv2d_hs3x3_train_cells(L, N, H, W, stats_floats);
+  ADX_REQUIRE(fmt == 0 || train_cells || (stats_part == nullptr && conv2d_hs3x3_plain(L, N, H, W)),
               "conv2d: the cell layout belongs to plain launches of the pipelined 3x3 kernel (%d -> %d, k%d s%d)", L.cin, L.cout, L.k, L.stride);
   if (conv2d_hs_eligible(L)) {
     if (stats_part != nullptr && stats_p != nullptr && conv2d_hs_stats_tiles(L, a) > 0 &&

@@ -1553,7 +1553,7 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
   const int nchunks = a.cin_pad / kHsCC;
   a.ksplit = 1; a.cper = nchunks; a.part_stride = 0;
   const bool fp32_layout = !(a.x_cells || a.y_cells || a.res_cells);
-  const bool vrow = fp32_layout && hs_vrow_ok(a);
+  const bool vrow = (fp32_layout || (a.stats_part != nullptr && !a.y_cells && !a.res_cells)) && hs_vrow_ok(a);   // (a training forward may read cells)
   auto set_vrow = [&]() -> size_t {           // column tiles over the images side by side (one shared zero column between neighbours)
     a.vw = a.OW + 1;
     a.inv_vw = 1.f / (float)a.vw;
@@ -1565,7 +1565,22 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
     const int slots = vrow ? a.tiles_y * a.tiles_x : a.N * a.tiles_y * a.tiles_x;
     ADX_REQUIRE(a.stats_p == slots, "conv2d_hs: statistics buffer laid out for %d tiles, launch has %d", a.stats_p, slots);
     a.part = nullptr;
-    if (vrow) {
+    if (a.x_cells) {
+      // training forward on a cell-layout input (resnet_train.hip: the activation between a block's two convs): the staging copies
+      // cells instead of converting fp32 values, everything else -- fp32 conv output, statistics -- as below
+      ADX_REQUIRE(a.bs_raw == nullptr && a.x_amax == nullptr && !a.y_cells && !a.res_cells,
+                  "conv2d_hs: a cell-layout input with statistics belongs to a training-forward launch");
+      ADX_REQUIRE((size_t)a.N * a.Cin * a.H * a.W * sizeof(float) < 0xC0000000u, "conv2d_hs: a cell-layout tensor exceeds the 32-bit byte offsets");
+      static std::atomic<uint64_t> xattr{0};
+      if (first_on_device(xattr)) {
+        ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 1, true, false, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 1, true, false, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      }
+      if (vrow) conv2d_hs3x3_kernel<MODE, 1, true, false, true><<<dim3((unsigned)sgrid), dim3(NT), lds, s>>>(a);
+      else conv2d_hs3x3_kernel<MODE, 1, true, false, false><<<dim3((unsigned)sgrid), dim3(NT), lds, s>>>(a);
+    } else if (vrow) {
       if (a.bs_raw != nullptr) conv2d_hs3x3_kernel<MODE, 2, false, false, true><<<dim3((unsigned)sgrid), dim3(NT), lds_bs, s>>>(a);
       else conv2d_hs3x3_kernel<MODE, 1, false, false, true><<<dim3((unsigned)sgrid), dim3(NT), lds, s>>>(a);
     } else {
@@ -1659,11 +1674,22 @@ bool conv2d_hs3x3_plain(const ConvSpec& L, int N, int H, int W) {
   return mode != 0 || grid0 > 64 || L.cin_pad / kHsCC < 8;       // hs3x3_launch<0> splits the reduction of smaller launches
 }
 
+bool conv2d_hs3x3_train_cells(const ConvSpec& L, int N, int H, int W, size_t stats_floats) {
+  if (!debug_switches().train_cells || !conv2d_hs_eligible(L) || L.dgrad) return false;     // ADX_TRAIN_CELLS=0: fp32 NCHW everywhere
+  Conv2dArgs a{};
+  a.N = N; a.Cin = L.cin; a.Cout = L.cout; a.H = H; a.W = W;
+  a.OH = conv_out_dim(H, L.k, L.stride, L.pad); a.OW = conv_out_dim(W, L.k, L.stride, L.pad);
+  a.x_cells = 1;
+  if (hs3x3_mode(L, a) < 0 || L.cin % 16 != 0 || L.cin != L.cin_pad || L.cout % 64 != 0) return false;
+  if ((size_t)N * L.cin * H * W * sizeof(float) >= 0xC0000000u) return false;
+  const int tiles = conv2d_hs_stats_tiles(L, a);
+  return tiles > 0 && (size_t)tiles * L.cout * 2 <= stats_floats;
+}
+
 int conv2d_hs_stats_tiles(const ConvSpec& L, const Conv2dArgs& a) {
   const int mode = hs3x3_mode(L, a);
   if (mode < 0) return 0;
-  const bool fp32_layout = !(a.x_cells || a.y_cells || a.res_cells);
-  if (fp32_layout && hs_vrow_ok(a)) return ceil_div(a.OH, mode == 1 ? 16 : 8) * hs_vrow_tiles_x(a);
+  if (!(a.y_cells || a.res_cells) && hs_vrow_ok(a)) return ceil_div(a.OH, mode == 1 ? 16 : 8) * hs_vrow_tiles_x(a);
   return a.N * ceil_div(a.OH, mode == 1 ? 16 : 8) * ceil_div(a.OW, kTileW);
 }
 

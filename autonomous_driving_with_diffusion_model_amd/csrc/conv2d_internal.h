@@ -106,6 +106,9 @@ int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const f
 // true when this launch will run the pipelined 3x3 stride-1 kernel as ONE launch (no split reduction): the launches whose
 // input / output / residual may be in the cell layout (fmt: kFmt*)
 bool conv2d_hs3x3_plain(const ConvSpec& L, int N, int H, int W);
+// true when a training-forward launch of this conv (statistics in the epilogue, fp32 output) can read its input as a cell tensor
+// (fmt = kFmtXCells together with stats_part): the pipelined 3x3 stride-1 kernel with room for its partial sums in stats_floats
+bool conv2d_hs3x3_train_cells(const ConvSpec& L, int N, int H, int W, size_t stats_floats);
 // stats_part (optional, stats_floats floats): where the launch may leave per-workgroup partial sums of its output and of its
 // squares ([Cout][2][P] floats); *stats_p = P when it did (the pipelined 3x3 stride-1 kernel does), 0 when the caller has to
 // compute the statistics from the output itself
@@ -163,8 +166,10 @@ inline bool resnet_fuses_ds(const ConvSpec& c1, const ConvSpec& ds) {
 }
 // conv2d_wgrad_hs.hip: weight gradient of the 3x3 convs on the fp16 matrix cores; dw must be zero on entry
 bool conv2d_wgrad_hs_eligible(int Cin, int Cout, int k, int stride, int pad);
+// x_cells: x is a cell tensor (the layout of the inference executor's activations; resnet_train.hip keeps a block's first
+// activation that way)
 int conv2d_wgrad_hs(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, int stride,
-                    const uint32_t* dy_amax, int dy_amax_n, hipStream_t s);
+                    const uint32_t* dy_amax, int dy_amax_n, hipStream_t s, bool x_cells = false);
 // ADX_WGRAD_DETERMINISTIC=1: scratch for the per-split copies of dw that conv2d_wgrad_hs reduces in index order (lent by the calling
 // thread's executor until cleared; conv2d_wgrad_partials_floats() = what to lend, 0 when the switch is off)
 void conv2d_wgrad_set_partials(float* p, size_t floats);

@@ -32,7 +32,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) h4 lds_h4;
 
 struct WgradHsArgs {
-  const float* x;        // [N][Cin][H][W]
+  const float* x;        // [N][Cin][H][W], or (XC) the same bytes as a cell tensor [N][Cin/8][hi, lo][H][W][8 halves]
   const float* dy;       // [N][Cout][OH][OW]
   float* dw;             // [Cout][Cin][3][3], zeroed by the caller (conv2d_wgrad)
   const uint32_t* dy_amax;
@@ -57,7 +57,10 @@ __device__ __forceinline__ f16x8 tr_pair(const unsigned char* p) {
   return __builtin_bit_cast(f16x8, v);
 }
 
-template <int NPX, int S>
+// XC: x arrives already split -- the cell tensor the training forward keeps between a block's convs (resnet_train.hip:
+// bn_apply_cells_kernel; the same hi / lo halves this kernel's staging would compute from the fp32 map): two 16-byte loads per
+// staged cell instead of eight dwords and the conversion
+template <int NPX, int S, bool XC = false>
 __global__ void __launch_bounds__(kWThreads) conv2d_wgrad_hs_kernel(const WgradHsArgs a) {
   constexpr int NPXB = S * NPX + 2;               // x row segment with its halo columns
   constexpr int NSLOT = S == 1 ? 4 : 6;           // x rows kept: 3 in use + S arriving
@@ -172,10 +175,18 @@ __global__ void __launch_bounds__(kWThreads) conv2d_wgrad_hs_kernel(const WgradH
         } else {
           const int row = xrow0 + rsel[k], col = S * ox0 + colv[k];
           const bool ok = sto[k] >= 0 && row >= 0 && row < a.H && col >= 0 && col < a.W;
-          const uint32_t vo = ok ? chan[k] + (uint32_t)(row * a.W + col) * 4u : kOutside;
+          if constexpr (XC) {
+            const uint32_t vo = ok ? chan[k] + (uint32_t)(row * a.W + col) * 16u : kOutside;
+            const u32x4 h4 = __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 0, 0);
+            const u32x4 l4 = __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 4 * plane_bytes, 0);
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            pv[k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo, j * plane_bytes, 0));
+            for (int j = 0; j < 4; ++j) { pv[k][j] = u2f(h4[j]); pv[k][4 + j] = u2f(l4[j]); }
+          } else {
+            const uint32_t vo = ok ? chan[k] + (uint32_t)(row * a.W + col) * 4u : kOutside;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              pv[k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo, j * plane_bytes, 0));
+          }
         }
       }
       // kernel row 0 of output row 0 would read x row -1 (zero padding): nothing to add
@@ -199,6 +210,15 @@ __global__ void __launch_bounds__(kWThreads) conv2d_wgrad_hs_kernel(const WgradH
       for (int k = 0; k < PIT; ++k) {
         if (sto[k] < 0) continue;
         const bool ka = isA[k];
+        unsigned char* d = ka ? lA + ((t + 1) & 1) * A_BUF + sto[k] : lB + ((xrow0 + rsel[k]) % NSLOT) * B_SLOT + sto[k];
+        if (XC && __builtin_amdgcn_readfirstlane((int)ka) == 0) {       // an x cell: the halves as they were loaded
+          u32x4 h4, l4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { h4[j] = f2u(pv[k][j]); l4[j] = f2u(pv[k][4 + j]); }
+          *reinterpret_cast<u32x4*>(d) = h4;
+          *reinterpret_cast<u32x4*>(d + B_PLANE) = l4;
+          continue;
+        }
         f16x8 h, l;
         const float sc = ka ? xs : 1.f;
 #pragma unroll
@@ -208,7 +228,6 @@ __global__ void __launch_bounds__(kWThreads) conv2d_wgrad_hs_kernel(const WgradH
           h[j] = hj;
           l[j] = (_Float16)((v - (float)hj) * kWLo);
         }
-        unsigned char* d = ka ? lA + ((t + 1) & 1) * A_BUF + sto[k] : lB + ((xrow0 + rsel[k]) % NSLOT) * B_SLOT + sto[k];
         *reinterpret_cast<u32x4*>(d) = __builtin_bit_cast(u32x4, h);
         *reinterpret_cast<u32x4*>(d + (ka ? A_PLANE : B_PLANE)) = __builtin_bit_cast(u32x4, l);
       }
@@ -268,7 +287,7 @@ bool conv2d_wgrad_hs_eligible(int Cin, int Cout, int k, int stride, int pad) {
   return !exact && k == 3 && (stride == 1 || stride == 2) && pad == 1 && Cin % 64 == 0 && Cout % 64 == 0;
 }
 
-template <int NPX, int S>
+template <int NPX, int S, bool XC>
 static int wgrad_hs_launch(WgradHsArgs a, hipStream_t s) {
   constexpr int NSLOT = S == 1 ? 4 : 6;
   constexpr size_t lds = (size_t)2 * (2 * 2 * NPX * 64) + (size_t)NSLOT * (2 * 2 * (S * NPX + 2) * 64) + 64;
@@ -276,7 +295,7 @@ static int wgrad_hs_launch(WgradHsArgs a, hipStream_t s) {
   static_assert(need <= 160 * 1024, "LDS budget");
   static std::atomic<uint64_t> attr{0};
   if (first_on_device(attr)) {
-    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad_hs_kernel<NPX, S>),
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad_hs_kernel<NPX, S, XC>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
   }
   a.segs = ceil_div(a.OW, NPX);
@@ -297,7 +316,7 @@ static int wgrad_hs_launch(WgradHsArgs a, hipStream_t s) {
                 (size_t)splits * a.part_stride, t_wgrad_parts_floats);
     a.part = t_wgrad_parts;
   }
-  conv2d_wgrad_hs_kernel<NPX, S><<<dim3((unsigned)(tiles * splits)), dim3(kWThreads), need, s>>>(a);
+  conv2d_wgrad_hs_kernel<NPX, S, XC><<<dim3((unsigned)(tiles * splits)), dim3(kWThreads), need, s>>>(a);
   ADX_LAUNCH_CHECK();
   if (a.part != nullptr) {
     const size_t total4 = a.part_stride / 4;
@@ -308,7 +327,7 @@ static int wgrad_hs_launch(WgradHsArgs a, hipStream_t s) {
 }
 
 int conv2d_wgrad_hs(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, int stride,
-                    const uint32_t* dy_amax, int dy_amax_n, hipStream_t s) {
+                    const uint32_t* dy_amax, int dy_amax_n, hipStream_t s, bool x_cells) {
   ADX_REQUIRE(x && dy && dw, "conv2d_wgrad_hs: null tensor");
   ADX_REQUIRE((size_t)64 * H * W * sizeof(float) < 0xC0000000u, "conv2d_wgrad_hs: image too large for 32-bit offsets");
   WgradHsArgs a{};
@@ -316,10 +335,11 @@ int conv2d_wgrad_hs(const float* x, const float* dy, float* dw, int N, int Cin, 
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
   a.OH = conv_out_dim(H, 3, stride, 1); a.OW = conv_out_dim(W, 3, stride, 1);
   a.n_ci_tiles = Cin / 64; a.n_co_tiles = Cout / 64;
-  if (stride == 2) return wgrad_hs_launch<32, 2>(a, s);
+  if (stride == 2) return x_cells ? wgrad_hs_launch<32, 2, true>(a, s) : wgrad_hs_launch<32, 2, false>(a, s);
   // rows of <= 32 (or 33..48 -> two 32-pixel segments waste less than one 64) pixels use the narrow variant
   const int waste64 = ceil_div(a.OW, 64) * 64 - a.OW, waste32 = ceil_div(a.OW, 32) * 32 - a.OW;
-  return waste32 < waste64 ? wgrad_hs_launch<32, 1>(a, s) : wgrad_hs_launch<64, 1>(a, s);
+  if (x_cells) return waste32 < waste64 ? wgrad_hs_launch<32, 1, true>(a, s) : wgrad_hs_launch<64, 1, true>(a, s);
+  return waste32 < waste64 ? wgrad_hs_launch<32, 1, false>(a, s) : wgrad_hs_launch<64, 1, false>(a, s);
 }
 
 }  // namespace adx

@@ -14,6 +14,7 @@
 
 #include "batch_ops.h"
 #include "conv2d_internal.h"
+#include "conv2d_hs_common.h"
 
 namespace adx {
 
@@ -213,6 +214,37 @@ __global__ void __launch_bounds__(256) bn_apply_planes_kernel(const float* __res
       }
       o4[i] = v;
     }
+  }
+}
+
+// BatchNorm apply (+ ReLU) whose output is a CELL tensor -- per image [C/8][hi, lo][H][W] 16-byte cells of 8 channels, the
+// pre-split operand layout of the pipelined 3x3 kernel (conv2d_hs.hip: XCELLS) and of the weight gradient (conv2d_wgrad_hs.hip:
+// XC) -- for an activation only convolutions read: the map between a BasicBlock's two convs (modeling/resnet.py:87-93).  The
+// halves are the ones those kernels' staging would compute from the fp32 map (split8), so nothing downstream changes by a bit;
+// what changes is that the conversion happens once here instead of once per workgroup column of the consumer.  Same bytes as
+// the fp32 map.  A thread owns one pixel of one 8-channel group: eight coalesced plane reads, two coalesced 16-byte stores.
+__global__ void __launch_bounds__(256) bn_apply_cells_kernel(const float* __restrict__ raw, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, u32x4* __restrict__ out,
+                                                              int C, int HW, int groups, int relu) {
+  const int per = (HW + 255) / 256;                 // workgroups per (image, channel group)
+  for (int w = blockIdx.x; w < groups * per; w += gridDim.x) {
+    const int g = w / per, pix = (w - g * per) * 256 + threadIdx.x;      // g = n * (C / 8) + channel group
+    if (pix >= HW) continue;
+    const int c0 = (g % (C >> 3)) * 8;
+    const float* r = raw + (size_t)g * 8 * HW + pix;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = r[(size_t)j * HW];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      v[j] = bn_eval(v[j], scale[c0 + j], shift[c0 + j]);
+      if (relu) v[j] = v[j] > 0.f ? v[j] : 0.f;
+    }
+    u32x4 hi, lo;
+    split8(v, 1.f, hi, lo);
+    u32x4* o = out + (size_t)g * 2 * HW + pix;
+    o[0] = hi;
+    o[HW] = lo;
   }
 }
 
@@ -829,8 +861,10 @@ __global__ void centre_tap_add_kernel(float* __restrict__ dw, const float* __res
 // kernel even though eight of its nine taps are thrown away
 int conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, int k, int stride,
                  int pad, hipStream_t s, const uint32_t* dy_amax = nullptr, int dy_amax_n = 0, bool zero = true,
-                 float* scratch9 = nullptr) {
+                 float* scratch9 = nullptr, bool x_cells = false) {
   ADX_REQUIRE(x && dy && dw, "conv2d_wgrad: null tensor");
+  ADX_REQUIRE(!x_cells || (conv2d_wgrad_hs_eligible(Cin, Cout, k, stride, pad) && k == 3),
+              "conv2d_wgrad: a cell-layout input belongs to the split-fp16 3x3 weight gradient");
   // zero = false: the caller has already cleared dw (the training executor clears every weight gradient in one batch)
   if (zero) ADX_CHECK_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cout * Cin * k * k, s));
   if (scratch9 != nullptr && k == 1 && stride == 2 && pad == 0 && conv2d_wgrad_hs_eligible(Cin, Cout, 3, 2, 1)) {
@@ -842,7 +876,7 @@ int conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int
     return ADX_OK;
   }
   if (conv2d_wgrad_hs_eligible(Cin, Cout, k, stride, pad))
-    return conv2d_wgrad_hs(x, dy, dw, N, Cin, H, W, Cout, stride, dy_amax, dy_amax_n, s);
+    return conv2d_wgrad_hs(x, dy, dw, N, Cin, H, W, Cout, stride, dy_amax, dy_amax_n, s, x_cells);
   // the stem: split-fp16 kernel when the gradient's range is known (it is far below fp16's), the exact-fp32 kernel otherwise
   if (dy_amax != nullptr && conv2d_wgrad_stem_hs_eligible(Cin, Cout, k, stride, pad))
     return conv2d_wgrad_stem_hs(x, dy, dw, N, H, W, dy_amax, dy_amax_n, s);
@@ -972,6 +1006,8 @@ struct adx_resnet_tape {
     const float* identity = nullptr;
     float* mean = nullptr; float* rstd = nullptr;
     int H = 0, W = 0, OH = 0, OW = 0, relu = 0;
+    bool x_cells = false;           // x is a cell tensor (bn_apply_cells_kernel), `out` of the record that produced it likewise
+    bool out_cells = false;
   };
   std::vector<Rec> recs;
   int batch = 0, h = 0, w = 0;
@@ -1065,10 +1101,13 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
   float* stats_part = ws.take(kStatsPartFloats);
   tape->stats_part = stats_part;
   int rc = ADX_OK;
+  // x_cells: x is a cell tensor; out_cells: leave the post-BN map as one (its only readers are the next conv and that conv's
+  // weight gradient)
   auto conv_bn = [&](const ConvSpec& L, const float* x, int H, int W, const float* identity, int relu,
-                     bool apply = true, float* raw_done = nullptr) -> float* {
+                     bool apply = true, float* raw_done = nullptr, bool x_cells = false, bool out_cells = false) -> float* {
     adx_resnet_tape::Rec rec;
     rec.L = &L; rec.x = x; rec.H = H; rec.W = W; rec.relu = relu; rec.identity = identity;
+    rec.x_cells = x_cells; rec.out_cells = out_cells;
     rec.OH = conv_out_dim(H, L.k, L.stride, L.pad); rec.OW = conv_out_dim(W, L.k, L.stride, L.pad);
     const size_t n = (size_t)batch * L.cout * rec.OH * rec.OW;
     // apply == false (the stem): the post-BN map is never formed, so it gets no storage either (0.94 GB at B = 64)
@@ -1079,7 +1118,7 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
     int stats_p = 0;     // > 0: the conv's own epilogue left per-workgroup partial sums (the 3x3 stride-1 layers)
     if (raw_done == nullptr)
       rc = conv2d_launch_raw(L, x, base + L.o_w, nullptr, nullptr, nullptr, rec.raw, batch, H, W, 0, s, nullptr, 0, stats_part,
-                             kStatsPartFloats, &stats_p);
+                             kStatsPartFloats, &stats_p, x_cells ? kFmtXCells : 0);
     if (rc != ADX_OK) { tape->recs.push_back(rec); return rec.out; }
     const int HW = rec.OH * rec.OW;
     double* sums = sums_all + (size_t)(&L - r->convs.data()) * 2 * 512;
@@ -1096,6 +1135,10 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
     }
     if (!apply) {
       // the caller consumes (raw, scale, shift) itself before the next conv_bn overwrites scale / shift (stream order)
+    } else if (out_cells) {
+      const int groups = batch * (L.cout / 8), per = ceil_div(HW, 256);
+      bn_apply_cells_kernel<<<dim3((unsigned)std::min<long>((long)groups * per, 1L << 20)), dim3(256), 0, s>>>(
+          rec.raw, scale, shift, reinterpret_cast<u32x4*>(rec.out), L.cout, HW, groups, relu);
     } else if (bn_planes_ok(HW, rec.raw, identity, rec.out)) {
       const int planes = batch * L.cout;
       bn_apply_planes_kernel<<<dim3(std::min(ceil_div(planes, 4), 8192)), dim3(256), 0, s>>>(rec.raw, scale, shift, identity,
@@ -1106,6 +1149,13 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
     }
     tape->recs.push_back(rec);
     return rec.out;
+  };
+  // The map between a block's convs as a cell tensor: when conv2's forward launch and its weight gradient both read cells
+  // (the split-fp16 kernels; ADX_TRAIN_CELLS=0 / the exact-fp32 switches keep fp32 NCHW)
+  auto mid_cells = [&](const ConvSpec& c1, const ConvSpec& c2, int OH, int OW) {
+    return c1.cout % 8 == 0 && c2.k == 3 && c2.stride == 1 && c2.pad == 1 && conv2d_wgrad_hs_eligible(c2.cin, c2.cout, 3, 1, 1) &&
+           conv2d_hs3x3_train_cells(c2, batch, OH, OW, kStatsPartFloats) &&
+           (reinterpret_cast<uintptr_t>(workspace) & 15) == 0;
   };
   size_t ci = 0;
   // stem: conv -> batch statistics -> [BN apply + ReLU + MaxPool + arg-max code] in one pass over the conv output; the
@@ -1130,6 +1180,7 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
     const int OH = conv_out_dim(H, 3, c1.stride, 1), OW = conv_out_dim(W, 3, c1.stride, 1);
     float* o1;
     const float* identity = cur;
+    const size_t o1_rec = tape->recs.size();         // conv1's record is the next one pushed
     if (r->block_has_ds[b] && resnet_fuses_ds(c1, r->convs[ci])) {
       // conv1 (3x3 stride 2) and the downsample (1x1 stride 2) read the same pixels: ONE launch leaves both raw outputs (the
       // downsample alone was a launch of the exact-fp32 1x1 kernel: 0.12 ms x 3 per step)
@@ -1140,13 +1191,13 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
       if (ws.ok && rc == ADX_OK)
         rc = conv2d_hs_launch_block_s2(c1, ds, cur, base + c1.o_w, nullptr, nullptr, raw1, base + ds.o_w, nullptr, nullptr, rawd,
                                        batch, H, W, s, 0, 0, 0);
-      o1 = conv_bn(c1, cur, H, W, nullptr, 1, true, raw1);
+      o1 = conv_bn(c1, cur, H, W, nullptr, 1, true, raw1, false, mid_cells(c1, c2, OH, OW));
       identity = conv_bn(ds, cur, H, W, nullptr, 0, true, rawd);
     } else {
-      o1 = conv_bn(c1, cur, H, W, nullptr, 1);
+      o1 = conv_bn(c1, cur, H, W, nullptr, 1, true, nullptr, false, mid_cells(c1, c2, OH, OW));
       if (r->block_has_ds[b]) identity = conv_bn(r->convs[ci++], cur, H, W, nullptr, 0);
     }
-    cur = conv_bn(c2, o1, OH, OW, identity, 1);
+    cur = conv_bn(c2, o1, OH, OW, identity, 1, true, nullptr, tape->recs[o1_rec].out_cells);
     H = OH; W = OW;
   }
   if (rc != ADX_OK) return rc;
@@ -1294,7 +1345,8 @@ int adx_resnet_backward_events(adx_resnet* r, const float* const* T, float* cons
           G[L.t_g], G[L.t_b]);
     }
     ADX_LAUNCH_CHECK();
-    int rc2 = conv2d_wgrad(rec.x, draw, G[L.t_w], batch, L.cin, rec.H, rec.W, L.cout, L.k, L.stride, L.pad, s, amax, n_amax, false, wgrad9);
+    int rc2 = conv2d_wgrad(rec.x, draw, G[L.t_w], batch, L.cin, rec.H, rec.W, L.cout, L.k, L.stride, L.pad, s, amax, n_amax, false, wgrad9,
+                           rec.x_cells);
     if (rc2 != ADX_OK || !need_dx) return rc2;
     // data gradient
     ConvSpec g{};

@@ -1,6 +1,8 @@
 """GPU parity, training row (T1): gradients of the temporal stack against torch autograd through the
 CPU oracle on identical inputs.  Tolerance: per-tensor relative error of the gradient norm-difference
 <= 2e-4 (fp32, atomically reduced weight gradients => summation order differs run to run)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -240,6 +242,33 @@ def test_unet_gradients_vs_oracle_autograd(use_cond, H, B):
         assert named["cond_mlp.0.weight"].grad.abs().max().item() == 0.0
         for k in ("cond_mlp.0.bias", "cond_mlp.2.weight", "cond_mlp.2.bias"):
             assert named[k].grad.abs().max().item() > 0.0, k
+
+
+def test_training_cell_tensors_change_no_bit(tmp_path):
+    """The training executor keeps the activation between a BasicBlock's two convs as a pre-split cell tensor (csrc/resnet_train.hip:
+    bn_apply_cells_kernel; the second conv's forward and its weight gradient read the halves their staging would have computed).
+    With the weight gradients reduced in index order, a train-mode forward + backward must come out bit for bit as with fp32
+    NCHW activations everywhere (ADX_TRAIN_CELLS=0): feature, every gradient, the running statistics."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for cells in ("0", "1"):
+        out = str(tmp_path / f"cells{cells}.pt")
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "train_cells_worker.py"), out],
+                           env=dict(os.environ, ADX_TRAIN_CELLS=cells, ADX_WGRAD_DETERMINISTIC="1"), capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[cells] = torch.load(out)
+    assert outs["0"].keys() == outs["1"].keys() and len(outs["0"]) == 4
+    for case, a in outs["0"].items():
+        b = outs["1"][case]
+        assert a.keys() == b.keys() and len(a) > 100
+        for k in a:
+            if k in ("grad.conv1.weight", "grad.fc.weight", "grad.fc.bias"):       # reduced with float atomics in either mode
+                assert (a[k] - b[k]).abs().max().item() <= 2e-6 * a[k].abs().max().item(), (case, k)
+                continue
+            assert torch.equal(a[k], b[k]), (case, k, (a[k].double() - b[k].double()).abs().max().item())
 
 
 @pytest.mark.parametrize("hw,small_gamma", [((64, 96), False), ((70, 102), False), ((64, 96), True)])
