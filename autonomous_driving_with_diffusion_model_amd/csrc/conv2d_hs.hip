@@ -869,10 +869,20 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
 #pragma unroll
           for (int r = 0; r < 16; ++r) accm[rr][half][r] = (accm[rr][half][r] + accl[rr][half][r] * (1.f / kLoScale)) * xs_inv;
       const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bs_raw + img), 0, img_bytes, 0x00020000);
+      const bool mask_bits = a.bs_mask == 1 && a.bs_bits != nullptr;       // the forward's mask bits instead of its fp32 output
+      const bool mask_out = a.bs_mask == 1 && !mask_bits;
       const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<float*>(a.bs_mask == 1 ? a.bs_out + img : a.y), 0, a.bs_mask == 1 ? img_bytes : 0, 0x00020000);
+          const_cast<float*>(mask_out ? a.bs_out + img : a.y), 0, mask_out ? img_bytes : 0, 0x00020000);
+      // mask bits: byte [n][c / 8][pixel]; this lane's channels of a register group r >> 2 are bits 4 khalf .. 4 khalf + 3 of one byte
+      const uint32_t bplane = (uint32_t)(a.OH * a.OW);
+      const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<uint8_t*>(mask_bits ? a.bs_bits + (size_t)n * (a.Cout >> 3) * bplane : reinterpret_cast<const uint8_t*>(a.y)), 0,
+          mask_bits ? (int)((VROW ? (uint32_t)a.N : 1u) * (uint32_t)(a.Cout >> 3) * bplane) : 0, 0x00020000);
+      uint32_t boff[2];
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr)
+        boff[rr] = inside[rr] ? (VROW ? (uint32_t)nl * (uint32_t)(a.Cout >> 3) * bplane : 0u) + pix[rr] : kOutside;
       const float* bsw = bsl + slab * 64;
-      const bool mask_out = a.bs_mask == 1;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         float rs_[2][16], rw_[2][16], ro_[2][16];
@@ -894,6 +904,15 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
               ro_[rr][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(orsrc, voff[rr], so, 0));
             }
         }
+        uint32_t mb[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+        if (mask_bits) {       // eight byte loads instead
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              mb[rr][q] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(brsrc, boff[rr], ((uint32_t)(cout0 >> 3) + (uint32_t)(half * 4 + q)) * bplane, 0)
+                          >> (4 * khalf);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int cu = half * 32 + (r & 3) + 8 * (r >> 2);
@@ -905,7 +924,8 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
             const float y = accm[rr][half][r] + rs_[rr][r];            // scale 1, shift 0, no ReLU: what `finish` would store
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, y), yrsrc, voff[rr], cbase_o + cu * plane_ob, 0);
             const bool keep = (rr == 0 ? val0 : val1) &&
-                              (mask_out ? ro_[rr][r] > 0.f : __builtin_fmaf(rw_[rr][r], msc, msh) > 0.f);
+                              (mask_bits ? ((mb[rr][r >> 2] >> (r & 3)) & 1u) != 0u
+                                         : (mask_out ? ro_[rr][r] > 0.f : __builtin_fmaf(rw_[rr][r], msc, msh) > 0.f));
             p[rr] = keep ? y : 0.f;
             q[rr] = p[rr] * ((rw_[rr][r] - mu) * rsd);
           }

@@ -65,6 +65,9 @@ struct Conv2dArgs {
   // mean gamma rstd) > 0 (ReLU straight after BatchNorm).
   const float* bs_raw; const float* bs_out; const float* bs_mean; const float* bs_rstd; const float* bs_gamma; const float* bs_beta;
   int bs_mask;
+  // bs_mask == 1 with bs_bits != null: the mask as the forward pass left it (resnet_train.hip: bn_apply_groups_kernel), one BIT per
+  // element -- byte [n][c / 8][pixel], bit c % 8 -- instead of the fp32 map bs_out
+  const uint8_t* bs_bits;
   // conv2d_hs3x3 only (inference executor): x / y / res in the cell layout instead of fp32 NCHW (conv2d_hs.hip: XCELLS)
   int x_cells, y_cells, res_cells;
   int vw;       // y_cells: columns of one image in the virtual row the column tiles run over (W + 1: the images side by side with
@@ -98,7 +101,8 @@ namespace adx {
 // one conv2d launch: y = [relu](conv(x, w) [* scale + shift] [+ res]); w = packed [tap][cin_pad][cout]
 // x_amax (optional, device): x_amax_n bit patterns whose maximum is max|x| over the whole input; the split-fp16 kernels use it to move x
 // into fp16's normal range by an exact power of two (data gradients are far below 2^-14)
-struct BnBwdStats { const float* raw; const float* out; const float* mean; const float* rstd; const float* gamma; const float* beta; int mask; };
+struct BnBwdStats { const float* raw; const float* out; const float* mean; const float* rstd; const float* gamma; const float* beta; int mask;
+                    const uint8_t* bits = nullptr; };
 int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const float* scale, const float* shift,
                       const float* res, float* y, int N, int H, int W, int relu, hipStream_t s,
                       const uint32_t* x_amax = nullptr, int x_amax_n = 0, float* stats_part = nullptr, size_t stats_floats = 0,

@@ -41,10 +41,14 @@ __global__ void __launch_bounds__(256) channel_sums_kernel(const float* __restri
                                                             const float* __restrict__ raw, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, double* __restrict__ sums,
                                                             int C, int HW, int relu_mask, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta) {
+                                                            const float* __restrict__ beta, const uint8_t* __restrict__ bits = nullptr) {
+  // bits (relu_mask == 1): the forward's mask, one bit per element -- byte [n][c / 8][pixel], bit c % 8 (bn_apply_groups_kernel) --
+  // read instead of `out`
   const int plane = blockIdx.x;            // n * C + c
   const int c = plane % C, tid = threadIdx.x;
   const size_t base = (size_t)plane * HW;
+  const uint8_t* bp = bits != nullptr ? bits + ((size_t)(plane / C) * (C >> 3) + (c >> 3)) * HW : nullptr;
+  const int bit = c & 7;
   double s0 = 0.0, s1 = 0.0;
   const float mu = MODE == 1 ? mean[c] : 0.f, rs = MODE == 1 ? rstd[c] : 0.f;
   float sc = 0.f, sh = 0.f;
@@ -60,8 +64,10 @@ __global__ void __launch_bounds__(256) channel_sums_kernel(const float* __restri
       s1 += (double)v * (double)((rw - mu) * rs);
     }
   };
+  const bool use_bits = MODE == 1 && relu_mask == 1 && bp != nullptr;
   const bool vec = (HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(a) | (MODE == 1 ? reinterpret_cast<uintptr_t>(raw) : 0) |
-                                      (MODE == 1 && relu_mask == 1 ? reinterpret_cast<uintptr_t>(out) : 0)) & 15) == 0;
+                                      (MODE == 1 && relu_mask == 1 && !use_bits ? reinterpret_cast<uintptr_t>(out) : 0)) & 15) == 0 &&
+                   (!use_bits || (reinterpret_cast<uintptr_t>(bits) & 3) == 0);
   if (vec) {     // 16-byte loads: a plane starts on a 16-byte boundary when HW % 4 == 0
     const f32x4* a4 = reinterpret_cast<const f32x4*>(a + base);
     const f32x4* r4 = reinterpret_cast<const f32x4*>(raw + base);
@@ -70,13 +76,18 @@ __global__ void __launch_bounds__(256) channel_sums_kernel(const float* __restri
       const f32x4 v = a4[i];
       f32x4 rw = f32x4{0.f, 0.f, 0.f, 0.f}, o = f32x4{0.f, 0.f, 0.f, 0.f};
       if (MODE == 1) rw = r4[i];
-      if (MODE == 1 && relu_mask == 1) o = o4[i];
+      if (use_bits) {
+        const uint32_t m = reinterpret_cast<const uint32_t*>(bp)[i] >> bit;       // four pixels' bytes
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (m >> (8 * k)) & 1u ? 1.f : 0.f;
+      } else if (MODE == 1 && relu_mask == 1) o = o4[i];
 #pragma unroll
       for (int k = 0; k < 4; ++k) one(v[k], rw[k], o[k]);
     }
   } else {
     for (int i = tid; i < HW; i += 256)
-      one(a[base + i], MODE == 1 ? raw[base + i] : 0.f, MODE == 1 && relu_mask == 1 ? out[base + i] : 0.f);
+      one(a[base + i], MODE == 1 ? raw[base + i] : 0.f,
+          use_bits ? (float)((bp[i] >> bit) & 1) : (MODE == 1 && relu_mask == 1 ? out[base + i] : 0.f));
   }
   __shared__ double red[8];
   s0 = wave_sum_d(s0);
@@ -217,34 +228,60 @@ __global__ void __launch_bounds__(256) bn_apply_planes_kernel(const float* __res
   }
 }
 
-// BatchNorm apply (+ ReLU) whose output is a CELL tensor -- per image [C/8][hi, lo][H][W] 16-byte cells of 8 channels, the
-// pre-split operand layout of the pipelined 3x3 kernel (conv2d_hs.hip: XCELLS) and of the weight gradient (conv2d_wgrad_hs.hip:
-// XC) -- for an activation only convolutions read: the map between a BasicBlock's two convs (modeling/resnet.py:87-93).  The
-// halves are the ones those kernels' staging would compute from the fp32 map (split8), so nothing downstream changes by a bit;
-// what changes is that the conversion happens once here instead of once per workgroup column of the consumer.  Same bytes as
-// the fp32 map.  A thread owns one pixel of one 8-channel group: eight coalesced plane reads, two coalesced 16-byte stores.
-__global__ void __launch_bounds__(256) bn_apply_cells_kernel(const float* __restrict__ raw, const float* __restrict__ scale,
-                                                              const float* __restrict__ shift, u32x4* __restrict__ out,
-                                                              int C, int HW, int groups, int relu) {
+// BatchNorm apply [+ identity] [+ ReLU] by 8-CHANNEL GROUPS: a thread owns one pixel of one group of 8 channels (eight coalesced
+// plane reads per fp32 operand).  What the group form buys:
+//  * OUT_CELLS: the output as a CELL tensor -- per image [C/8][hi, lo][H][W] 16-byte cells of 8 channels, the pre-split operand
+//    layout of the pipelined 3x3 kernel (conv2d_hs.hip: XCELLS) and of the weight gradient (conv2d_wgrad_hs.hip: XC) -- for an
+//    activation only convolutions read: the map between a BasicBlock's two convs (modeling/resnet.py:87-93).  The halves are the
+//    ones those kernels' staging would compute from the fp32 map (split8), so nothing downstream changes by a bit; the
+//    conversion happens once here instead of once per workgroup column of the consumer.  Same bytes as the fp32 map.
+//  * BITS: the ReLU mask of a block's output (ReLU after the residual add, modeling/resnet.py:99-100) as one BIT per element --
+//    byte [n][c / 8][pixel], bit c % 8 -- so that the backward pass reads 1/32 of the bytes of `out` to know where the ReLU let
+//    the gradient through (bn_bwd_apply*, channel_sums_kernel<1>, the data-gradient epilogue of conv2d_hs.hip).
+// RES: 0 no identity, 1 fp32 NCHW, 2 a cell tensor (hi + lo / 2^11).
+template <bool OUT_CELLS, int RES, bool BITS>
+__global__ void __launch_bounds__(256) bn_apply_groups_kernel(const float* __restrict__ raw, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, const void* __restrict__ res,
+                                                               void* __restrict__ out, uint8_t* __restrict__ bits, int C, int HW,
+                                                               int groups, int relu) {
   const int per = (HW + 255) / 256;                 // workgroups per (image, channel group)
   for (int w = blockIdx.x; w < groups * per; w += gridDim.x) {
     const int g = w / per, pix = (w - g * per) * 256 + threadIdx.x;      // g = n * (C / 8) + channel group
     if (pix >= HW) continue;
     const int c0 = (g % (C >> 3)) * 8;
-    const float* r = raw + (size_t)g * 8 * HW + pix;
+    const size_t p0 = (size_t)g * 8 * HW + pix;
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = r[(size_t)j * HW];
+    for (int j = 0; j < 8; ++j) v[j] = raw[p0 + (size_t)j * HW];
+    float id[8];
+    if constexpr (RES == 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) id[j] = reinterpret_cast<const float*>(res)[p0 + (size_t)j * HW];
+    } else if constexpr (RES == 2) {
+      const u32x4* rc = reinterpret_cast<const u32x4*>(res) + (size_t)g * 2 * HW + pix;
+      const f16x8 h = __builtin_bit_cast(f16x8, rc[0]), l = __builtin_bit_cast(f16x8, rc[HW]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) id[j] = __builtin_fmaf((float)l[j], 1.f / kLoScale, (float)h[j]);
+    }
+    uint32_t m = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       v[j] = bn_eval(v[j], scale[c0 + j], shift[c0 + j]);
+      if constexpr (RES != 0) v[j] += id[j];
+      if (BITS && v[j] > 0.f) m |= 1u << j;
       if (relu) v[j] = v[j] > 0.f ? v[j] : 0.f;
     }
-    u32x4 hi, lo;
-    split8(v, 1.f, hi, lo);
-    u32x4* o = out + (size_t)g * 2 * HW + pix;
-    o[0] = hi;
-    o[HW] = lo;
+    if constexpr (OUT_CELLS) {
+      u32x4 hi, lo;
+      split8(v, 1.f, hi, lo);
+      u32x4* o = reinterpret_cast<u32x4*>(out) + (size_t)g * 2 * HW + pix;
+      o[0] = hi;
+      o[HW] = lo;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) reinterpret_cast<float*>(out)[p0 + (size_t)j * HW] = v[j];
+    }
+    if constexpr (BITS) bits[(size_t)g * HW + pix] = (uint8_t)m;
   }
 }
 
@@ -259,7 +296,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
                                                             float* __restrict__ dz_out, int C, int HW, size_t total,
                                                             double count, int relu_mask, uint32_t* __restrict__ amax,
                                                             const float* __restrict__ beta, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta) {
+                                                            float* __restrict__ dbeta, const uint8_t* __restrict__ bits = nullptr) {
   // grid-stride: a fixed number of workgroups, each leaving max |draw| of its share in amax[blockIdx.x] (bits:
   // monotonic for non-negative floats); the data-gradient conv reduces those partials for its dynamic range
   __shared__ uint32_t red[4];
@@ -271,7 +308,16 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
     const int c = small ? (int)(((uint32_t)i / (uint32_t)HW) % (uint32_t)C) : (int)((i / HW) % C);
     float dz = dout[i];
     const float rw = raw[i];
-    if (relu_mask == 1 && !(out[i] > 0.f)) dz = 0.f;
+    if (relu_mask == 1) {
+      bool on;
+      if (bits != nullptr) {        // byte [n][c / 8][pixel], bit c % 8
+        const size_t pl = i / HW;
+        on = (bits[((pl / C) * (C >> 3) + (c >> 3)) * HW + (i - pl * HW)] >> (c & 7)) & 1;
+      } else {
+        on = out[i] > 0.f;
+      }
+      if (!on) dz = 0.f;
+    }
     if (relu_mask == 2) {
       float sc, sh;
       bn_affine(gamma[c], beta[c], mean[c], rstd[c], sc, sh);
@@ -307,7 +353,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_planes_kernel(const float* _
                                                                    float* __restrict__ dz_out, int C, int HW, int planes,
                                                                    double count, int relu_mask, uint32_t* __restrict__ amax,
                                                                    const float* __restrict__ beta, float* __restrict__ dgamma,
-                                                                   float* __restrict__ dbeta) {
+                                                                   float* __restrict__ dbeta, const uint8_t* __restrict__ bits = nullptr) {
   __shared__ uint32_t red[4];
   if (blockIdx.x == 0 && dgamma != nullptr)
     for (int c = threadIdx.x; c < C; c += 256) { dbeta[c] = (float)sums[2 * c]; dgamma[c] = (float)sums[2 * c + 1]; }
@@ -326,10 +372,17 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_planes_kernel(const float* _
     const f32x4* o4 = reinterpret_cast<const f32x4*>(out) + base;
     f32x4* w4 = reinterpret_cast<f32x4*>(draw) + base;
     f32x4* z4 = reinterpret_cast<f32x4*>(dz_out) + base;
+    // the forward's mask bits (byte [n][c / 8][pixel], bit c % 8): four pixels' bytes in one dword
+    const uint32_t* b4 = bits != nullptr ? reinterpret_cast<const uint32_t*>(bits + ((size_t)(pl / C) * (C >> 3) + (c >> 3)) * HW) : nullptr;
     for (int i = lane; i < hw4; i += 64) {
       f32x4 dz = d4[i];
       const f32x4 rw = r4[i];
-      if (relu_mask == 1) {
+      if (relu_mask == 1 && b4 != nullptr) {
+        const uint32_t m = b4[i] >> (c & 7);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (!((m >> (8 * k)) & 1u)) dz[k] = 0.f;
+      } else if (relu_mask == 1) {
         const f32x4 o = o4[i];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -1006,8 +1059,9 @@ struct adx_resnet_tape {
     const float* identity = nullptr;
     float* mean = nullptr; float* rstd = nullptr;
     int H = 0, W = 0, OH = 0, OW = 0, relu = 0;
-    bool x_cells = false;           // x is a cell tensor (bn_apply_cells_kernel), `out` of the record that produced it likewise
+    bool x_cells = false;           // x is a cell tensor (bn_apply_groups_kernel), `out` of the record that produced it likewise
     bool out_cells = false;
+    uint8_t* bits = nullptr;        // ReLU mask of `out`, one bit per element (ReLU after the residual add), or null: read `out`
   };
   std::vector<Rec> recs;
   int batch = 0, h = 0, w = 0;
@@ -1036,7 +1090,7 @@ size_t adx_resnet_train_workspace_bytes(const adx_resnet* r, int32_t batch, int3
   auto conv = [&](const ConvSpec& L, int H, int W, bool apply = true) {
     const int OH = conv_out_dim(H, L.k, L.stride, L.pad), OW = conv_out_dim(W, L.k, L.stride, L.pad);
     const size_t n = (size_t)batch * L.cout * OH * OW;
-    f += (apply ? 2 : 1) * al64(n) + 2 * al64(L.cout);      // conv output (+ post-BN map) + saved mean / rstd
+    f += (apply ? 2 : 1) * al64(n) + 2 * al64(L.cout) + al64(n / 32 + 1);      // conv output (+ post-BN map) + saved mean / rstd + mask bits
     big = std::max(big, n);
     big = std::max(big, (size_t)batch * L.cin * H * W);
     wmax = std::max(wmax, (size_t)L.k * L.k * L.cout * L.cin);
@@ -1114,6 +1168,9 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
     // raw_done: the conv output already sits there (the fused stride-2 launch of a downsample block)
     rec.raw = raw_done != nullptr ? raw_done : ws.take(n);
     rec.out = apply ? ws.take(n) : nullptr; rec.mean = ws.take(L.cout); rec.rstd = ws.take(L.cout);
+    // a block's output: the ReLU mask as bits for the backward pass (ADX_TRAIN_CELLS=0: it reads `out`)
+    const bool want_bits = apply && relu && identity != nullptr && !out_cells && L.cout % 8 == 0 && debug_switches().train_cells;
+    if (want_bits) rec.bits = reinterpret_cast<uint8_t*>(ws.take((n / 8 + 3) / 4));
     if (!ws.ok || rc != ADX_OK) { tape->recs.push_back(rec); return rec.out; }
     int stats_p = 0;     // > 0: the conv's own epilogue left per-workgroup partial sums (the 3x3 stride-1 layers)
     if (raw_done == nullptr)
@@ -1135,10 +1192,11 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
     }
     if (!apply) {
       // the caller consumes (raw, scale, shift) itself before the next conv_bn overwrites scale / shift (stream order)
-    } else if (out_cells) {
+    } else if (out_cells || rec.bits != nullptr) {
       const int groups = batch * (L.cout / 8), per = ceil_div(HW, 256);
-      bn_apply_cells_kernel<<<dim3((unsigned)std::min<long>((long)groups * per, 1L << 20)), dim3(256), 0, s>>>(
-          rec.raw, scale, shift, reinterpret_cast<u32x4*>(rec.out), L.cout, HW, groups, relu);
+      const dim3 grid((unsigned)std::min<long>((long)groups * per, 1L << 20));
+      if (out_cells) bn_apply_groups_kernel<true, 0, false><<<grid, dim3(256), 0, s>>>(rec.raw, scale, shift, nullptr, rec.out, nullptr, L.cout, HW, groups, relu);
+      else bn_apply_groups_kernel<false, 1, true><<<grid, dim3(256), 0, s>>>(rec.raw, scale, shift, identity, rec.out, rec.bits, L.cout, HW, groups, relu);
     } else if (bn_planes_ok(HW, rec.raw, identity, rec.out)) {
       const int planes = batch * L.cout;
       bn_apply_planes_kernel<<<dim3(std::min(ceil_div(planes, 4), 8192)), dim3(256), 0, s>>>(rec.raw, scale, shift, identity,
@@ -1329,7 +1387,7 @@ int adx_resnet_backward_events(adx_resnet* r, const float* const* T, float* cons
     const int mask = !rec.relu ? 0 : (rec.identity != nullptr ? 1 : 2);
     if (sums_ready != &rec)
       channel_sums_kernel<1><<<dim3(batch * L.cout), dim3(256), 0, s>>>(dout, rec.out, rec.raw, rec.mean, rec.rstd, sums,
-                                                                        L.cout, HW, mask, T[L.t_g], T[L.t_b]);
+                                                                        L.cout, HW, mask, T[L.t_g], T[L.t_b], rec.bits);
     sums_ready = nullptr;
     int n_amax;
     if (bn_planes_ok(HW, dout, rec.raw, draw) && bn_planes_ok(HW, rec.out, dz_keep, nullptr)) {
@@ -1337,12 +1395,12 @@ int adx_resnet_backward_events(adx_resnet* r, const float* const* T, float* cons
       n_amax = (int)std::min<size_t>(kAmaxPartials, (size_t)ceil_div(planes, 4));
       bn_bwd_apply_planes_kernel<<<dim3(n_amax), dim3(256), 0, s>>>(dout, rec.out, rec.raw, rec.mean, rec.rstd, T[L.t_g], sums,
                                                                     draw, dz_keep, L.cout, HW, planes, count, mask, amax, T[L.t_b],
-                                                                    G[L.t_g], G[L.t_b]);
+                                                                    G[L.t_g], G[L.t_b], rec.bits);
     } else {
       n_amax = (int)std::min<size_t>(kAmaxPartials, (n + 255) / 256);
       bn_bwd_apply_kernel<<<dim3(n_amax), dim3(256), 0, s>>>(
           dout, rec.out, rec.raw, rec.mean, rec.rstd, T[L.t_g], sums, draw, dz_keep, L.cout, HW, n, count, mask, amax, T[L.t_b],
-          G[L.t_g], G[L.t_b]);
+          G[L.t_g], G[L.t_b], rec.bits);
     }
     ADX_LAUNCH_CHECK();
     int rc2 = conv2d_wgrad(rec.x, draw, G[L.t_w], batch, L.cin, rec.H, rec.W, L.cout, L.k, L.stride, L.pad, s, amax, n_amax, false, wgrad9,
@@ -1356,7 +1414,7 @@ int adx_resnet_backward_events(adx_resnet* r, const float* const* T, float* cons
       if (next_mask != 0 && tape->stats_part != nullptr) {
         const ConvSpec& Ln = *next->L;
         ADX_REQUIRE(Ln.cout == L.cin && next->OH == rec.H && next->OW == rec.W, "adx_resnet_backward: consumer record does not match dx");
-        const BnBwdStats bst{next->raw, next->out, next->mean, next->rstd, T[Ln.t_g], T[Ln.t_b], next_mask};
+        const BnBwdStats bst{next->raw, next->out, next->mean, next->rstd, T[Ln.t_g], T[Ln.t_b], next_mask, next->bits};
         int stats_p = 0;
         rc2 = conv2d_launch_raw(g, draw, pre, nullptr, nullptr, dx_has ? dx : nullptr, dx, batch, rec.OH, rec.OW, 0, s, amax, n_amax,
                                 tape->stats_part, kStatsPartFloats, &stats_p, 0, &bst);
