@@ -1695,7 +1695,7 @@ bool conv2d_hs3x3_plain(const ConvSpec& L, int N, int H, int W) {
 }
 
 bool conv2d_hs3x3_train_cells(const ConvSpec& L, int N, int H, int W, size_t stats_floats) {
-  if (!debug_switches().train_cells || !conv2d_hs_eligible(L) || L.dgrad) return false;     // ADX_TRAIN_CELLS=0: fp32 NCHW everywhere
+  if (debug_switches().train_cells == 0 || !conv2d_hs_eligible(L) || L.dgrad) return false;     // ADX_TRAIN_CELLS=0: fp32 NCHW everywhere
   Conv2dArgs a{};
   a.N = N; a.Cin = L.cin; a.Cout = L.cout; a.H = H; a.W = W;
   a.OH = conv_out_dim(H, L.k, L.stride, L.pad); a.OW = conv_out_dim(W, L.k, L.stride, L.pad);

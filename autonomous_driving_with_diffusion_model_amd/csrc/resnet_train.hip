@@ -916,13 +916,14 @@ int conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int
                  int pad, hipStream_t s, const uint32_t* dy_amax = nullptr, int dy_amax_n = 0, bool zero = true,
                  float* scratch9 = nullptr, bool x_cells = false) {
   ADX_REQUIRE(x && dy && dw, "conv2d_wgrad: null tensor");
-  ADX_REQUIRE(!x_cells || (conv2d_wgrad_hs_eligible(Cin, Cout, k, stride, pad) && k == 3),
+  ADX_REQUIRE(!x_cells || (conv2d_wgrad_hs_eligible(Cin, Cout, k, stride, pad) && k == 3) ||
+                  (scratch9 != nullptr && k == 1 && stride == 2 && pad == 0 && conv2d_wgrad_hs_eligible(Cin, Cout, 3, 2, 1)),
               "conv2d_wgrad: a cell-layout input belongs to the split-fp16 3x3 weight gradient");
   // zero = false: the caller has already cleared dw (the training executor clears every weight gradient in one batch)
   if (zero) ADX_CHECK_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cout * Cin * k * k, s));
   if (scratch9 != nullptr && k == 1 && stride == 2 && pad == 0 && conv2d_wgrad_hs_eligible(Cin, Cout, 3, 2, 1)) {
     ADX_CHECK_HIP(hipMemsetAsync(scratch9, 0, sizeof(float) * (size_t)Cout * Cin * 9, s));
-    const int rc = conv2d_wgrad_hs(x, dy, scratch9, N, Cin, H, W, Cout, 2, dy_amax, dy_amax_n, s);
+    const int rc = conv2d_wgrad_hs(x, dy, scratch9, N, Cin, H, W, Cout, 2, dy_amax, dy_amax_n, s, x_cells);
     if (rc != ADX_OK) return rc;
     centre_tap_add_kernel<<<dim3(ceil_div(Cout * Cin, 256)), dim3(256), 0, s>>>(dw, scratch9, Cout * Cin);
     ADX_LAUNCH_CHECK();
@@ -1158,7 +1159,8 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
   // x_cells: x is a cell tensor; out_cells: leave the post-BN map as one (its only readers are the next conv and that conv's
   // weight gradient)
   auto conv_bn = [&](const ConvSpec& L, const float* x, int H, int W, const float* identity, int relu,
-                     bool apply = true, float* raw_done = nullptr, bool x_cells = false, bool out_cells = false) -> float* {
+                     bool apply = true, float* raw_done = nullptr, bool x_cells = false, bool out_cells = false,
+                     bool id_cells = false) -> float* {
     adx_resnet_tape::Rec rec;
     rec.L = &L; rec.x = x; rec.H = H; rec.W = W; rec.relu = relu; rec.identity = identity;
     rec.x_cells = x_cells; rec.out_cells = out_cells;
@@ -1169,7 +1171,11 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
     rec.raw = raw_done != nullptr ? raw_done : ws.take(n);
     rec.out = apply ? ws.take(n) : nullptr; rec.mean = ws.take(L.cout); rec.rstd = ws.take(L.cout);
     // a block's output: the ReLU mask as bits for the backward pass (ADX_TRAIN_CELLS=0: it reads `out`)
-    const bool want_bits = apply && relu && identity != nullptr && !out_cells && L.cout % 8 == 0 && debug_switches().train_cells;
+    const bool want_bits = apply && relu && identity != nullptr && L.cout % 8 == 0 && debug_switches().train_cells;
+    if (rc == ADX_OK && ((out_cells && identity != nullptr && !want_bits) || (id_cells && !want_bits))) {
+      set_error("adx_resnet_forward_train: a cell-layout block output needs the group form of the BatchNorm apply pass");
+      rc = ADX_ERR_STATE;
+    }
     if (want_bits) rec.bits = reinterpret_cast<uint8_t*>(ws.take((n / 8 + 3) / 4));
     if (!ws.ok || rc != ADX_OK) { tape->recs.push_back(rec); return rec.out; }
     int stats_p = 0;     // > 0: the conv's own epilogue left per-workgroup partial sums (the 3x3 stride-1 layers)
@@ -1195,8 +1201,14 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
     } else if (out_cells || rec.bits != nullptr) {
       const int groups = batch * (L.cout / 8), per = ceil_div(HW, 256);
       const dim3 grid((unsigned)std::min<long>((long)groups * per, 1L << 20));
-      if (out_cells) bn_apply_groups_kernel<true, 0, false><<<grid, dim3(256), 0, s>>>(rec.raw, scale, shift, nullptr, rec.out, nullptr, L.cout, HW, groups, relu);
-      else bn_apply_groups_kernel<false, 1, true><<<grid, dim3(256), 0, s>>>(rec.raw, scale, shift, identity, rec.out, rec.bits, L.cout, HW, groups, relu);
+#define ADX_BN_GROUPS(OC, RES, BITS) \
+  bn_apply_groups_kernel<OC, RES, BITS><<<grid, dim3(256), 0, s>>>(rec.raw, scale, shift, identity, rec.out, rec.bits, L.cout, HW, groups, relu)
+      if (rec.bits == nullptr) ADX_BN_GROUPS(true, 0, false);             // the map between a block's convs
+      else if (out_cells && id_cells) ADX_BN_GROUPS(true, 2, true);       // a block's output, by layout of (output, identity)
+      else if (out_cells) ADX_BN_GROUPS(true, 1, true);
+      else if (id_cells) ADX_BN_GROUPS(false, 2, true);
+      else ADX_BN_GROUPS(false, 1, true);
+#undef ADX_BN_GROUPS
     } else if (bn_planes_ok(HW, rec.raw, identity, rec.out)) {
       const int planes = batch * L.cout;
       bn_apply_planes_kernel<<<dim3(std::min(ceil_div(planes, 4), 8192)), dim3(256), 0, s>>>(rec.raw, scale, shift, identity,
@@ -1230,7 +1242,25 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
   }
   tape->pool_in = stem; tape->pool_out = pooled; tape->ph = h1; tape->pw = w1; tape->poh = h2; tape->pow_ = w2;
   tape->pool_code = pcode;
+  // A block's OUTPUT as a cell tensor: when everything that reads it reads cells -- the next block's conv1 (3x3 stride 1, or the
+  // fused stride-2 conv1 + downsample launch), the weight gradients of those convs, and the residual add of the next block's
+  // BatchNorm apply pass (group form).  The pooled map (block 0's input) and the last block's output (average pool, its
+  // backward) stay fp32.  What is rounded: the identity the next block adds is hi + lo / 2^11 (22 bits) instead of the fp32
+  // value -- what the inference executor does at every block.
+  auto block_in_cells = [&](size_t b, size_t first_conv, int Hb, int Wb) {
+    if (debug_switches().train_cells < 2 || b == 0 || b >= r->block_has_ds.size() || (reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return false;
+    const ConvSpec& a1 = r->convs[first_conv];
+    const ConvSpec& a2 = r->convs[first_conv + 1];
+    if (a1.cin % 8 != 0 || a2.cout % 8 != 0 || (size_t)batch * a1.cin * Hb * Wb * sizeof(float) >= 0xC0000000u) return false;
+    if (r->block_has_ds[b]) {
+      const ConvSpec& ad = r->convs[first_conv + 2];
+      return resnet_fuses_ds(a1, ad) && conv2d_wgrad_hs_eligible(a1.cin, a1.cout, 3, 2, 1);     // (the 1x1 gradient runs as that kernel's centre tap)
+    }
+    return a1.k == 3 && a1.stride == 1 && a1.pad == 1 && conv2d_wgrad_hs_eligible(a1.cin, a1.cout, 3, 1, 1) &&
+           conv2d_hs3x3_train_cells(a1, batch, Hb, Wb, kStatsPartFloats);
+  };
   float* cur = pooled;
+  bool cur_cells = false;
   int H = h2, W = w2;
   for (size_t b = 0; b < r->block_has_ds.size(); ++b) {
     const ConvSpec& c1 = r->convs[ci++];
@@ -1238,6 +1268,7 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
     const int OH = conv_out_dim(H, 3, c1.stride, 1), OW = conv_out_dim(W, 3, c1.stride, 1);
     float* o1;
     const float* identity = cur;
+    bool id_cells = cur_cells;
     const size_t o1_rec = tape->recs.size();         // conv1's record is the next one pushed
     if (r->block_has_ds[b] && resnet_fuses_ds(c1, r->convs[ci])) {
       // conv1 (3x3 stride 2) and the downsample (1x1 stride 2) read the same pixels: ONE launch leaves both raw outputs (the
@@ -1248,14 +1279,21 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
       float* rawd = ws.take(n);
       if (ws.ok && rc == ADX_OK)
         rc = conv2d_hs_launch_block_s2(c1, ds, cur, base + c1.o_w, nullptr, nullptr, raw1, base + ds.o_w, nullptr, nullptr, rawd,
-                                       batch, H, W, s, 0, 0, 0);
-      o1 = conv_bn(c1, cur, H, W, nullptr, 1, true, raw1, false, mid_cells(c1, c2, OH, OW));
-      identity = conv_bn(ds, cur, H, W, nullptr, 0, true, rawd);
+                                       batch, H, W, s, cur_cells ? 1 : 0, 0, 0);
+      o1 = conv_bn(c1, cur, H, W, nullptr, 1, true, raw1, cur_cells, mid_cells(c1, c2, OH, OW));
+      identity = conv_bn(ds, cur, H, W, nullptr, 0, true, rawd, cur_cells);
+      id_cells = false;
     } else {
-      o1 = conv_bn(c1, cur, H, W, nullptr, 1, true, nullptr, false, mid_cells(c1, c2, OH, OW));
-      if (r->block_has_ds[b]) identity = conv_bn(r->convs[ci++], cur, H, W, nullptr, 0);
+      if (rc == ADX_OK && cur_cells && r->block_has_ds[b]) {
+        set_error("adx_resnet_forward_train: a cell-layout block input needs the fused stride-2 launch");
+        rc = ADX_ERR_STATE;
+      }
+      o1 = conv_bn(c1, cur, H, W, nullptr, 1, true, nullptr, cur_cells, mid_cells(c1, c2, OH, OW));
+      if (r->block_has_ds[b]) { identity = conv_bn(r->convs[ci++], cur, H, W, nullptr, 0); id_cells = false; }
     }
-    cur = conv_bn(c2, o1, OH, OW, identity, 1, true, nullptr, tape->recs[o1_rec].out_cells);
+    const bool out_cells = block_in_cells(b + 1, ci, OH, OW);
+    cur = conv_bn(c2, o1, OH, OW, identity, 1, true, nullptr, tape->recs[o1_rec].out_cells, out_cells, id_cells);
+    cur_cells = out_cells;
     H = OH; W = OW;
   }
   if (rc != ADX_OK) return rc;
