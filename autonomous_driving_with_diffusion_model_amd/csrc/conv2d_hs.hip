@@ -33,11 +33,6 @@
 
 namespace adx {
 
-template <int CTRL>
-__device__ __forceinline__ float hs_dpp(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-
 // Cell-layout store of one lane's 16 accumulator values of a 32-channel group (v[r]: channel (r & 3) + 8 (r >> 2) + 4 khalf
 // of the lane's pixel; lane + 32 holds the other halves of the same cells).  Four v_permlane32_swap per pair of cells
 // leave lanes 0-31 with cells 0 and 2 of the group and lanes 32-63 with cells 1 and 3, eight channels each (v[8 i + 0..7] =
@@ -1580,6 +1575,10 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
     a.tiles_x = hs_vrow_tiles_x(a);
     return (size_t)a.cout_tiles * a.tiles_x * a.tiles_y;
   };
+  if (a.stats_part != nullptr && a.x_cells && conv2d_hs3x3q_train_eligible(a)) {      // the 16x16x32 kernel where its tile rules hold
+    a.part = nullptr;
+    return conv2d_hs3x3q_launch(a, s);
+  }
   if (a.stats_part != nullptr) {          // training forward: statistics in the epilogue (one workgroup per tile: no split)
     const size_t sgrid = vrow ? set_vrow() : grid;
     const int slots = vrow ? a.tiles_y * a.tiles_x : a.N * a.tiles_y * a.tiles_x;
@@ -1709,6 +1708,7 @@ bool conv2d_hs3x3_train_cells(const ConvSpec& L, int N, int H, int W, size_t sta
 int conv2d_hs_stats_tiles(const ConvSpec& L, const Conv2dArgs& a) {
   const int mode = hs3x3_mode(L, a);
   if (mode < 0) return 0;
+  if (a.x_cells && conv2d_hs3x3q_train_eligible(a)) return conv2d_hs3x3q_train_tiles(a);
   if (!(a.y_cells || a.res_cells) && hs_vrow_ok(a)) return ceil_div(a.OH, mode == 1 ? 16 : 8) * hs_vrow_tiles_x(a);
   return a.N * ceil_div(a.OH, mode == 1 ? 16 : 8) * ceil_div(a.OW, kTileW);
 }

@@ -60,7 +60,10 @@ __device__ __forceinline__ void half4(uint32_t h0, uint32_t h1, uint32_t l0, uin
 
 }  // namespace
 
-template <bool DMA>
+// TRAIN: the training forward's launch on a cell-layout input (resnet_train.hip): the raw conv output as fp32 NCHW (BatchNorm
+// needs batch statistics before anything can be applied) and, like conv2d_hs3x3_kernel's STATS == 1, per-workgroup partial sums
+// of the output and of its squares per channel ([Cout][2][tiles] floats, pixels outside the map excluded).
+template <bool DMA, bool TRAIN = false>
 __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs a) {
   constexpr int NT = kQNT, PW = kQPW, PLANE = DMA ? kQPlaneD : kQPlane, PP = DMA ? kQPlaneD : kQPlaneP, PIT = kQPit, WST = kQWst;
   constexpr int NPAIRS = DMA ? kQPairsD : kQPairs;
@@ -239,6 +242,78 @@ __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs
     }
   }
 
+  if constexpr (TRAIN) {
+    // ---- training epilogue ----
+    // statistics first, from the accumulators as they lie: lane (j, kq) holds channels 16 cb + 4 kq + i of its four pixels (row
+    // pb >> 1, virtual column 16 (pb & 1) + j); the four pixels in the lane, then the 16 lanes of a DPP row; lanes j == 0 park
+    // the row's totals in LDS (the operand images are dead: every wave is past the last stage's barrier) and 256 threads add
+    // the four row-pair waves of a slab in a fixed order.
+    const uint32_t plane_ob = (uint32_t)(a.OH * a.OW) * (uint32_t)sizeof(float);
+    float* red = reinterpret_cast<float*>(smem_raw);          // [wave][kq][cb][i][2]
+    float valid[4];
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) {
+      const int vc = vx0 + 16 * (pb & 1) + j;
+      const int np = vdiv(vc), xp = vc - np * a.vw;
+      valid[pb] = (np < a.N && xp < a.W && oy0 + rowpair * 2 + (pb >> 1) < a.OH) ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+          const float v = (accm[cb][pb][i] + accl[cb][pb][i] * (1.f / kLoScale)) * valid[pb];
+          accm[cb][pb][i] = v;                    // (a pixel outside the map is never stored: its lane's store offset is out of range)
+          sm += v;
+          sq = __builtin_fmaf(v, v, sq);
+        }
+        sm += hs_dpp<0xB1>(sm);  sq += hs_dpp<0xB1>(sq);      // quad_perm [1,0,3,2]
+        sm += hs_dpp<0x4E>(sm);  sq += hs_dpp<0x4E>(sq);      // quad_perm [2,3,0,1]
+        sm += hs_dpp<0x141>(sm); sq += hs_dpp<0x141>(sq);     // row_half_mirror
+        sm += hs_dpp<0x140>(sm); sq += hs_dpp<0x140>(sq);     // row_mirror: every lane of a row of 16 holds the row's total
+        if (j == 0) {
+          float* d = red + ((((wave * 4 + kq) * 4 + cb) * 4) + i) * 2;
+          d[0] = sm;
+          d[1] = sq;
+        }
+      }
+    __syncthreads();
+    if (tid < 256) {
+      const int which = tid & 1, ch = tid >> 1, sl = ch >> 6, cl = ch & 63;        // channel ch of the workgroup's 128
+      const int cb = cl >> 4, q = (cl >> 2) & 3, i = cl & 3;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) t += red[(((((sl * 4 + w) * 4 + q) * 4 + cb) * 4) + i) * 2 + which];
+      a.stats_part[((size_t)(ct * 128 + ch) * 2 + which) * a.stats_p + (ty * a.tiles_x + tx)] = t;
+    }
+    // the conv output: after the swap of a row's two pixel blocks lane (j, rw = kq) holds channels 16 cb + 8 (rw >> 1) .. + 7 of
+    // the pixel at column 16 (rw & 1) + j, i.e. the 32 lanes of a half wave are 32 consecutive pixels of one channel plane
+    const int rw = kq;
+    const int vcol = vx0 + 16 * (rw & 1) + j;
+    const int nl = vdiv(vcol), xl = vcol - nl * a.vw;
+    const bool col_valid = nl < a.N && xl < a.W;
+    const uint32_t img_bytes = (uint32_t)a.N * (uint32_t)a.Cout * plane_ob;
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)img_bytes, 0x00020000);
+    const int cout0 = ct * 128 + slab * 64;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int oy = oy0 + rowpair * 2 + rr;
+      const uint32_t voff = (col_valid && oy < a.OH)
+                                ? (uint32_t)nl * (uint32_t)a.Cout * plane_ob + (uint32_t)(oy * a.OW + xl) * 4u + (uint32_t)(8 * (rw >> 1)) * plane_ob
+                                : kOutside;
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const auto sw = __builtin_amdgcn_permlane16_swap(f2u(accm[cb][2 * rr][i]), f2u(accm[cb][2 * rr + 1][i]), false, false);
+          __builtin_amdgcn_raw_buffer_store_b32(sw[0], yrsrc, voff, (uint32_t)(cout0 + 16 * cb + i) * plane_ob, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(sw[1], yrsrc, voff, (uint32_t)(cout0 + 16 * cb + 4 + i) * plane_ob, 0);
+        }
+    }
+    return;
+  }
   // ---- epilogue: one cell (8 channels of a pixel, hi + lo) per lane and (channel block, row) ----
   // Accumulator lane (j, kq) holds channels 16 cb + 4 kq + i of pixel (row pb >> 1, column 16 (pb & 1) + j).  After the swaps of
   // a row's two pixel blocks lane (j, rw = kq) holds the cell of channels 16 cb + 8 (rw >> 1) .. + 7 at column 16 (rw & 1) + j.
@@ -311,6 +386,18 @@ __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs
     }
 }
 
+// a training-forward launch (cells in, fp32 + statistics out) the TRAIN variant serves
+bool conv2d_hs3x3q_train_eligible(const Conv2dArgs& a) {
+  return debug_switches().hs_mode < 0 && debug_switches().train_cells >= 3 && a.x_cells && !a.y_cells && !a.res_cells && a.res == nullptr &&
+         a.x_amax == nullptr && a.bs_raw == nullptr && a.scale == nullptr && a.Cout % 128 == 0 && a.cin_pad % 64 == 0 && a.cin_pad == a.Cin &&
+         a.pad == 1 && a.stride == 1 && a.KH == 3 && a.KW == 3 && a.H == a.OH && a.W == a.OW && (long)a.N * (a.OW + 1) < (1L << 21) &&
+         (size_t)a.N * a.Cout * a.OH * a.OW * sizeof(float) < 0xC0000000u && (size_t)a.N * a.Cin * a.H * a.W * sizeof(float) < 0xC0000000u;
+}
+int conv2d_hs3x3q_train_tiles(const Conv2dArgs& a) {
+  const int vw = a.N > 1 ? a.OW + 1 : a.OW;
+  return ceil_div(a.OH, kQTH) * ceil_div(a.N * vw - (a.N > 1 ? 1 : 0), 32);
+}
+
 bool conv2d_hs3x3q_eligible(const Conv2dArgs& a) {
   const int pin = debug_switches().hs_mode;            // ADX_HS_MODE=0|1|2 pins a tile mode of the 32x32x16 kernel
   return pin < 0 && a.x_cells && a.y_cells && (a.res == nullptr || a.res_cells) && a.x_amax == nullptr && a.stats_part == nullptr &&
@@ -319,11 +406,14 @@ bool conv2d_hs3x3q_eligible(const Conv2dArgs& a) {
 }
 
 int conv2d_hs3x3q_launch(Conv2dArgs a, hipStream_t s) {
-  ADX_REQUIRE(conv2d_hs3x3q_eligible(a), "conv2d_hs3x3q: launch outside the kernel's rules");
+  const bool train = a.stats_part != nullptr;
+  ADX_REQUIRE(train ? conv2d_hs3x3q_train_eligible(a) : conv2d_hs3x3q_eligible(a), "conv2d_hs3x3q: launch outside the kernel's rules");
   static std::atomic<uint64_t> attr{0};
   if (first_on_device(attr)) {
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3q_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQLds));
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3q_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQLdsD));
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3q_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQLds));
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3q_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQLdsD));
   }
   a.vw = a.N > 1 ? a.OW + 1 : a.OW;
   a.inv_vw = 1.f / (float)a.vw;
@@ -335,7 +425,12 @@ int conv2d_hs3x3q_launch(Conv2dArgs a, hipStream_t s) {
   ADX_REQUIRE(grid < (1u << 31), "conv2d_hs: grid too large");
   ADX_REQUIRE((size_t)a.N * a.Cout * a.OH * a.OW * sizeof(float) < 0xC0000000u && (size_t)a.N * a.Cin * a.H * a.W * sizeof(float) < 0xC0000000u,
               "conv2d_hs: a cell-layout tensor exceeds the 32-bit byte offsets");
-  if (debug_switches().hs_dma) conv2d_hs3x3q_kernel<true><<<dim3((unsigned)grid), dim3(kQNT), kQLdsD, s>>>(a);
+  if (train) {
+    ADX_REQUIRE(a.stats_p == a.tiles_y * a.tiles_x, "conv2d_hs3x3q: statistics buffer laid out for %d tiles, launch has %d", a.stats_p,
+                a.tiles_y * a.tiles_x);
+    if (debug_switches().hs_dma) conv2d_hs3x3q_kernel<true, true><<<dim3((unsigned)grid), dim3(kQNT), kQLdsD, s>>>(a);
+    else conv2d_hs3x3q_kernel<false, true><<<dim3((unsigned)grid), dim3(kQNT), kQLds, s>>>(a);
+  } else if (debug_switches().hs_dma) conv2d_hs3x3q_kernel<true><<<dim3((unsigned)grid), dim3(kQNT), kQLdsD, s>>>(a);
   else conv2d_hs3x3q_kernel<false><<<dim3((unsigned)grid), dim3(kQNT), kQLds, s>>>(a);
   ADX_LAUNCH_CHECK();
   return ADX_OK;

@@ -29,6 +29,11 @@ __device__ __forceinline__ f32x16 hs_mfma(f16x8 a, f16x8 b, f32x16 c) {
 __device__ __forceinline__ f32x16 hs_mfma(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 #endif
 
+template <int CTRL>
+__device__ __forceinline__ float hs_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
 // x = hi + lo / 2^11 with hi = fp16(x), lo = fp16((x - hi) * 2^11) (conv2d_hs.hip header)
 __device__ __forceinline__ void split8(const float* v, float xs, u32x4& hi, u32x4& lo) {
   f16x8 h, l;

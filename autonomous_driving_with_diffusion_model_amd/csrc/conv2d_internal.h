@@ -113,6 +113,9 @@ bool conv2d_hs3x3_plain(const ConvSpec& L, int N, int H, int W);
 // true when a training-forward launch of this conv (statistics in the epilogue, fp32 output) can read its input as a cell tensor
 // (fmt = kFmtXCells together with stats_part): the pipelined 3x3 stride-1 kernel with room for its partial sums in stats_floats
 bool conv2d_hs3x3_train_cells(const ConvSpec& L, int N, int H, int W, size_t stats_floats);
+// conv2d_hs16.hip: the 16x16x32 kernel's training-forward variant (cells in, fp32 + statistics out) and its tile count
+bool conv2d_hs3x3q_train_eligible(const Conv2dArgs& a);
+int conv2d_hs3x3q_train_tiles(const Conv2dArgs& a);
 // stats_part (optional, stats_floats floats): where the launch may leave per-workgroup partial sums of its output and of its
 // squares ([Cout][2][P] floats); *stats_p = P when it did (the pipelined 3x3 stride-1 kernel does), 0 when the caller has to
 // compute the statistics from the output itself
