@@ -49,7 +49,7 @@ struct DebugSwitches {
   bool unet_pipe = true;       // ADX_UNET_PIPE=0    the deepest level's layer run as launches, not as one pipeline launch (tconv_pipe.hip)
   bool conv_vrow = true;       // ADX_CONV_VROW=0    fp32-layout 3x3 launches tile every image on its own (no virtual row over the batch)
   bool conv_cells = true;      // ADX_CONV_CELLS=0   fp32 NCHW between all perception convs (no pre-split cell tensors)
-  int train_cells = 3;         // ADX_TRAIN_CELLS=0  the training forward keeps every activation as fp32 NCHW and no mask bits; =1 only what
+  int train_cells = 4;         // ADX_TRAIN_CELLS=0  the training forward keeps every activation as fp32 NCHW and no mask bits; =1 only what
                                //                    changes no bit (the map between a block's convs as cells, the ReLU mask as bits); =2 the
                                //                    blocks' outputs as cells too (the next block's identity is then hi + lo / 2^11); default 3:
                                //                    and the 16x16x32 kernel for the forward launches it tiles (conv2d_hs16.hip: TRAIN)

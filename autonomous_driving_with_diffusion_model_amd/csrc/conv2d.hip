@@ -418,11 +418,15 @@ int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const f
   // cells: plain launches of the pipelined 3x3 kernel (the inference executor), or the INPUT of a training-forward launch
   const bool train_cells = fmt == kFmtXCells && stats_part != nullptr && stats_p != nullptr && bst == nullptr && x_amax == nullptr &&
                            conv2d_hs3x3_train_cells(L, N, H, W, stats_floats);
-  ADX_REQUIRE(fmt == 0 || train_cells || (stats_part == nullptr && conv2d_hs3x3_plain(L, N, H, W)),
+  // ... or the input of a data-gradient launch: a gradient written as cells under a known power-of-two scale
+  const bool dgrad_cells = fmt == (kFmtXCells | kFmtXScaled) && L.dgrad && x_amax != nullptr && x_amax_n < 0 &&
+                           conv2d_hs3x3_dgrad_cells(L, N, H, W);
+  if (dgrad_cells) fmt = kFmtXCells;
+  ADX_REQUIRE(fmt == 0 || train_cells || dgrad_cells || (stats_part == nullptr && conv2d_hs3x3_plain(L, N, H, W)),
               "conv2d: the cell layout belongs to plain launches of the pipelined 3x3 kernel (%d -> %d, k%d s%d)", L.cin, L.cout, L.k, L.stride);
   if (conv2d_hs_eligible(L)) {
     if (stats_part != nullptr && stats_p != nullptr && conv2d_hs_stats_tiles(L, a) > 0 &&
-        (size_t)conv2d_hs_stats_tiles(L, a) * L.cout * 2 <= stats_floats) {
+        (size_t)conv2d_hs_stats_tiles(L, a) * (L.cout * 2 + L.cout / 64) <= stats_floats) {     // (+ the data gradient's max |dz| per slab)
       a.stats_part = stats_part;
       a.stats_p = conv2d_hs_stats_tiles(L, a);
       *stats_p = a.stats_p;

@@ -578,7 +578,9 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
     bsv = which == 0 ? mu : (which == 1 ? rs : (which == 2 ? sc : __builtin_fmaf(-mu, sc, a.bs_beta[c])));
   }
   float xs = 1.f, xs_inv = 1.f;
-  if (a.x_amax != nullptr) {
+  if (a.x_amax != nullptr && a.x_amax_n < 0) {          // a cell-layout gradient: scaled when it was written
+    xs_inv = reinterpret_cast<const float*>(a.x_amax)[1];
+  } else if (a.x_amax != nullptr) {
     uint32_t* red = reinterpret_cast<uint32_t*>(ss + 2 * 64 * CT);
     uint32_t b = 0;
     for (int i = tid; i < a.x_amax_n; i += NT) b = a.x_amax[i] > b ? a.x_amax[i] : b;
@@ -878,6 +880,7 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
       for (int rr = 0; rr < 2; ++rr)
         boff[rr] = inside[rr] ? (VROW ? (uint32_t)nl * (uint32_t)(a.Cout >> 3) * bplane : 0u) + pix[rr] : kOutside;
       const float* bsw = bsl + slab * 64;
+      float dmx = 0.f;          // max |dz| of this lane: the BatchNorm-backward apply pass bounds its output's range with it
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         float rs_[2][16], rw_[2][16], ro_[2][16];
@@ -923,12 +926,25 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
                                          : (mask_out ? ro_[rr][r] > 0.f : __builtin_fmaf(rw_[rr][r], msc, msh) > 0.f));
             p[rr] = keep ? y : 0.f;
             q[rr] = p[rr] * ((rw_[rr][r] - mu) * rsd);
+            dmx = __builtin_fmaxf(dmx, __builtin_fabsf(p[rr]));
           }
           park(half, r, p[0] + p[1], q[0] + q[1]);
         }
       }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) dmx = __builtin_fmaxf(dmx, __shfl_xor(dmx, off, 64));
+      if (lane == 0) red[4096 + wave] = dmx;
     }
     __syncthreads();
+    if (STATS == 2 && tid >= 2 * 64 * CT && tid < 2 * 64 * CT + CT) {      // one thread per 64-channel slab: max over its waves
+      const int sl = tid - 2 * 64 * CT;
+      constexpr int WPS = (NT / 64) / CT;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < WPS; ++w) t = __builtin_fmaxf(t, red[4096 + (MODE == 2 ? sl * WPS + w : w)]);
+      const int p = (n * a.tiles_y + ty) * a.tiles_x + tx;
+      a.stats_part[(size_t)a.Cout * 2 * a.stats_p + (size_t)(ct * CT + sl) * a.stats_p + p] = t;
+    }
     if (tid < 2 * 64 * CT) {
       const int which = tid & 1, chs = tid >> 1, sl = chs >> 6, ch = chs & 63;     // channel ch of slab sl
       const int c5 = ch & 31, kh2 = (c5 >> 2) & 1, r = (c5 & 3) + 4 * (c5 >> 3), idx32 = (ch >> 5) * 16 + r;
@@ -1568,7 +1584,9 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
   const int nchunks = a.cin_pad / kHsCC;
   a.ksplit = 1; a.cper = nchunks; a.part_stride = 0;
   const bool fp32_layout = !(a.x_cells || a.y_cells || a.res_cells);
-  const bool vrow = (fp32_layout || (a.stats_part != nullptr && !a.y_cells && !a.res_cells)) && hs_vrow_ok(a);   // (a training forward may read cells)
+  // (a training forward may read cells, and so may a data gradient whose cells carry their scale)
+  const bool xscaled = a.x_amax != nullptr && a.x_amax_n < 0;
+  const bool vrow = (fp32_layout || ((a.stats_part != nullptr || xscaled) && !a.y_cells && !a.res_cells)) && hs_vrow_ok(a);
   auto set_vrow = [&]() -> size_t {           // column tiles over the images side by side (one shared zero column between neighbours)
     a.vw = a.OW + 1;
     a.inv_vw = 1.f / (float)a.vw;
@@ -1587,8 +1605,9 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
     if (a.x_cells) {
       // training forward on a cell-layout input (resnet_train.hip: the activation between a block's two convs): the staging copies
       // cells instead of converting fp32 values, everything else -- fp32 conv output, statistics -- as below
-      ADX_REQUIRE(a.bs_raw == nullptr && a.x_amax == nullptr && !a.y_cells && !a.res_cells,
-                  "conv2d_hs: a cell-layout input with statistics belongs to a training-forward launch");
+      // ... or a data gradient with the consumer BatchNorm's sums in its epilogue, reading a gradient that was written as cells
+      ADX_REQUIRE((a.x_amax == nullptr || xscaled) && (a.bs_raw == nullptr) == (a.x_amax == nullptr) && !a.y_cells && !a.res_cells,
+                  "conv2d_hs: a cell-layout input with statistics belongs to a training-forward launch or to a data gradient with its scale");
       ADX_REQUIRE((size_t)a.N * a.Cin * a.H * a.W * sizeof(float) < 0xC0000000u, "conv2d_hs: a cell-layout tensor exceeds the 32-bit byte offsets");
       static std::atomic<uint64_t> xattr{0};
       if (first_on_device(xattr)) {
@@ -1596,8 +1615,15 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 1, true, false, false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 2, true, false, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bs));
+        ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 2, true, false, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bs));
       }
-      if (vrow) conv2d_hs3x3_kernel<MODE, 1, true, false, true><<<dim3((unsigned)sgrid), dim3(NT), lds, s>>>(a);
+      if (a.bs_raw != nullptr) {
+        if (vrow) conv2d_hs3x3_kernel<MODE, 2, true, false, true><<<dim3((unsigned)sgrid), dim3(NT), lds_bs, s>>>(a);
+        else conv2d_hs3x3_kernel<MODE, 2, true, false, false><<<dim3((unsigned)sgrid), dim3(NT), lds_bs, s>>>(a);
+      } else if (vrow) conv2d_hs3x3_kernel<MODE, 1, true, false, true><<<dim3((unsigned)sgrid), dim3(NT), lds, s>>>(a);
       else conv2d_hs3x3_kernel<MODE, 1, true, false, false><<<dim3((unsigned)sgrid), dim3(NT), lds, s>>>(a);
     } else if (vrow) {
       if (a.bs_raw != nullptr) conv2d_hs3x3_kernel<MODE, 2, false, false, true><<<dim3((unsigned)sgrid), dim3(NT), lds_bs, s>>>(a);
@@ -1627,6 +1653,25 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
     }
   }
   a.part = nullptr;
+  if (a.x_cells && xscaled && !a.y_cells && !a.res_cells) {
+    // a data gradient (no statistics wanted from it) on a gradient that was written as cells: fp32 output [+ fp32 residual]
+    static std::atomic<uint64_t> dattr{0};
+    if (first_on_device(dattr)) {
+      ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 0, true, false, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 0, true, false, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    ADX_REQUIRE((size_t)a.N * a.Cin * a.H * a.W * sizeof(float) < 0xC0000000u, "conv2d_hs: a cell-layout tensor exceeds the 32-bit byte offsets");
+    if (vrow) {
+      const size_t vgrid = set_vrow();
+      conv2d_hs3x3_kernel<MODE, 0, true, false, true><<<dim3((unsigned)vgrid), dim3(NT), lds, s>>>(a);
+    } else {
+      conv2d_hs3x3_kernel<MODE, 0, true, false, false><<<dim3((unsigned)grid), dim3(NT), lds, s>>>(a);
+    }
+    ADX_LAUNCH_CHECK();
+    return ADX_OK;
+  }
   if (a.x_cells || a.y_cells || a.res_cells) {
     // the executor keeps a layer's 3x3 convs in the cell layout from the first one's output to the last one's (the stride-2
     // kernel and the average pool read cells too), so a cell operand always comes with a cell output
@@ -1691,6 +1736,15 @@ bool conv2d_hs3x3_plain(const ConvSpec& L, int N, int H, int W) {
   if ((size_t)N * L.cin * H * W * sizeof(float) >= 0xC0000000u || (size_t)N * L.cout * a.OH * a.OW * sizeof(float) >= 0xC0000000u) return false;
   const long grid0 = (long)a.N * ceil_div(a.OH, 8) * ceil_div(a.OW, kTileW) * (a.Cout / kHsCout);
   return mode != 0 || grid0 > 64 || L.cin_pad / kHsCC < 8;       // hs3x3_launch<0> splits the reduction of smaller launches
+}
+
+bool conv2d_hs3x3_dgrad_cells(const ConvSpec& L, int N, int H, int W) {
+  if (debug_switches().train_cells < 4 || !conv2d_hs_eligible(L) || !L.dgrad) return false;
+  Conv2dArgs a{};
+  a.N = N; a.Cin = L.cin; a.Cout = L.cout; a.H = H; a.W = W;
+  a.OH = conv_out_dim(H, L.k, L.stride, L.pad); a.OW = conv_out_dim(W, L.k, L.stride, L.pad);
+  return hs3x3_mode(L, a) >= 0 && L.cin % 16 == 0 && L.cin == L.cin_pad && L.cout % 64 == 0 &&
+         (size_t)N * L.cin * H * W * sizeof(float) < 0xC0000000u;
 }
 
 bool conv2d_hs3x3_train_cells(const ConvSpec& L, int N, int H, int W, size_t stats_floats) {

@@ -29,8 +29,9 @@ struct Conv2dArgs {
   const float* scale_ds;
   const float* shift_ds;
   float* y_ds;
-  const uint32_t* x_amax;  // optional: x_amax_n partial maxima of |x| as bit patterns (conv2d_hs rescales x by a power of two)
-  int x_amax_n;
+  const uint32_t* x_amax;  // optional: x_amax_n partial maxima of |x| as bit patterns (conv2d_hs rescales x by a power of two);
+  int x_amax_n;            // x_amax_n < 0: x_amax points at two floats {xs, 1 / xs} instead -- the power of two a cell-layout x was
+                           // ALREADY multiplied by when it was written (resnet_train.hip: bn_bwd_apply_groups_kernel)
   // stem only: the camera frames as uint8 [N][H][W][3]; ToTensor + Normalize ((v / 255 - mean) / std, the arithmetic of
   // image_normalize_kernel) happen in the staging load and the fp32 NCHW tensor is never written (x is unused then)
   const uint8_t* x_u8;
@@ -77,6 +78,7 @@ struct Conv2dArgs {
 
 // activation formats of one launch of the inference executor (bits)
 constexpr int kFmtXCells = 1, kFmtYCells = 2, kFmtResCells = 4;
+constexpr int kFmtXScaled = 8;      // with kFmtXCells: a data-gradient launch whose cell-layout x carries its scale (x_amax_n < 0)
 
 
 }  // namespace adx
@@ -113,6 +115,8 @@ bool conv2d_hs3x3_plain(const ConvSpec& L, int N, int H, int W);
 // true when a training-forward launch of this conv (statistics in the epilogue, fp32 output) can read its input as a cell tensor
 // (fmt = kFmtXCells together with stats_part): the pipelined 3x3 stride-1 kernel with room for its partial sums in stats_floats
 bool conv2d_hs3x3_train_cells(const ConvSpec& L, int N, int H, int W, size_t stats_floats);
+// true when a data-gradient launch of this (dgrad) spec can read a cell-layout, pre-scaled gradient (fmt = kFmtXCells | kFmtXScaled)
+bool conv2d_hs3x3_dgrad_cells(const ConvSpec& L, int N, int H, int W);
 // conv2d_hs16.hip: the 16x16x32 kernel's training-forward variant (cells in, fp32 + statistics out) and its tile count
 bool conv2d_hs3x3q_train_eligible(const Conv2dArgs& a);
 int conv2d_hs3x3q_train_tiles(const Conv2dArgs& a);
@@ -176,7 +180,7 @@ bool conv2d_wgrad_hs_eligible(int Cin, int Cout, int k, int stride, int pad);
 // x_cells: x is a cell tensor (the layout of the inference executor's activations; resnet_train.hip keeps a block's first
 // activation that way)
 int conv2d_wgrad_hs(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, int stride,
-                    const uint32_t* dy_amax, int dy_amax_n, hipStream_t s, bool x_cells = false);
+                    const uint32_t* dy_amax, int dy_amax_n, hipStream_t s, bool x_cells = false, bool dy_cells = false);
 // ADX_WGRAD_DETERMINISTIC=1: scratch for the per-split copies of dw that conv2d_wgrad_hs reduces in index order (lent by the calling
 // thread's executor until cleared; conv2d_wgrad_partials_floats() = what to lend, 0 when the switch is off)
 void conv2d_wgrad_set_partials(float* p, size_t floats);

@@ -33,10 +33,10 @@ typedef __attribute__((address_space(3))) h4 lds_h4;
 
 struct WgradHsArgs {
   const float* x;        // [N][Cin][H][W], or (XC) the same bytes as a cell tensor [N][Cin/8][hi, lo][H][W][8 halves]
-  const float* dy;       // [N][Cout][OH][OW]
+  const float* dy;       // [N][Cout][OH][OW], or (XA) a cell tensor already multiplied by the power of two dy_amax points at
   float* dw;             // [Cout][Cin][3][3], zeroed by the caller (conv2d_wgrad)
   const uint32_t* dy_amax;
-  int dy_amax_n;
+  int dy_amax_n;         // < 0: dy_amax points at two floats {xs, 1 / xs} (XA: the scale dy's cells were written with)
   int N, Cin, Cout, H, W, OH, OW;
   int segs, units, units_per_wg, n_ci_tiles, n_co_tiles;
   float* part;           // deterministic mode: [splits][Cout][Cin][9] partial sums (split s of a tile writes its own copy), else null
@@ -60,7 +60,9 @@ __device__ __forceinline__ f16x8 tr_pair(const unsigned char* p) {
 // XC: x arrives already split -- the cell tensor the training forward keeps between a block's convs (resnet_train.hip:
 // bn_apply_cells_kernel; the same hi / lo halves this kernel's staging would compute from the fp32 map): two 16-byte loads per
 // staged cell instead of eight dwords and the conversion
-template <int NPX, int S, bool XC = false>
+// XA: the same for dy -- a gradient the BatchNorm-backward apply pass wrote as cells under a scale it chose from a bound
+// (resnet_train.hip: bn_bwd_apply_groups_kernel)
+template <int NPX, int S, bool XC = false, bool XA = false>
 __global__ void __launch_bounds__(kWThreads) conv2d_wgrad_hs_kernel(const WgradHsArgs a) {
   constexpr int NPXB = S * NPX + 2;               // x row segment with its halo columns
   constexpr int NSLOT = S == 1 ? 4 : 6;           // x rows kept: 3 in use + S arriving
@@ -88,7 +90,9 @@ __global__ void __launch_bounds__(kWThreads) conv2d_wgrad_hs_kernel(const WgradH
 
   // dy's dynamic range: scale so that max|dy| lands in [2^14, 2^15), undone exactly in the epilogue
   float xs = 1.f, xs_inv = 1.f;
-  if (a.dy_amax != nullptr) {
+  if (a.dy_amax != nullptr && a.dy_amax_n < 0) {
+    xs_inv = reinterpret_cast<const float*>(a.dy_amax)[1];
+  } else if (a.dy_amax != nullptr) {
     uint32_t b = 0;
     for (int i = tid; i < a.dy_amax_n; i += kWThreads) b = a.dy_amax[i] > b ? a.dy_amax[i] : b;
 #pragma unroll
@@ -168,10 +172,18 @@ __global__ void __launch_bounds__(kWThreads) conv2d_wgrad_hs_kernel(const WgradH
         if (ka) {
           const int row = t + 1, col = ox0 + colv[k];
           const bool ok = row >= 0 && row < a.OH && col < a.OW;
-          const uint32_t vo = ok ? chan[k] + (uint32_t)(row * a.OW + col) * 4u : kOutside;
+          if constexpr (XA) {
+            const uint32_t vo = ok ? chan[k] + (uint32_t)(row * a.OW + col) * 16u : kOutside;
+            const u32x4 h4 = __builtin_amdgcn_raw_buffer_load_b128(rdy, vo, 0, 0);
+            const u32x4 l4 = __builtin_amdgcn_raw_buffer_load_b128(rdy, vo, 4 * dplane_bytes, 0);
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            pv[k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdy, vo, j * dplane_bytes, 0));
+            for (int j = 0; j < 4; ++j) { pv[k][j] = u2f(h4[j]); pv[k][4 + j] = u2f(l4[j]); }
+          } else {
+            const uint32_t vo = ok ? chan[k] + (uint32_t)(row * a.OW + col) * 4u : kOutside;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              pv[k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdy, vo, j * dplane_bytes, 0));
+          }
         } else {
           const int row = xrow0 + rsel[k], col = S * ox0 + colv[k];
           const bool ok = sto[k] >= 0 && row >= 0 && row < a.H && col >= 0 && col < a.W;
@@ -211,12 +223,13 @@ __global__ void __launch_bounds__(kWThreads) conv2d_wgrad_hs_kernel(const WgradH
         if (sto[k] < 0) continue;
         const bool ka = isA[k];
         unsigned char* d = ka ? lA + ((t + 1) & 1) * A_BUF + sto[k] : lB + ((xrow0 + rsel[k]) % NSLOT) * B_SLOT + sto[k];
-        if (XC && __builtin_amdgcn_readfirstlane((int)ka) == 0) {       // an x cell: the halves as they were loaded
+        const bool kau = __builtin_amdgcn_readfirstlane((int)ka) != 0;
+        if ((XC && !kau) || (XA && kau)) {       // a cell: the halves as they were loaded
           u32x4 h4, l4;
 #pragma unroll
           for (int j = 0; j < 4; ++j) { h4[j] = f2u(pv[k][j]); l4[j] = f2u(pv[k][4 + j]); }
           *reinterpret_cast<u32x4*>(d) = h4;
-          *reinterpret_cast<u32x4*>(d + B_PLANE) = l4;
+          *reinterpret_cast<u32x4*>(d + (kau ? A_PLANE : B_PLANE)) = l4;
           continue;
         }
         f16x8 h, l;
@@ -287,7 +300,7 @@ bool conv2d_wgrad_hs_eligible(int Cin, int Cout, int k, int stride, int pad) {
   return !exact && k == 3 && (stride == 1 || stride == 2) && pad == 1 && Cin % 64 == 0 && Cout % 64 == 0;
 }
 
-template <int NPX, int S, bool XC>
+template <int NPX, int S, bool XC, bool XA = false>
 static int wgrad_hs_launch(WgradHsArgs a, hipStream_t s) {
   constexpr int NSLOT = S == 1 ? 4 : 6;
   constexpr size_t lds = (size_t)2 * (2 * 2 * NPX * 64) + (size_t)NSLOT * (2 * 2 * (S * NPX + 2) * 64) + 64;
@@ -295,7 +308,7 @@ static int wgrad_hs_launch(WgradHsArgs a, hipStream_t s) {
   static_assert(need <= 160 * 1024, "LDS budget");
   static std::atomic<uint64_t> attr{0};
   if (first_on_device(attr)) {
-    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad_hs_kernel<NPX, S, XC>),
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad_hs_kernel<NPX, S, XC, XA>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
   }
   a.segs = ceil_div(a.OW, NPX);
@@ -316,7 +329,7 @@ static int wgrad_hs_launch(WgradHsArgs a, hipStream_t s) {
                 (size_t)splits * a.part_stride, t_wgrad_parts_floats);
     a.part = t_wgrad_parts;
   }
-  conv2d_wgrad_hs_kernel<NPX, S, XC><<<dim3((unsigned)(tiles * splits)), dim3(kWThreads), need, s>>>(a);
+  conv2d_wgrad_hs_kernel<NPX, S, XC, XA><<<dim3((unsigned)(tiles * splits)), dim3(kWThreads), need, s>>>(a);
   ADX_LAUNCH_CHECK();
   if (a.part != nullptr) {
     const size_t total4 = a.part_stride / 4;
@@ -327,7 +340,7 @@ static int wgrad_hs_launch(WgradHsArgs a, hipStream_t s) {
 }
 
 int conv2d_wgrad_hs(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, int stride,
-                    const uint32_t* dy_amax, int dy_amax_n, hipStream_t s, bool x_cells) {
+                    const uint32_t* dy_amax, int dy_amax_n, hipStream_t s, bool x_cells, bool dy_cells) {
   ADX_REQUIRE(x && dy && dw, "conv2d_wgrad_hs: null tensor");
   ADX_REQUIRE((size_t)64 * H * W * sizeof(float) < 0xC0000000u, "conv2d_wgrad_hs: image too large for 32-bit offsets");
   WgradHsArgs a{};
@@ -335,6 +348,12 @@ int conv2d_wgrad_hs(const float* x, const float* dy, float* dw, int N, int Cin, 
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
   a.OH = conv_out_dim(H, 3, stride, 1); a.OW = conv_out_dim(W, 3, stride, 1);
   a.n_ci_tiles = Cin / 64; a.n_co_tiles = Cout / 64;
+  ADX_REQUIRE(!dy_cells || (stride == 1 && dy_amax != nullptr && dy_amax_n < 0), "conv2d_wgrad_hs: a cell-layout dy comes with its scale (stride 1)");
+  if (dy_cells) {
+    const bool narrow = ceil_div(a.OW, 32) * 32 - a.OW < ceil_div(a.OW, 64) * 64 - a.OW;
+    if (x_cells) return narrow ? wgrad_hs_launch<32, 1, true, true>(a, s) : wgrad_hs_launch<64, 1, true, true>(a, s);
+    return narrow ? wgrad_hs_launch<32, 1, false, true>(a, s) : wgrad_hs_launch<64, 1, false, true>(a, s);
+  }
   if (stride == 2) return x_cells ? wgrad_hs_launch<32, 2, true>(a, s) : wgrad_hs_launch<32, 2, false>(a, s);
   // rows of <= 32 (or 33..48 -> two 32-pixel segments waste less than one 64) pixels use the narrow variant
   const int waste64 = ceil_div(a.OW, 64) * 64 - a.OW, waste32 = ceil_div(a.OW, 32) * 32 - a.OW;

@@ -41,7 +41,9 @@ __global__ void __launch_bounds__(256) channel_sums_kernel(const float* __restri
                                                             const float* __restrict__ raw, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, double* __restrict__ sums,
                                                             int C, int HW, int relu_mask, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, const uint8_t* __restrict__ bits = nullptr) {
+                                                            const float* __restrict__ beta, const uint8_t* __restrict__ bits = nullptr,
+                                                            uint32_t* __restrict__ dmax = nullptr) {
+  // dmax (MODE 1): atomic maximum of |dz| over the tensor, as bits (bn_bwd_consts_kernel bounds the range of draw with it)
   // bits (relu_mask == 1): the forward's mask, one bit per element -- byte [n][c / 8][pixel], bit c % 8 (bn_apply_groups_kernel) --
   // read instead of `out`
   const int plane = blockIdx.x;            // n * C + c
@@ -50,6 +52,7 @@ __global__ void __launch_bounds__(256) channel_sums_kernel(const float* __restri
   const uint8_t* bp = bits != nullptr ? bits + ((size_t)(plane / C) * (C >> 3) + (c >> 3)) * HW : nullptr;
   const int bit = c & 7;
   double s0 = 0.0, s1 = 0.0;
+  float vmax = 0.f;
   const float mu = MODE == 1 ? mean[c] : 0.f, rs = MODE == 1 ? rstd[c] : 0.f;
   float sc = 0.f, sh = 0.f;
   if (MODE == 1 && relu_mask == 2) bn_affine(gamma[c], beta[c], mu, rs, sc, sh);
@@ -60,6 +63,7 @@ __global__ void __launch_bounds__(256) channel_sums_kernel(const float* __restri
     } else {
       if (relu_mask == 1 && !(o > 0.f)) v = 0.f;
       if (relu_mask == 2 && !(bn_eval(rw, sc, sh) > 0.f)) v = 0.f;
+      vmax = __builtin_fmaxf(vmax, __builtin_fabsf(v));
       s0 += v;
       s1 += (double)v * (double)((rw - mu) * rs);
     }
@@ -98,6 +102,11 @@ __global__ void __launch_bounds__(256) channel_sums_kernel(const float* __restri
     atomicAdd(sums + 2 * c, (red[0] + red[2]) + (red[4] + red[6]));
     atomicAdd(sums + 2 * c + 1, (red[1] + red[3]) + (red[5] + red[7]));
   }
+  if (MODE == 1 && dmax != nullptr) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = __builtin_fmaxf(vmax, __shfl_xor(vmax, off, 64));
+    if ((tid & 63) == 0 && vmax > 0.f) atomicMax(dmax, f2u(vmax));       // (non-negative floats order like their bit patterns)
+  }
 }
 
 // The pipelined 3x3 conv leaves per-workgroup partial sums of its output and of its squares ([C][2][P] floats, conv2d_hs.hip:
@@ -131,7 +140,21 @@ __global__ void __launch_bounds__(256) stats_reduce_finalize_kernel(const float*
 
 // the same reduction without the forward's finalisation: the partial sums are those of a BatchNorm BACKWARD (sum dz, sum dz
 // xhat), left by the data-gradient conv that produced dz's tensor (conv2d_hs.hip: STATS == 2)
-__global__ void __launch_bounds__(256) stats_reduce_kernel(const float* __restrict__ part, double* __restrict__ sums, int P) {
+// Workgroup C (one past the channels): the maximum of the launch's per-(slab, tile) max |dz| partials, behind the sums in `part`
+__global__ void __launch_bounds__(256) stats_reduce_kernel(const float* __restrict__ part, double* __restrict__ sums, int P,
+                                                            uint32_t* __restrict__ dmax = nullptr, int C = 0) {
+  if ((int)blockIdx.x == C && dmax != nullptr) {
+    const float* src = part + (size_t)2 * C * P;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < (C / 64) * P; i += 256) m = __builtin_fmaxf(m, src[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off, 64));
+    __shared__ float mred[4];
+    if ((threadIdx.x & 63) == 0) mred[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) *dmax = f2u(__builtin_fmaxf(__builtin_fmaxf(mred[0], mred[1]), __builtin_fmaxf(mred[2], mred[3])));
+    return;
+  }
   const int c = blockIdx.x, moment = threadIdx.x >> 7, t = threadIdx.x & 127;
   const float* src = part + (size_t)(2 * c + moment) * P;
   double s = 0.0;
@@ -415,6 +438,92 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_planes_kernel(const float* _
   if (threadIdx.x == 0) {
     const uint32_t m01 = red[0] > red[1] ? red[0] : red[1], m23 = red[2] > red[3] ? red[2] : red[3];
     amax[blockIdx.x] = m01 > m23 ? m01 : m23;
+  }
+}
+
+// ---- the BatchNorm-backward apply pass by 8-channel groups, with draw written as a CELL tensor ----
+// A gradient's range is only known once it has been written (the `amax` partials of the plane pass above), and a cell tensor needs
+// its power-of-two scale WHEN it is written.  What is known beforehand is a bound: with D = max |dz| (from the pass that computed
+// the sums: channel_sums_kernel<1> / the data-gradient epilogue) and |xhat| <= sqrt(count - 1) (Samuelson),
+//     |draw_c| <= |gamma_c rstd_c| (D + |m1_c| + sqrt(count - 1) |m2_c|).
+// The scale moves the largest such bound into [2^14, 2^15): whatever the bound overshoots costs RANGE below (values smaller than
+// 2^-29 of the bound lose bits), never precision of the values that matter -- fp16 hi + lo keeps 22 bits across 29 octaves.
+// bn_bwd_consts_kernel: one workgroup per record: per-channel constants [C][8] = {gamma rstd, m1, m2, mean, rstd, mask scale, mask
+// shift, 0}, the affine gradients (the finished sums), and {xs, 1 / xs}.
+__global__ void __launch_bounds__(256) bn_bwd_consts_kernel(const double* __restrict__ sums, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const uint32_t* __restrict__ dmax,
+                                                             double count, int C, float* __restrict__ consts,
+                                                             float* __restrict__ xscale, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta) {
+  const float D = u2f(*dmax), X = (float)sqrt(count > 1.0 ? count - 1.0 : 1.0);
+  float bound = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float mu = mean[c], rs = rstd[c], ga = gamma[c];
+    float sc, sh;
+    bn_affine(ga, beta[c], mu, rs, sc, sh);
+    const float m1 = (float)(sums[2 * c] / count), m2 = (float)(sums[2 * c + 1] / count);
+    float* k = consts + (size_t)c * 8;
+    k[0] = ga * rs; k[1] = m1; k[2] = m2; k[3] = mu; k[4] = rs; k[5] = sc; k[6] = sh; k[7] = 0.f;
+    if (dgamma != nullptr) { dbeta[c] = (float)sums[2 * c]; dgamma[c] = (float)sums[2 * c + 1]; }
+    bound = __builtin_fmaxf(bound, __builtin_fabsf(ga * rs) * (D + __builtin_fabsf(m1) + X * __builtin_fabsf(m2)));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) bound = __builtin_fmaxf(bound, __shfl_xor(bound, off, 64));
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = bound;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t b = f2u(__builtin_fmaxf(__builtin_fmaxf(red[0], red[1]), __builtin_fmaxf(red[2], red[3])));
+    const int e = (int)((b >> 23) & 0xFF);
+    float xs = 1.f, xs_inv = 1.f;
+    if (e != 0 && e != 255) {
+      int sh = 127 + 14 - e;
+      sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+      xs = u2f((uint32_t)(127 + sh) << 23);
+      xs_inv = u2f((uint32_t)(127 - sh) << 23);
+    }
+    xscale[0] = xs;
+    xscale[1] = xs_inv;
+  }
+}
+
+// MASK: 0 none, 1 the forward's bits, 2 re-derived from the conv output.  KEEP: also leave dz (fp32 NCHW: the identity path's
+// gradient and the residual of the next data gradient's epilogue).
+template <int MASK, bool KEEP>
+__global__ void __launch_bounds__(256) bn_bwd_apply_groups_kernel(const float* __restrict__ dout, const float* __restrict__ raw,
+                                                                   const uint8_t* __restrict__ bits, const float* __restrict__ consts,
+                                                                   const float* __restrict__ xscale, u32x4* __restrict__ draw,
+                                                                   float* __restrict__ dz_out, int C, int HW, int groups) {
+  const float xs = xscale[0];
+  const int per = (HW + 255) / 256;
+  for (int w = blockIdx.x; w < groups * per; w += gridDim.x) {
+    const int g = w / per, pix = (w - g * per) * 256 + threadIdx.x;
+    if (pix >= HW) continue;
+    const float* k = consts + (size_t)(g % (C >> 3)) * 64;        // this group's eight channels
+    const size_t p0 = (size_t)g * 8 * HW + pix;
+    float dz[8], rw[8], v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dz[j] = dout[p0 + (size_t)j * HW]; rw[j] = raw[p0 + (size_t)j * HW]; }
+    uint32_t m = 0xFFu;
+    if constexpr (MASK == 1) m = bits[(size_t)g * HW + pix];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float* kj = k + 8 * j;
+      if (MASK == 1 && !((m >> j) & 1u)) dz[j] = 0.f;
+      if (MASK == 2 && !(bn_eval(rw[j], kj[5], kj[6]) > 0.f)) dz[j] = 0.f;
+      const float xh = (rw[j] - kj[3]) * kj[4];
+      v[j] = kj[0] * (dz[j] - kj[1] - xh * kj[2]);
+    }
+    if constexpr (KEEP) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dz_out[p0 + (size_t)j * HW] = dz[j];
+    }
+    u32x4 hi, lo;
+    split8(v, xs, hi, lo);
+    u32x4* o = draw + (size_t)g * 2 * HW + pix;
+    o[0] = hi;
+    o[HW] = lo;
   }
 }
 
@@ -914,8 +1023,10 @@ __global__ void centre_tap_add_kernel(float* __restrict__ dw, const float* __res
 // kernel even though eight of its nine taps are thrown away
 int conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, int k, int stride,
                  int pad, hipStream_t s, const uint32_t* dy_amax = nullptr, int dy_amax_n = 0, bool zero = true,
-                 float* scratch9 = nullptr, bool x_cells = false) {
+                 float* scratch9 = nullptr, bool x_cells = false, bool dy_cells = false) {
   ADX_REQUIRE(x && dy && dw, "conv2d_wgrad: null tensor");
+  ADX_REQUIRE(!dy_cells || (conv2d_wgrad_hs_eligible(Cin, Cout, k, stride, pad) && k == 3 && stride == 1),
+              "conv2d_wgrad: a cell-layout gradient belongs to the split-fp16 3x3 stride-1 weight gradient");
   ADX_REQUIRE(!x_cells || (conv2d_wgrad_hs_eligible(Cin, Cout, k, stride, pad) && k == 3) ||
                   (scratch9 != nullptr && k == 1 && stride == 2 && pad == 0 && conv2d_wgrad_hs_eligible(Cin, Cout, 3, 2, 1)),
               "conv2d_wgrad: a cell-layout input belongs to the split-fp16 3x3 weight gradient");
@@ -930,7 +1041,7 @@ int conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int
     return ADX_OK;
   }
   if (conv2d_wgrad_hs_eligible(Cin, Cout, k, stride, pad))
-    return conv2d_wgrad_hs(x, dy, dw, N, Cin, H, W, Cout, stride, dy_amax, dy_amax_n, s, x_cells);
+    return conv2d_wgrad_hs(x, dy, dw, N, Cin, H, W, Cout, stride, dy_amax, dy_amax_n, s, x_cells, dy_cells);
   // the stem: split-fp16 kernel when the gradient's range is known (it is far below fp16's), the exact-fp32 kernel otherwise
   if (dy_amax != nullptr && conv2d_wgrad_stem_hs_eligible(Cin, Cout, k, stride, pad))
     return conv2d_wgrad_stem_hs(x, dy, dw, N, H, W, dy_amax, dy_amax_n, s);
@@ -1112,7 +1223,7 @@ size_t adx_resnet_train_workspace_bytes(const adx_resnet* r, int32_t batch, int3
     conv(c2, OH, OW);
     H = OH; W = OW;
   }
-  f += al64(r->convs.size() * 2 * 512 * 2) + al64(kAmaxPartials) + al64((size_t)512 * 256 * 9) + al64(conv2d_wgrad_partials_floats()) + 5 * al64(big) + 2 * al64(wmax) + wall;   // backward: sums, amax, 3x3 image of a 1x1 gradient, 5 gradient buffers, dgrad weights (one scratch pair + a slot per stride-1 3x3 conv)
+  f += al64(r->convs.size()) + al64(512 * 8) + al64(2) + al64(r->convs.size() * 2 * 512 * 2) + al64(kAmaxPartials) + al64((size_t)512 * 256 * 9) + al64(conv2d_wgrad_partials_floats()) + 5 * al64(big) + 2 * al64(wmax) + wall;   // backward: sums, amax, 3x3 image of a 1x1 gradient, 5 gradient buffers, dgrad weights (one scratch pair + a slot per stride-1 3x3 conv)
   return (f + 1024) * sizeof(float);
 }
 
@@ -1354,6 +1465,10 @@ int adx_resnet_backward_events(adx_resnet* r, const float* const* T, float* cons
     if (rf != ADX_OK) return rf;
   }
   uint32_t* amax = reinterpret_cast<uint32_t*>(ws.take(kAmaxPartials));   // per-workgroup max |draw| of the conv being differentiated
+  uint32_t* dmax_all = reinterpret_cast<uint32_t*>(ws.take(n_convs));      // per conv: max |dz| of its incoming gradient (bits)
+  float* bconsts = ws.take((size_t)512 * 8);                              // per-channel constants of the record being differentiated
+  float* xscale = ws.take(2);                                             // {xs, 1 / xs} of its cell-layout draw
+  if (ws.ok) ADX_CHECK_HIP(hipMemsetAsync(dmax_all, 0, sizeof(uint32_t) * n_convs, s));
   float* wgrad9 = ws.take((size_t)512 * 256 * 9);     // 3x3 image of the largest 1x1 downsample gradient (conv2d_wgrad)
   struct PartsScope {
     ~PartsScope() { conv2d_wgrad_set_partials(nullptr, 0); }
@@ -1423,12 +1538,36 @@ int adx_resnet_backward_events(adx_resnet* r, const float* const* T, float* cons
     double* sums = sums_all + (size_t)(&L - r->convs.data()) * 2 * 512;
     // ReLU mask: straight after BN it is re-derived from the conv output (one tensor read less in both passes)
     const int mask = !rec.relu ? 0 : (rec.identity != nullptr ? 1 : 2);
+    uint32_t* const dmax = dmax_all + (&L - r->convs.data());
     if (sums_ready != &rec)
       channel_sums_kernel<1><<<dim3(batch * L.cout), dim3(256), 0, s>>>(dout, rec.out, rec.raw, rec.mean, rec.rstd, sums,
-                                                                        L.cout, HW, mask, T[L.t_g], T[L.t_b], rec.bits);
+                                                                        L.cout, HW, mask, T[L.t_g], T[L.t_b], rec.bits, dmax);
     sums_ready = nullptr;
+    // draw as a cell tensor (ADX_TRAIN_CELLS >= 4): the stride-1 3x3 convs whose weight and data gradient both run on the
+    // split-fp16 kernels; the scale comes from a bound (bn_bwd_consts_kernel), `amax` is not produced
+    ConvSpec gq{};
+    gq.cin = L.cout; gq.cout = L.cin; gq.k = L.k; gq.stride = 1; gq.pad = L.k - 1 - L.pad; gq.cc = 16; gq.cin_pad = L.cout; gq.dgrad = 1;
+    const bool draw_cells = L.k == 3 && L.stride == 1 && L.pad == 1 && L.cout % 8 == 0 && need_dx && dgrad_img[&L - r->convs.data()] != nullptr &&
+                            conv2d_wgrad_hs_eligible(L.cin, L.cout, 3, 1, 1) && conv2d_hs3x3_dgrad_cells(gq, batch, rec.OH, rec.OW) &&
+                            (mask != 1 || rec.bits != nullptr) && (reinterpret_cast<uintptr_t>(draw) & 15) == 0;
     int n_amax;
-    if (bn_planes_ok(HW, dout, rec.raw, draw) && bn_planes_ok(HW, rec.out, dz_keep, nullptr)) {
+    if (draw_cells) {
+      n_amax = -1;
+      bn_bwd_consts_kernel<<<dim3(1), dim3(256), 0, s>>>(sums, rec.mean, rec.rstd, T[L.t_g], T[L.t_b], dmax, count, L.cout, bconsts, xscale,
+                                                         G[L.t_g], G[L.t_b]);
+      const int groups = batch * (L.cout / 8), per = ceil_div(HW, 256);
+      const dim3 grid((unsigned)std::min<long>((long)groups * per, 1L << 20));
+#define ADX_BWD_GROUPS(MASK, KEEP) \
+  bn_bwd_apply_groups_kernel<MASK, KEEP><<<grid, dim3(256), 0, s>>>(dout, rec.raw, rec.bits, bconsts, xscale, reinterpret_cast<u32x4*>(draw), \
+                                                                    dz_keep, L.cout, HW, groups)
+      if (mask == 1 && dz_keep != nullptr) ADX_BWD_GROUPS(1, true);
+      else if (mask == 1) ADX_BWD_GROUPS(1, false);
+      else if (mask == 2 && dz_keep != nullptr) ADX_BWD_GROUPS(2, true);
+      else if (mask == 2) ADX_BWD_GROUPS(2, false);
+      else if (dz_keep != nullptr) ADX_BWD_GROUPS(0, true);
+      else ADX_BWD_GROUPS(0, false);
+#undef ADX_BWD_GROUPS
+    } else if (bn_planes_ok(HW, dout, rec.raw, draw) && bn_planes_ok(HW, rec.out, dz_keep, nullptr)) {
       const int planes = batch * L.cout;
       n_amax = (int)std::min<size_t>(kAmaxPartials, (size_t)ceil_div(planes, 4));
       bn_bwd_apply_planes_kernel<<<dim3(n_amax), dim3(256), 0, s>>>(dout, rec.out, rec.raw, rec.mean, rec.rstd, T[L.t_g], sums,
@@ -1441,8 +1580,9 @@ int adx_resnet_backward_events(adx_resnet* r, const float* const* T, float* cons
           G[L.t_g], G[L.t_b], rec.bits);
     }
     ADX_LAUNCH_CHECK();
-    int rc2 = conv2d_wgrad(rec.x, draw, G[L.t_w], batch, L.cin, rec.H, rec.W, L.cout, L.k, L.stride, L.pad, s, amax, n_amax, false, wgrad9,
-                           rec.x_cells);
+    const uint32_t* const range = draw_cells ? reinterpret_cast<const uint32_t*>(xscale) : amax;      // (n_amax < 0: the scale itself)
+    int rc2 = conv2d_wgrad(rec.x, draw, G[L.t_w], batch, L.cin, rec.H, rec.W, L.cout, L.k, L.stride, L.pad, s, range, n_amax, false, wgrad9,
+                           rec.x_cells, draw_cells);
     if (rc2 != ADX_OK || !need_dx) return rc2;
     // data gradient
     ConvSpec g{};
@@ -1454,16 +1594,17 @@ int adx_resnet_backward_events(adx_resnet* r, const float* const* T, float* cons
         ADX_REQUIRE(Ln.cout == L.cin && next->OH == rec.H && next->OW == rec.W, "adx_resnet_backward: consumer record does not match dx");
         const BnBwdStats bst{next->raw, next->out, next->mean, next->rstd, T[Ln.t_g], T[Ln.t_b], next_mask, next->bits};
         int stats_p = 0;
-        rc2 = conv2d_launch_raw(g, draw, pre, nullptr, nullptr, dx_has ? dx : nullptr, dx, batch, rec.OH, rec.OW, 0, s, amax, n_amax,
-                                tape->stats_part, kStatsPartFloats, &stats_p, 0, &bst);
+        rc2 = conv2d_launch_raw(g, draw, pre, nullptr, nullptr, dx_has ? dx : nullptr, dx, batch, rec.OH, rec.OW, 0, s, range, n_amax,
+                                tape->stats_part, kStatsPartFloats, &stats_p, draw_cells ? (kFmtXCells | kFmtXScaled) : 0, &bst);
         if (rc2 == ADX_OK && stats_p > 0) {
-          stats_reduce_kernel<<<dim3(Ln.cout), dim3(256), 0, s>>>(tape->stats_part, sums_all + (size_t)(&Ln - r->convs.data()) * 2 * 512,
-                                                                 stats_p);
+          stats_reduce_kernel<<<dim3(Ln.cout + 1), dim3(256), 0, s>>>(tape->stats_part, sums_all + (size_t)(&Ln - r->convs.data()) * 2 * 512,
+                                                                     stats_p, dmax_all + (&Ln - r->convs.data()), Ln.cout);
           sums_ready = next;
         }
         return rc2;
       }
-      return conv2d_launch_raw(g, draw, pre, nullptr, nullptr, dx_has ? dx : nullptr, dx, batch, rec.OH, rec.OW, 0, s, amax, n_amax);
+      return conv2d_launch_raw(g, draw, pre, nullptr, nullptr, dx_has ? dx : nullptr, dx, batch, rec.OH, rec.OW, 0, s, range, n_amax, nullptr, 0,
+                               nullptr, draw_cells ? (kFmtXCells | kFmtXScaled) : 0);
     }
     rc2 = conv2d_pack_spec(g, T[L.t_w], wimg, 1, s);
     if (rc2 != ADX_OK) return rc2;

@@ -250,40 +250,45 @@ def test_training_cell_tensors(tmp_path):
     gradient read the halves their staging would have computed) and the ReLU mask of a block's output as one bit per element.  With
     the weight gradients reduced in index order a train-mode forward + backward must then come out BIT FOR BIT as with fp32 NCHW
     activations everywhere (ADX_TRAIN_CELLS=0): feature, every gradient, the running statistics.
-    Default (2): the blocks' outputs are cell tensors too, and the identity the next block adds is hi + lo / 2^11 -- 22 bits of the
-    fp32 value, as in the inference executor: the feature within 2e-6 of its scale, gradients within what a handful of ReLU units
+    Level 2: the blocks' outputs are cell tensors too, and the identity the next block adds is hi + lo / 2^11 -- 22 bits of the
+    fp32 value, as in the inference executor; default (4): + the 16x16x32 forward launches and the conv-output gradients as cell
+    tensors under a scale taken from a bound (bn_bwd_apply_groups_kernel): the feature within 2e-6 of its scale, gradients within what a handful of ReLU units
     flipping costs on these small batches (the oracle-referenced bars are test_perception_train_mode_vs_oracle_autograd's and the full-size tests')."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
-    for cells in ("0", "1", "2"):
+    for cells in ("0", "1", "2", "4"):
         out = str(tmp_path / f"cells{cells}.pt")
         r = subprocess.run([sys.executable, os.path.join(root, "tests", "train_cells_worker.py"), out],
                            env=dict(os.environ, ADX_TRAIN_CELLS=cells, ADX_WGRAD_DETERMINISTIC="1"), capture_output=True, text=True,
                            timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
         outs[cells] = torch.load(out)
-    assert outs["0"].keys() == outs["1"].keys() == outs["2"].keys() and len(outs["0"]) == 4
+    assert outs["0"].keys() == outs["1"].keys() == outs["2"].keys() == outs["4"].keys() and len(outs["0"]) == 4
     for case, a in outs["0"].items():
-        b, c = outs["1"][case], outs["2"][case]
-        assert a.keys() == b.keys() == c.keys() and len(a) > 100
+        b = outs["1"][case]
+        assert a.keys() == b.keys() and len(a) > 100
         for k in a:
             if k in ("grad.conv1.weight", "grad.fc.weight", "grad.fc.bias"):       # reduced with float atomics in either mode
                 assert (a[k] - b[k]).abs().max().item() <= 2e-6 * a[k].abs().max().item(), (case, k)
             else:
                 assert torch.equal(a[k], b[k]), (case, k, (a[k].double() - b[k].double()).abs().max().item())
-            if not a[k].is_floating_point():
-                assert torch.equal(a[k], c[k]), (case, k)
-                continue
-            scale = a[k].abs().max().item() + 1e-30
-            err = (a[k].double() - c[k].double()).abs().max().item() / scale
-            if k == "feature" or k.startswith("buffer."):
-                assert err <= 2e-6, (case, k, err)
-            else:
-                rel = ((a[k].double() - c[k].double()).norm() / (a[k].double().norm() + 1e-30)).item()
-                assert rel <= 3e-2, (case, k, rel)      # (a batch of 1..8 small images: a flipped ReLU unit is percents of a gradient)
-        assert any(not torch.equal(a[k], c[k]) for k in a), case       # (level 2 did run: something is rounded differently)
+        for level in ("2", "4"):
+            c = outs[level][case]
+            assert a.keys() == c.keys()
+            for k in a:
+                if not a[k].is_floating_point():
+                    assert torch.equal(a[k], c[k]), (case, level, k)
+                    continue
+                scale = a[k].abs().max().item() + 1e-30
+                err = (a[k].double() - c[k].double()).abs().max().item() / scale
+                if k == "feature" or k.startswith("buffer."):
+                    assert err <= 2e-6, (case, level, k, err)
+                else:
+                    rel = ((a[k].double() - c[k].double()).norm() / (a[k].double().norm() + 1e-30)).item()
+                    assert rel <= 3e-2, (case, level, k, rel)      # (a batch of 1..8 small images: a flipped ReLU unit is percents of a gradient)
+            assert any(not torch.equal(a[k], c[k]) for k in a), (case, level)       # (the level did run: something is rounded differently)
 
 
 @pytest.mark.parametrize("hw,small_gamma", [((64, 96), False), ((70, 102), False), ((64, 96), True)])
