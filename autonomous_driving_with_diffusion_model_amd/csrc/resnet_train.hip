@@ -43,7 +43,8 @@ __global__ void __launch_bounds__(256) channel_sums_kernel(const float* __restri
                                                             int C, int HW, int relu_mask, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const uint8_t* __restrict__ bits = nullptr,
                                                             uint32_t* __restrict__ dmax = nullptr) {
-  // dmax (MODE 1): atomic maximum of |dz| over the tensor, as bits (bn_bwd_consts_kernel bounds the range of draw with it)
+  // dmax (MODE 1): dmax[c] = atomic maximum of |dz| over channel c, as bits (bn_bwd_consts_kernel bounds the range of draw with
+  // the largest of them; one slot per channel: a single word would serialise batch x C atomics)
   // bits (relu_mask == 1): the forward's mask, one bit per element -- byte [n][c / 8][pixel], bit c % 8 (bn_apply_groups_kernel) --
   // read instead of `out`
   const int plane = blockIdx.x;            // n * C + c
@@ -103,9 +104,15 @@ __global__ void __launch_bounds__(256) channel_sums_kernel(const float* __restri
     atomicAdd(sums + 2 * c + 1, (red[1] + red[3]) + (red[5] + red[7]));
   }
   if (MODE == 1 && dmax != nullptr) {
+    __shared__ float mred[4];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) vmax = __builtin_fmaxf(vmax, __shfl_xor(vmax, off, 64));
-    if ((tid & 63) == 0 && vmax > 0.f) atomicMax(dmax, f2u(vmax));       // (non-negative floats order like their bit patterns)
+    if ((tid & 63) == 0) mred[tid >> 6] = vmax;
+    __syncthreads();
+    if (tid == 0) {
+      const float m = __builtin_fmaxf(__builtin_fmaxf(mred[0], mred[1]), __builtin_fmaxf(mred[2], mred[3]));
+      if (m > 0.f) atomicMax(dmax + c, f2u(m));       // (non-negative floats order like their bit patterns)
+    }
   }
 }
 
@@ -456,7 +463,17 @@ __global__ void __launch_bounds__(256) bn_bwd_consts_kernel(const double* __rest
                                                              double count, int C, float* __restrict__ consts,
                                                              float* __restrict__ xscale, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta) {
-  const float D = u2f(*dmax), X = (float)sqrt(count > 1.0 ? count - 1.0 : 1.0);
+  // D: the largest of the per-channel maxima (the data-gradient epilogue's path leaves the tensor's maximum in slot 0)
+  __shared__ float red[4];
+  float dm = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) dm = __builtin_fmaxf(dm, u2f(dmax[c]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) dm = __builtin_fmaxf(dm, __shfl_xor(dm, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dm;
+  __syncthreads();
+  const float D = __builtin_fmaxf(__builtin_fmaxf(red[0], red[1]), __builtin_fmaxf(red[2], red[3]));
+  const float X = (float)sqrt(count > 1.0 ? count - 1.0 : 1.0);
+  __syncthreads();
   float bound = 0.f;
   for (int c = threadIdx.x; c < C; c += 256) {
     const float mu = mean[c], rs = rstd[c], ga = gamma[c];
@@ -470,7 +487,6 @@ __global__ void __launch_bounds__(256) bn_bwd_consts_kernel(const double* __rest
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) bound = __builtin_fmaxf(bound, __shfl_xor(bound, off, 64));
-  __shared__ float red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = bound;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1223,7 +1239,7 @@ size_t adx_resnet_train_workspace_bytes(const adx_resnet* r, int32_t batch, int3
     conv(c2, OH, OW);
     H = OH; W = OW;
   }
-  f += al64(r->convs.size()) + al64(512 * 8) + al64(2) + al64(r->convs.size() * 2 * 512 * 2) + al64(kAmaxPartials) + al64((size_t)512 * 256 * 9) + al64(conv2d_wgrad_partials_floats()) + 5 * al64(big) + 2 * al64(wmax) + wall;   // backward: sums, amax, 3x3 image of a 1x1 gradient, 5 gradient buffers, dgrad weights (one scratch pair + a slot per stride-1 3x3 conv)
+  f += al64(r->convs.size() * 512) + al64(512 * 8) + al64(2) + al64(r->convs.size() * 2 * 512 * 2) + al64(kAmaxPartials) + al64((size_t)512 * 256 * 9) + al64(conv2d_wgrad_partials_floats()) + 5 * al64(big) + 2 * al64(wmax) + wall;   // backward: sums, amax, 3x3 image of a 1x1 gradient, 5 gradient buffers, dgrad weights (one scratch pair + a slot per stride-1 3x3 conv)
   return (f + 1024) * sizeof(float);
 }
 
@@ -1465,10 +1481,10 @@ int adx_resnet_backward_events(adx_resnet* r, const float* const* T, float* cons
     if (rf != ADX_OK) return rf;
   }
   uint32_t* amax = reinterpret_cast<uint32_t*>(ws.take(kAmaxPartials));   // per-workgroup max |draw| of the conv being differentiated
-  uint32_t* dmax_all = reinterpret_cast<uint32_t*>(ws.take(n_convs));      // per conv: max |dz| of its incoming gradient (bits)
+  uint32_t* dmax_all = reinterpret_cast<uint32_t*>(ws.take(n_convs * 512));      // per conv and channel: max |dz| of its incoming gradient (bits)
   float* bconsts = ws.take((size_t)512 * 8);                              // per-channel constants of the record being differentiated
   float* xscale = ws.take(2);                                             // {xs, 1 / xs} of its cell-layout draw
-  if (ws.ok) ADX_CHECK_HIP(hipMemsetAsync(dmax_all, 0, sizeof(uint32_t) * n_convs, s));
+  if (ws.ok) ADX_CHECK_HIP(hipMemsetAsync(dmax_all, 0, sizeof(uint32_t) * n_convs * 512, s));
   float* wgrad9 = ws.take((size_t)512 * 256 * 9);     // 3x3 image of the largest 1x1 downsample gradient (conv2d_wgrad)
   struct PartsScope {
     ~PartsScope() { conv2d_wgrad_set_partials(nullptr, 0); }
@@ -1538,7 +1554,7 @@ int adx_resnet_backward_events(adx_resnet* r, const float* const* T, float* cons
     double* sums = sums_all + (size_t)(&L - r->convs.data()) * 2 * 512;
     // ReLU mask: straight after BN it is re-derived from the conv output (one tensor read less in both passes)
     const int mask = !rec.relu ? 0 : (rec.identity != nullptr ? 1 : 2);
-    uint32_t* const dmax = dmax_all + (&L - r->convs.data());
+    uint32_t* const dmax = dmax_all + (size_t)(&L - r->convs.data()) * 512;
     if (sums_ready != &rec)
       channel_sums_kernel<1><<<dim3(batch * L.cout), dim3(256), 0, s>>>(dout, rec.out, rec.raw, rec.mean, rec.rstd, sums,
                                                                         L.cout, HW, mask, T[L.t_g], T[L.t_b], rec.bits, dmax);
@@ -1598,7 +1614,7 @@ int adx_resnet_backward_events(adx_resnet* r, const float* const* T, float* cons
                                 tape->stats_part, kStatsPartFloats, &stats_p, draw_cells ? (kFmtXCells | kFmtXScaled) : 0, &bst);
         if (rc2 == ADX_OK && stats_p > 0) {
           stats_reduce_kernel<<<dim3(Ln.cout + 1), dim3(256), 0, s>>>(tape->stats_part, sums_all + (size_t)(&Ln - r->convs.data()) * 2 * 512,
-                                                                     stats_p, dmax_all + (&Ln - r->convs.data()), Ln.cout);
+                                                                     stats_p, dmax_all + (size_t)(&Ln - r->convs.data()) * 512, Ln.cout);
           sums_ready = next;
         }
         return rc2;
