@@ -19,6 +19,15 @@ rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${R}_tick_free -- pyt
 MODE=classifier rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${R}_tick_cls -- python3 tools/tick_timeline.py run >> gpurun_out/${R}_tick_run.log 2>&1
 python tools/tick_timeline.py analyze gpurun_out/${R}_tick_free > gpurun_out/${R}_tick_free_b1.txt
 python tools/tick_timeline.py analyze gpurun_out/${R}_tick_cls > gpurun_out/${R}_tick_classifier_b1.txt
+# the training step: kernel table, the activation-layout levels A/B, idle time of the traced step, host clock
+rm -rf gpurun_out/prof_tr gpurun_out/${R}_tr_trace
+bash tools/profile_train.sh > gpurun_out/${R}_train_step_kernels.txt 2>&1
+cp $(ls -t gpurun_out/prof_tr/*/*kernel_stats.csv | head -1) gpurun_out/${R}_train_kernel_stats.csv
+python tools/ab_env_train.py ADX_TRAIN_CELLS 0 1 2 3 4 > gpurun_out/${R}_ab_train_cells.txt 2>&1
+NOSYNC=1 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${R}_tr_trace -- python3 tools/train_time.py > /dev/null 2>&1
+python tools/train_gaps.py gpurun_out/${R}_tr_trace > gpurun_out/${R}_train_gaps.txt 2>&1
+rm -rf gpurun_out/${R}_tr_trace
+python3 tools/host_times.py 2>/dev/null | tail -22 > gpurun_out/${R}_train_host_times.txt
 python bench.py > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.err
 ls gpurun_out/${R}_*/*/ | head -30
 tail -c 400 gpurun_out/${R}_bench_default.json
