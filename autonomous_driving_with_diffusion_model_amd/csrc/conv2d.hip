@@ -406,13 +406,17 @@ int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const f
   a.d2s_cin = 0; a.d2s_h = 0; a.d2s_w = 0; a.stem_seg_tiles = 0; a.stem_nseg = 1;
   a.ksplit = 1; a.cper = 0; a.part = t_split_scratch; a.part_stride = t_split_floats;   // part_stride: capacity until the launch fixes it
   a.stats_part = nullptr; a.stats_p = 0;
-  a.bs_raw = a.bs_out = a.bs_mean = a.bs_rstd = a.bs_gamma = a.bs_beta = nullptr; a.bs_mask = 0; a.bs_bits = nullptr;
+  a.bs_raw = a.bs_out = a.bs_mean = a.bs_rstd = a.bs_gamma = a.bs_beta = nullptr; a.bs_mask = 0; a.bs_bits = nullptr; a.res_bits = nullptr;
   if (bst != nullptr) {
     ADX_REQUIRE(bst->raw && bst->mean && bst->rstd && bst->gamma && bst->beta && (bst->mask == 2 || (bst->mask == 1 && (bst->out || bst->bits))),
                 "conv2d: incomplete BatchNorm-backward statistics request");
     ADX_REQUIRE(scale == nullptr && relu == 0, "conv2d: BatchNorm-backward statistics belong to data-gradient launches");
     a.bs_raw = bst->raw; a.bs_out = bst->out; a.bs_mean = bst->mean; a.bs_rstd = bst->rstd; a.bs_gamma = bst->gamma;
     a.bs_beta = bst->beta; a.bs_mask = bst->mask; a.bs_bits = bst->mask == 1 ? bst->bits : nullptr;
+    a.res_bits = bst->res_bits;
+    ADX_REQUIRE(a.res_bits == nullptr || (res != nullptr && stats_part != nullptr &&
+                                          conv2d_hs3x3_dgrad_stats(L, N, H, W, (fmt & kFmtXCells) != 0, stats_floats)),
+                "conv2d: a masked residual belongs to a data-gradient launch with the statistics epilogue");
   }
   a.x_cells = (fmt & kFmtXCells) != 0; a.y_cells = (fmt & kFmtYCells) != 0; a.res_cells = (fmt & kFmtResCells) != 0 && res != nullptr;
   // cells: plain launches of the pipelined 3x3 kernel (the inference executor), or the INPUT of a training-forward launch

@@ -879,6 +879,11 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
 #pragma unroll
       for (int rr = 0; rr < 2; ++rr)
         boff[rr] = inside[rr] ? (VROW ? (uint32_t)nl * (uint32_t)(a.Cout >> 3) * bplane : 0u) + pix[rr] : kOutside;
+      // the residual's own mask bits (same layout): the identity path's gradient is res where the block's output was positive
+      const bool res_masked = a.res_bits != nullptr;
+      const __amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<uint8_t*>(res_masked ? a.res_bits + (size_t)n * (a.Cout >> 3) * bplane : reinterpret_cast<const uint8_t*>(a.y)), 0,
+          res_masked ? (int)((VROW ? (uint32_t)a.N : 1u) * (uint32_t)(a.Cout >> 3) * bplane) : 0, 0x00020000);
       const float* bsw = bsl + slab * 64;
       float dmx = 0.f;          // max |dz| of this lane: the BatchNorm-backward apply pass bounds its output's range with it
 #pragma unroll
@@ -900,6 +905,18 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
             for (int r = 0; r < 16; ++r) {
               const uint32_t so = cbase_o + (uint32_t)(half * 32 + (r & 3) + 8 * (r >> 2)) * plane_ob;
               ro_[rr][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(orsrc, voff[rr], so, 0));
+            }
+        }
+        if (res_masked) {      // wave-uniform
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const uint32_t m = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(qrsrc, boff[rr], ((uint32_t)(cout0 >> 3) + (uint32_t)(half * 4 + q)) * bplane, 0)
+                                 >> (4 * khalf);
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                if (!((m >> i) & 1u)) rs_[rr][4 * q + i] = 0.f;
             }
         }
         uint32_t mb[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
@@ -1745,6 +1762,17 @@ bool conv2d_hs3x3_dgrad_cells(const ConvSpec& L, int N, int H, int W) {
   a.OH = conv_out_dim(H, L.k, L.stride, L.pad); a.OW = conv_out_dim(W, L.k, L.stride, L.pad);
   return hs3x3_mode(L, a) >= 0 && L.cin % 16 == 0 && L.cin == L.cin_pad && L.cout % 64 == 0 &&
          (size_t)N * L.cin * H * W * sizeof(float) < 0xC0000000u;
+}
+
+bool conv2d_hs3x3_dgrad_stats(const ConvSpec& L, int N, int H, int W, bool x_cells, size_t stats_floats) {
+  if (!conv2d_hs_eligible(L) || !L.dgrad) return false;
+  Conv2dArgs a{};
+  a.N = N; a.Cin = L.cin; a.Cout = L.cout; a.H = H; a.W = W;
+  a.OH = conv_out_dim(H, L.k, L.stride, L.pad); a.OW = conv_out_dim(W, L.k, L.stride, L.pad);
+  a.KH = L.k; a.KW = L.k; a.stride = L.stride; a.pad = L.pad; a.cin_pad = L.cin_pad;
+  a.x_cells = x_cells ? 1 : 0;
+  const int tiles = conv2d_hs_stats_tiles(L, a);
+  return L.k == 3 && L.stride == 1 && tiles > 0 && (size_t)tiles * (L.cout * 2 + L.cout / 64) <= stats_floats;
 }
 
 bool conv2d_hs3x3_train_cells(const ConvSpec& L, int N, int H, int W, size_t stats_floats) {

@@ -69,6 +69,10 @@ struct Conv2dArgs {
   // bs_mask == 1 with bs_bits != null: the mask as the forward pass left it (resnet_train.hip: bn_apply_groups_kernel), one BIT per
   // element -- byte [n][c / 8][pixel], bit c % 8 -- instead of the fp32 map bs_out
   const uint8_t* bs_bits;
+  // bs_raw != null only: the residual `res` passes through a ReLU mask given as bits in the same layout (the identity path of a
+  // BasicBlock's backward: res = d(block output), the mask = where the block's output was positive), so that the masked gradient
+  // is never written as a tensor of its own
+  const uint8_t* res_bits;
   // conv2d_hs3x3 only (inference executor): x / y / res in the cell layout instead of fp32 NCHW (conv2d_hs.hip: XCELLS)
   int x_cells, y_cells, res_cells;
   int vw;       // y_cells: columns of one image in the virtual row the column tiles run over (W + 1: the images side by side with
@@ -104,7 +108,7 @@ namespace adx {
 // x_amax (optional, device): x_amax_n bit patterns whose maximum is max|x| over the whole input; the split-fp16 kernels use it to move x
 // into fp16's normal range by an exact power of two (data gradients are far below 2^-14)
 struct BnBwdStats { const float* raw; const float* out; const float* mean; const float* rstd; const float* gamma; const float* beta; int mask;
-                    const uint8_t* bits = nullptr; };
+                    const uint8_t* bits = nullptr; const uint8_t* res_bits = nullptr; };
 int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const float* scale, const float* shift,
                       const float* res, float* y, int N, int H, int W, int relu, hipStream_t s,
                       const uint32_t* x_amax = nullptr, int x_amax_n = 0, float* stats_part = nullptr, size_t stats_floats = 0,
@@ -117,6 +121,9 @@ bool conv2d_hs3x3_plain(const ConvSpec& L, int N, int H, int W);
 bool conv2d_hs3x3_train_cells(const ConvSpec& L, int N, int H, int W, size_t stats_floats);
 // true when a data-gradient launch of this (dgrad) spec can read a cell-layout, pre-scaled gradient (fmt = kFmtXCells | kFmtXScaled)
 bool conv2d_hs3x3_dgrad_cells(const ConvSpec& L, int N, int H, int W);
+// true when a data-gradient launch of this spec with a BnBwdStats request will run the pipelined 3x3 kernel's statistics epilogue
+// (the launches that can take BnBwdStats::res_bits)
+bool conv2d_hs3x3_dgrad_stats(const ConvSpec& L, int N, int H, int W, bool x_cells, size_t stats_floats);
 // conv2d_hs16.hip: the 16x16x32 kernel's training-forward variant (cells in, fp32 + statistics out) and its tile count
 bool conv2d_hs3x3q_train_eligible(const Conv2dArgs& a);
 int conv2d_hs3x3q_train_tiles(const Conv2dArgs& a);

@@ -1545,8 +1545,24 @@ int adx_resnet_backward_events(adx_resnet* r, const float* const* T, float* cons
   // STATS == 2), so channel_sums_kernel<1>'s pass over that gradient is not needed.  `next`: the record dx flows into (null:
   // nobody's statistics can come from this launch -- dx is completed by a later launch, or feeds no BatchNorm).
   const adx_resnet_tape::Rec* sums_ready = nullptr;
+  auto dgrad_spec = [](const ConvSpec& L) {
+    ConvSpec g{};
+    g.cin = L.cout; g.cout = L.cin; g.k = L.k; g.stride = 1; g.pad = L.k - 1 - L.pad; g.cc = 16; g.cin_pad = L.cout; g.dgrad = 1;
+    return g;
+  };
+  // draw as a cell tensor (ADX_TRAIN_CELLS >= 4): the stride-1 3x3 convs whose weight and data gradient both run on the
+  // split-fp16 kernels; the scale comes from a bound (bn_bwd_consts_kernel), `amax` is not produced
+  auto draw_cells_of = [&](const adx_resnet_tape::Rec& rec, bool need_dx) {
+    const ConvSpec& L = *rec.L;
+    const int mask = !rec.relu ? 0 : (rec.identity != nullptr ? 1 : 2);
+    return L.k == 3 && L.stride == 1 && L.pad == 1 && L.cout % 8 == 0 && need_dx && dgrad_img[&L - r->convs.data()] != nullptr &&
+           conv2d_wgrad_hs_eligible(L.cin, L.cout, 3, 1, 1) && conv2d_hs3x3_dgrad_cells(dgrad_spec(L), batch, rec.OH, rec.OW) &&
+           (mask != 1 || rec.bits != nullptr);
+  };
+  // res_bits: dx's residual is `dx` itself (in place) passed through these mask bits -- the identity path of a block without a
+  // downsample: d(block input) += d(block output) where the block's output was positive; only with `next` (statistics epilogue)
   auto conv_bn_bwd = [&](const adx_resnet_tape::Rec& rec, const float* dout, float* dz_keep, float* draw, float* dx,
-                         bool dx_has, bool need_dx, const adx_resnet_tape::Rec* next = nullptr) -> int {
+                         bool dx_has, bool need_dx, const adx_resnet_tape::Rec* next = nullptr, const uint8_t* res_bits = nullptr) -> int {
     const ConvSpec& L = *rec.L;
     const int HW = rec.OH * rec.OW;
     const size_t n = (size_t)batch * L.cout * HW;
@@ -1559,13 +1575,7 @@ int adx_resnet_backward_events(adx_resnet* r, const float* const* T, float* cons
       channel_sums_kernel<1><<<dim3(batch * L.cout), dim3(256), 0, s>>>(dout, rec.out, rec.raw, rec.mean, rec.rstd, sums,
                                                                         L.cout, HW, mask, T[L.t_g], T[L.t_b], rec.bits, dmax);
     sums_ready = nullptr;
-    // draw as a cell tensor (ADX_TRAIN_CELLS >= 4): the stride-1 3x3 convs whose weight and data gradient both run on the
-    // split-fp16 kernels; the scale comes from a bound (bn_bwd_consts_kernel), `amax` is not produced
-    ConvSpec gq{};
-    gq.cin = L.cout; gq.cout = L.cin; gq.k = L.k; gq.stride = 1; gq.pad = L.k - 1 - L.pad; gq.cc = 16; gq.cin_pad = L.cout; gq.dgrad = 1;
-    const bool draw_cells = L.k == 3 && L.stride == 1 && L.pad == 1 && L.cout % 8 == 0 && need_dx && dgrad_img[&L - r->convs.data()] != nullptr &&
-                            conv2d_wgrad_hs_eligible(L.cin, L.cout, 3, 1, 1) && conv2d_hs3x3_dgrad_cells(gq, batch, rec.OH, rec.OW) &&
-                            (mask != 1 || rec.bits != nullptr) && (reinterpret_cast<uintptr_t>(draw) & 15) == 0;
+    const bool draw_cells = draw_cells_of(rec, need_dx) && (reinterpret_cast<uintptr_t>(draw) & 15) == 0;
     int n_amax;
     if (draw_cells) {
       n_amax = -1;
@@ -1601,14 +1611,15 @@ int adx_resnet_backward_events(adx_resnet* r, const float* const* T, float* cons
                            rec.x_cells, draw_cells);
     if (rc2 != ADX_OK || !need_dx) return rc2;
     // data gradient
-    ConvSpec g{};
-    g.cin = L.cout; g.cout = L.cin; g.k = L.k; g.stride = 1; g.pad = L.k - 1 - L.pad; g.cc = 16; g.cin_pad = L.cout; g.dgrad = 1;
+    const ConvSpec g = dgrad_spec(L);
+    ADX_REQUIRE(res_bits == nullptr || (next != nullptr && dx_has && dgrad_img[&L - r->convs.data()] != nullptr && tape->stats_part != nullptr),
+                "adx_resnet_backward: a masked residual needs the statistics epilogue of the pipelined data gradient");
     if (const float* pre = dgrad_img[&L - r->convs.data()]) {      // stride-1 3x3: image packed with the others at the start
       const int next_mask = next == nullptr || !next->relu ? 0 : (next->identity != nullptr ? 1 : 2);
       if (next_mask != 0 && tape->stats_part != nullptr) {
         const ConvSpec& Ln = *next->L;
         ADX_REQUIRE(Ln.cout == L.cin && next->OH == rec.H && next->OW == rec.W, "adx_resnet_backward: consumer record does not match dx");
-        const BnBwdStats bst{next->raw, next->out, next->mean, next->rstd, T[Ln.t_g], T[Ln.t_b], next_mask, next->bits};
+        const BnBwdStats bst{next->raw, next->out, next->mean, next->rstd, T[Ln.t_g], T[Ln.t_b], next_mask, next->bits, res_bits};
         int stats_p = 0;
         rc2 = conv2d_launch_raw(g, draw, pre, nullptr, nullptr, dx_has ? dx : nullptr, dx, batch, rec.OH, rec.OW, 0, s, range, n_amax,
                                 tape->stats_part, kStatsPartFloats, &stats_p, draw_cells ? (kFmtXCells | kFmtXScaled) : 0, &bst);
@@ -1664,10 +1675,19 @@ int adx_resnet_backward_events(adx_resnet* r, const float* const* T, float* cons
     int k = 0;
     for (auto p : gb) if (p != g_cur && p != gb[4] && k < 4) others[k++] = p;
     float* dz2 = others[0]; float* draw = others[1]; float* do1 = others[2];
-    rc = conv_bn_bwd(c2, g_cur, dz2, draw, do1, false, true, &c1);       // -> do1 = d(o1) (c1's incoming gradient), dz2 = masked dout
+    // A block without a downsample, not the first: the identity path's gradient -- d(block out) where the block's output was
+    // positive -- is not written as a tensor (dz2): conv1's data gradient adds d(block out) IN PLACE through the mask bits
+    const adx_resnet_tape::Rec* prev = b > 0 ? &tape->recs[ri - 1] : nullptr;
+    const bool masked_res = !ds && prev != nullptr && prev->relu && c2.bits != nullptr && tape->stats_part != nullptr &&
+                            dgrad_img[c1.L - r->convs.data()] != nullptr &&
+                            conv2d_hs3x3_dgrad_stats(dgrad_spec(*c1.L), batch, c1.OH, c1.OW,
+                                                     draw_cells_of(c1, true) && (reinterpret_cast<uintptr_t>(draw) & 15) == 0, kStatsPartFloats);
+    rc = conv_bn_bwd(c2, g_cur, masked_res ? nullptr : dz2, draw, do1, false, true, &c1);   // -> do1 = d(o1) (c1's incoming gradient), dz2 = masked dout
     if (rc != ADX_OK) break;
     float* dx = g_cur;                                                   // d(block out) is dead now: reuse for d(block in)
-    if (ds) {
+    if (masked_res) {
+      rc = conv_bn_bwd(c1, do1, nullptr, draw, g_cur, true, true, prev, c2.bits);
+    } else if (ds) {
       rc = conv_bn_bwd(c1, do1, nullptr, draw, dx, false, true);         // main path: writes every pixel of d(block in)
       if (rc != ADX_OK) break;
       rc = conv_bn_bwd(*dsr, dz2, nullptr, draw, dx, true, true);        // identity path through the downsample conv adds to
