@@ -243,9 +243,10 @@ def conv2d_roofline(dev, reps=10):
             "achieved_note": "achieved / frac (the contract figures, SURVEY 8d) = ALGORITHMIC conv flops (2*M*N*K) per launch / "
                              "HIP-event launch time, against the dense fp16 MFMA peak; achieved_issued / frac_issued = the fp16 "
                              "MFMA flops the kernel actually issues (3 x algorithmic: hi*hi + hi*lo + lo*hi) / the same time",
-            # the inference instantiations (cell tensors in and out: "<MODE, false, true, true>"); the same summary also holds the
-            # training leg's fp32-layout launches of this kernel
-            "avg_launch_ms_rocprof": rocprof_avg_ms(lambda n: "conv2d_hs3x3q_kernel" in n or ("conv2d_hs3x3_kernel" in n and "true, true>(" in n)),
+            # the inference instantiations (cell tensors in and out); the same summary also holds the training leg's launches of
+            # these kernels (statistics epilogues, fp32 outputs)
+            "avg_launch_ms_rocprof": rocprof_avg_ms(lambda n: ("conv2d_hs3x3q_kernel<" in n and ", false>(" in n)         # (<DMA, TRAIN = false>)
+                                                    or ("conv2d_hs3x3_kernel<" in n and ", 0, true, true" in n)),          # (<MODE, STATS = 0, XCELLS, YCELLS, ..>)
             "fp32_mfma_peak_tflops": PEAK_F32_TFLOPS, "frac_of_fp32_mfma_peak": round(equiv / PEAK_F32_TFLOPS, 3),
             "traffic": pmc_traffic("conv2d_hs3x3_kernel"),
             "traffic_note": "bytes/launch, 2 x FETCH_SIZE (gfx950 correction, calibrated: tools/micro/fetch_calib.hip) + WRITE_SIZE from profiles/" + os.path.basename(pmc_traffic_file() or "(none)") + " (separate rocprofv3 --pmc passes)",
