@@ -49,12 +49,13 @@ struct DebugSwitches {
   bool unet_pipe = true;       // ADX_UNET_PIPE=0    the deepest level's layer run as launches, not as one pipeline launch (tconv_pipe.hip)
   bool conv_vrow = true;       // ADX_CONV_VROW=0    fp32-layout 3x3 launches tile every image on its own (no virtual row over the batch)
   bool conv_cells = true;      // ADX_CONV_CELLS=0   fp32 NCHW between all perception convs (no pre-split cell tensors)
-  int train_cells = 4;         // ADX_TRAIN_CELLS=0  the training executor keeps every tensor as fp32 NCHW and no mask bits; =1 only what changes
+  int train_cells = 5;         // ADX_TRAIN_CELLS=0  the training executor keeps every tensor as fp32 NCHW and no mask bits; =1 only what changes
                                //                    no bit (the map between a block's convs as cells, the ReLU mask as bits, the identity
                                //                    gradient added through the bits); =2 the blocks' outputs as cells too (the next block's
                                //                    identity is then hi + lo / 2^11); =3 + the 16x16x32 kernel for the forward launches it
                                //                    tiles (conv2d_hs16.hip: TRAIN); default 4: + the conv-output gradients of the stride-1
-                               //                    3x3 convs as cells under a scale taken from a bound (bn_bwd_apply_groups_kernel)
+                               //                    3x3 convs as cells under a scale taken from a bound (bn_bwd_apply_groups_kernel);
+                               //                    5 (default): + their data gradients with Cout % 128 == 0 on the 16x16x32 kernel (TRAIN == 2)
   int hs_mode = -1;            // ADX_HS_MODE=0|1|2  pins the tile mode of the pipelined 3x3 kernel
   bool wgrad_deterministic = false;   // ADX_WGRAD_DETERMINISTIC=1  the 3x3 weight gradients (conv2d_wgrad_hs) reduce per-workgroup partial
                                //                    sums in index order instead of with float atomics: bit-reproducible, one more pass

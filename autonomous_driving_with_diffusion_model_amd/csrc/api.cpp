@@ -27,7 +27,7 @@ const DebugSwitches& debug_switches() {
     d.unet_pipe = !is("ADX_UNET_PIPE", '0');
     d.conv_cells = !is("ADX_CONV_CELLS", '0');
     d.conv_vrow = !is("ADX_CONV_VROW", '0');
-    d.train_cells = is("ADX_TRAIN_CELLS", '0') ? 0 : (is("ADX_TRAIN_CELLS", '1') ? 1 : (is("ADX_TRAIN_CELLS", '2') ? 2 : (is("ADX_TRAIN_CELLS", '3') ? 3 : 4)));
+    d.train_cells = is("ADX_TRAIN_CELLS", '0') ? 0 : (is("ADX_TRAIN_CELLS", '1') ? 1 : (is("ADX_TRAIN_CELLS", '2') ? 2 : (is("ADX_TRAIN_CELLS", '3') ? 3 : (is("ADX_TRAIN_CELLS", '4') ? 4 : 5))));
     d.check_range = is("ADX_CHECK_RANGE", '1');
     d.hs_dma = !is("ADX_HS_DMA", '0');
     d.wgrad_deterministic = is("ADX_WGRAD_DETERMINISTIC", '1');

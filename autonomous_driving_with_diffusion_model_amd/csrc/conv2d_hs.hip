@@ -1610,7 +1610,7 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
     a.tiles_x = hs_vrow_tiles_x(a);
     return (size_t)a.cout_tiles * a.tiles_x * a.tiles_y;
   };
-  if (a.stats_part != nullptr && a.x_cells && conv2d_hs3x3q_train_eligible(a)) {      // the 16x16x32 kernel where its tile rules hold
+  if (a.stats_part != nullptr && a.x_cells && (conv2d_hs3x3q_train_eligible(a) || conv2d_hs3x3q_dgrad_eligible(a))) {      // the 16x16x32 kernel where its tile rules hold
     a.part = nullptr;
     return conv2d_hs3x3q_launch(a, s);
   }
@@ -1790,7 +1790,7 @@ bool conv2d_hs3x3_train_cells(const ConvSpec& L, int N, int H, int W, size_t sta
 int conv2d_hs_stats_tiles(const ConvSpec& L, const Conv2dArgs& a) {
   const int mode = hs3x3_mode(L, a);
   if (mode < 0) return 0;
-  if (a.x_cells && conv2d_hs3x3q_train_eligible(a)) return conv2d_hs3x3q_train_tiles(a);
+  if (a.x_cells && (conv2d_hs3x3q_train_eligible(a) || conv2d_hs3x3q_dgrad_eligible(a))) return conv2d_hs3x3q_train_tiles(a);
   if (!(a.y_cells || a.res_cells) && hs_vrow_ok(a)) return ceil_div(a.OH, mode == 1 ? 16 : 8) * hs_vrow_tiles_x(a);
   return a.N * ceil_div(a.OH, mode == 1 ? 16 : 8) * ceil_div(a.OW, kTileW);
 }

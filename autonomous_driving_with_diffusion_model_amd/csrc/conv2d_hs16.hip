@@ -38,13 +38,13 @@ constexpr int kQPlaneP = 344;              // pitch of one [k-group][plane] imag
 constexpr int kQPairs = 4 * kQPlane;       // (k-group, pixel) cell pairs of a 32-channel chunk
 constexpr int kQPit = (kQPairs + kQNT - 1) / kQNT;   // 3 rounds
 constexpr int kQWst = 1024;                // weight cells of a stage: [slab][16-channel half][plane][k-half][64]
-constexpr size_t kQLds = (size_t)2 * 8 * kQPlaneP * 16 + (size_t)2 * kQWst * 16 + 256 * sizeof(float) + 2 * 16;
+constexpr size_t kQLds = (size_t)2 * 8 * kQPlaneP * 16 + (size_t)2 * kQWst * 16 + 256 * sizeof(float) + 2 * 16 + 512 * sizeof(float);
 // DMA variant (buffer_load / global_load ... lds: the staged cells go from memory to LDS without passing through registers): a wave's
 // 64 lanes write 64 CONSECUTIVE cells, so the patch image is [plane][k-group][pitch] with the cell pairs of a chunk numbered
 // linearly over (k-group, pixel); pitch 352 = 22 x 16 cells keeps the four k-groups of a fragment read on one bank phase
 constexpr int kQPlaneD = 352;
 constexpr int kQPairsD = 4 * kQPlaneD;     // 1408 = 22 waves of 64: whole waves only
-constexpr size_t kQLdsD = (size_t)2 * 8 * kQPlaneD * 16 + (size_t)2 * kQWst * 16 + 256 * sizeof(float) + 2 * 16;
+constexpr size_t kQLdsD = (size_t)2 * 8 * kQPlaneD * 16 + (size_t)2 * kQWst * 16 + 256 * sizeof(float) + 2 * 16 + 512 * sizeof(float);
 typedef __attribute__((address_space(3))) void lds_void;
 
 __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
@@ -63,7 +63,10 @@ __device__ __forceinline__ void half4(uint32_t h0, uint32_t h1, uint32_t l0, uin
 // TRAIN: the training forward's launch on a cell-layout input (resnet_train.hip): the raw conv output as fp32 NCHW (BatchNorm
 // needs batch statistics before anything can be applied) and, like conv2d_hs3x3_kernel's STATS == 1, per-workgroup partial sums
 // of the output and of its squares per channel ([Cout][2][tiles] floats, pixels outside the map excluded).
-template <bool DMA, bool TRAIN = false>
+// TRAIN == 2: a data gradient of the training backward on a cell-layout, pre-scaled gradient (x_amax_n < 0): dx = conv + residual
+// (fp32 NCHW, the residual optionally through mask bits) and, like conv2d_hs3x3_kernel's STATS == 2, the consumer BatchNorm's
+// backward sums (sum dz, sum dz xhat per channel) and max |dz| per workgroup.
+template <bool DMA, int TRAIN = 0>
 __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs a) {
   constexpr int NT = kQNT, PW = kQPW, PLANE = DMA ? kQPlaneD : kQPlane, PP = DMA ? kQPlaneD : kQPlaneP, PIT = kQPit, WST = kQWst;
   constexpr int NPAIRS = DMA ? kQPairsD : kQPairs;
@@ -74,6 +77,7 @@ __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs
   u32x4* wl = patch + 2 * 8 * PP;                             // 2 x [slab][16-channel half][plane][k-half][64]
   float* ss = reinterpret_cast<float*>(wl + 2 * WST);         // scale[128], shift[128]
   u32x4* dummy = reinterpret_cast<u32x4*>(ss + 256);          // where the idle threads of the last patch round write
+  float* bsl = reinterpret_cast<float*>(dummy + 2);           // TRAIN == 2: [mean | rstd | mask scale | mask shift] x 128
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rowpair = wave & 3, slab = wave >> 2;
@@ -185,6 +189,12 @@ __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs
   for (int k = 0; k < PIT; ++k) { load_p(0, k, 0); store_p(0, k, 0); }
   if constexpr (!DMA) load_w(1, 1);
   if (tid < 256) ss[tid] = ssv;
+  if constexpr (TRAIN == 2) {
+    const int which = tid >> 7, c = ct * 128 + (tid & 127);
+    const float mu = a.bs_mean[c], rs = a.bs_rstd[c];
+    const float sc = a.bs_gamma[c] * rs;          // the mask's affine form exactly as the forward pass applied it (resnet_train.hip: bn_affine)
+    bsl[tid] = which == 0 ? mu : (which == 1 ? rs : (which == 2 ? sc : __builtin_fmaf(-mu, sc, a.bs_beta[c])));
+  }
   if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -242,7 +252,114 @@ __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs
     }
   }
 
-  if constexpr (TRAIN) {
+  if constexpr (TRAIN == 2) {
+    // ---- data-gradient epilogue: everything AFTER the swap (lane (j, rw = kq): channels 16 cb + 8 (rw >> 1) .. + 7 of the pixel at
+    // column 16 (rw & 1) + j: a half wave = 32 consecutive pixels of a channel plane, 128-byte runs for every fp32 access) ----
+    const float xs_inv = reinterpret_cast<const float*>(a.x_amax)[1];
+    const uint32_t plane_ob = (uint32_t)(a.OH * a.OW) * (uint32_t)sizeof(float);
+    const uint32_t bplane = (uint32_t)(a.OH * a.OW);
+    const uint32_t img_bytes = (uint32_t)a.N * (uint32_t)a.Cout * plane_ob, bit_bytes = (uint32_t)a.N * (uint32_t)(a.Cout >> 3) * bplane;
+    const int rw = kq;
+    const int vcol = vx0 + 16 * (rw & 1) + j;
+    const int nl = vdiv(vcol), xl = vcol - nl * a.vw;
+    const bool col_valid = nl < a.N && xl < a.W;
+    const bool mask_bits = a.bs_mask == 1, res_masked = a.res_bits != nullptr;
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.res != nullptr ? a.res : a.y), 0, a.res != nullptr ? (int)img_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bs_raw), 0, (int)img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(mask_bits ? a.bs_bits : reinterpret_cast<const uint8_t*>(a.y)), 0, mask_bits ? (int)bit_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(res_masked ? a.res_bits : reinterpret_cast<const uint8_t*>(a.y)), 0, res_masked ? (int)bit_bytes : 0, 0x00020000);
+    const int cout0 = ct * 128 + slab * 64;
+    const float* bsw = bsl + slab * 64 + 8 * (rw >> 1);         // + 16 cb + c8: this lane's channels
+    float* red = reinterpret_cast<float*>(smem_raw);            // [wave][rw][cb][c8][2], then [4096 + wave]: max |dz|
+    uint32_t voff[2], boff[2];
+    bool valid[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int oy = oy0 + rowpair * 2 + rr;
+      valid[rr] = col_valid && oy < a.OH;
+      voff[rr] = valid[rr] ? (uint32_t)nl * (uint32_t)a.Cout * plane_ob + (uint32_t)(oy * a.OW + xl) * 4u + (uint32_t)(8 * (rw >> 1)) * plane_ob : kOutside;
+      boff[rr] = valid[rr] ? (uint32_t)nl * (uint32_t)(a.Cout >> 3) * bplane + (uint32_t)(oy * a.OW + xl) + (uint32_t)(rw >> 1) * bplane : kOutside;
+    }
+    float dmx = 0.f;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      float sm[8], sq[8];
+#pragma unroll
+      for (int c8 = 0; c8 < 8; ++c8) { sm[c8] = 0.f; sq[c8] = 0.f; }
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        float o[8], res8[8], rw8[8];
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) {
+          const uint32_t so = (uint32_t)(cout0 + 16 * cb + c8) * plane_ob;
+          res8[c8] = u2f(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, voff[rr], so, 0));
+          rw8[c8] = u2f(__builtin_amdgcn_raw_buffer_load_b32(wrsrc, voff[rr], so, 0));
+        }
+        const uint32_t bso = (uint32_t)((cout0 >> 3) + 2 * cb) * bplane;
+        const uint32_t mres = res_masked ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(qrsrc, boff[rr], bso, 0) : 0xFFu;
+        const uint32_t mbs = mask_bits ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(brsrc, boff[rr], bso, 0) : 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float x = (accm[cb][2 * rr][i] + accl[cb][2 * rr][i] * (1.f / kLoScale)) * xs_inv;
+          const float y = (accm[cb][2 * rr + 1][i] + accl[cb][2 * rr + 1][i] * (1.f / kLoScale)) * xs_inv;
+          const auto sw = __builtin_amdgcn_permlane16_swap(f2u(x), f2u(y), false, false);
+          o[i] = u2f(sw[0]);
+          o[4 + i] = u2f(sw[1]);
+        }
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) {
+          const float* kc = bsw + 16 * cb + c8;
+          const float yv = o[c8] + (((mres >> c8) & 1u) ? res8[c8] : 0.f);
+          __builtin_amdgcn_raw_buffer_store_b32(f2u(yv), yrsrc, voff[rr], (uint32_t)(cout0 + 16 * cb + c8) * plane_ob, 0);
+          const bool keep = valid[rr] && (mask_bits ? ((mbs >> c8) & 1u) != 0u : __builtin_fmaf(rw8[c8], kc[256], kc[384]) > 0.f);
+          const float pz = keep ? yv : 0.f;
+          sm[c8] += pz;
+          sq[c8] = __builtin_fmaf(pz, (rw8[c8] - kc[0]) * kc[128], sq[c8]);
+          dmx = __builtin_fmaxf(dmx, __builtin_fabsf(pz));
+        }
+      }
+#pragma unroll
+      for (int c8 = 0; c8 < 8; ++c8) {
+        float s0 = sm[c8], s1 = sq[c8];
+        s0 += hs_dpp<0xB1>(s0);  s1 += hs_dpp<0xB1>(s1);
+        s0 += hs_dpp<0x4E>(s0);  s1 += hs_dpp<0x4E>(s1);
+        s0 += hs_dpp<0x141>(s0); s1 += hs_dpp<0x141>(s1);
+        s0 += hs_dpp<0x140>(s0); s1 += hs_dpp<0x140>(s1);
+        if (j == 0) {
+          float* d = red + ((((wave * 4 + rw) * 4 + cb) * 8) + c8) * 2;
+          d[0] = s0;
+          d[1] = s1;
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dmx = __builtin_fmaxf(dmx, __shfl_xor(dmx, off, 64));
+    if (lane == 0) red[4096 + wave] = dmx;
+    __syncthreads();
+    const int ptile = ty * a.tiles_x + tx;
+    if (tid < 256) {
+      const int which = tid & 1, ch = tid >> 1, sl = ch >> 6, cl = ch & 63;
+      const int cb = cl >> 4, h8 = (cl >> 3) & 1, c8 = cl & 7;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) t += red[(((((sl * 4 + w) * 4 + 2 * h8 + e) * 4 + cb) * 8) + c8) * 2 + which];
+      a.stats_part[((size_t)(ct * 128 + ch) * 2 + which) * a.stats_p + ptile] = t;
+    } else if (tid < 258) {
+      const int sl = tid - 256;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) t = __builtin_fmaxf(t, red[4096 + sl * 4 + w]);
+      a.stats_part[(size_t)a.Cout * 2 * a.stats_p + (size_t)(ct * 2 + sl) * a.stats_p + ptile] = t;
+    }
+    return;
+  }
+  if constexpr (TRAIN == 1) {
     // ---- training epilogue ----
     // statistics first, from the accumulators as they lie: lane (j, kq) holds channels 16 cb + 4 kq + i of its four pixels (row
     // pb >> 1, virtual column 16 (pb & 1) + j); the four pixels in the lane, then the 16 lanes of a DPP row; lanes j == 0 park
@@ -393,6 +510,14 @@ bool conv2d_hs3x3q_train_eligible(const Conv2dArgs& a) {
          a.pad == 1 && a.stride == 1 && a.KH == 3 && a.KW == 3 && a.H == a.OH && a.W == a.OW && (long)a.N * (a.OW + 1) < (1L << 21) &&
          (size_t)a.N * a.Cout * a.OH * a.OW * sizeof(float) < 0xC0000000u && (size_t)a.N * a.Cin * a.H * a.W * sizeof(float) < 0xC0000000u;
 }
+// a data-gradient launch with the consumer BatchNorm's sums (cells in under their scale, fp32 out) the TRAIN == 2 variant serves
+bool conv2d_hs3x3q_dgrad_eligible(const Conv2dArgs& a) {
+  return debug_switches().hs_mode < 0 && debug_switches().train_cells >= 5 && a.x_cells && !a.y_cells && !a.res_cells &&
+         a.x_amax != nullptr && a.x_amax_n < 0 && a.bs_raw != nullptr && (a.bs_mask == 2 || (a.bs_mask == 1 && a.bs_bits != nullptr)) &&
+         a.scale == nullptr && a.relu == 0 && a.Cout % 128 == 0 && a.cin_pad % 64 == 0 && a.cin_pad == a.Cin &&
+         a.pad == 1 && a.stride == 1 && a.KH == 3 && a.KW == 3 && a.H == a.OH && a.W == a.OW && (long)a.N * (a.OW + 1) < (1L << 21) &&
+         (size_t)a.N * a.Cout * a.OH * a.OW * sizeof(float) < 0xC0000000u && (size_t)a.N * a.Cin * a.H * a.W * sizeof(float) < 0xC0000000u;
+}
 int conv2d_hs3x3q_train_tiles(const Conv2dArgs& a) {
   const int vw = a.N > 1 ? a.OW + 1 : a.OW;
   return ceil_div(a.OH, kQTH) * ceil_div(a.N * vw - (a.N > 1 ? 1 : 0), 32);
@@ -406,14 +531,17 @@ bool conv2d_hs3x3q_eligible(const Conv2dArgs& a) {
 }
 
 int conv2d_hs3x3q_launch(Conv2dArgs a, hipStream_t s) {
-  const bool train = a.stats_part != nullptr;
-  ADX_REQUIRE(train ? conv2d_hs3x3q_train_eligible(a) : conv2d_hs3x3q_eligible(a), "conv2d_hs3x3q: launch outside the kernel's rules");
+  const bool train = a.stats_part != nullptr, dgrad = train && a.bs_raw != nullptr;
+  ADX_REQUIRE(dgrad ? conv2d_hs3x3q_dgrad_eligible(a) : (train ? conv2d_hs3x3q_train_eligible(a) : conv2d_hs3x3q_eligible(a)),
+              "conv2d_hs3x3q: launch outside the kernel's rules");
   static std::atomic<uint64_t> attr{0};
   if (first_on_device(attr)) {
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3q_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQLds));
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3q_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQLdsD));
-    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3q_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQLds));
-    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3q_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQLdsD));
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3q_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQLds));
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3q_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQLdsD));
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3q_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQLds));
+    ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3q_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQLdsD));
   }
   a.vw = a.N > 1 ? a.OW + 1 : a.OW;
   a.inv_vw = 1.f / (float)a.vw;
@@ -428,8 +556,11 @@ int conv2d_hs3x3q_launch(Conv2dArgs a, hipStream_t s) {
   if (train) {
     ADX_REQUIRE(a.stats_p == a.tiles_y * a.tiles_x, "conv2d_hs3x3q: statistics buffer laid out for %d tiles, launch has %d", a.stats_p,
                 a.tiles_y * a.tiles_x);
-    if (debug_switches().hs_dma) conv2d_hs3x3q_kernel<true, true><<<dim3((unsigned)grid), dim3(kQNT), kQLdsD, s>>>(a);
-    else conv2d_hs3x3q_kernel<false, true><<<dim3((unsigned)grid), dim3(kQNT), kQLds, s>>>(a);
+    if (dgrad) {
+      if (debug_switches().hs_dma) conv2d_hs3x3q_kernel<true, 2><<<dim3((unsigned)grid), dim3(kQNT), kQLdsD, s>>>(a);
+      else conv2d_hs3x3q_kernel<false, 2><<<dim3((unsigned)grid), dim3(kQNT), kQLds, s>>>(a);
+    } else if (debug_switches().hs_dma) conv2d_hs3x3q_kernel<true, 1><<<dim3((unsigned)grid), dim3(kQNT), kQLdsD, s>>>(a);
+    else conv2d_hs3x3q_kernel<false, 1><<<dim3((unsigned)grid), dim3(kQNT), kQLds, s>>>(a);
   } else if (debug_switches().hs_dma) conv2d_hs3x3q_kernel<true><<<dim3((unsigned)grid), dim3(kQNT), kQLdsD, s>>>(a);
   else conv2d_hs3x3q_kernel<false><<<dim3((unsigned)grid), dim3(kQNT), kQLds, s>>>(a);
   ADX_LAUNCH_CHECK();

@@ -126,6 +126,7 @@ bool conv2d_hs3x3_dgrad_cells(const ConvSpec& L, int N, int H, int W);
 bool conv2d_hs3x3_dgrad_stats(const ConvSpec& L, int N, int H, int W, bool x_cells, size_t stats_floats);
 // conv2d_hs16.hip: the 16x16x32 kernel's training-forward variant (cells in, fp32 + statistics out) and its tile count
 bool conv2d_hs3x3q_train_eligible(const Conv2dArgs& a);
+bool conv2d_hs3x3q_dgrad_eligible(const Conv2dArgs& a);
 int conv2d_hs3x3q_train_tiles(const Conv2dArgs& a);
 // stats_part (optional, stats_floats floats): where the launch may leave per-workgroup partial sums of its output and of its
 // squares ([Cout][2][P] floats); *stats_p = P when it did (the pipelined 3x3 stride-1 kernel does), 0 when the caller has to

@@ -251,21 +251,21 @@ def test_training_cell_tensors(tmp_path):
     the weight gradients reduced in index order a train-mode forward + backward must then come out BIT FOR BIT as with fp32 NCHW
     activations everywhere (ADX_TRAIN_CELLS=0): feature, every gradient, the running statistics.
     Level 2: the blocks' outputs are cell tensors too, and the identity the next block adds is hi + lo / 2^11 -- 22 bits of the
-    fp32 value, as in the inference executor; default (4): + the 16x16x32 forward launches and the conv-output gradients as cell
-    tensors under a scale taken from a bound (bn_bwd_apply_groups_kernel): the feature within 2e-6 of its scale, gradients within what a handful of ReLU units
+    fp32 value, as in the inference executor; 4: + the 16x16x32 forward launches and the conv-output gradients as cell tensors under a
+    scale taken from a bound (bn_bwd_apply_groups_kernel); default (5): + the 16x16x32 data gradients: the feature within 2e-6 of its scale, gradients within what a handful of ReLU units
     flipping costs on these small batches (the oracle-referenced bars are test_perception_train_mode_vs_oracle_autograd's and the full-size tests')."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
-    for cells in ("0", "1", "2", "4"):
+    for cells in ("0", "1", "2", "4", "5"):
         out = str(tmp_path / f"cells{cells}.pt")
         r = subprocess.run([sys.executable, os.path.join(root, "tests", "train_cells_worker.py"), out],
                            env=dict(os.environ, ADX_TRAIN_CELLS=cells, ADX_WGRAD_DETERMINISTIC="1"), capture_output=True, text=True,
                            timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
         outs[cells] = torch.load(out)
-    assert outs["0"].keys() == outs["1"].keys() == outs["2"].keys() == outs["4"].keys() and len(outs["0"]) == 4
+    assert outs["0"].keys() == outs["1"].keys() == outs["2"].keys() == outs["4"].keys() == outs["5"].keys() and len(outs["0"]) == 4
     for case, a in outs["0"].items():
         b = outs["1"][case]
         assert a.keys() == b.keys() and len(a) > 100
@@ -274,7 +274,7 @@ def test_training_cell_tensors(tmp_path):
                 assert (a[k] - b[k]).abs().max().item() <= 2e-6 * a[k].abs().max().item(), (case, k)
             else:
                 assert torch.equal(a[k], b[k]), (case, k, (a[k].double() - b[k].double()).abs().max().item())
-        for level in ("2", "4"):
+        for level in ("2", "4", "5"):
             c = outs[level][case]
             assert a.keys() == c.keys()
             for k in a:
