@@ -62,6 +62,9 @@ __device__ __forceinline__ f16x8 tr_pair(const unsigned char* p) {
 // staged cell instead of eight dwords and the conversion
 // XA: the same for dy -- a gradient the BatchNorm-backward apply pass wrote as cells under a scale it chose from a bound
 // (resnet_train.hip: bn_bwd_apply_groups_kernel)
+// (With both operands as cells a staged row is a copy; LDS-DMA loads for it -- a wave writes 16 pixels x the 4 cell groups of a panel,
+// issued at the top of an iteration, awaited before its barrier -- were built and measured 0.3 ms per training step SLOWER than the
+// register path, where the same loads in conv2d_hs16.hip gain 0.3: profiles/README.md, round 5.  Removed.)
 template <int NPX, int S, bool XC = false, bool XA = false>
 __global__ void __launch_bounds__(kWThreads) conv2d_wgrad_hs_kernel(const WgradHsArgs a) {
   constexpr int NPXB = S * NPX + 2;               // x row segment with its halo columns

@@ -23,7 +23,7 @@ python tools/tick_timeline.py analyze gpurun_out/${R}_tick_cls > gpurun_out/${R}
 rm -rf gpurun_out/prof_tr gpurun_out/${R}_tr_trace
 bash tools/profile_train.sh > gpurun_out/${R}_train_step_kernels.txt 2>&1
 cp $(ls -t gpurun_out/prof_tr/*/*kernel_stats.csv | head -1) gpurun_out/${R}_train_kernel_stats.csv
-python tools/ab_env_train.py ADX_TRAIN_CELLS 0 1 2 3 4 > gpurun_out/${R}_ab_train_cells.txt 2>&1
+python tools/ab_env_train.py ADX_TRAIN_CELLS 0 1 2 3 4 5 > gpurun_out/${R}_ab_train_cells.txt 2>&1
 NOSYNC=1 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${R}_tr_trace -- python3 tools/train_time.py > /dev/null 2>&1
 python tools/train_gaps.py gpurun_out/${R}_tr_trace > gpurun_out/${R}_train_gaps.txt 2>&1
 rm -rf gpurun_out/${R}_tr_trace
