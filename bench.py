@@ -245,7 +245,7 @@ def conv2d_roofline(dev, reps=10):
                              "MFMA flops the kernel actually issues (3 x algorithmic: hi*hi + hi*lo + lo*hi) / the same time",
             # the inference instantiations (cell tensors in and out); the same summary also holds the training leg's launches of
             # these kernels (statistics epilogues, fp32 outputs)
-            "avg_launch_ms_rocprof": rocprof_avg_ms(lambda n: ("conv2d_hs3x3q_kernel<" in n and ", false>(" in n)         # (<DMA, TRAIN = false>)
+            "avg_launch_ms_rocprof": rocprof_avg_ms(lambda n: ("conv2d_hs3x3q_kernel<" in n and ", 0>(" in n)             # (<DMA, TRAIN = 0>)
                                                     or ("conv2d_hs3x3_kernel<" in n and ", 0, true, true" in n)),          # (<MODE, STATS = 0, XCELLS, YCELLS, ..>)
             "fp32_mfma_peak_tflops": PEAK_F32_TFLOPS, "frac_of_fp32_mfma_peak": round(equiv / PEAK_F32_TFLOPS, 3),
             "traffic": pmc_traffic("conv2d_hs3x3_kernel"),
