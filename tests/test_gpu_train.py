@@ -291,6 +291,36 @@ def test_training_cell_tensors(tmp_path):
             assert any(not torch.equal(a[k], c[k]) for k in a), (case, level)       # (the level did run: something is rounded differently)
 
 
+def test_perception_backward_is_exactly_linear_in_the_incoming_gradient(tmp_path):
+    """The perception backward is linear in d(loss)/d(feature), and every scale the split-fp16 kernels choose for a gradient tensor is
+    a power of two taken from that tensor's own range (exact maxima for the fp32-layout launches, the bound of
+    bn_bwd_consts_kernel for the cell-layout ones): multiplying the incoming gradient by 2^k must multiply EVERY parameter gradient by
+    exactly 2^k -- same mantissas, bit for bit -- for tiny and for large gradients alike (k = -24, +10), with the weight gradients
+    reduced in index order.  A scale that ignored the tensor's range (or an underflowing intermediate) breaks this."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for k in ("0", "-24", "10"):
+        out = str(tmp_path / f"scale{k}.pt")
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "train_cells_worker.py"), out],
+                           env=dict(os.environ, ADX_WGRAD_DETERMINISTIC="1", ADX_TEST_GRAD_SCALE_LOG2=k), capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[k] = torch.load(out)
+    for case, a in outs["0"].items():
+        for k in ("-24", "10"):
+            b, f = outs[k][case], 2.0 ** float(k)
+            assert torch.equal(a["feature"], b["feature"]), (case, k)
+            for name in a:
+                if not name.startswith("grad."):
+                    continue
+                if name in ("grad.conv1.weight", "grad.fc.weight", "grad.fc.bias"):       # reduced with float atomics
+                    assert (a[name] * f - b[name]).abs().max().item() <= 2e-6 * f * a[name].abs().max().item(), (case, k, name)
+                else:
+                    assert torch.equal(a[name] * f, b[name]), (case, k, name, ((a[name] * f).double() - b[name].double()).abs().max().item())
+
+
 @pytest.mark.parametrize("hw,small_gamma", [((64, 96), False), ((70, 102), False), ((64, 96), True)])
 def test_perception_train_mode_vs_oracle_autograd(hw, small_gamma):
     """Batch-statistics BatchNorm forward, running-buffer update and every ResNet-34 parameter gradient ((70, 102): odd map

@@ -21,7 +21,8 @@ def run():
         img = P.synthetic_batch(b, 16, image_hw=hw, seed=23)["imgs"].to("cuda:0")
         w = P._uniform("perc.w", 23, (b, 64), -1.0, 1.0).to("cuda:0")
         feat = m.perception(img)
-        (feat * w).sum().backward()
+        # ADX_TEST_GRAD_SCALE_LOG2=k: d(loss)/d(feature) times 2^k (the backward pass is linear in it: test_gpu_train.py)
+        (feat * (w * 2.0 ** float(os.environ.get("ADX_TEST_GRAD_SCALE_LOG2", "0")))).sum().backward()
         res = {"feature": feat.detach().cpu()}
         for k, p in m.perception.named_parameters():
             res["grad." + k] = p.grad.cpu()
