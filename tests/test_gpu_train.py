@@ -299,6 +299,8 @@ def test_perception_backward_is_exactly_linear_in_the_incoming_gradient(tmp_path
     reduced in index order.  A scale that ignored the tensor's range (or an underflowing intermediate) breaks this."""
     import subprocess
     import sys
+    if os.environ.get("ADX_CONV_EXACT") == "1" or os.environ.get("ADX_WGRAD_EXACT") == "1":
+        pytest.skip("the exact-fp32 weight-gradient kernel reduces with float atomics: no bit-for-bit statement")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
     for k in ("0", "-24", "10"):
