@@ -1,6 +1,7 @@
 // Shared device/host helpers for libadx (gfx950 only: wave64, fp32 MFMA).
 #pragma once
 #include <atomic>
+#include <mutex>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -69,13 +70,31 @@ const DebugSwitches& debug_switches();
 
 // "once per device" for per-device state such as hipFuncSetAttribute(MaxDynamicSharedMemorySize): a process-wide flag would
 // leave a second GPU of the same process without the attribute (one process per GPU is the deployment, but not a rule).
-// True the first time the calling thread's current device meets this flag (devices folded modulo 64).
-inline bool first_on_device(std::atomic<uint64_t>& done) {
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  const uint64_t bit = 1ull << (dev & 63);
-  return (done.fetch_or(bit, std::memory_order_relaxed) & bit) == 0;
-}
+//   if (DeviceOnce once{flag}; once) { ADX_CHECK_HIP(hipFuncSetAttribute(...)); ...; once.commit(); }
+// The body runs under a mutex the first time the calling thread's current device meets `flag` (devices folded modulo 64) and
+// the device's bit is published only by commit(), i.e. after every attribute call has succeeded: a second host thread on the
+// same device either waits for the setup or finds it done -- it never launches in between --, and a setup that failed (the
+// ADX_CHECK_HIP in the body returned) is retried by the next call instead of leaving every later launch to fail.
+struct DeviceOnce {
+  std::atomic<uint64_t>& done;
+  uint64_t bit = 0;
+  bool owner = false;
+  static std::mutex& mu() { static std::mutex m; return m; }
+  explicit DeviceOnce(std::atomic<uint64_t>& d) : done(d) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    mu().lock();
+    if (done.load(std::memory_order_relaxed) & bit) { mu().unlock(); return; }
+    owner = true;
+  }
+  ~DeviceOnce() { if (owner) mu().unlock(); }
+  DeviceOnce(const DeviceOnce&) = delete;
+  DeviceOnce& operator=(const DeviceOnce&) = delete;
+  explicit operator bool() const { return owner; }
+  void commit() { done.fetch_or(bit, std::memory_order_release); }
+};
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -19,7 +19,8 @@ void set_error(const char* fmt, ...) {
 const DebugSwitches& debug_switches() {
   static const DebugSwitches sw = [] {
     DebugSwitches d;
-    auto is = [](const char* name, char v) { const char* e = getenv(name); return e != nullptr && e[0] == v; };
+    // exact one-character values: "10" is not "1" (the Python side compares whole strings too)
+    auto is = [](const char* name, char v) { const char* e = getenv(name); return e != nullptr && e[0] == v && e[1] == '\0'; };
     d.conv_exact = is("ADX_CONV_EXACT", '1');
     d.wgrad_exact = is("ADX_WGRAD_EXACT", '1');
     d.tconv_exact = is("ADX_TCONV_EXACT", '1');

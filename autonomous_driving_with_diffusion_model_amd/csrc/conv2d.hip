@@ -451,13 +451,14 @@ int conv2d_launch_raw(const ConvSpec& L, const float* x, const float* w, const f
   const size_t grid = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y * N;
   ADX_REQUIRE(grid < (1u << 31), "conv2d: grid too large");
   static std::atomic<uint64_t> attr_set{0};  // dynamic LDS above 64 KB must be opted into once per kernel
-  if (first_on_device(attr_set)) {
+  if (DeviceOnce once{attr_set}; once) {
     const void* fns[6] = {reinterpret_cast<const void*>(&conv2d_kernel<1, 3, 1>), reinterpret_cast<const void*>(&conv2d_kernel<2, 3, 1>),
                           reinterpret_cast<const void*>(&conv2d_kernel<2, 1, 1>), reinterpret_cast<const void*>(&conv2d_kernel<2, 7, 1>),
                           reinterpret_cast<const void*>(&conv2d_kernel<1, 1, 1>), reinterpret_cast<const void*>(&conv2d_kernel<1, 3, 2>)};
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_kernel<1, 3, 2, 8>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
     for (const void* f : fns) ADX_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+    once.commit();
   }
   const dim3 g((unsigned)grid), blk(256);
   if (L.stride == 1 && L.k == 3 && rows == 2 && cch == 8) conv2d_kernel<1, 3, 2, 8><<<g, blk, lds, s>>>(a);
@@ -665,7 +666,7 @@ __global__ void __launch_bounds__(256) range_scan_kernel(const uint32_t* __restr
   if (bad) atomicOr(flag, 1u);
 }
 
-static int range_check(const char* what, int index, const float* t, size_t floats, bool cells, hipStream_t s) {
+extern "C++" int adx::conv2d_range_check(const char* what, int index, const float* t, size_t floats, bool cells, hipStream_t s) {
   if (!debug_switches().check_range) return ADX_OK;
   static unsigned* flag = nullptr;
   if (flag == nullptr) ADX_CHECK_HIP(hipMalloc(&flag, sizeof(unsigned)));
@@ -737,7 +738,7 @@ static int resnet_forward_impl(adx_resnet* r, const void* packed, void* workspac
       if (rc != ADX_OK) return rc;
     }
     st = Cursor{1, 0, h2, w2, pooled_cells};
-    return range_check("the stem (conv1 + bn1 + relu + maxpool), tensor", 0, pooled, (size_t)n * 64 * h2 * w2, pooled_cells, s);
+    return conv2d_range_check("the stem (conv1 + bn1 + relu + maxpool), tensor", 0, pooled, (size_t)n * 64 * h2 * w2, pooled_cells, s);
   };
 
   // Activation formats (conv2d_hs.hip: XCELLS).  Where a layer's 3x3 stride-1 convs run as plain launches of the pipelined
@@ -806,12 +807,12 @@ static int resnet_forward_impl(adx_resnet* r, const void* packed, void* workspac
     }
     ADX_REQUIRE(out_cells || !(mid_cells || id_cells),
                 "adx_resnet_forward: internal error (a conv with cell-layout operands whose reader wants fp32)");
-    rc = range_check("conv1 + bn1 + relu of BasicBlock", (int)b, buf[mid] + off_out, (size_t)n * c1.cout * OH * OW, mid_cells, s);
+    rc = conv2d_range_check("conv1 + bn1 + relu of BasicBlock", (int)b, buf[mid] + off_out, (size_t)n * c1.cout * OH * OW, mid_cells, s);
     if (rc != ADX_OK) return rc;
     rc = conv2d_launch(c2, base, buf[mid] + off_out, identity, dst, n, OH, OW, 1, s,
                        (mid_cells ? kFmtXCells : 0) | (out_cells ? kFmtYCells : 0) | (id_cells ? kFmtResCells : 0));
     if (rc != ADX_OK) return rc;
-    rc = range_check("the output of BasicBlock", (int)b, dst, (size_t)n * c2.cout * OH * OW, out_cells, s);
+    rc = conv2d_range_check("the output of BasicBlock", (int)b, dst, (size_t)n * c2.cout * OH * OW, out_cells, s);
     if (rc != ADX_OK) return rc;
     st = Cursor{ci, r->block_has_ds[b] ? cur : outb, OH, OW, out_cells};
     return ADX_OK;
@@ -845,7 +846,11 @@ static int resnet_forward_impl(adx_resnet* r, const void* packed, void* workspac
     if (r->side_device != dev || r->side[nsub - 2] == nullptr) {
       {
         if (r->side_device != dev) {
+          // the handle moved to another device (module.to(other_gpu)): streams AND events belong to the device they were
+          // created on -- recording an old event on a new stream fails -- so all of them are recreated here
           for (auto& st : r->side) if (st != nullptr) { (void)hipStreamDestroy(st); st = nullptr; }
+          if (r->ev_fork != nullptr) { (void)hipEventDestroy(r->ev_fork); r->ev_fork = nullptr; }
+          for (auto& ev : r->ev_join) if (ev != nullptr) { (void)hipEventDestroy(ev); ev = nullptr; }
           r->side_device = dev;
         }
         if (r->ev_fork == nullptr) ADX_CHECK_HIP(hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming));

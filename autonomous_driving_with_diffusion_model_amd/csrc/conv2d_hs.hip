@@ -1455,9 +1455,10 @@ static int hs_launch_t(Conv2dArgs a, hipStream_t s) {
                          (DS ? 4 : 2) * kHsCout * sizeof(float) + 16;
   static_assert(lds <= 80 * 1024, "two workgroups per CU need <= 80 KB each");
   static std::atomic<uint64_t> attr{0};
-  if (first_on_device(attr)) {
+  if (DeviceOnce once{attr}; once) {
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs_kernel<STRIDE, K, ROWS, PBUF, DS, XCELLS, YCELLS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    once.commit();
   }
   a.tiles_x = ceil_div(a.OW, kTileW); a.tiles_y = ceil_div(a.OH, TH); a.cout_tiles = a.Cout / kHsCout;
   const size_t grid = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y * a.N;
@@ -1475,9 +1476,10 @@ static int hs_stem_launch(Conv2dArgs a, hipStream_t s) {
                          (POOL ? (4 * 64 + 2) * sizeof(float) : 0);     // parked columns + the dummy words of the other lanes
   static_assert(lds <= 80 * 1024, "two workgroups per CU need <= 80 KB each");
   static std::atomic<uint64_t> attr{0};
-  if (first_on_device(attr)) {
+  if (DeviceOnce once{attr}; once) {
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs_stem_kernel<POOL, U8>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    once.commit();
   }
   a.tiles_x = ceil_div(a.OW, kTileW); a.cout_tiles = 1;
   a.tiles_y = POOL ? ceil_div((a.OH - 1) / 2 + 1, 4) : ceil_div(a.OH, 8);
@@ -1575,7 +1577,7 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
   constexpr size_t lds_bs = lds + 4 * 64 * CT * sizeof(float);       // STATS == 2: + the consumer BatchNorm's constants
   static_assert(lds_bs <= (MODE == 0 ? 80 : 160) * 1024, "LDS budget");
   static std::atomic<uint64_t> attr{0};
-  if (first_on_device(attr)) {
+  if (DeviceOnce once{attr}; once) {
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 0>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 1>),
@@ -1588,6 +1590,7 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 2, false, false, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bs));
+    once.commit();
   }
   a.tiles_x = ceil_div(a.OW, kTileW); a.tiles_y = ceil_div(a.OH, TH); a.cout_tiles = a.Cout / (kHsCout * CT);
   const size_t grid = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y * a.N;
@@ -1627,7 +1630,7 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
                   "conv2d_hs: a cell-layout input with statistics belongs to a training-forward launch or to a data gradient with its scale");
       ADX_REQUIRE((size_t)a.N * a.Cin * a.H * a.W * sizeof(float) < 0xC0000000u, "conv2d_hs: a cell-layout tensor exceeds the 32-bit byte offsets");
       static std::atomic<uint64_t> xattr{0};
-      if (first_on_device(xattr)) {
+      if (DeviceOnce once{xattr}; once) {
         ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 1, true, false, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 1, true, false, false>),
@@ -1636,6 +1639,7 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bs));
         ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 2, true, false, false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bs));
+        once.commit();
       }
       if (a.bs_raw != nullptr) {
         if (vrow) conv2d_hs3x3_kernel<MODE, 2, true, false, true><<<dim3((unsigned)sgrid), dim3(NT), lds_bs, s>>>(a);
@@ -1673,11 +1677,12 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
   if (a.x_cells && xscaled && !a.y_cells && !a.res_cells) {
     // a data gradient (no statistics wanted from it) on a gradient that was written as cells: fp32 output [+ fp32 residual]
     static std::atomic<uint64_t> dattr{0};
-    if (first_on_device(dattr)) {
+    if (DeviceOnce once{dattr}; once) {
       ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 0, true, false, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 0, true, false, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      once.commit();
     }
     ADX_REQUIRE((size_t)a.N * a.Cin * a.H * a.W * sizeof(float) < 0xC0000000u, "conv2d_hs: a cell-layout tensor exceeds the 32-bit byte offsets");
     if (vrow) {
@@ -1696,10 +1701,11 @@ static int hs3x3_launch(Conv2dArgs a, hipStream_t s) {
     if (conv2d_hs3x3q_eligible(a)) return conv2d_hs3x3q_launch(a, s);      // the 16x16x32 kernel (conv2d_hs16.hip) where its tile rules hold
     constexpr size_t clds = lds;
     static std::atomic<uint64_t> cattr{0};
-    if (first_on_device(cattr)) {
+    if (DeviceOnce once{cattr}; once) {
       const void* fns[2] = {reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 0, true, true>),
                             reinterpret_cast<const void*>(&conv2d_hs3x3_kernel<MODE, 0, false, true>)};
       for (const void* f : fns) ADX_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
+      once.commit();
     }
     // column tiles over the images side by side with one shared zero column between neighbours (conv2d_hs3x3_kernel: YCELLS):
     // one padded MFMA column per image instead of the round-up to 32

@@ -535,13 +535,14 @@ int conv2d_hs3x3q_launch(Conv2dArgs a, hipStream_t s) {
   ADX_REQUIRE(dgrad ? conv2d_hs3x3q_dgrad_eligible(a) : (train ? conv2d_hs3x3q_train_eligible(a) : conv2d_hs3x3q_eligible(a)),
               "conv2d_hs3x3q: launch outside the kernel's rules");
   static std::atomic<uint64_t> attr{0};
-  if (first_on_device(attr)) {
+  if (DeviceOnce once{attr}; once) {
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3q_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQLds));
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3q_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQLdsD));
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3q_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQLds));
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3q_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQLdsD));
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3q_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQLds));
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_hs3x3q_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kQLdsD));
+    once.commit();
   }
   a.vw = a.N > 1 ? a.OW + 1 : a.OW;
   a.inv_vw = 1.f / (float)a.vw;

@@ -198,6 +198,9 @@ bool conv2d_wgrad_stem_hs_eligible(int Cin, int Cout, int k, int stride, int pad
 int conv2d_wgrad_stem_hs(const float* x, const float* dy, float* dw, int N, int H, int W, const uint32_t* dy_amax, int dy_amax_n,
                          hipStream_t s);
 inline int conv_out_dim(int h, int k, int s, int p) { return (h + 2 * p - k) / s + 1; }
+// ADX_CHECK_RANGE=1 (no-op otherwise): fails with ADX_ERR_RANGE naming (what, index) when the tensor holds |x| >= 65504 or a
+// non-finite value (cells: an fp16 hi half that is inf / NaN); synchronises the stream
+int conv2d_range_check(const char* what, int index, const float* t, size_t floats, bool cells, hipStream_t s);
 int maxpool_launch(const float* x, float* y, int planes, int H, int W, int OH, int OW, hipStream_t s);
 int avgpool_fc_launch(const float* x, const float* fw, const float* fb, float* out, int batch, int C, int HW, int out_dim,
                       hipStream_t s, int x_cells = 0);

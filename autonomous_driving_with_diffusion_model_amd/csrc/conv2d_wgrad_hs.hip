@@ -310,9 +310,10 @@ static int wgrad_hs_launch(WgradHsArgs a, hipStream_t s) {
   constexpr size_t need = std::max(lds, (size_t)32 * 576 * sizeof(float));
   static_assert(need <= 160 * 1024, "LDS budget");
   static std::atomic<uint64_t> attr{0};
-  if (first_on_device(attr)) {
+  if (DeviceOnce once{attr}; once) {
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad_hs_kernel<NPX, S, XC, XA>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+    once.commit();
   }
   a.segs = ceil_div(a.OW, NPX);
   a.units = a.N * a.segs;

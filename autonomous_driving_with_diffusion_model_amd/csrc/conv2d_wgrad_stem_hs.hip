@@ -312,9 +312,10 @@ int conv2d_wgrad_stem_hs(const float* x, const float* dy, float* dw, int N, int 
   a.row_chunks = ceil_div(a.OH, a.rows_per_unit);
   a.units = N * a.segs * a.row_chunks;
   static std::atomic<uint64_t> attr{0};
-  if (first_on_device(attr)) {
+  if (DeviceOnce once{attr}; once) {
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad_stem_hs_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
+    once.commit();
   }
   static_assert(kLds <= 160 * 1024 && (size_t)64 * 160 * sizeof(float) <= kLds, "LDS budget");
   const int grid = std::min(a.units, 256);

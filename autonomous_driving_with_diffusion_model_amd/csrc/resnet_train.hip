@@ -1089,12 +1089,13 @@ int conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int
     return sizeof(float) * std::max(stage, red);
   };
   static std::atomic<uint64_t> attr_set{0};
-  if (first_on_device(attr_set)) {
+  if (DeviceOnce once{attr_set}; once) {
     const void* fns[4] = {reinterpret_cast<const void*>(&conv2d_wgrad_kernel<1, 3, 9, 32>),
                           reinterpret_cast<const void*>(&conv2d_wgrad_kernel<2, 3, 9, 16>),
                           reinterpret_cast<const void*>(&conv2d_wgrad_kernel<2, 1, 1, 32>),
                           reinterpret_cast<const void*>(&conv2d_wgrad_kernel<2, 7, 5, 3>)};
     for (const void* f : fns) ADX_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    once.commit();
   }
   if (stride == 1 && k == 3) conv2d_wgrad_kernel<1, 3, 9, 32><<<grid, blk, lds_bytes(32, 9), s>>>(a);
   else if (stride == 2 && k == 3) conv2d_wgrad_kernel<2, 3, 9, 16><<<grid, blk, lds_bytes(16, 9), s>>>(a);
@@ -1137,13 +1138,16 @@ size_t adx_conv2d_wgrad_scratch_bytes(void) {
   return adx::kAmaxPartials * sizeof(uint32_t) + adx::conv2d_wgrad_partials_floats() * sizeof(float);     // [range partials | ADX_WGRAD_DETERMINISTIC's copies]
 }
 
-int adx_conv2d_wgrad(const adx_conv2d_desc* d, const float* x, const float* dy, float* dw, int32_t n, int32_t h,
-                     int32_t w, void* scratch, adx_stream stream) {
+int adx_conv2d_wgrad_ex(const adx_conv2d_desc* d, const float* x, const float* dy, float* dw, int32_t n, int32_t h,
+                        int32_t w, void* scratch, int32_t estimate_range, adx_stream stream) {
   using namespace adx;
   ADX_REQUIRE(d && x && dy && dw, "adx_conv2d_wgrad: null argument");
   ADX_REQUIRE(n >= 1 && h + 2 * d->pad >= d->k && w + 2 * d->pad >= d->k, "adx_conv2d_wgrad: input too small");
+  ADX_REQUIRE(!estimate_range || scratch != nullptr, "adx_conv2d_wgrad: the range estimate needs the scratch buffer");
   hipStream_t s = (hipStream_t)stream;
-  uint32_t* amax = (uint32_t*)scratch;
+  // the scratch holds [range partials | ADX_WGRAD_DETERMINISTIC's per-split copies]; the two uses are independent: the range
+  // estimate (which also moves the stem onto the split-fp16 kernel) runs only when asked for
+  uint32_t* amax = estimate_range ? (uint32_t*)scratch : nullptr;
   int n_amax = 0;
   if (amax != nullptr) {
     const size_t total = (size_t)n * d->cout * conv_out_dim(h, d->k, d->stride, d->pad) * conv_out_dim(w, d->k, d->stride, d->pad);
@@ -1154,9 +1158,14 @@ int adx_conv2d_wgrad(const adx_conv2d_desc* d, const float* x, const float* dy, 
   struct PartsScope {
     ~PartsScope() { conv2d_wgrad_set_partials(nullptr, 0); }
   } parts_scope;
-  if (amax != nullptr && conv2d_wgrad_partials_floats() > 0)
-    conv2d_wgrad_set_partials(reinterpret_cast<float*>(amax + kAmaxPartials), conv2d_wgrad_partials_floats());
+  if (scratch != nullptr && conv2d_wgrad_partials_floats() > 0)
+    conv2d_wgrad_set_partials(reinterpret_cast<float*>((uint32_t*)scratch + kAmaxPartials), conv2d_wgrad_partials_floats());
   return conv2d_wgrad(x, dy, dw, n, d->cin, h, w, d->cout, d->k, d->stride, d->pad, s, amax, n_amax);
+}
+
+int adx_conv2d_wgrad(const adx_conv2d_desc* d, const float* x, const float* dy, float* dw, int32_t n, int32_t h,
+                     int32_t w, void* scratch, adx_stream stream) {
+  return adx_conv2d_wgrad_ex(d, x, dy, dw, n, h, w, scratch, scratch != nullptr ? 1 : 0, stream);
 }
 
 }  // extern "C"
@@ -1428,6 +1437,16 @@ int adx_resnet_forward_train(adx_resnet* r, const float* const* T, int32_t n_ten
   tape->final_map = cur; tape->fh = H; tape->fw_ = W;
   tape->fwd_floats = ws.off;
   ADX_LAUNCH_CHECK();
+  if (debug_switches().check_range) {
+    // ADX_CHECK_RANGE=1, training: every tensor a split-fp16 conv multiplies -- the input of each conv, fp32 or cells -- scanned
+    // after the pass (the tape holds them all); names the first conv whose operand leaves the fp16 range
+    for (size_t i = 1; i < tape->recs.size(); ++i) {
+      const adx_resnet_tape::Rec& q = tape->recs[i];
+      if (q.x == nullptr || q.L == nullptr) continue;
+      int rc2 = conv2d_range_check("the training forward's input of conv", (int)i, q.x, (size_t)batch * q.L->cin * q.H * q.W, q.x_cells, s);
+      if (rc2 != ADX_OK) return rc2;
+    }
+  }
   return avgpool_fc_launch(cur, T[r->t_fcw], T[r->t_fcb], feature, batch, 512, H * W, r->out_dim, s);
 }
 

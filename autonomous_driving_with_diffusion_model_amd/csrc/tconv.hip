@@ -414,13 +414,14 @@ static int launch(const TConvArgs& a, int grid, size_t lds, int nw, hipStream_t 
   constexpr int PF = NF >= 8 ? 2 : ((MF * NF >= 4) ? 4 : 8);
   constexpr int PF16 = NF >= 8 ? 2 : (MF * NF >= 8 ? 2 : 4);  // 1024-thread workgroups: <= 128 VGPRs per lane
   static std::atomic<uint64_t> attr_set{0};  // dynamic LDS above 64 KB must be opted into once per kernel
-  if (first_on_device(attr_set)) {
+  if (DeviceOnce once{attr_set}; once) {
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_kernel<MF, NF, PF16, 16>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxTconvLds));
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_kernel<MF, NF, PF, 8>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxTconvLds));
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_kernel<MF, NF, PF, 4>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxTconvLds));
+    once.commit();
   }
   if (nw == 16) tconv_kernel<MF, NF, PF16, 16><<<dim3(grid), dim3(1024), lds, s>>>(a);
   else if (nw == 8) tconv_kernel<MF, NF, PF, 8><<<dim3(grid), dim3(512), lds, s>>>(a);

@@ -465,9 +465,10 @@ int chain_pack(const adx_tconv_desc* d, const float* w, const adx_tconv_desc* r,
 
 int chain_launch(const ChainArgs& ca, int grid, size_t lds_bytes, hipStream_t s) {
   static std::atomic<uint64_t> attr_set{0};
-  if (first_on_device(attr_set)) {
+  if (DeviceOnce once{attr_set}; once) {
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_chain_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainMaxLds));
+    once.commit();
   }
   ADX_REQUIRE(lds_bytes <= kChainMaxLds, "tconv_chain: %zu bytes of LDS exceed %zu", lds_bytes, kChainMaxLds);
   tconv_chain_kernel<<<dim3(grid), dim3(kChNT), lds_bytes, s>>>(ca);

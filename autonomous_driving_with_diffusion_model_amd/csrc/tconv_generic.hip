@@ -165,9 +165,10 @@ int tconv_generic_forward(const adx_tconv_desc* d, const adx_tconv_io* io, hipSt
   ADX_REQUIRE(lds <= kMaxGenericLds, "tconv (general-shape kernel): a sample's input of %d x %d floats does not fit the LDS",
               a.cin, a.lin);
   static std::atomic<uint64_t> attr_set{0};
-  if (first_on_device(attr_set)) {
+  if (DeviceOnce once{attr_set}; once) {
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_generic_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxGenericLds));
+    once.commit();
   }
   tconv_generic_kernel<<<dim3(io->batch * a.ntiles), dim3(256), lds, s>>>(a);
   ADX_LAUNCH_CHECK();

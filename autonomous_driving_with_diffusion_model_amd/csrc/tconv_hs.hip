@@ -879,9 +879,10 @@ static int hs_tile(const adx_tconv_desc* d, int batch, HsTile* t) {
 template <int NF, int NW, int PF>
 static int hs_launch(const HsArgs& a, int grid, size_t lds, hipStream_t s) {
   static std::atomic<uint64_t> attr_set{0};  // dynamic LDS above 64 KB must be opted into once per kernel
-  if (first_on_device(attr_set)) {
+  if (DeviceOnce once{attr_set}; once) {
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_hs_kernel<NF, NW, PF>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxHsLds));
+    once.commit();
   }
   tconv_hs_kernel<NF, NW, PF><<<dim3(grid), dim3(64 * NW), lds, s>>>(a);
   ADX_LAUNCH_CHECK();
@@ -907,11 +908,12 @@ static bool hsd_prepare(const adx_tconv_desc* d, const HsArgs& ha, const HsTile&
 
 static int hsd_launch(const HsdArgs& da, int grid, size_t lds, hipStream_t s) {
   static std::atomic<uint64_t> attr_set{0};
-  if (first_on_device(attr_set)) {
+  if (DeviceOnce once{attr_set}; once) {
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_hsd_kernel<kHsdPF, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_hsd_kernel<kHsdPF, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    once.commit();
   }
   if (da.log2_ncell >= 2) tconv_hsd_kernel<kHsdPF, true><<<dim3(grid), dim3(256), lds, s>>>(da);
   else tconv_hsd_kernel<kHsdPF, false><<<dim3(grid), dim3(256), lds, s>>>(da);
@@ -921,11 +923,12 @@ static int hsd_launch(const HsdArgs& da, int grid, size_t lds, hipStream_t s) {
 
 static int hsd_launch_pair(const HsdPair& pr, int grid, size_t lds, hipStream_t s) {
   static std::atomic<uint64_t> attr_set{0};
-  if (first_on_device(attr_set)) {
+  if (DeviceOnce once{attr_set}; once) {
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_hsd_pair_kernel<kHsdPF, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_hsd_pair_kernel<kHsdPF, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    once.commit();
   }
   if (pr.a.log2_ncell >= 2) tconv_hsd_pair_kernel<kHsdPF, true><<<dim3(grid), dim3(256), lds, s>>>(pr);
   else tconv_hsd_pair_kernel<kHsdPF, false><<<dim3(grid), dim3(256), lds, s>>>(pr);
@@ -1056,11 +1059,12 @@ int tconv_hs_forward(const adx_tconv_desc* d, const adx_tconv_io* io, hipStream_
 template <int NF, int PF>
 static int hs_launch_mixed(const HsMixed& pr, int grid, size_t lds, hipStream_t s) {
   static std::atomic<uint64_t> attr_set{0};
-  if (first_on_device(attr_set)) {
+  if (DeviceOnce once{attr_set}; once) {
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_hs_mixed_kernel<NF, 8, PF, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxHsLds));
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_hs_mixed_kernel<NF, 8, PF, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxHsLds));
+    once.commit();
   }
   if (pr.b.log2_ncell >= 2) tconv_hs_mixed_kernel<NF, 8, PF, true><<<dim3(grid), dim3(512), lds, s>>>(pr);
   else tconv_hs_mixed_kernel<NF, 8, PF, false><<<dim3(grid), dim3(512), lds, s>>>(pr);

@@ -526,9 +526,10 @@ int pipe_launch(const PipeArgs& a, hipStream_t s) {
   ADX_REQUIRE((a.C / a.groups) % 4 == 0, "tconv_pipe: GroupNorm group width must be a multiple of 4");
   const size_t lds = pipe_lds_bytes(a.C, a.rows * a.L, a.ntap);
   static std::atomic<uint64_t> attr{0};
-  if (first_on_device(attr)) {
+  if (DeviceOnce once{attr}; once) {
     ADX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_pipe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)kPipeMaxLds));
+    once.commit();
   }
   tconv_pipe_kernel<<<dim3((unsigned)(a.n_conv * a.P + 1)), dim3(kPipeNT), lds, s>>>(a);
   ADX_LAUNCH_CHECK();

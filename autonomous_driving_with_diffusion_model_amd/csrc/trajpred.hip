@@ -846,7 +846,7 @@ static int tp_common(adx_trajpred* t, const void* packed, int batch, int T, Traj
   a->B = batch;
   a->T = T;
   static std::atomic<uint64_t> attr_set{0};
-  if (first_on_device(attr_set)) {
+  if (DeviceOnce once{attr_set}; once) {
     const void* f32s[3] = {reinterpret_cast<const void*>(&trajpred_forward_kernel<32>),
                            reinterpret_cast<const void*>(&trajpred_backward_kernel<32>),
                            reinterpret_cast<const void*>(&guided_output_kernel<32>)};
@@ -857,6 +857,7 @@ static int tp_common(adx_trajpred* t, const void* packed, int batch, int T, Traj
       ADX_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats<32>() * sizeof(float))));
     for (const void* f : f64s)
       ADX_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats<64>() * sizeof(float))));
+    once.commit();
   }
   if (T >= 32) {
     const size_t need = adx_trajpred_scratch_bytes(t, batch, T);

@@ -84,7 +84,14 @@ class _PerceptionTrainFn(torch.autograd.Function):
                 for i, e in enumerate(entries):
                     grp = module._tensor_groups[i]
                     if not e.is_buffer and grp >= 0:
-                        named[e.key]._adx_grad_event = (grp, events[grp])
+                        # the group's event covers this gradient only where the native call wrote it INTO the bucket view; a
+                        # buffer of its own (`.grad` already present: accumulation over several backwards; the view lent to
+                        # another node of the graph) reaches the bucket through AccumulateGrad's add, which is queued on the
+                        # compute stream after this whole call -- tagged (grp, None): "no event covers this one"
+                        p = named[e.key]
+                        view = getattr(p, "_adx_grad_view", None)
+                        in_view = view is not None and slots[i].data_ptr() == view.data_ptr()
+                        p._adx_grad_event = (grp, events[grp] if in_view else None)
         finally:
             ctx.tape.release()
             ctx.ws = None            # 27 GB of taped activations at B = 64: free them with the tape
@@ -102,11 +109,17 @@ class PerceptionResNet34(nn.Module):
         self._packed = None
         self._pack_key = None
         self._ws = None
-        # eval passes of >= 16 images run on a stream of their own and may run ahead of the caller's queued work when the
-        # image is the one of the previous pass (_on_pass_stream); ADX_PERCEPTION_AHEAD=0 or `.run_ahead = False`: caller's stream
-        self.run_ahead = os.environ.get("ADX_PERCEPTION_AHEAD", "1") != "0"
+        # eval passes of >= 16 images run on a stream of their own and may run ahead of the caller's queued work when the image
+        # is the one of the previous pass (_on_pass_stream).  `.run_ahead`: "frozen" (default) -- only inside a `frozen_image`
+        # context, where the caller vouches that nothing writes the image; "version" -- also outside, on identity + autograd's
+        # version counter (the caller vouches that the image is only ever written through torch ops on ITS tensor object: a
+        # write through `img.data`, DLPack, or a raw data_ptr() moves no counter); False / ADX_PERCEPTION_AHEAD=0 -- never
+        env = os.environ.get("ADX_PERCEPTION_AHEAD", "frozen")
+        self.run_ahead = False if env == "0" else ("version" if env == "version" else "frozen")
         self._pass_stream = None
         self._pass_seen = None
+        self._pack_gen = 0            # moves whenever _ensure_packed re-lays the weight images (their key can repeat)
+        self._frozen = None           # (weakref(img), token) while a frozen_image context is open
 
     # -- native object management ------------------------------------------------------------
     def _native(self):
@@ -183,6 +196,10 @@ class PerceptionResNet34(nn.Module):
         L.check(L.lib().adx_resnet_pack(h, arr, n, self._packed.data_ptr(), L.stream_ptr(ts[0].device)),
                 "adx_resnet_pack")
         self._pack_key = key
+        # the re-lay was queued on the caller's stream: the next pass must join it, even when the new key EQUALS the one it
+        # remembers (native running-statistics writes move no version counter: train-mode forward, no optimizer step, eval)
+        self._pack_gen += 1
+        self._pass_seen = None
 
     def forward_frames(self, frames_u8: torch.Tensor, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)) -> torch.Tensor:
         """Eval-mode forward straight from uint8 camera frames [N, H, W, 3] (or [H, W, 3]): the agents'
@@ -236,25 +253,55 @@ class PerceptionResNet34(nn.Module):
         return self._on_pass_stream(img, run)
 
     # -- the eval pass on a stream of its own --------------------------------------------------------------------------
+    def frozen_image(self, img: torch.Tensor):
+        """Context manager: the caller vouches that NOTHING writes `img` (by any route: torch ops, `.data`, raw pointers,
+        other streams) while the context is open -- what a sampling loop knows about the image of its tick (the reference's
+        loops pass the same, untouched tensor to every denoising step: interact.py:133-155, train.py:80-88).  Inside, eval
+        passes on that tensor object may run ahead of the caller's queued work (_on_pass_stream); the first pass of a context
+        always joins the caller's stream (the image's producer), and every pass is joined by it afterwards, so writes queued
+        after the context has closed are ordered behind the last pass."""
+        import contextlib
+        import weakref
+
+        @contextlib.contextmanager
+        def ctx():
+            prev = self._frozen
+            self._frozen = (weakref.ref(img), object())
+            try:
+                yield self
+            finally:
+                self._frozen = prev
+        return ctx()
+
     def _on_pass_stream(self, img: torch.Tensor, run):
         """Large eval passes run on a stream of their own, which the caller's stream joins when the pass is done.  What that
-        buys: a caller that passes the SAME image tensor again, unwritten -- the reference's sampling loop runs the encoder in
-        every denoising step on the image of the tick (modeling/temporal.py:203) -- gets a pass that needs nothing of what the
-        caller has queued since the previous one (that step's temporal stack and scheduler step), so it runs AHEAD of it: the
-        previous step's ~30 small latency-bound launches execute beside this step's encoder instead of in front of it.  A pass
-        on a new tensor object, on one written since (version counter), with re-packed weights, on an inference tensor (no
-        version counter), under a stream capture or of fewer than 16 images joins the caller's stream first, as any launch would."""
+        buys: a pass on an image that is KNOWN to be the one of the previous pass, unwritten -- the reference's sampling loop
+        runs the encoder in every denoising step on the image of the tick (modeling/temporal.py:203) -- needs nothing of what
+        the caller has queued since (that step's temporal stack and scheduler step), so it runs AHEAD of it: the previous
+        step's ~30 small latency-bound launches execute beside this step's encoder instead of in front of it.
+
+        "Known" is the caller's statement, not a guess: inside `frozen_image(img)` (this package's loops, bench.py), or with
+        `run_ahead = "version"` on identity + version counter.  Everything else -- another tensor object, a moved version
+        counter, re-laid weights (pack generation), another workspace, an inference tensor outside a frozen context, a stream
+        capture, fewer than 16 images, a pass that bypassed this stream in between -- joins the caller's stream first, as any
+        launch would.  A write the caller did not declare (through `img.data`, a raw pointer) is therefore only ever missed
+        where the caller said there is none (tests/test_gpu_model.py::test_perception_pass_sees_undeclared_image_writes)."""
         dev = img.device
         cur = torch.cuda.current_stream(dev)
-        if not self.run_ahead or img.shape[0] < 16 or torch.cuda.is_current_stream_capturing():
+        mode = "version" if self.run_ahead is True else self.run_ahead
+        if not mode or img.shape[0] < 16 or torch.cuda.is_current_stream_capturing():
+            self._pass_seen = None       # this pass uses the workspace on the caller's stream: the next one must join it
             return run()
         if self._pass_stream is None or self._pass_stream.device != dev:
             self._pass_stream = torch.cuda.Stream(device=dev)
             self._pass_seen = None
         ps = self._pass_stream
         seen = self._pass_seen
-        same = (seen is not None and seen[0]() is img and not img.is_inference() and seen[1] == img._version
-                and seen[2] == self._pack_key and seen[3] == self._ws.data_ptr())
+        token = self._frozen[1] if (self._frozen is not None and self._frozen[0]() is img) else None
+        stamp = None if img.is_inference() else img._version
+        same = (seen is not None and seen[0]() is img and seen[2] == self._pack_gen and seen[3] == self._ws.data_ptr()
+                and ((token is not None and seen[4] is token)
+                     or (mode == "version" and stamp is not None and seen[1] == stamp)))
         if not same:
             ps.wait_stream(cur)          # the image's producer, the weight images' re-lay, whoever used the workspace before
             self._ws.record_stream(ps)   # allocated on the caller's stream, used on this one
@@ -265,5 +312,5 @@ class PerceptionResNet34(nn.Module):
         out.record_stream(cur)           # allocated on the pass stream, consumed on the caller's
         img.record_stream(ps)
         import weakref
-        self._pass_seen = (weakref.ref(img), None if img.is_inference() else img._version, self._pack_key, self._ws.data_ptr())
+        self._pass_seen = (weakref.ref(img), stamp, self._pack_gen, self._ws.data_ptr(), token)
         return out

@@ -166,11 +166,11 @@ def conv2d_weight_grad(x: torch.Tensor, dy: torch.Tensor, k: int, *, stride: int
     cout = dy.shape[1]
     d = L.Conv2dDesc(cin, cout, k, stride, pad)
     dw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=x.device)
-    scratch = None
-    if estimate_range or os.environ.get("ADX_WGRAD_DETERMINISTIC") == "1":     # the deterministic mode's per-split copies ride in the scratch
-        scratch = torch.empty(L.lib().adx_conv2d_wgrad_scratch_bytes(), dtype=torch.uint8, device=x.device)
-    L.check(L.lib().adx_conv2d_wgrad(C.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, h, w, L.ptr(scratch),
-                                     L.stream_ptr(x.device)), "adx_conv2d_wgrad")
+    # the scratch carries the range partials AND, under ADX_WGRAD_DETERMINISTIC=1, the per-split copies of dW: the library
+    # says how much that is (no second parse of the environment here), the range estimate is asked for explicitly
+    scratch = torch.empty(L.lib().adx_conv2d_wgrad_scratch_bytes(), dtype=torch.uint8, device=x.device)
+    L.check(L.lib().adx_conv2d_wgrad_ex(C.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, h, w, scratch.data_ptr(),
+                                        int(bool(estimate_range)), L.stream_ptr(x.device)), "adx_conv2d_wgrad_ex")
     return dw
 
 

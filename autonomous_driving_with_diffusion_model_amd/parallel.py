@@ -13,6 +13,8 @@ from __future__ import annotations
 
 from typing import Iterable, List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -60,13 +62,22 @@ class GradientAverager:
                `FusedAdamWEMA(grad_scale=...)` folds it into its single pass over the gradients."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 64.0, group=None,
-                 primitive: str = "all_reduce", mean: bool = True):
+                 primitive: str = "all_reduce", mean: bool = True, force: Optional[bool] = None):
         if primitive not in ("all_reduce", "reduce_scatter"):
             raise ValueError(f"primitive must be 'all_reduce' or 'reduce_scatter', got {primitive!r}")
         self.params = [p for p in params if p.requires_grad]
         self.group, self.primitive, self.mean = group, primitive, mean
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # force (or ADX_FORCE_COLLECTIVES=1): issue every collective on a ONE-rank group too.  One-rank collectives are
+        # identities, so the gradients do not change -- but the real RCCL kernels then run on the side stream behind the
+        # per-group events while backward is still running: the whole transport path on the one GPU a box has
+        # (tests/test_gpu_parallel.py::test_one_rank_rccl_behind_the_events).
+        if force is None:
+            force = os.environ.get("ADX_FORCE_COLLECTIVES", "0") == "1"
+        if force and not dist.is_initialized():
+            raise RuntimeError("GradientAverager(force=True) needs an initialised process group (a one-rank group will do)")
+        self.active = self.world > 1 or bool(force)
         self.grad_scale = 1.0 if mean else 1.0 / self.world
         self.buckets = make_buckets([p.numel() for p in self.params], int(bucket_mb * 1024 * 1024 / 4))
         self._flat: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
@@ -81,7 +92,7 @@ class GradientAverager:
         self._trace_events: list = []
         self._comm_stream = None
         self._avg_ok = True
-        if self.world > 1:
+        if self.active:
             for bi in range(len(self.buckets)):
                 self._ensure_bucket(bi)
             if mean and self.params:
@@ -149,13 +160,17 @@ class GradientAverager:
     def _make_hook(self, i: int):
         def hook(_param):
             _param._adx_grad_leased = False        # accumulated: the bucket view may be lent again once .grad is cleared
-            if self.world == 1:
+            if not self.active:
                 return
             bi = self._where[i]
-            if getattr(_param, "_adx_grad_event", None) is not None:
+            tag = getattr(_param, "_adx_grad_event", None)
+            if tag is not None and tag[1] is not None:
                 self._seen_tagged[bi] = True
-            elif self._seen_tagged[bi]:
-                self._untagged_late[bi] = True       # an untagged gradient behind a tagged one: no event covers it
+            elif tag is not None or self._seen_tagged[bi]:
+                # a gradient of the event-recording call that was NOT written into its bucket view by that call (`.grad` already
+                # existed, the view was lent to another node: AccumulateGrad's add runs on the compute stream after the whole
+                # call), or an untagged gradient behind a tagged one: no event covers the bucket
+                self._untagged_late[bi] = True
             self._ready[bi] += 1
             if self._ready[bi] == len(self.buckets[bi]):
                 self._ready[bi] = 0
@@ -173,7 +188,7 @@ class GradientAverager:
     @torch.no_grad()
     def synchronize(self) -> None:
         """Overlap mode: wait for the collectives the hooks launched (and write back what had to be copied in)."""
-        if self.world == 1:
+        if not self.active:
             return
         if any(self._ready):
             raise RuntimeError("a bucket is incomplete: every rank must produce every gradient in every backward")
@@ -219,12 +234,16 @@ class GradientAverager:
         # is ONE native call whose layer groups finish one after the other: modeling/perception.py), the side stream waits for
         # the LAST of those events -- the bucket is reduced while the compute stream is still differentiating the layers below.
         # Otherwise it joins everything queued on the compute stream so far (the temporal stack's per-layer nodes).
-        tagged = [t for t in (getattr(self.params[i], "_adx_grad_event", None) for i in idxs) if t is not None]
+        tags = [getattr(self.params[i], "_adx_grad_event", None) for i in idxs]
+        tagged = [t for t in tags if t is not None and t[1] is not None]
         for i in idxs:
             self.params[i]._adx_grad_event = None            # an event belongs to the backward that recorded it
         # gradients of the bucket without an event are covered by the last event as long as they were accumulated BEFORE the
-        # first tagged one (their kernels precede it on the compute stream); _make_hook keeps that book per bucket
+        # first tagged one (their kernels precede it on the compute stream); _make_hook keeps that book per bucket.  A
+        # gradient that had to be copied into the bucket just now (`copied`: the copy was queued on the compute stream a
+        # moment ago) or one the recording call did not write into its view (tag without an event) is covered by no event.
         late = self._untagged_late[bi] if bi < len(self._untagged_late) else True
+        late = late or bool(copied) or any(t is not None and t[1] is None for t in tags)
         if bi < len(self._untagged_late):
             self._untagged_late[bi] = self._seen_tagged[bi] = False
         last = max(tagged, key=lambda t: t[0]) if tagged and not late else None
@@ -260,7 +279,7 @@ class GradientAverager:
     @torch.no_grad()
     def average(self, async_op: bool = False):
         """Reduce every bucket after backward (no hooks).  Returns the list of pending reductions when async_op."""
-        if self.world == 1:
+        if not self.active:
             return []
         works = [self._launch(bi) for bi in range(len(self.buckets))]
         if async_op:
@@ -335,7 +354,7 @@ class DataParallel(torch.nn.Module):
     `.module` is the wrapped model, like DDP's attribute that `accelerator.unwrap_model` reads."""
 
     def __init__(self, module: torch.nn.Module, bucket_mb: float = 64.0, broadcast_buffers: bool = True, group=None,
-                 primitive: str = "all_reduce", optimizer=None):
+                 primitive: str = "all_reduce", optimizer=None, force: Optional[bool] = None):
         """optimizer: a `FusedAdamWEMA` over the same parameters.  The buckets then carry the SUM and the 1 / world goes
         into the optimizer's single pass over the gradients (`optimizer.grad_scale`); `.grad` between `synchronize()` and
         `optimizer.step()` is the sum, not the mean.  Without it `.grad` holds the mean, as under DDP."""
@@ -344,7 +363,7 @@ class DataParallel(torch.nn.Module):
         broadcast_parameters(module, src=0, group=group)
         self.buffers_sync = BufferBroadcaster(module, src=0, group=group) if broadcast_buffers else None
         self.averager = GradientAverager(module.parameters(), bucket_mb=bucket_mb, group=group, primitive=primitive,
-                                         mean=optimizer is None).attach()
+                                         mean=optimizer is None, force=force).attach()
         if optimizer is not None:
             optimizer.grad_scale = self.averager.grad_scale
 

@@ -13,6 +13,7 @@ Differences from the callers, both optional and numerically identical:
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Callable, Optional
 
 import torch
@@ -50,7 +51,6 @@ def generate_traj(model, scheduler, cfg, image: torch.Tensor, target: Optional[t
     if set_timesteps:
         scheduler.set_timesteps(cfg.EVAL.SAMPLE_STEPS, device=device)
     is_ddpm = not getattr(scheduler, "_is_ddim", False)
-    action = None
     # What the UNet derives from (t, target, image feature) alone does not change inside the loop: with the perception
     # memo on (the product default) it is computed for all timesteps in one pass, and each step then starts at the first
     # convolution.  The reference-faithful mode (cache_perception = False) keeps the reference's per-step recomputation.
@@ -62,6 +62,19 @@ def generate_traj(model, scheduler, cfg, image: torch.Tensor, target: Optional[t
         with torch.no_grad():
             tc = model.time_conditioning(image, ts.to(device), cond=cond, rows=rows)
     pair = (lambda x: x) if B == 1 and tc is not None else (lambda x: torch.cat([x, x], dim=0))
+    # nothing in this loop writes `image`: say so, so that the reference-faithful per-step encoder pass of a batched tick may run
+    # beside the previous step's temporal stack (modeling/perception.py:frozen_image; a no-op for holders without the method)
+    frozen = getattr(getattr(model, "perception", None), "frozen_image", None)
+    with (frozen(image) if frozen is not None else contextlib.nullcontext()):
+        trajs = _tick_loop(model, scheduler, cfg, use, image, trajs, B, tgt, cond, tc, pair, fuse, is_ddpm, step_noise, device)
+    trajs = trajs.to(torch.float32).clamp(-1, 1)
+    if scale_xy:
+        trajs[..., :2] *= model.magic_num
+    return trajs
+
+
+def _tick_loop(model, scheduler, cfg, use, image, trajs, B, tgt, cond, tc, pair, fuse, is_ddpm, step_noise, device):
+    action = None
     for i, t in enumerate(scheduler.timesteps):
         tck = None if tc is None else (tc, i)
         extra = {}
@@ -102,9 +115,6 @@ def generate_traj(model, scheduler, cfg, image: torch.Tensor, target: Optional[t
                 continue
             trajs = scheduler.step(model_output, t, trajs, **extra).prev_sample
         trajs[:, 0, :3] = 0.0
-    trajs = trajs.to(torch.float32).clamp(-1, 1)
-    if scale_xy:
-        trajs[..., :2] *= model.magic_num
     return trajs
 
 

@@ -459,7 +459,7 @@ def cpu_baseline(steps=5):
             "s_per_step": round(per, 3), "unet_only_steps_per_sec": round(1.0 / unet_s, 3)}
 
 
-def train_leg(dev, world, use_cond="NO_GUIDANCE", steps=20, warm=3, trace_overlap=False):
+def train_leg(dev, world, use_cond="NO_GUIDANCE", steps=20, warm=3, trace_overlap=False, force_collectives=False):
     """One training leg at B = 64 per GPU, H = 32, 3x256x900: add_noise -> train-mode forward (batch-statistics BatchNorm)
     -> MSE -> backward -> fused nan_to_num + AdamW + EMA (train.py:221-261); one optimizer step = one denoising step.
 
@@ -490,7 +490,10 @@ def train_leg(dev, world, use_cond="NO_GUIDANCE", steps=20, warm=3, trace_overla
     opt = FusedAdamWEMA(model.parameters(), lr=1e-4, warmup_steps=1000, lr_ticks_per_step=world)
     # rank 0's weights and buffers to everyone, per-forward BatchNorm-buffer broadcast, bucketed all-reduce from hooks
     # during backward (the reference's DistributedDataParallel semantics, train.py:176-178)
-    dp = DataParallel(model, optimizer=opt) if world > 1 else None       # buckets carry the sum, 1 / world folded into opt.step
+    # --force-collectives (N = 1): a one-rank RCCL group and GradientAverager(force=True) -- the collectives are identities, but
+    # the RCCL kernels run on the side stream behind the per-group events exactly as on a rank of an 8-GPU job
+    dp = (DataParallel(model, optimizer=opt, force=force_collectives or None)
+          if (world > 1 or force_collectives) else None)       # buckets carry the sum, 1 / world folded into opt.step
     fwd = dp if dp is not None else model
     sch = S.DDPMScheduler(**SCHED_KW)
     d = {k: v.to(dev) for k, v in P.synthetic_batch(B, H, image_hw=IMG, seed=7 + rank).items()}
@@ -556,7 +559,8 @@ def train_leg(dev, world, use_cond="NO_GUIDANCE", steps=20, warm=3, trace_overla
     name = ("configs/guidance/free_guidance.yaml train step, FREE_GUIDANCE (cond=None with probability 0.3 per batch and rank)"
             if free else "configs/default.yaml train step, NO_GUIDANCE")
     res = {"workload": name + ", batch 64 per GPU, horizon 32, image 3x256x900, fwd + bwd + fused AdamW/EMA"
-                       + (" + RCCL gradient all-reduce" if world > 1 else ""),
+                       + (" + RCCL gradient all-reduce" if world > 1 else "")
+                       + (" + one-rank RCCL all-reduce behind the per-group events (--force-collectives)" if force_collectives and world == 1 else ""),
            "value": round(world * steps / dt, 3), "unit": "train-steps/sec", "ms_per_step": round(1e3 * dt / steps, 2),
            "steps": steps, "approx_tflops_per_gpu": round(flops * steps / dt / 1e12, 1), "first_step_loss": round(first, 7),
            "first_step_loss_oracle": expected, "final_loss": round(float(loss.detach()), 5)}
@@ -566,7 +570,7 @@ def train_leg(dev, world, use_cond="NO_GUIDANCE", steps=20, warm=3, trace_overla
     if not parity_ok:
         res["parity_failed"] = {"first_step_loss": first, "expected": expected, "tolerance": "2e-5 relative"}
         res["value"] = res["ms_per_step"] = None
-    if world > 1:
+    if dp is not None:
         res["per_rank_ms_per_step"] = [round(1e3 * t / steps, 2) for t in per_rank]
         res["gradient_buckets"] = {"primitive": dp.averager.primitive, "n": len(dp.averager.buckets),
                                    "copied_in_last_step": dp.averager.copied_in}
@@ -663,6 +667,9 @@ def main():
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--train-steps", type=int, default=20, help="timed optimizer steps per training leg")
     ap.add_argument("--no-deployed", action="store_true")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="N = 1: run the FREE_GUIDANCE training leg under parallel.DataParallel(force=True) on a one-rank RCCL group "
+                         "(train_free.gradient_buckets.overlap_rank0 then reports the bucket reductions against backward)")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--short-sampling", action="store_true", help=argparse.SUPPRESS)   # tests: skip the hoisted / graph legs
     args = ap.parse_args()
@@ -724,7 +731,9 @@ def main():
     def run(n_steps, start=0):
         trajs = d["init_trajs"].clone()
         trajs[:, 0, :3] = 0
-        with torch.no_grad():
+        # the tick's image tensor is written by nobody while the loop runs (the reference's loops pass the same untouched tensor to
+        # every step, interact.py:133-155): declared, so that the per-step encoder pass may run ahead (modeling/perception.py)
+        with torch.no_grad(), model.perception.frozen_image(d["imgs"]):
             # product default (perception memo on): like sampling.generate_traj, everything the UNet derives from (t, target,
             # image feature) alone is computed once per loop; reference-faithful mode recomputes it every step
             tc = model.time_conditioning(d["imgs"], sch.timesteps.tensor, cond=cond, rows=2 * B) if model.cache_perception else None
@@ -791,7 +800,17 @@ def main():
         try:
             if world == 1:
                 train = train_leg(dev, world, "NO_GUIDANCE", steps=args.train_steps)
-            train_free = train_leg(dev, world, "FREE_GUIDANCE", steps=args.train_steps, trace_overlap=world > 1)
+            force = args.force_collectives and world == 1
+            if force:
+                import socket
+                import torch.distributed as dist
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    port = sk.getsockname()[1]
+                dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                        device_id=torch.device("cuda", local))
+            train_free = train_leg(dev, world, "FREE_GUIDANCE", steps=args.train_steps, trace_overlap=world > 1 or force,
+                                   force_collectives=force)
         except Exception as e:   # the headline sampling metric must survive a failure of the secondary leg
             if world > 1:
                 raise            # ... but not at the price of a hang: the other ranks are inside this leg's collectives

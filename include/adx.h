@@ -254,6 +254,11 @@ int adx_conv2d_forward_cells(const adx_conv2d_desc* d, const void* x, const floa
 size_t adx_conv2d_wgrad_scratch_bytes(void);
 int adx_conv2d_wgrad(const adx_conv2d_desc* d, const float* x, const float* dy, float* dw, int32_t n, int32_t h,
                      int32_t w, void* scratch, adx_stream s);
+/* The same with the two uses of the scratch told apart: estimate_range != 0 asks for the range estimate above (scratch
+ * required); estimate_range == 0 takes dy as is, and a non-NULL scratch then only carries the per-split copies of the
+ * bit-reproducible reduction (ADX_WGRAD_DETERMINISTIC=1; adx_conv2d_wgrad_scratch_bytes() covers both). */
+int adx_conv2d_wgrad_ex(const adx_conv2d_desc* d, const float* x, const float* dy, float* dw, int32_t n, int32_t h,
+                        int32_t w, void* scratch, int32_t estimate_range, adx_stream s);
 
 /* Training-mode perception (train.py:242 with model.train()): batch-statistics BatchNorm, running buffers
  * updated in place (momentum 0.1), everything the backward needs kept in the workspace. */

@@ -1,4 +1,6 @@
 """Shared test helpers: procedural state dicts built from the spec table (no reference needed)."""
+import os
+
 import torch
 
 from autonomous_driving_with_diffusion_model_amd.modeling.spec import unet_entries
@@ -10,7 +12,78 @@ SCHED_KW = dict(num_train_timesteps=100, prediction_type="sample", beta_schedule
 
 
 def oracle_sd(use_cond: str, seed: int = 0):
-    return P.procedural_state_dict(((e.key, e.shape) for e in unet_entries(use_cond)), seed)
+    sd = P.procedural_state_dict(((e.key, e.shape) for e in unet_entries(use_cond)), seed)
+    if os.environ.get("ADX_TEST_STATE") == "imagenet_like":
+        sd.update(_imagenet_like_perception(seed))
+    return sd
+
+
+_REAL_SCALE = {}
+
+
+def _imagenet_like_perception(seed: int = 0):
+    """A perception state at REAL-WEIGHT scale (ADX_TEST_STATE=imagenet_like; no pretrained file exists offline,
+    modeling/resnet.py:304-310): conv weights = torchvision's kaiming-normal fan-out init (modeling/resnet.py:212-217) times a
+    per-output-channel factor 10^U(-1.5, 1) -- a trained net's filters differ in norm by decades --, BatchNorm running statistics
+    CALIBRATED layer by layer on four full-size frames (a trained net's statistics describe its own activations; statistics
+    drawn independently of them would scale every layer by a random 0.1x..30x and overflow any arithmetic within ten layers):
+    running_var = the measured variance x 10^U(-0.15, 0.15) -- it spans the decades of the filter norms, 1e-3 .. 1e2 and
+    beyond --, running_mean = the measured mean +- 0.1 sigma, gamma ~ U(0, 3) with 3 % exact zeros, beta ~ U(-2, 2).
+    Test infrastructure (plain torch-CPU ops); depends on (seed) only."""
+    if seed in _REAL_SCALE:
+        return _REAL_SCALE[seed]
+    import numpy as np
+    import torch.nn.functional as F
+    from autonomous_driving_with_diffusion_model_amd.modeling.spec import resnet34_entries
+    shapes = {e.key: tuple(e.shape) for e in resnet34_entries("perception.", 64)}
+    out = {}
+    rng = lambda name: P._rng("imagenet_like." + name, seed)      # noqa: E731
+
+    def conv_w(key):
+        co, ci, k, _ = shapes[key]
+        r = rng(key)
+        w = r.standard_normal(size=(co, ci, k, k)) * np.sqrt(2.0 / (co * k * k))
+        w *= (10.0 ** r.uniform(-1.5, 1.0, size=(co, 1, 1, 1)))
+        out[key] = torch.from_numpy(w.astype(np.float32))
+        return out[key]
+
+    def bn(prefix, y):
+        c = y.shape[1]
+        r = rng(prefix)
+        mean = y.mean((0, 2, 3)).double().numpy()
+        var = y.var((0, 2, 3), unbiased=False).double().numpy()
+        rm = mean + 0.1 * np.sqrt(var) * r.uniform(-1, 1, size=c)
+        rv = var * 10.0 ** r.uniform(-0.15, 0.15, size=c)
+        gamma = r.uniform(0.0, 3.0, size=c)
+        gamma[r.random(size=c) < 0.03] = 0.0
+        beta = r.uniform(-2.0, 2.0, size=c)
+        for leaf, v in (("running_mean", rm), ("running_var", rv), ("weight", gamma), ("bias", beta)):
+            out[prefix + leaf] = torch.from_numpy(v.astype(np.float32))
+        out[prefix + "num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
+        return F.batch_norm(y, out[prefix + "running_mean"], out[prefix + "running_var"], out[prefix + "weight"], out[prefix + "bias"],
+                            False, 0.1, 1e-5)
+
+    with torch.no_grad():
+        x = P.synthetic_batch(4, 16, image_hw=(256, 900), seed=71)["imgs"]
+        p = "perception."
+        x = F.relu(bn(p + "bn1.", F.conv2d(x, conv_w(p + "conv1.weight"), None, stride=2, padding=3)))
+        x = F.max_pool2d(x, 3, 2, 1)
+        for li, n in enumerate((3, 4, 6, 3), start=1):
+            for bi in range(n):
+                q = f"{p}layer{li}.{bi}."
+                stride = 2 if (li > 1 and bi == 0) else 1
+                o = F.relu(bn(q + "bn1.", F.conv2d(x, conv_w(q + "conv1.weight"), None, stride=stride, padding=1)))
+                o = bn(q + "bn2.", F.conv2d(o, conv_w(q + "conv2.weight"), None, stride=1, padding=1))
+                idt = x
+                if (q + "downsample.0.weight") in shapes:
+                    idt = bn(q + "downsample.1.", F.conv2d(x, conv_w(q + "downsample.0.weight"), None, stride=stride))
+                x = F.relu(o + idt)
+    for key in ("fc.weight", "fc.bias"):
+        out[p + key] = P.procedural_tensor(p + key, shapes[p + key], seed)
+    missing = set(shapes) - set(out)
+    assert not missing, sorted(missing)[:5]
+    _REAL_SCALE[seed] = out
+    return out
 
 
 def uni(name, shape, seed=7, lo=-1.0, hi=1.0):

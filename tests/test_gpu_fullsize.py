@@ -30,8 +30,9 @@ def _record(name, payload):
     """Measured errors go to gpurun_out/ so that the bars in this file can be read against what was observed."""
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        state = os.environ.get("ADX_TEST_STATE")
         with open(os.path.join(ROOT, "gpurun_out", "fullsize_parity.jsonl"), "a") as f:
-            f.write(json.dumps({"test": name, **payload}) + "\n")
+            f.write(json.dumps({"test": name + (f"[{state}]" if state else ""), **payload}) + "\n")
     except OSError:
         pass
 
@@ -70,7 +71,8 @@ def test_perception_b64_fullsize_vs_oracle(full):
     err = (f - full.feat).abs()
     _record("perception_b64", {"max_abs_err": err.max().item(), "feat_abs_max": full.feat.abs().max().item(),
                                "batch_vs_single_max": (f[5:6] - f1).abs().max().item()})
-    close(f, full.feat, 2e-4, rtol=1e-5)                         # |feature| ~ 30: same bar as the B = 1 golden test
+    fmax = full.feat.abs().max().item()
+    close(f, full.feat, 7e-6 * max(1.0, fmax), rtol=1e-5)        # 2e-4 at |feature| ~ 29 (the B = 1 golden test's bar), relative otherwise
     close(f[5:6], f1, 2e-5, rtol=1e-6)                           # the batch does not change a scene's feature
 
 
@@ -277,3 +279,25 @@ def test_cfg5_free_guidance_train_step_b64_fullsize_both_branches_vs_oracle_forw
             assert w0 > 0.0
     assert abs(out["cond"]["loss"] - out["cond_none"]["loss"]) > 1e-4          # the two branches are different computations
     _record("cfg5_free_train_b64", out)
+
+
+def test_fullsize_parity_at_real_weight_scale():
+    """Every figure of this repository is on procedural weights; the reference runs `resnet34(pretrained=True)` + a trained
+    checkpoint (modeling/resnet.py:212-217,304-310, interact.py:102-106), and the split-fp16 kernels turn |x| >= 65504 into inf.
+    The same two full-size checks -- the eval perception pass at B = 64 against the oracle, every gradient tensor of the
+    train-mode step at B = 16 against the oracle's autograd in fp64 -- on an ImageNet-LIKE state (helpers.py:
+    _imagenet_like_perception: kaiming fan-out filters whose norms span 2.5 decades, calibrated running statistics with
+    running_var over 1e-4 .. 1e3, gamma in [0, 3] with exact zeros, beta up to +-2), at the same bars, in a process started with
+    ADX_CHECK_RANGE=1: every activation tensor of the eval pass and every conv operand of the training forward is scanned and
+    the run fails with the first layer that leaves the fp16 range."""
+    import subprocess
+    import sys
+    if os.environ.get("ADX_TEST_STATE"):
+        pytest.skip("this IS the inner run")
+    env = dict(os.environ, ADX_TEST_STATE="imagenet_like", ADX_CHECK_RANGE="1")
+    me = os.path.join(ROOT, "tests", "test_gpu_fullsize.py")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        me + "::test_perception_b64_fullsize_vs_oracle",
+                        me + "::test_cfg2_train_step_fullsize_vs_oracle_autograd[NO_GUIDANCE-16]"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=2400)
+    assert r.returncode == 0 and "2 passed" in r.stdout, (r.stdout + r.stderr)[-4000:]

@@ -103,3 +103,32 @@ def test_bench_two_ranks_same_device_fullsize_free_train_leg():
     # but the last (layer3's lower blocks ... the stem) is ready -- and its reduction launched -- while the layers below it
     # are still being differentiated; before, all 85 MB of perception gradients became "ready" together at the end of backward
     assert all(o["ready_ms"] < -3.0 for o in ov[:-1]), ov
+
+
+@pytest.mark.parametrize("primitive", ["all_reduce", "reduce_scatter"])
+def test_one_rank_rccl_behind_the_events(tmp_path, primitive):
+    """RCCL behind the averager's events on the one GPU a box has (train.py:174-178,249): a ONE-rank nccl group with
+    `GradientAverager(force=True)` keeps the world-1 early returns out, so the real RCCL kernels run on the side stream behind
+    the perception backward's per-layer-group events while backward is still running.  Full-size FREE_GUIDANCE step (B = 64,
+    H = 32, 3 x 256 x 900): one-rank collectives are identities, so every gradient is bit-equal to a plain backward; nothing is
+    copied in; every bucket but the last is ready >= 3 ms before backward ends.  Then the two paths the per-group events do NOT
+    cover: accumulation over two backwards without clearing .grad, and the module twice in one graph -- bit-equal as well.
+    The all_reduce run's trace is the artifact profiles/r06_overlap_trace.json is a copy of."""
+    import json
+    out = os.path.join(tmp_path, "res.json")
+    trace = os.path.join(ROOT, "gpurun_out", f"overlap_trace_{primitive}.json")
+    os.makedirs(os.path.dirname(trace), exist_ok=True)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(ADX_WGRAD_DETERMINISTIC="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_one_rank_worker.py"), out, primitive, "64", "32", "256", "900",
+                        trace], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    res = json.load(open(out))
+    assert "nccl" in res["backend"]
+    assert res["n_buckets"] >= 3 and res["born_in_bucket"] and res["copied_in"] == 0 and res["loss_equal"]
+    assert res["step_mismatch"] == [], res["step_mismatch"][:5]
+    ov = res["overlap"]
+    assert len(ov) == res["n_buckets"] and all(o["done_ms"] >= o["ready_ms"] for o in ov), ov
+    assert all(o["ready_ms"] < -3.0 for o in ov[:-1]), ov          # reduced while the layers below are still differentiated
+    assert res["accum_mismatch"] == [], res["accum_mismatch"][:5]
+    assert res["twice_mismatch"] == [], res["twice_mismatch"][:5]
