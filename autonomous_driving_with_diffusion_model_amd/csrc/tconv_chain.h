@@ -52,6 +52,7 @@ struct ChainArgs {
   int n_tb; int tb_col[4], tb_cout[4], tb_lds[4];   // time-bias slices: column in tb, channels, LDS float offset of [bt][cout_pad]
   int tab_lds;                         // where the kernel parks the stage table
   unsigned* zero_words; int n_zero;    // words workgroup 0 clears (<= 512): the ticket words of the forward this launch opens
+  unsigned* epoch_ctr; int epoch_slot; // ... except word epoch_slot, which receives the forward's number drawn from *epoch_ctr (tconv_pipe.h)
   int xch_lds;                         // GroupNorm partials of stages whose samples span two row tiles
   ChainStage st[kChainMaxStages];
 };

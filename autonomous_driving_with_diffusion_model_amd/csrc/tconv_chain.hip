@@ -198,7 +198,9 @@ __global__ void __launch_bounds__(kChNT) tconv_chain_kernel(const ChainArgs ca) 
 
   // first launch of a UNet forward: the split-reduction ticket words start every forward at zero whatever the caller's
   // workspace held (an uninitialised buffer, the debris of a launch that never finished); their users come later in stream order
-  if (ca.zero_words != nullptr && blockIdx.x == 0 && tid < ca.n_zero) ca.zero_words[tid] = 0u;
+  if (ca.zero_words != nullptr && blockIdx.x == 0 && tid < ca.n_zero)
+    ca.zero_words[tid] = (ca.epoch_ctr != nullptr && tid == ca.epoch_slot)
+                             ? __hip_atomic_fetch_add(ca.epoch_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u : 0u;
   int* ltab = reinterpret_cast<int*>(smem + ca.tab_lds);
 #if defined(__HIP_DEVICE_COMPILE__)
   {

@@ -69,12 +69,19 @@ struct HsArgs {
 };
 
 __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
+#if defined(ADX_TCONV_STAGE_PROBE)
+  // timing-only builds (csrc/build.sh -DADX_TCONV_STAGE_PROBE=1|2, garbage results): what the staging's fp32 -> hi / lo split costs
+  // -- the upper bound of what pre-split activation tensors between the temporal layers could save (profiles/README.md, round 6)
+  hi = __builtin_bit_cast(h8, f32x4{v[0], v[1], v[2], v[3]});
+  lo = __builtin_bit_cast(h8, f32x4{v[4], v[5], v[6], v[7]});
+#else
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const _Float16 h = (_Float16)v[j];
     hi[j] = h;
     lo[j] = (_Float16)((v[j] - (float)h) * kLoScale);
   }
+#endif
 }
 
 // Stage rows [0, nrows] x channels [c0, c0 + ckc) of this workgroup's samples into LDS as split cells.  Every global load
@@ -101,7 +108,11 @@ __device__ __forceinline__ void hs_stage(const TConvArgs& a, const HsArgs& ha, u
         const float* base = first ? a.io.x0 : a.io.x1;
         const int64_t off = first ? (int64_t)cc * a.io.x0_sc + (int64_t)bc * a.io.x0_sb
                                   : (int64_t)(cc - a.c0) * a.io.x1_sc + (int64_t)bc * a.io.x1_sb;
+#if defined(ADX_TCONV_STAGE_PROBE) && ADX_TCONV_STAGE_PROBE == 2
+        v[j] = f32x4{(float)off, 1.f, 2.f, 3.f};          // (2: no global loads at all -- the whole staging round trip)
+#else
         v[j] = *reinterpret_cast<const f32x4*>(base + off + 4 * q);
+#endif
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j)
@@ -135,7 +146,11 @@ __device__ __forceinline__ void hs_stage(const TConvArgs& a, const HsArgs& ha, u
         const float* base = first ? a.io.x0 : a.io.x1;
         const int64_t off = first ? (int64_t)bc * a.io.x0_sb + (int64_t)cc * a.io.x0_sc + (int64_t)ip * a.io.x0_sl
                                   : (int64_t)bc * a.io.x1_sb + (int64_t)(cc - a.c0) * a.io.x1_sc + (int64_t)ip * a.io.x1_sl;
+#if defined(ADX_TCONV_STAGE_PROBE) && ADX_TCONV_STAGE_PROBE == 2
+        t8[j] = (float)off;
+#else
         t8[j] = base[off];
+#endif
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j)

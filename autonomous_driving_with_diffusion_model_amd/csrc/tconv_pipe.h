@@ -34,8 +34,8 @@ struct PipeArgs {
   int C, L, rows, P;       // channels (in = out), positions per sample, samples, workgroups per stage = C / 16
   int groups, taps, pad, tap0, ntap;   // GroupNorm groups; conv taps and padding; live taps [tap0, tap0 + ntap)
   float eps;
-  float* records;          // [n_conv][P][16 rows][16 channels]
-  unsigned* counters;      // n_conv arrival counters, 16 words apart, zero on entry (the executor's ticket words)
+  float* records;          // [n_conv][P][16 rows][6 units of (three channels, tag)]: pipe_record_floats(); written by pipeline launches only
+  const unsigned* epoch;   // this forward's number (drawn from pipe_epoch_counter by the launch that opens the forward)
   unsigned* fault;         // host-visible word (pipe_fault_word) a timed-out stage sets; null: the NaN output is the only signal
 };
 
@@ -45,6 +45,12 @@ struct PipeArgs {
 // pipe_fault_take(): its value, cleared.
 unsigned* pipe_fault_word();
 unsigned pipe_fault_take();
+// The forward numbers behind the records' tags: one monotonic device word per GPU, owned by the library (allocate: only where
+// no stream capture can be open); pipe_tickets_reset clears `n` ticket words and leaves a freshly drawn number in words[epoch_slot]
+// (what tconv_chain's workgroup 0 does when a chained level opens the forward: ChainArgs::epoch_ctr).
+unsigned* pipe_epoch_counter(bool allocate);
+int pipe_tickets_reset(unsigned* words, int n, int epoch_slot, hipStream_t s);
+size_t pipe_record_floats(int n_conv, int P);
 
 // live taps of a stride-1 conv on L positions, and whether a layer run of this shape fits the kernel (weights of one workgroup
 // in LDS, the whole batch in one 16-row tile)

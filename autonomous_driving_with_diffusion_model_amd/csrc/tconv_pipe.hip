@@ -9,20 +9,28 @@
 // How: stage k of the pipeline = P = C / 16 workgroups, one per CU, each owning 16 output channels of layer k.
 //   * A workgroup's weight share (live taps x C x 16 channels, fp16 hi / lo pairs: 96 KB) goes into LDS at kernel entry; for every
 //     stage but the first that load runs while the stage waits for its input.
-//   * A stage publishes RAW conv sums + bias ([rows x L][16 channels] per workgroup, write-through stores), drains them, and adds
-//     one to its arrival counter (relaxed, agent scope) -- the hand-off recipe of the CDNA guide, no fence anywhere.
-//   * The next stage waits for that counter to reach P, reads the P records with sc1 loads (they bypass its L2: the producers sit
-//     on other XCDs) and forms its input ITSELF: GroupNorm (two-pass statistics over the group's channels x positions, which it
-//     holds completely) -> Mish -> + time bias or + residual, exactly the epilogue the producer would have run -- but the producer
-//     could not: a GroupNorm group spans four workgroups.  So a layer costs ONE hand-off.
+//   * A stage publishes RAW conv sums + bias as EPOCH-TAGGED 16-byte records (round 6): a unit = three channels of one row + the
+//     tag of THIS forward ([rows x L][6 units] per workgroup), written with ONE write-through 16-byte store each -- a unit is in
+//     memory whole or not at all, so the tag IS the signal: no drain, no barrier, no counter, no atomic on the producer's side.
+//     The tag is a bijective hash of a forward number drawn from a monotonic counter the LIBRARY owns (pipe_epoch_counter: one
+//     device word per GPU; the launch that clears a forward's ticket words draws the number and leaves it in the workspace's
+//     ticket area for this kernel to read): whatever an earlier forward of the process left in the records region carries an
+//     older number, nothing else writes that region (the tail of the executor's scratch), and the caller's workspace holds no
+//     state that must survive between forwards.
+//   * The next stage's threads poll the units THEY need (sc1 loads: they bypass the L2; the producers sit on other XCDs) until
+//     every tag is this forward's, and the stage forms its input ITSELF: GroupNorm (two-pass statistics over the group's
+//     channels x positions, which it holds completely) -> Mish -> + time bias or + residual, exactly the epilogue the producer
+//     would have run -- but the producer could not: a GroupNorm group spans four workgroups.  So a layer costs ONE hand-off.
 //   * A block's output (a later residual, the level's skip, the run's result) is written by rank 0 of the stage that formed it;
-//     the residual's readers are ordered behind that write by the counters in between.  The finisher (one workgroup) forms and
-//     writes the last layer's output.
+//     rank 0 drains those stores before it publishes its own records, and every reader of the tensor has seen records that were
+//     published after rank 0's (two hand-offs later at the earliest).  The finisher (one workgroup) forms and writes the last
+//     layer's output.
 // Deadlock-free without a cooperative launch: a stage waits only for workgroups with LOWER ids, which every XCD dispatches first;
 // every spin is bounded (a timeout leaves the result wrong, never the GPU hung).  Arithmetic = tconv_hs.hip's split-fp16 scheme
 // (x = hi + 2^-11 lo, three v_mfma_f32_16x16x32_f16 per product, fp32 accumulation); fixed summation order: bit-reproducible.
 // Prototype and its measurement: tools/micro/coop_pipeline.hip, profiles/r04_coop_pipeline.txt (5.4 us per layer).
 #include <algorithm>
+#include <mutex>
 
 #include "adx_common.h"
 #include "tconv_pipe.h"
@@ -34,7 +42,9 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 constexpr float kPipeLoScale = 2048.f;
 constexpr int kPipeNT = 256;
-constexpr int kPipeCtrStride = 16;   // words between two stages' arrival counters: a 64-byte line each
+constexpr int kPipeUnits = 6;        // 16-byte record units per (row, workgroup): five of three channels + one of one, each with its tag
+constexpr int kPipeRecWords = kPipeRows * kPipeUnits * 4;      // words per (stage, workgroup)
+__host__ __device__ __forceinline__ unsigned pipe_tag(unsigned n) { return n * 2654435761u + 0x7F4A7C15u; }   // bijective: numbers differ, tags differ
 constexpr int kPipeQ = 9;            // quads per thread of the formed input: 16 rows x C / 4 over 256 threads, C <= 576
 
 // Mish with the hardware exp2 / rcp (same closed form as mish_f, ~3e-7 relative: tconv_hs.hip's fast epilogue uses the same)
@@ -80,6 +90,8 @@ bool pipe_shape_ok(int C, int L, int rows, int taps, int pad, int groups) {
   if ((kPipeMaxStages - 1) * P + 1 > 256) return false;             // every workgroup of the longest run on a CU of its own
   return pipe_lds_bytes(C, rows * L, nt) <= kPipeMaxLds;
 }
+
+size_t pipe_record_floats(int n_conv, int P) { return (size_t)n_conv * P * kPipeRecWords; }
 
 size_t pipe_packed_floats(int C, int taps, int pad, int L) {
   int t0, nt;
@@ -127,6 +139,7 @@ __global__ void __launch_bounds__(256) pipe_repack_kernel(const PipeRepackJobs j
 // made whenever the K-split images they are re-laid from are made)
 int pipe_repack_from_hs_many(const float* const* hs_images, float* const* packed, int n, int C, int taps, int pad, int L, hipStream_t s) {
   ADX_REQUIRE(n >= 1 && n <= 8, "pipe_repack_from_hs_many: %d layers (1..8)", n);
+  (void)pipe_epoch_counter(true);      // (adx_unet_pack: never inside a capture) the forward-number word of this device exists from here on
   int t0, nt;
   pipe_live_taps(taps, pad, L, &t0, &nt);
   const int steps = nt * (C / 32);
@@ -178,10 +191,12 @@ __global__ void __launch_bounds__(kPipeNT) tconv_pipe_kernel(const PipeArgs a) {
   // everything below reads that copy.
   __shared__ PipeStage S_lds;
   __shared__ int hdr_lds[16];
-  __shared__ int got;                    // 0: the producer stage has not been seen complete yet; 1: seen; 2: gave up
+  __shared__ int got;                    // 1: fine; 2: a thread gave up waiting for a record of the producing stage
   __shared__ float rs1[kPipeRows * 8], rs2[kPipeRows * 8];     // fast GroupNorm statistics: per (row, group) partial sums
+  __shared__ float rec_lds[kPipeRows * kPipeCh];               // this workgroup's sums, regrouped into three-channel units
   const int P = a.P;
   const int stage = blockIdx.x / P, rank = blockIdx.x - stage * P;      // the finisher: stage == n_conv, rank 0
+  const unsigned epoch_n = *a.epoch;     // this forward's number (requested now: needed behind the weight load at the earliest)
   PIPE_STAMP(0);
 #if defined(__HIP_DEVICE_COMPILE__)
   {
@@ -189,7 +204,7 @@ __global__ void __launch_bounds__(kPipeNT) tconv_pipe_kernel(const PipeArgs a) {
     kernarg_words kraw = (kernarg_words)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int SW = (int)(sizeof(PipeStage) / 4), HW = (int)((sizeof(PipeArgs) - offsetof(PipeArgs, n_conv)) / 4);
     static_assert(HW <= 16 + 4, "header words");
-    if (tid == 255) got = stage > 0 ? 0 : 1;
+    if (tid == 255) got = 1;
     if (tid < SW) reinterpret_cast<int*>(&S_lds)[tid] = kraw[stage * SW + tid];
     else if (tid >= 64 && tid < 64 + 12) hdr_lds[tid - 64] = kraw[(int)(offsetof(PipeArgs, n_conv) / 4) + tid - 64];
   }
@@ -239,13 +254,14 @@ __global__ void __launch_bounds__(kPipeNT) tconv_pipe_kernel(const PipeArgs a) {
   const bool from_records = S.in == nullptr;
   constexpr int kOut = 0x7FFFFFF0;                                        // out-of-range offset: loads return 0, stores are dropped
   f32x4 ga[kPipeQ], be[kPipeQ], ad[kPipeQ];
-  int roff[kPipeQ], aoff[kPipeQ], poff[kPipeQ], sgi[kPipeQ], mg[kPipeQ], mg0[kPipeQ];
+  int roff[kPipeQ], rsel[kPipeQ], aoff[kPipeQ], poff[kPipeQ], sgi[kPipeQ], mg[kPipeQ], mg0[kPipeQ];
   const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(S.add), 0, S.add_kind >= 2 ? M * C * 4 : 0, 0x00020000);
 #pragma unroll
   for (int i = 0; i < kPipeQ; ++i) {
     ga[i] = be[i] = ad[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     roff[i] = aoff[i] = poff[i] = kOut;
+    rsel[i] = 0;
     sgi[i] = 0;
     mg[i] = 0;
     mg0[i] = 0;
@@ -255,7 +271,9 @@ __global__ void __launch_bounds__(kPipeNT) tconv_pipe_kernel(const PipeArgs a) {
       const int m = q / c4n, c = (q - m * c4n) * 4, sb = m >> log2L, l = m & (L - 1);
       ga[i] = *reinterpret_cast<const f32x4*>(S.gamma + c);
       be[i] = *reinterpret_cast<const f32x4*>(S.beta + c);
-      roff[i] = (((c >> 4) * kPipeRows + m) * kPipeCh + (c & 15)) * 4;
+      // the quad's channels c' = c & 15 in {0, 4, 8, 12} of producer c >> 4 lie in the units c' / 3 and c' / 3 + 1 of row m
+      roff[i] = ((((c >> 4) * kPipeRows + m) * kPipeUnits + (c & 15) / 3) * 4) * 4;
+      rsel[i] = (c >> 2) & 3;
       sgi[i] = sb * groups + c / cg;                                      // (a quad never straddles a group: cg % 4 == 0)
       mg[i] = m * groups + c / cg;
       mg0[i] = (m - l) * groups + c / cg;                                 // the sample's first row, same group
@@ -272,30 +290,20 @@ __global__ void __launch_bounds__(kPipeNT) tconv_pipe_kernel(const PipeArgs a) {
   }
 
   // ---- (3) wait for the producing stage -----------------------------------------------------------------------------------
-  // Only the stage whose producer is already running polls tightly: until stage k - 2 is complete, stage k looks at THAT counter
-  // every ~2 us (hundreds of tight pollers on the counters' lines delayed the producers' own atomics); every counter sits on
-  // a 64-byte line of its own (kPipeCtrStride).
-  if (tid == 0 && stage > 0) {
+  // Only the stage whose producer is already running polls its records tightly (256 threads x a few 16-byte loads per round):
+  // until the stage two hops up has started to publish, ONE thread looks at one of THAT stage's units every ~2 us (hundreds of
+  // tight pollers in the fabric delayed the producers' own stores).  Every spin is bounded.
+  const unsigned tag = pipe_tag(epoch_n);
+  if (tid == 0 && stage >= 2) {
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
+        a.records + (size_t)(stage - 2) * P * kPipeRecWords, 0, P * kPipeRecWords * 4, 0x00020000);
     unsigned spins = 0;
-    if (stage >= 2)
-      while (__hip_atomic_load(a.counters + (stage - 2) * kPipeCtrStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)P) {
-        __builtin_amdgcn_s_sleep(64);
-        if (++spins > (1u << 18)) break;
-      }
-    while (__hip_atomic_load(a.counters + (stage - 1) * kPipeCtrStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)P) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1u << 22)) { got = 2; break; }                      // bounded: a wrong result, never a hung GPU
+    while (__builtin_amdgcn_raw_buffer_load_b32(crs, ((P - 1) * kPipeRecWords + 3) * 4, 0, 16) != tag) {     // row 0, unit 0 of the last rank
+      __builtin_amdgcn_s_sleep(64);
+      if (++spins > (1u << 18)) break;
     }
   }
-  __syncthreads();
-  if (got == 2) {
-    // The producers never arrived (a hung or evicted workgroup: nothing a correct run produces).  Every later stage times out in
-    // turn; the finisher makes the failure LOUD instead of leaving whatever the output buffer held: the run's output becomes NaN.
-    if (!conv && S.pub != nullptr)
-      for (int q = tid; q < M * C; q += kPipeNT) S.pub[q] = __builtin_nanf("");
-    if (tid == 0 && a.fault != nullptr) __hip_atomic_store(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    return;
-  }
+  if (stage >= 2) __syncthreads();
   PIPE_STAMP(3);
 
   // ---- (4) form the input: [M][C] fp32 in xf ---------------------------------------------------------------------------------
@@ -314,13 +322,50 @@ __global__ void __launch_bounds__(kPipeNT) tconv_pipe_kernel(const PipeArgs a) {
     // the producer's records (raw conv sums + bias, [P][16 rows][16 channels], written through to memory by other XCDs) and,
     // where the addend is a residual an earlier stage of THIS launch wrote, that tensor: all loads in flight together
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
-        a.records + (size_t)(stage - 1) * P * kPipeRows * kPipeCh, 0, P * kPipeRows * kPipeCh * 4, 0x00020000);
+        a.records + (size_t)(stage - 1) * P * kPipeRecWords, 0, P * kPipeRecWords * 4, 0x00020000);
     u32x4 rv[kPipeQ];
+    {
+      // poll: both units of every quad of this thread, all loads of a round in flight together; a unit is this forward's when its
+      // fourth word is the tag (the producer wrote the 16 bytes with one store).  Quads past the batch carry the out-of-range offset:
+      // their loads return zero and are not waited for.
+      u32x4 ua[kPipeQ], ub[kPipeQ];
+      unsigned spins = 0;
+      bool all;
+      do {
+        all = true;
+#pragma unroll
+        for (int i = 0; i < kPipeQ; ++i) {
+          if (i * kPipeNT >= nq) continue;                                  // uniform
+          ua[i] = __builtin_amdgcn_raw_buffer_load_b128(rrs, roff[i], 0, 16);                                   // sc1
+          ub[i] = __builtin_amdgcn_raw_buffer_load_b128(rrs, roff[i] == kOut ? kOut : roff[i] + 16, 0, 16);
+        }
+#pragma unroll
+        for (int i = 0; i < kPipeQ; ++i) {
+          if (i * kPipeNT >= nq) continue;
+          all = all && (roff[i] == kOut || (ua[i][3] == tag && ub[i][3] == tag));
+        }
+        if (!all) {
+          if (++spins > (1u << 20)) { got = 2; break; }                    // bounded: a wrong result, never a hung GPU
+          __builtin_amdgcn_s_sleep(1);
+        }
+      } while (!all);
+#pragma unroll
+      for (int i = 0; i < kPipeQ; ++i) {
+        rv[i] = u32x4{0u, 0u, 0u, 0u};
+        if (i * kPipeNT >= nq) continue;
+        const int sl = rsel[i];             // c' = 4 sl: the quad is {A0 A1 A2 B0}, {A1 A2 B0 B1}, {A2 B0 B1 B2}, {A0 A1 A2 B0}
+        const uint32_t A0 = ua[i][0], A1 = ua[i][1], A2 = ua[i][2], B0 = ub[i][0], B1 = ub[i][1], B2 = ub[i][2];
+        rv[i][0] = sl == 1 ? A1 : (sl == 2 ? A2 : A0);
+        rv[i][1] = sl == 1 ? A2 : (sl == 2 ? B0 : A1);
+        rv[i][2] = sl == 1 ? B0 : (sl == 2 ? B1 : A2);
+        rv[i][3] = sl == 1 ? B1 : (sl == 2 ? B2 : B0);
+      }
+    }
+    // where the addend is a residual an earlier stage of THIS launch wrote, that tensor (its writer drained it before publishing
+    // records this stage's producers had to see first)
 #pragma unroll
     for (int i = 0; i < kPipeQ; ++i) {
-      rv[i] = u32x4{0u, 0u, 0u, 0u};
       if (i * kPipeNT >= nq) continue;                                    // uniform
-      rv[i] = __builtin_amdgcn_raw_buffer_load_b128(rrs, roff[i], 0, 16);   // sc1
       if (S.add_kind == 3) {
         const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(ars, aoff[i], 0, 16);
         ad[i] = f32x4{u2f(t[0]), u2f(t[1]), u2f(t[2]), u2f(t[3])};
@@ -334,6 +379,15 @@ __global__ void __launch_bounds__(kPipeNT) tconv_pipe_kernel(const PipeArgs a) {
     for (int i = 0; i < kPipeQ; ++i)
       if (tid + i * kPipeNT < nq) *reinterpret_cast<u32x4*>(xf + (tid + i * kPipeNT) * 4) = rv[i];
     __syncthreads();
+    if (got == 2) {
+      // A producer never arrived (a hung or evicted workgroup: nothing a correct run produces).  This stage publishes nothing, so
+      // every later stage times out in turn; the finisher makes the failure LOUD instead of leaving whatever the output buffer
+      // held: the run's output becomes NaN, and the pinned host word makes the next forward of the process report it.
+      if (!conv && S.pub != nullptr)
+        for (int q = tid; q < M * C; q += kPipeNT) S.pub[q] = __builtin_nanf("");
+      if (tid == 0 && a.fault != nullptr) __hip_atomic_store(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
     PIPE_STAMP(4);
     const int n_sg = rows * groups, per = cg * L;
     float qmean[kPipeQ], qrstd[kPipeQ];
@@ -419,6 +473,9 @@ __global__ void __launch_bounds__(kPipeNT) tconv_pipe_kernel(const PipeArgs a) {
       if (S.pub2 != nullptr && rank == 0)       // a second copy in the pipeline's own layout (a later stage's residual reads it fast)
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{f2u(x[0]), f2u(x[1]), f2u(x[2]), f2u(x[3])}, prs2, (tid + i * kPipeNT) * 16, 0, 16);
     }
+    // rank 0's copies of the formed input are in memory before the barrier that precedes its record stores (a microsecond of
+    // conv later): whoever sees those records may read the copies
+    if (rank == 0 && (S.pub_kind != 0 || S.pub2 != nullptr)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     PIPE_STAMP(6);
   }
@@ -469,22 +526,63 @@ __global__ void __launch_bounds__(kPipeNT) tconv_pipe_kernel(const PipeArgs a) {
   __syncthreads();
   PIPE_STAMP(8);
 
-  // ---- (7) publish: raw sums + bias, [16 rows][16 channels] of this workgroup, write-through; drain; ONE atomic ---------------------
+  // ---- (7) publish: raw sums + bias of this workgroup's [16 rows][16 channels] as tagged units, one write-through 16-byte store each ----
+  float* rec = rec_lds;
   if (tid < 64) {
     const int col = tid & 15, kg = tid >> 4;                              // accumulator lane: channel col, rows 4 kg .. 4 kg + 3
     const f32x4 sum = *reinterpret_cast<const f32x4*>(red + tid * 4) + *reinterpret_cast<const f32x4*>(red + 256 + tid * 4) +
                       (*reinterpret_cast<const f32x4*>(red + 512 + tid * 4) + *reinterpret_cast<const f32x4*>(red + 768 + tid * 4));
     const float b = S.bias[rank * kPipeCh + col];
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        a.records + ((size_t)stage * P + rank) * kPipeRows * kPipeCh, 0, kPipeRows * kPipeCh * 4, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (4 * kg + i < M) __builtin_amdgcn_raw_buffer_store_b32(f2u(sum[i] + b), wrs, ((4 * kg + i) * kPipeCh + col) * 4, 0, 16);   // sc1
+    for (int i = 0; i < 4; ++i) rec[(4 * kg + i) * kPipeCh + col] = sum[i] + b;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores (rank 0's activation too) ...
-  __syncthreads();                                       // ... before ONE lane signals
-  if (tid == 0) __hip_atomic_fetch_add(a.counters + stage * kPipeCtrStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (tid < kPipeRows * kPipeUnits) {
+    const int row = tid / kPipeUnits, u = tid - row * kPipeUnits;
+    if (row < M) {
+      const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+          a.records + ((size_t)stage * P + rank) * kPipeRecWords, 0, kPipeRecWords * 4, 0x00020000);
+      const float* r3 = rec + row * kPipeCh + 3 * u;
+      const u32x4 unit = {f2u(r3[0]), u < 5 ? f2u(r3[1]) : 0u, u < 5 ? f2u(r3[2]) : 0u, tag};
+      __builtin_amdgcn_raw_buffer_store_b128(unit, wrs, tid * 16, 0, 16);            // sc1; unit (row, u) sits at (row * 6 + u) * 16 = tid * 16
+    }
+  }
   PIPE_STAMP(9);
+}
+
+// The forward numbers: one device word per GPU, owned by the library for the life of the process, only ever incremented (by the
+// launch that opens a forward: tconv_chain's workgroup 0 or tickets_reset_kernel).  Allocated where no stream capture can be
+// open (adx_unet_pack); null if that never happened or failed -- the executor then keeps the launch chain.
+static unsigned* g_epoch_ctr[64] = {};
+static std::mutex g_epoch_mu;
+
+unsigned* pipe_epoch_counter(bool allocate) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(g_epoch_mu);
+  unsigned*& p = g_epoch_ctr[dev & 63];
+  if (p == nullptr && allocate) {
+    void* d = nullptr;
+    if (hipMalloc(&d, 64) == hipSuccess) {
+      if (hipMemset(d, 0, 64) == hipSuccess) p = (unsigned*)d;
+      else (void)hipFree(d);
+    }
+  }
+  return p;
+}
+
+// the launch that opens a forward where no chained level does: clears the ticket words and draws the forward's number
+__global__ void __launch_bounds__(256) tickets_reset_kernel(unsigned* words, int n, unsigned* epoch_ctr, int epoch_slot) {
+  const int tid = threadIdx.x;
+  if (tid < n && tid != epoch_slot) words[tid] = 0u;
+  if (tid == epoch_slot) words[tid] = epoch_ctr != nullptr ? __hip_atomic_fetch_add(epoch_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u : 0u;
+}
+
+int pipe_tickets_reset(unsigned* words, int n, int epoch_slot, hipStream_t s) {
+  ADX_REQUIRE(words != nullptr && n <= 256 && epoch_slot >= 0 && epoch_slot < n, "pipe_tickets_reset: bad arguments");
+  tickets_reset_kernel<<<dim3(1), dim3(256), 0, s>>>(words, n, pipe_epoch_counter(false), epoch_slot);
+  ADX_LAUNCH_CHECK();
+  return ADX_OK;
 }
 
 static unsigned* g_fault_host = nullptr;      // pinned, mapped: the kernel's store lands in host memory
@@ -520,7 +618,7 @@ unsigned pipe_fault_take() {
 }
 
 int pipe_launch(const PipeArgs& a, hipStream_t s) {
-  ADX_REQUIRE(a.n_conv >= 1 && a.n_conv < kPipeMaxStages && a.P == a.C / kPipeCh && a.records && a.counters,
+  ADX_REQUIRE(a.n_conv >= 1 && a.n_conv < kPipeMaxStages && a.P == a.C / kPipeCh && a.records && a.epoch,
               "tconv_pipe: bad argument block");
   ADX_REQUIRE(pipe_shape_ok(a.C, a.L, a.rows, a.taps, a.pad, a.groups), "tconv_pipe: shape outside the kernel's rules");
   ADX_REQUIRE((a.C / a.groups) % 4 == 0, "tconv_pipe: GroupNorm group width must be a multiple of 4");

@@ -414,8 +414,12 @@ static adx_tconv_io make_io(const ConvLayer& L, const float* base, const Act& x0
 // Split-reduction scratch of the forward call being enqueued on this thread (a region of ITS workspace; consumed in stream
 // order by the launches it is handed to, so two calls on different streams never share it).
 constexpr size_t kSplitScratchFloats = (size_t)2 << 20;
+// ... of which the LAST kPipeTailFloats belong to the pipeline launch alone (tconv_pipe.hip: its epoch-tagged records must
+// not be written by anything else -- a split reduction's partial tile in a tag slot would be data posing as a signal)
+constexpr size_t kPipeTailFloats = (size_t)192 << 10;
 static thread_local float* t_split_scratch = nullptr;
 constexpr size_t kTicketWords = 256;
+constexpr int kEpochSlot = 240;          // ticket word that receives the forward's number (the pipeline's stage tags)
 static thread_local uint32_t* t_split_tickets = nullptr;     // kTicketWords words (adx_tconv_io::tickets), cleared by every forward
 
 static int run_conv(const ConvLayer& L, const float* base, const Act& x0, const Act* x1, const float* tbias,
@@ -437,7 +441,7 @@ static adx_tconv_io make_io(const ConvLayer& L, const float* base, const Act& x0
   io.y = y; io.y_sb = y_sb; io.y_sc = y_sc; io.y_sl = y_sl;
   io.batch = rows;
   io.scratch = t_split_scratch;
-  io.scratch_floats = t_split_scratch != nullptr ? (int64_t)kSplitScratchFloats : 0;
+  io.scratch_floats = t_split_scratch != nullptr ? (int64_t)(kSplitScratchFloats - kPipeTailFloats) : 0;
   io.tickets = t_split_tickets;
   return io;
 }
@@ -660,7 +664,8 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
   ScratchScope scratch_scope(split_scratch, tickets_on ? split_tickets : nullptr);
   bool tickets_pending = tickets_on;      // still to be cleared by this call
   if (tickets_pending && !(io->time_bias != nullptr && u->down_chains[0].valid)) {
-    ADX_CHECK_HIP(hipMemsetAsync(split_tickets, 0, kTicketWords * sizeof(uint32_t), s));
+    const int rc0 = pipe_tickets_reset(split_tickets, (int)kTicketWords, kEpochSlot, s);     // zeroes them and draws this forward's number
+    if (rc0 != ADX_OK) return rc0;
     tickets_pending = false;
   }
 
@@ -731,6 +736,7 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
     a.batch = rows;
     if (tickets_pending) {
       a.zero_words = split_tickets; a.n_zero = (int)kTicketWords;
+      a.epoch_ctr = pipe_epoch_counter(false); a.epoch_slot = kEpochSlot;
       tickets_pending = false;
     }
     return chain_launch(a, ceil_div(rows, bt), lds, s);
@@ -756,7 +762,7 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
       if (rc != ADX_OK) return rc;
       continue;
     }
-    if (i == n - 1 && u->pipe_ok && tickets_on && split_scratch != nullptr &&
+    if (i == n - 1 && u->pipe_ok && tickets_on && split_scratch != nullptr && pipe_epoch_counter(false) != nullptr &&
         pipe_shape_ok(B0.cout, B0.len, rows, B0.b.d.taps, B0.b.d.pad, B0.b.d.groups)) {
       // Small batch: block 0's second conv, block 1 and both mid blocks -- seven same-shaped convs -- as ONE pipeline launch
       // (tconv_pipe.hip).  Block 0's first conv + 1x1 residual conv stay the pair / mixed launch they were.
@@ -778,15 +784,15 @@ int adx_unet_forward(adx_unet* u, const void* packed, void* workspace, const adx
       pa.n_conv = 7; pa.C = C; pa.L = Lp; pa.rows = rows; pa.P = C / kPipeCh;
       pa.groups = B0.b.d.groups; pa.taps = B0.b.d.taps; pa.pad = B0.b.d.pad; pa.eps = B0.b.d.eps;
       pipe_live_taps(pa.taps, pa.pad, Lp, &pa.tap0, &pa.ntap);
-      // scratch of this call: records of the seven stages, then the two block outputs only later residuals read
-      const size_t rec_floats = (size_t)7 * pa.P * kPipeRows * kPipeCh;
-      pa.records = split_scratch;
-      float* ya = split_scratch + align64(rec_floats);
+      // the tail of this call's scratch: records of the seven stages, then the three block outputs only later residuals read
+      const size_t rec_floats = pipe_record_floats(7, pa.P);
+      ADX_REQUIRE(align64(rec_floats) + 3 * align64((size_t)rows * Lp * C) <= kPipeTailFloats, "adx_unet_forward: pipeline tail too small");
+      pa.records = split_scratch + (kSplitScratchFloats - kPipeTailFloats);
+      float* ya = pa.records + align64(rec_floats);
       float* yb = ya + align64((size_t)rows * Lp * C);
       float* yc = yb + align64((size_t)rows * Lp * C);
       pa.fault = pipe_fault_word();
-      pa.counters = split_tickets + 128;                          // words 128, 144, ... 224: a 64-byte line per stage (the split
-                                                                  // reductions' tickets stay below 128), cleared at the head of this forward
+      pa.epoch = split_tickets + kEpochSlot;                      // this forward's number, left there by the launch that cleared the tickets
       for (int k = 0; k < 7; ++k) {
         pa.st[k].w = base + run[k]->o_pw;
         pa.st[k].bias = base + run[k]->o_b;

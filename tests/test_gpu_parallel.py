@@ -110,7 +110,8 @@ def test_one_rank_rccl_behind_the_events(tmp_path, primitive):
     """RCCL behind the averager's events on the one GPU a box has (train.py:174-178,249): a ONE-rank nccl group with
     `GradientAverager(force=True)` keeps the world-1 early returns out, so the real RCCL kernels run on the side stream behind
     the perception backward's per-layer-group events while backward is still running.  Full-size FREE_GUIDANCE step (B = 64,
-    H = 32, 3 x 256 x 900): one-rank collectives are identities, so every gradient is bit-equal to a plain backward; nothing is
+    H = 32, 3 x 256 x 900): one-rank collectives are identities, so every gradient is what a plain backward gives -- bit for bit wherever a
+    plain step is bit-reproducible, like two plain runs elsewhere (float atomics); nothing is
     copied in; every bucket but the last is ready >= 3 ms before backward ends.  Then the two paths the per-group events do NOT
     cover: accumulation over two backwards without clearing .grad, and the module twice in one graph -- bit-equal as well.
     The all_reduce run's trace is the artifact profiles/r06_overlap_trace.json is a copy of."""
@@ -126,9 +127,14 @@ def test_one_rank_rccl_behind_the_events(tmp_path, primitive):
     res = json.load(open(out))
     assert "nccl" in res["backend"]
     assert res["n_buckets"] >= 3 and res["born_in_bucket"] and res["copied_in"] == 0 and res["loss_equal"]
-    assert res["step_mismatch"] == [], res["step_mismatch"][:5]
+    # bit-equal wherever a plain step is bit-reproducible at all (the 3x3 conv weights under ADX_WGRAD_DETERMINISTIC=1, every
+    # BatchNorm affine ...: the worker runs the plain step twice to find out); the tensors reduced with float atomics agree like
+    # two plain runs do
+    assert res["n_bit_reproducible"] >= 100, res
+    tol = max(10 * res["plain_vs_plain_worst_rel"], 2e-6)
+    assert res["step_mismatch"] == [] and res["step_worst_rel"] <= tol, (res["step_mismatch"][:5], res["step_worst_rel"], tol)
     ov = res["overlap"]
     assert len(ov) == res["n_buckets"] and all(o["done_ms"] >= o["ready_ms"] for o in ov), ov
     assert all(o["ready_ms"] < -3.0 for o in ov[:-1]), ov          # reduced while the layers below are still differentiated
-    assert res["accum_mismatch"] == [], res["accum_mismatch"][:5]
-    assert res["twice_mismatch"] == [], res["twice_mismatch"][:5]
+    assert res["accum_mismatch"] == [] and res["accum_worst_rel"] <= tol, (res["accum_mismatch"][:5], res["accum_worst_rel"], tol)
+    assert res["twice_mismatch"] == [] and res["twice_worst_rel"] <= tol, (res["twice_mismatch"][:5], res["twice_worst_rel"], tol)
