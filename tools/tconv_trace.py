@@ -44,6 +44,10 @@ for name, (kind, taps, stride, pad, c0, c1, cout, lin, lout, groups) in LAYERS.i
     if groups:
         io.gamma, io.beta = g.data_ptr(), be.data_ptr()
     io.y, io.y_sb, io.y_sc, io.y_sl, io.batch = y.data_ptr(), cout * lout, lout, 1, ROWS
+    if os.environ.get("SPLIT") == "1":      # as inside a UNet forward: scratch + ticket words, so that hs_plan may split the reduction
+        scratch = torch.empty(2 << 20, device=DEV)
+        tickets = torch.zeros(256, dtype=torch.int32, device=DEV)
+        io.scratch, io.scratch_floats, io.tickets = scratch.data_ptr(), scratch.numel(), tickets.data_ptr()
     for _ in range(5):
         L.check(lib.adx_tconv_forward(C.byref(d), C.byref(io), s))
     torch.cuda.synchronize()
