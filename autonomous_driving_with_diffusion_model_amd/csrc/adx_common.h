@@ -61,6 +61,7 @@ struct DebugSwitches {
   bool wgrad_deterministic = false;   // ADX_WGRAD_DETERMINISTIC=1  the 3x3 weight gradients (conv2d_wgrad_hs) reduce per-workgroup partial
                                //                    sums in index order instead of with float atomics: bit-reproducible, one more pass
   bool hs_dma = true;          // ADX_HS_DMA=0       conv2d_hs3x3q stages its operands through registers instead of with LDS-DMA loads (conv2d_hs16.hip)
+  bool hs_persist = true;      // ADX_HS_PERSIST=0   conv2d_hs3x3q launches one workgroup per tile instead of one per CU that walks the tiles
   int resnet_streams = 2;      // ADX_RESNET_STREAMS=1..4  sub-batches of an inference perception pass at B >= 32, each on a stream of its own
   int resnet_split_from = -1;  // ADX_RESNET_SPLIT_FROM=<block>  first BasicBlock that runs per sub-batch (default: the first downsample block; 0: the stem too)
   bool check_range = false;    // ADX_CHECK_RANGE=1  perception forward: fail with the first layer whose activations leave the

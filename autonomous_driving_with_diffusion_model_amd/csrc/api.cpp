@@ -31,6 +31,7 @@ const DebugSwitches& debug_switches() {
     d.train_cells = is("ADX_TRAIN_CELLS", '0') ? 0 : (is("ADX_TRAIN_CELLS", '1') ? 1 : (is("ADX_TRAIN_CELLS", '2') ? 2 : (is("ADX_TRAIN_CELLS", '3') ? 3 : (is("ADX_TRAIN_CELLS", '4') ? 4 : 5))));
     d.check_range = is("ADX_CHECK_RANGE", '1');
     d.hs_dma = !is("ADX_HS_DMA", '0');
+    d.hs_persist = !is("ADX_HS_PERSIST", '0');
     d.wgrad_deterministic = is("ADX_WGRAD_DETERMINISTIC", '1');
     if (const char* e = getenv("ADX_CHAIN_MASK")) d.chain_mask = (unsigned)strtoul(e, nullptr, 0);
     if (const char* e = getenv("ADX_HS_MODE")) d.hs_mode = atoi(e);

@@ -44,7 +44,8 @@ constexpr size_t kQLds = (size_t)2 * 8 * kQPlaneP * 16 + (size_t)2 * kQWst * 16 
 // linearly over (k-group, pixel); pitch 352 = 22 x 16 cells keeps the four k-groups of a fragment read on one bank phase
 constexpr int kQPlaneD = 352;
 constexpr int kQPairsD = 4 * kQPlaneD;     // 1408 = 22 waves of 64: whole waves only
-constexpr size_t kQLdsD = (size_t)2 * 8 * kQPlaneD * 16 + (size_t)2 * kQWst * 16 + 256 * sizeof(float) + 2 * 16 + 512 * sizeof(float);
+constexpr size_t kQLdsD = (size_t)2 * 8 * kQPlaneD * 16 + (size_t)2 * kQWst * 16 + 256 * sizeof(float) + 2 * 16 + 512 * sizeof(float) +
+                          (size_t)kQPit * kQNT * sizeof(uint32_t);      // + the next tile's gather offsets, parked per thread
 typedef __attribute__((address_space(3))) void lds_void;
 
 __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
@@ -78,19 +79,27 @@ __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs
   float* ss = reinterpret_cast<float*>(wl + 2 * WST);         // scale[128], shift[128]
   u32x4* dummy = reinterpret_cast<u32x4*>(ss + 256);          // where the idle threads of the last patch round write
   float* bsl = reinterpret_cast<float*>(dummy + 2);           // TRAIN == 2: [mean | rstd | mask scale | mask shift] x 128
+  uint32_t* gnext = reinterpret_cast<uint32_t*>(bsl + 512);   // DMA: [round][thread] gather offsets of this workgroup's NEXT tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rowpair = wave & 3, slab = wave >> 2;
   const int j = lane & 15, kq = lane >> 4;
-  int bid = blockIdx.x;
-  {   // consecutive ids go to different XCDs: give each XCD one contiguous eighth of the tile space (shared halos and slabs meet in one L2)
-    const int per = gridDim.x >> 3;
-    if (bid < per * 8) bid = (bid & 7) * per + (bid >> 3);
-  }
-  const int ct = bid % a.cout_tiles; bid /= a.cout_tiles;
-  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
-  const int ty = bid;
-  const int oy0 = ty * kQTH, vx0 = tx * 32;
+  // Persistent over tiles (round 6): workgroup b = (XCD x = b & 7, cout tile ct, slot q) walks the spatial tiles x's eighth of the
+  // tile space holds -- one contiguous range per XCD, so shared halos meet in one L2, and the cout tiles of one spatial tile run
+  // side by side on it -- in steps of Q = slots per (XCD, cout tile).  While a tile's LAST chunk is multiplied, the idle patch
+  // buffer and the idle weight buffer receive the NEXT tile's first chunk and first tap -- the transfers that used to re-fetch
+  // the last chunk into buffers nobody read -- so only a workgroup's first tile has a prologue (a 128-channel layer at B = 64 is
+  // 3.6 tiles per CU: 2-3 us of exposed transfer latency per 45 us tile).  The cout tile never changes inside a workgroup, so
+  // neither do its weights' addresses nor its per-channel constants.  Q = the longest range: one tile per workgroup, the old launch.
+  const int Qs = a.q_slots;
+  const int xcd = blockIdx.x & 7, rr_ = blockIdx.x >> 3;
+  const int ct = rr_ % a.cout_tiles, slot = rr_ / a.cout_tiles;
+  const int nsp = a.tiles_x * a.tiles_y;
+  const int sp_end = (int)(((long)(xcd + 1) * nsp) >> 3);
+  int sp = (int)(((long)xcd * nsp) >> 3) + slot;
+  if (sp >= sp_end) return;                    // (uniform: a padding workgroup of a short range)
+  int ty = sp / a.tiles_x, tx = sp - ty * a.tiles_x;
+  int oy0 = ty * kQTH, vx0 = tx * 32;
   auto vdiv = [&](int v) { return (int)(((float)v + 0.5f) * a.inv_vw); };     // v / vw for 0 <= v < 2^21 (launch check)
   const size_t hw = (size_t)a.H * a.W;
   const int nch16 = a.cin_pad / 16, nch32 = a.cin_pad / 32, nstages = nch32 * 9;
@@ -98,19 +107,25 @@ __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.x), 0, (int)(uint32_t)((size_t)a.N * a.Cin * hw * sizeof(float)), 0x00020000);
   const uint32_t plane_bytes = (uint32_t)(hw * sizeof(float));
+  // gather offset of this thread's cell pair of patch round k for the tile at (ty_, tx_)
+  auto goff_of = [&](int t_, int k, int oy0_, int vx0_) -> uint32_t {
+    const int e = t_ + NT * k;
+    const int g = e / PLANE, p = e - g * PLANE;                // k-group, staged pixel (DMA: p >= 340 is padding of the pitch)
+    const int py = p / PW, px = p - py * PW;
+    const int iy = oy0_ - 1 + py;
+    const int v = vx0_ - 1 + px;                               // virtual column: image v / vw, column v % vw (column W of an image is zero)
+    const int ni = vdiv(v < 0 ? 0 : v);
+    const int ix = v - ni * a.vw;
+    const bool ok = e < NPAIRS && p < kQPlane && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && ni < a.N;
+    return !ok ? kOutside : (uint32_t)((size_t)ni * a.Cin * hw * sizeof(float) + (size_t)g * 8 * hw * sizeof(float) + ((size_t)iy * a.W + ix) * 16);
+  };
   uint32_t goff[PIT];
   int pcell[PIT];
 #pragma unroll
   for (int k = 0; k < PIT; ++k) {
     const int e = tid + NT * k;
-    const int g = e / PLANE, p = e - g * PLANE;                // k-group, staged pixel (DMA: p >= 340 is padding of the pitch)
-    const int py = p / PW, px = p - py * PW;
-    const int iy = oy0 - 1 + py;
-    const int v = vx0 - 1 + px;                                // virtual column: image v / vw, column v % vw (column W of an image is zero)
-    const int ni = vdiv(v < 0 ? 0 : v);
-    const int ix = v - ni * a.vw;
-    const bool ok = e < NPAIRS && p < kQPlane && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && ni < a.N;
-    goff[k] = !ok ? kOutside : (uint32_t)((size_t)ni * a.Cin * hw * sizeof(float) + (size_t)g * 8 * hw * sizeof(float) + ((size_t)iy * a.W + ix) * 16);
+    const int g = e / PLANE, p = e - g * PLANE;
+    goff[k] = goff_of(tid, k, oy0, vx0);
     pcell[k] = e < NPAIRS ? g * GST + p : -1;
   }
   // this thread's two weight cells of a stage: cell e of the LDS image is cell wsrc_off[k] + (18 chunk + tap) * 256 of the packed image
@@ -129,12 +144,6 @@ __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs
   }
 
   f32x4 accm[4][4], accl[4][4];            // [channel block][pixel block]: hi*hi sums, cross-term sums (scaled by 2^11)
-#pragma unroll
-  for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-    for (int pb = 0; pb < 4; ++pb)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { accm[cb][pb][i] = 0.f; accl[cb][pb][i] = 0.f; }
 
   u32x4 wv[2][2], pvh[2], pvl[2];          // register sets: weights of stage s in wv[s & 1]; the patch round fetched at stage s in pv*[s & 1]
   // DMA: the wave's first cell of round k (a wave-uniform LDS address goes into M0; lane l lands l cells further)
@@ -154,19 +163,20 @@ __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs
       for (int k = 0; k < 2; ++k) wl[buf * WST + tid + NT * k] = wv[set][k];
     }
   };
-  auto load_p = [&](int chunk, int k, int set) {    // DMA: `set` is the LDS patch buffer
+  auto load_p_at = [&](int chunk, int k, int set, uint32_t go) {    // DMA: `set` is the LDS patch buffer; go: the round's gather offset
     const uint32_t cbase = (uint32_t)chunk * 32u * plane_bytes;
     if constexpr (DMA) {
       if (k < PIT - 1 || wcell + NT * k < NPAIRS) {      // whole waves: 1408 = 22 x 64
         u32x4* d = patch + set * 8 * PP + wcell + NT * k;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)d, 16, goff[k], cbase, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(d + PLST), 16, goff[k], cbase + 4 * plane_bytes, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)d, 16, go, cbase, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(d + PLST), 16, go, cbase + 4 * plane_bytes, 0, 0);
       }
     } else {
-      pvh[set] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, goff[k], cbase, 0);
-      pvl[set] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, goff[k], cbase + 4 * plane_bytes, 0);
+      pvh[set] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, go, cbase, 0);
+      pvl[set] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, go, cbase + 4 * plane_bytes, 0);
     }
   };
+  auto load_p = [&](int chunk, int k, int set) { load_p_at(chunk, k, set, goff[k]); };
   auto store_p = [&](int set, int k, int buf) {
     if constexpr (!DMA) {
       u32x4* pd = patch + buf * 8 * PP + pcell[k];
@@ -179,10 +189,8 @@ __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs
 
   // fragment bases: B (pixels) of lane (j, kq): patch cell kq * 2 PP + (2 rowpair + kh + row) * PW + 16 colhalf + j + kw, + PP for lo;
   // A (channels) of lane (j, kq): weight cell slab * 512 + (kq >> 1) * 256 + plane * 128 + (kq & 1) * 64 + 16 cb + j
-  const int pb_lane = kq * GST + (rowpair * 2) * PW + j;
-  const int wa_lane = slab * 512 + (kq >> 1) * 256 + (kq & 1) * 64 + j;
 
-  // prologue: stage 0 complete in LDS, the weights of stage 1 in flight
+  // prologue (a workgroup's FIRST tile only): stage 0 complete in LDS, the weights of stage 1 in flight
   load_w(0, 0);
   store_w(0, 0);
 #pragma unroll
@@ -198,6 +206,44 @@ __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs
   if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  for (;;) {       // tiles of this workgroup
+  // Everything per-lane the stage loop needs is RE-DERIVED here from the thread id through an opaque zero instead of living in
+  // registers across the epilogue (which needs every register it can get: 128 accumulators + the residual cells): ~100 VALU
+  // instructions per tile against a dozen spilled registers.
+  int zero_ = 0;
+  asm volatile("" : "+s"(zero_));
+  const int tl = tid + zero_;
+  if constexpr (DMA) {
+#pragma unroll
+    for (int k = 0; k < PIT; ++k) goff[k] = goff_of(tl, k, oy0, vx0);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int e = tl + NT * k;
+      const int sl = e >> 9, half16 = (e >> 8) & 1, within = e & 255;
+      wsrc_off[k] = (((ct * 2 + sl) * nch16 + half16) * 9) * 256 + within;
+    }
+  }
+  const int j_l = tl & 15, kq_l = (tl & 63) >> 4;
+  const int pb_lane = kq_l * GST + (rowpair * 2) * PW + j_l;
+  const int wa_lane = slab * 512 + (kq_l >> 1) * 256 + (kq_l & 1) * 64 + j_l;
+  // the next tile (DMA only: the register-staged form runs one tile per workgroup)
+  const int sp_next = sp + Qs;
+  const bool has_next = DMA && sp_next < sp_end;
+  const int nty = sp_next / a.tiles_x, ntx = sp_next - nty * a.tiles_x;
+  const int n_oy0 = nty * kQTH, n_vx0 = ntx * 32;
+  // the next tile's gather offsets: parked in LDS (a thread's own words) until the last chunk asks for them -- in registers they
+  // pushed the stage loop over its budget, computed where they are used they kept a dozen scalars of the address arithmetic alive
+  if constexpr (DMA) {
+#pragma unroll
+    for (int k = 0; k < PIT; ++k) gnext[k * NT + tid] = has_next ? goff_of(tl, k, n_oy0, n_vx0) : goff[k];
+  }
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { accm[cb][pb][i] = 0.f; accl[cb][pb][i] = 0.f; }
+
   // (The compiler places each stage's barrier in the MIDDLE of the stage's MFMAs -- legal: the fragments are in registers -- so a
   // wave reads the next stage's fragments while its SIMD partner still multiplies.  Pinning the barrier to the stage's end, or
   // staggering waves 4-7 by half a stage against waves 0-3, measured 1-3 % slower: profiles/README.md, round 5.)
@@ -211,8 +257,14 @@ __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs
       if constexpr (DMA) {
         // one stage ahead, straight into LDS: the weights of stage s + 1 into the buffer stage s - 1 read (every wave is past that
         // stage's barrier), and at a kernel row's first tap one round of the NEXT chunk's patch into the idle patch buffer
-        load_w(s + 1 < nstages ? s + 1 : nstages - 1, (i + 1) & 1);
-        if (kw == 0) load_p(cp + cpar + 1 < nch32 ? cp + cpar + 1 : nch32 - 1, kh, (cpar + 1) & 1);
+        // -- past the tile's end: the NEXT tile's first tap / first chunk (buffers 0: the last stage is odd, the last chunk is
+        // chunk parity 1), or, without a next tile, the last stage / chunk again (never read)
+        load_w(s + 1 < nstages ? s + 1 : (has_next ? 0 : nstages - 1), (i + 1) & 1);
+        if (kw == 0) {
+          // (the tile's last chunk has chunk parity 1: the channel chunks come in pairs)
+          if (cpar == 0 || cp + cpar + 1 < nch32) load_p(cp + cpar + 1, kh, (cpar + 1) & 1);
+          else load_p_at(has_next ? 0 : nch32 - 1, kh, (cpar + 1) & 1, gnext[kh * NT + tid]);
+        }
       } else {
         // fetch two stages ahead: the weights of stage s + 2, and at a kernel row's first tap one round of the NEXT chunk's patch
         // (past the end the last stage / chunk is fetched again; its copy in the idle buffers is never read)
@@ -274,7 +326,8 @@ __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs
         const_cast<uint8_t*>(res_masked ? a.res_bits : reinterpret_cast<const uint8_t*>(a.y)), 0, res_masked ? (int)bit_bytes : 0, 0x00020000);
     const int cout0 = ct * 128 + slab * 64;
     const float* bsw = bsl + slab * 64 + 8 * (rw >> 1);         // + 16 cb + c8: this lane's channels
-    float* red = reinterpret_cast<float*>(smem_raw);            // [wave][rw][cb][c8][2], then [4096 + wave]: max |dz|
+    float* red = reinterpret_cast<float*>(patch + 8 * PP);      // [wave][rw][cb][c8][2], then [4096 + wave]: max |dz| (patch buffer 1: dead;
+                                                                // buffer 0 may already hold the next tile's first chunk)
     uint32_t voff[2], boff[2];
     bool valid[2];
 #pragma unroll
@@ -357,16 +410,14 @@ __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs
       for (int w = 0; w < 4; ++w) t = __builtin_fmaxf(t, red[4096 + sl * 4 + w]);
       a.stats_part[(size_t)a.Cout * 2 * a.stats_p + (size_t)(ct * 2 + sl) * a.stats_p + ptile] = t;
     }
-    return;
-  }
-  if constexpr (TRAIN == 1) {
+  } else if constexpr (TRAIN == 1) {
     // ---- training epilogue ----
     // statistics first, from the accumulators as they lie: lane (j, kq) holds channels 16 cb + 4 kq + i of its four pixels (row
     // pb >> 1, virtual column 16 (pb & 1) + j); the four pixels in the lane, then the 16 lanes of a DPP row; lanes j == 0 park
     // the row's totals in LDS (the operand images are dead: every wave is past the last stage's barrier) and 256 threads add
     // the four row-pair waves of a slab in a fixed order.
     const uint32_t plane_ob = (uint32_t)(a.OH * a.OW) * (uint32_t)sizeof(float);
-    float* red = reinterpret_cast<float*>(smem_raw);          // [wave][kq][cb][i][2]
+    float* red = reinterpret_cast<float*>(patch + 8 * PP);    // [wave][kq][cb][i][2] (patch buffer 1, as above)
     float valid[4];
 #pragma unroll
     for (int pb = 0; pb < 4; ++pb) {
@@ -429,8 +480,7 @@ __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs
           __builtin_amdgcn_raw_buffer_store_b32(sw[1], yrsrc, voff, (uint32_t)(cout0 + 16 * cb + 4 + i) * plane_ob, 0);
         }
     }
-    return;
-  }
+  } else {
   // ---- epilogue: one cell (8 channels of a pixel, hi + lo) per lane and (channel block, row) ----
   // Accumulator lane (j, kq) holds channels 16 cb + 4 kq + i of pixel (row pb >> 1, column 16 (pb & 1) + j).  After the swaps of
   // a row's two pixel blocks lane (j, rw = kq) holds the cell of channels 16 cb + 8 (rw >> 1) .. + 7 at column 16 (rw & 1) + j.
@@ -501,6 +551,12 @@ __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs
       // store (conv2d_hs.hip: cells_store32); keep both operands alive across one wait state
       asm volatile("s_nop 0" ::"v"(hi), "v"(lo));
     }
+  }
+  // ---- on to this workgroup's next tile: its first chunk and first tap are in LDS already ----
+  if (!has_next) break;
+  if constexpr (TRAIN != 0) __syncthreads();        // every wave is done with this tile's statistics area (patch buffer 1)
+  sp = sp_next; tx = ntx; ty = nty; oy0 = n_oy0; vx0 = n_vx0;
+  }
 }
 
 // a training-forward launch (cells in, fp32 + statistics out) the TRAIN variant serves
@@ -550,8 +606,29 @@ int conv2d_hs3x3q_launch(Conv2dArgs a, hipStream_t s) {
   a.tiles_x = ceil_div(a.N * a.vw - (a.N > 1 ? 1 : 0), 32);       // the last image's zero column needs no tile
   a.tiles_y = ceil_div(a.OH, kQTH);
   a.cout_tiles = a.Cout / 128;
-  const size_t grid = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y;
-  ADX_REQUIRE(grid < (1u << 31), "conv2d_hs: grid too large");
+  const size_t tiles = (size_t)a.cout_tiles * a.tiles_x * a.tiles_y;
+  ADX_REQUIRE(tiles < (1u << 31), "conv2d_hs: grid too large");
+  a.ntiles = (int)tiles;
+  // workgroup = (XCD, cout tile, slot); slots per (XCD, cout tile): as many as the longest eighth of the spatial tiles (one tile
+  // per workgroup: ADX_HS_PERSIST=0 and the register-staged form), or -- the LDS-DMA form -- as many as fit one workgroup per CU,
+  // each walking its XCD's range in steps of that count (bit-identical results either way)
+  const int nsp = a.tiles_x * a.tiles_y;
+  int slots = ceil_div(nsp, 8);
+  if (debug_switches().hs_dma && debug_switches().hs_persist) {
+    static std::atomic<int> n_cu{0};
+    int cus = n_cu.load(std::memory_order_relaxed);
+    if (cus == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      ADX_CHECK_HIP(hipGetDevice(&dev));
+      ADX_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+      cus = prop.multiProcessorCount > 8 ? prop.multiProcessorCount : 8;
+      n_cu.store(cus, std::memory_order_relaxed);
+    }
+    slots = std::min(slots, std::max(1, cus / (8 * a.cout_tiles)));
+  }
+  a.q_slots = slots;
+  const size_t grid = (size_t)8 * a.cout_tiles * slots;
   ADX_REQUIRE((size_t)a.N * a.Cout * a.OH * a.OW * sizeof(float) < 0xC0000000u && (size_t)a.N * a.Cin * a.H * a.W * sizeof(float) < 0xC0000000u,
               "conv2d_hs: a cell-layout tensor exceeds the 32-bit byte offsets");
   if (train) {

@@ -39,6 +39,7 @@ struct Conv2dArgs {
   int N, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, relu;
   int cin_pad, cc;      // channels padded to the chunk size, chunk size (16, or 4 for the stem)
   int tiles_x, tiles_y, cout_tiles, ntiles;
+  int q_slots;          // conv2d_hs3x3q only: workgroups per (XCD, cout tile); each walks its XCD's spatial tiles in steps of q_slots
   int PH, PW, PWp;      // staged patch rows, columns, padded row pitch
   // conv2d_hs3x3 only: the input-channel chunks split over `ksplit` workgroups per tile (small batches: a 512->512 layer
   // on one 8x29 map is 8 tiles); part kpart covers chunks [kpart * cper, (kpart + 1) * cper) and writes its raw sums to

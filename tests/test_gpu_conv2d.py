@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEV = "cuda:0"
 # ADX_CONV_EXACT=1 routes every conv to the exact-fp32 MFMA kernels (one sequential fp32 chain over K): their bar is
 # the looser one of test_exact_fp32_mfma_conv_shapes
@@ -309,3 +310,24 @@ def test_weight_gradient_deterministic_mode_is_bit_reproducible(tmp_path):
         dw = _ops().conv2d_weight_grad(x, dy, 3, stride=s, pad=1).cpu()
         err = (dw - dw_det).abs().max().item()
         assert err <= 2e-6 * dw.abs().max().item(), (shape, err)
+
+
+def test_conv3x3q_persistent_launch_is_bit_identical(tmp_path):
+    """csrc/conv2d_hs16.hip (round 6): the LDS-DMA launches are persistent -- one workgroup per CU walks its XCD's spatial tiles and
+    fetches the next tile's first chunk and first tap under the last chunk of the current one.  Which workgroup computes a tile, and
+    whether its first operands arrived in a prologue or under the previous tile, must not change a bit: the same launches with
+    ADX_HS_PERSIST=0 (one tile per workgroup, a process of its own) -- several tiles per CU at one, two and four cout tiles, with and
+    without a residual, ragged tile rows, tile counts that do not divide by eight, a single tile."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import conv_cells_worker as W
+    out = str(tmp_path / "one_tile_per_workgroup.pt")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "conv_cells_worker.py"), out],
+                       env=dict(os.environ, ADX_HS_PERSIST="0"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    ref = torch.load(out)
+    got = W.outputs()
+    assert set(got) == set(ref) and len(got) == len(W.CASES)
+    for k, v in got.items():
+        assert torch.equal(v, ref[k]), k
