@@ -8,6 +8,16 @@ Public surface mirrors the reference's packages:
     misc.constant.GuidanceType, misc.load_param.copy_parameters
 All compute runs in libadx.so (hand-written HIP for gfx950); there is no CPU fallback.
 """
-from . import _lib  # noqa: F401
+import os as _os
+
+# Kernel arguments in DEVICE memory (ROCm's HIP_FORCE_DEV_KERNARG, AMD's recommended setting for MI300-class parts): every
+# eagerly launched kernel otherwise fetches its argument block from host memory when it starts -- 1-2 us in front of kernels that
+# run for 5-10 us.  The reference's own loops launch eagerly (interact.py:131-164): measured on the deployed tick (one scene,
+# 50 DDIM steps) 17.5 -> 14.5 ms; HIP-graph replays keep their arguments on the device either way (profiles/README.md,
+# round 6).  The runtime reads the variable when it initialises, i.e. at the process's first GPU call: set here unless the
+# user decided otherwise; a process that has already touched the GPU before importing this package keeps what it had.
+_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
+from . import _lib  # noqa: F401,E402
 
 __all__ = ["modeling", "scheduler", "control", "misc", "config", "sampling"]
