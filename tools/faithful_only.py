@@ -30,7 +30,7 @@ cond = torch.cat([d["target"], torch.zeros_like(d["target"])], 0)
 ts = list(sch.timesteps)
 trajs = d["init_trajs"].clone()
 trajs[:, 0, :3] = 0
-with torch.no_grad():
+with torch.no_grad(), model.perception.frozen_image(d["imgs"]):      # as bench.py's loop: the tick's image is written by nobody
     n_steps = int(os.environ.get("STEPS", "23"))
     for i in range(n_steps):
         if i == 3:
