@@ -16,7 +16,9 @@
 //     device word per GPU; the launch that clears a forward's ticket words draws the number and leaves it in the workspace's
 //     ticket area for this kernel to read): whatever an earlier forward of the process left in the records region carries an
 //     older number, nothing else writes that region (the tail of the executor's scratch), and the caller's workspace holds no
-//     state that must survive between forwards.
+//     state that must survive between forwards.  (Bytes the CALLER leaves there pose as a record with probability 2^-32 per unit;
+//     the number wraps after 2^32 forwards of a process -- two weeks of back-to-back ticks -- onto tags whose records have been
+//     overwritten 2^32 times since.)
 //   * The next stage's threads poll the units THEY need (sc1 loads: they bypass the L2; the producers sit on other XCDs) until
 //     every tag is this forward's, and the stage forms its input ITSELF: GroupNorm (two-pass statistics over the group's
 //     channels x positions, which it holds completely) -> Mish -> + time bias or + residual, exactly the epilogue the producer

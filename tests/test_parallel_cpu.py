@@ -276,3 +276,39 @@ def test_bench_launches_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"],
                        env=dict(env, ADX_LAUNCH_CHECK_FAIL_RANK="1"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 7, (r.returncode, r.stderr[-500:])
+
+
+def _forced_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    res = {}
+    for primitive in ("all_reduce", "reduce_scatter"):
+        model = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3))
+        plain = [p.detach().clone().requires_grad_() for p in model.parameters()]
+        x = torch.randn(4, 5)
+        idle = GradientAverager(model.parameters(), bucket_mb=1e-4, primitive=primitive)          # world 1, not forced: a no-op
+        forced = GradientAverager(model.parameters(), bucket_mb=1e-4, primitive=primitive, force=True).attach()
+        assert not idle.active and idle.average() == [] and forced.active and forced.world == 1 and len(forced.buckets) >= 2
+        for step in range(2):                      # the second backward accumulates into .grad (no zero_grad in between)
+            model(x * (step + 1)).square().sum().backward()
+            forced.synchronize()
+            h = torch.tanh(torch.nn.functional.linear(x * (step + 1), plain[0], plain[1]))
+            torch.nn.functional.linear(h, plain[2], plain[3]).square().sum().backward()
+        res[primitive] = {"equal": all(torch.equal(p.grad, q.grad) for p, q in zip(model.parameters(), plain)),
+                          "copied_in_second": forced.copied_in}
+        forced.detach()
+    torch.save(res, out)
+    dist.destroy_process_group()
+
+
+def test_forced_one_rank_collectives_are_identities(tmp_path):
+    """GradientAverager(force=True) / ADX_FORCE_COLLECTIVES=1 (the GPU form runs RCCL on a one-rank group behind the perception
+    backward's events: tests/test_gpu_parallel.py): with one rank every collective is an identity -- the gradients are what a plain
+    backward gives, also when a second backward accumulates into buckets that were already reduced once -- and without the switch a
+    one-rank averager does nothing at all."""
+    out = str(tmp_path / "forced.pt")
+    mp.spawn(_forced_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    res = torch.load(out)
+    for primitive, r in res.items():
+        assert r["equal"], primitive
