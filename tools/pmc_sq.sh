@@ -1,3 +1,4 @@
+export HIP_FORCE_DEV_KERNARG=1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for shape in "512 8 29" "256 16 57" "64 64 225"; do
 tag=$(echo $shape | tr ' ' '_')

@@ -1,7 +1,8 @@
 # Round profile (run on the GPU box through gpurun): kernel stats of the whole bench, PMC traffic of the two roofline
 # kernels (separate --pmc passes, --kernel-trace only), the per-layer timeline of the temporal stack, the kernel make-up of
 # the two deployed ticks (B = 1: classifier-free and classifier guidance), the default bench.
-R=${R:-r05}
+R=${R:-r06}
+export HIP_FORCE_DEV_KERNARG=1     # as the package sets it at import (under the profiler the GPU is initialised before Python starts)
 rm -rf gpurun_out/${R}_stats gpurun_out/${R}_stats2 gpurun_out/${R}_pmc_fetch gpurun_out/${R}_pmc_write gpurun_out/${R}_tconv_trace
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 # kernel stats of the bench: ONE stream for the perception pass (ADX_RESNET_STREAMS=1 ADX_PERCEPTION_AHEAD=0), so that a kernel's
@@ -23,7 +24,7 @@ python tools/tick_timeline.py analyze gpurun_out/${R}_tick_cls > gpurun_out/${R}
 rm -rf gpurun_out/prof_tr gpurun_out/${R}_tr_trace
 bash tools/profile_train.sh > gpurun_out/${R}_train_step_kernels.txt 2>&1
 cp $(ls -t gpurun_out/prof_tr/*/*kernel_stats.csv | head -1) gpurun_out/${R}_train_kernel_stats.csv
-python tools/ab_env_train.py ADX_TRAIN_CELLS 0 1 2 3 4 5 > gpurun_out/${R}_ab_train_cells.txt 2>&1
+[ -n "$AB_TRAIN_CELLS" ] && python tools/ab_env_train.py ADX_TRAIN_CELLS 0 1 2 3 4 5 > gpurun_out/${R}_ab_train_cells.txt 2>&1
 NOSYNC=1 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${R}_tr_trace -- python3 tools/train_time.py > /dev/null 2>&1
 python tools/train_gaps.py gpurun_out/${R}_tr_trace > gpurun_out/${R}_train_gaps.txt 2>&1
 rm -rf gpurun_out/${R}_tr_trace

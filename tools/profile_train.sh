@@ -1,3 +1,4 @@
+export HIP_FORCE_DEV_KERNARG=1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_tr -- python3 tools/train_time.py > gpurun_out/prof_tr.log 2>&1
 f=$(ls -t gpurun_out/prof_tr/*/*kernel_stats.csv | head -1)
