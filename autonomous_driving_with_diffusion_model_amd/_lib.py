@@ -110,6 +110,7 @@ _SIGS = {
     "adx_conv2d_wgrad_scratch_bytes": (C.c_size_t, []),
     "adx_conv2d_wgrad": (i32, [C.POINTER(Conv2dDesc), vp, vp, vp, i32, i32, i32, vp, vp]),
     "adx_conv2d_wgrad_ex": (i32, [C.POINTER(Conv2dDesc), vp, vp, vp, i32, i32, i32, vp, i32, vp]),
+    "adx_conv2d_wgrad_cells": (i32, [C.POINTER(Conv2dDesc), vp, vp, vp, vp, i32, i32, i32, vp, vp]),
     "adx_trajpred_create": (i32, [i32, C.POINTER(vp)]),
     "adx_trajpred_destroy": (None, [vp]),
     "adx_trajpred_num_params": (i32, [vp]),

@@ -1168,6 +1168,22 @@ int adx_conv2d_wgrad(const adx_conv2d_desc* d, const float* x, const float* dy, 
   return adx_conv2d_wgrad_ex(d, x, dy, dw, n, h, w, scratch, scratch != nullptr ? 1 : 0, stream);
 }
 
+int adx_conv2d_wgrad_cells(const adx_conv2d_desc* d, const void* x_cells, const void* dy_cells, const float* dy_scale, float* dw,
+                           int32_t n, int32_t h, int32_t w, void* scratch, adx_stream stream) {
+  using namespace adx;
+  ADX_REQUIRE(d && x_cells && dy_cells && dy_scale && dw, "adx_conv2d_wgrad_cells: null argument");
+  ADX_REQUIRE(d->k == 3 && d->stride == 1 && d->pad == 1 && conv2d_wgrad_hs_eligible(d->cin, d->cout, 3, 1, 1),
+              "adx_conv2d_wgrad_cells: 3x3 stride-1 pad-1 convolutions with cin, cout multiples of 64 (and no ADX_*_EXACT switch)");
+  ADX_REQUIRE(n >= 1 && h >= 1 && w >= 1, "adx_conv2d_wgrad_cells: empty input");
+  struct PartsScope {
+    ~PartsScope() { conv2d_wgrad_set_partials(nullptr, 0); }
+  } parts_scope;
+  if (scratch != nullptr && conv2d_wgrad_partials_floats() > 0)
+    conv2d_wgrad_set_partials(reinterpret_cast<float*>((uint32_t*)scratch + kAmaxPartials), conv2d_wgrad_partials_floats());
+  return conv2d_wgrad(reinterpret_cast<const float*>(x_cells), reinterpret_cast<const float*>(dy_cells), dw, n, d->cin, h, w, d->cout, 3, 1, 1,
+                      (hipStream_t)stream, reinterpret_cast<const uint32_t*>(dy_scale), -1, true, nullptr, true, true);
+}
+
 }  // extern "C"
 
 namespace adx {

@@ -4,6 +4,7 @@ native executors (adx_unet_forward / adx_resnet_forward)."""
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 from typing import Optional
 
@@ -171,6 +172,25 @@ def conv2d_weight_grad(x: torch.Tensor, dy: torch.Tensor, k: int, *, stride: int
     scratch = torch.empty(L.lib().adx_conv2d_wgrad_scratch_bytes(), dtype=torch.uint8, device=x.device)
     L.check(L.lib().adx_conv2d_wgrad_ex(C.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, h, w, scratch.data_ptr(),
                                         int(bool(estimate_range)), L.stream_ptr(x.device)), "adx_conv2d_wgrad_ex")
+    return dw
+
+
+def conv2d_weight_grad_cells(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    """d(loss)/d(weight) of a 3x3 stride-1 pad-1 convolution with both operands handed over as CELL tensors, the way the training
+    executor holds them (csrc/resnet_train.hip): x [n, cin, h, w] and dy [n, cout, h, w] fp32 are re-laid here (`to_cells`), dy
+    under the power of two that moves its maximum into [2^14, 2^15).  Returns dw [cout, cin, 3, 3]."""
+    assert x.is_cuda and dy.is_cuda and x.dtype == dy.dtype == torch.float32
+    n, cin, h, w = x.shape
+    cout = dy.shape[1]
+    amax = float(dy.abs().max())
+    s = 2.0 ** (14 - math.floor(math.log2(amax))) if amax > 0 else 1.0
+    scale = torch.tensor([s, 1.0 / s], dtype=torch.float32, device=x.device)
+    d = L.Conv2dDesc(cin, cout, 3, 1, 1)
+    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
+    scratch = torch.empty(L.lib().adx_conv2d_wgrad_scratch_bytes(), dtype=torch.uint8, device=x.device)
+    xc, dc = to_cells(x.contiguous()), to_cells((dy * s).contiguous())
+    L.check(L.lib().adx_conv2d_wgrad_cells(C.byref(d), xc.data_ptr(), dc.data_ptr(), scale.data_ptr(), dw.data_ptr(), n, h, w,
+                                           scratch.data_ptr(), L.stream_ptr(x.device)), "adx_conv2d_wgrad_cells")
     return dw
 
 

@@ -259,6 +259,12 @@ int adx_conv2d_wgrad(const adx_conv2d_desc* d, const float* x, const float* dy, 
  * bit-reproducible reduction (ADX_WGRAD_DETERMINISTIC=1; adx_conv2d_wgrad_scratch_bytes() covers both). */
 int adx_conv2d_wgrad_ex(const adx_conv2d_desc* d, const float* x, const float* dy, float* dw, int32_t n, int32_t h,
                         int32_t w, void* scratch, int32_t estimate_range, adx_stream s);
+/* The same for a 3x3 stride-1 pad-1 convolution with BOTH operands as cell tensors -- how the training executor holds the
+ * activations between a BasicBlock's convs and the conv-output gradients (train.py:251, loss.backward()): x_cells
+ * [n][cin / 8][hi, lo][h][w] cells, dy_cells likewise over cout, holding dy * dy_scale[0]; dy_scale = two floats {s, 1 / s} on
+ * the device, s a power of two.  scratch: NULL, or adx_conv2d_wgrad_scratch_bytes() (ADX_WGRAD_DETERMINISTIC=1). */
+int adx_conv2d_wgrad_cells(const adx_conv2d_desc* d, const void* x_cells, const void* dy_cells, const float* dy_scale, float* dw,
+                           int32_t n, int32_t h, int32_t w, void* scratch, adx_stream s);
 
 /* Training-mode perception (train.py:242 with model.train()): batch-statistics BatchNorm, running buffers
  * updated in place (momentum 0.1), everything the backward needs kept in the workspace. */

@@ -331,3 +331,24 @@ def test_conv3x3q_persistent_launch_is_bit_identical(tmp_path):
     assert set(got) == set(ref) and len(got) == len(W.CASES)
     for k, v in got.items():
         assert torch.equal(v, ref[k]), k
+
+
+@pytest.mark.parametrize("cin,cout,h,w,n,dyscale", [(128, 128, 12, 113, 9, 1.0), (256, 256, 9, 57, 16, 3e-7), (512, 512, 8, 29, 33, 1e-3),
+                                                    (64, 128, 7, 50, 5, 1e-5), (128, 256, 5, 29, 3, 30.0), (64, 64, 6, 70, 4, 1.0)])
+def test_conv3x3_weight_gradient_of_cell_operands(cin, cout, h, w, n, dyscale, tmp_path):
+    """adx_conv2d_wgrad_cells: the weight gradient as the training executor launches it -- both operands pre-split cell tensors, dy
+    under a power-of-two scale (`conv2d_wgrad_hs_kernel<NPX, 1, true, true>`).  Same bar as the fp32-operand launch: fp64 reference,
+    1.5 x torch's own fp32 weight gradient, per input channel; relu'd x (half the activations exactly zero) with channel scales over
+    three decades, 0.01 .. 10.  (Round 6 built a 128 x 64 block on ONE accumulator with unscaled lo halves behind this entry point:
+    4-6 % slower and 1.5e-6 where the bar is 1.1e-6 on the smallest reduction here -- removed, profiles/README.md.)"""
+    g = torch.Generator().manual_seed(cin + w)
+    x = torch.randn(n, cin, h, w, generator=g).relu_() * torch.logspace(-2, 1, cin, base=10.0).reshape(1, cin, 1, 1)
+    dy = torch.randn(n, cout, h, w, generator=g) * dyscale
+    ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, 3, 3), dy.double(), stride=1, padding=1)
+    f32 = torch.nn.grad.conv2d_weight(x, (cout, cin, 3, 3), dy, stride=1, padding=1)
+    g32 = torch.nn.grad.conv2d_weight(x.to(DEV), (cout, cin, 3, 3), dy.to(DEV), stride=1, padding=1).cpu()
+    dw = _ops().conv2d_weight_grad_cells(x.to(DEV), dy.to(DEV))
+    # per input channel (their scales span three decades: a global maximum would hide the small ones)
+    den = ref.abs().amax(dim=(0, 2, 3), keepdim=True)
+    err = lambda t: ((t.double().cpu() - ref).abs() / den).max().item()  # noqa: E731
+    assert err(dw) <= BAR * max(err(f32), err(g32)) + 2e-7, (err(dw), err(f32), err(g32))
