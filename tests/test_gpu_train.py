@@ -613,3 +613,30 @@ def test_fused_adamw_ema_matches_torch_adamw():
             close(p.detach().cpu(), q.detach().cpu(), 2e-6, rtol=1e-5)
             close(e.cpu(), s_.cpu(), 2e-6, rtol=1e-5)
     assert ps[0]._version > 0
+
+
+def test_training_conv_launches_persistent_vs_one_tile_per_workgroup_bit_identical(tmp_path):
+    """csrc/conv2d_hs16.hip (round 6): the training forward (`conv2d_hs3x3q_kernel<DMA, 1>`: fp32 output + BatchNorm partial sums)
+    and data-gradient (`<DMA, 2>`: dx + the consumer BatchNorm's backward sums through mask bits) launches are persistent like the
+    inference ones -- a workgroup walks several tiles and uses the dead patch buffer as its statistics scratch while the other
+    already holds the next tile's first chunk.  Full-size NO_GUIDANCE step (B = 64, 3 x 256 x 900: 3.6 / 1.8 tiles per workgroup on
+    the 128 / 256-channel layers) with ADX_HS_PERSIST=0 against the default, both with ADX_WGRAD_DETERMINISTIC=1: every gradient
+    tensor that two DEFAULT runs reproduce bit for bit (all of the encoder's 3x3 conv weights and BatchNorm affines: the weight
+    gradients that reduce with float atomics -- the stem's, the temporal stack's -- drop out) has the same bits."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = {}
+    for tag, env in (("a", {}), ("b", {}), ("one_tile", {"ADX_HS_PERSIST": "0"})):
+        out = str(tmp_path / f"{tag}.json")
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "train_checksum_worker.py"), out, "64", "32", "256", "900", "7"],
+                           env=dict(os.environ, ADX_WGRAD_DETERMINISTIC="1", **env), capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, r.stderr[-3000:]
+        runs[tag] = json.load(open(out))
+    stable = [k for k, v in runs["a"]["sums"].items() if runs["b"]["sums"][k] == v]
+    enc = [k for k in stable if k.startswith("perception.layer") and (k.endswith("conv1.weight") or k.endswith("conv2.weight"))]
+    assert len(enc) >= 28, (len(stable), len(enc))        # the 3x3 conv weights behind the persistent launches are among them
+    assert runs["a"]["loss"] == runs["one_tile"]["loss"]
+    diff = [k for k in stable if runs["one_tile"]["sums"][k] != runs["a"]["sums"][k]]
+    assert diff == [], diff[:8]
