@@ -885,6 +885,8 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
           const_cast<uint8_t*>(res_masked ? a.res_bits + (size_t)n * (a.Cout >> 3) * bplane : reinterpret_cast<const uint8_t*>(a.y)), 0,
           res_masked ? (int)((VROW ? (uint32_t)a.N : 1u) * (uint32_t)(a.Cout >> 3) * bplane) : 0, 0x00020000);
       const float* bsw = bsl + slab * 64;
+      const uint32_t use_bit = mask_bits ? 1u : 0u, use_out = mask_out ? 1u : 0u, use_raw = 1u - use_bit - use_out;
+      const uint32_t v0u = val0 ? 1u : 0u, v1u = val1 ? 1u : 0u;
       float dmx = 0.f;          // max |dz| of this lane: the BatchNorm-backward apply pass bounds its output's range with it
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
@@ -938,9 +940,12 @@ __global__ void __launch_bounds__(MODE == 0 ? 256 : 512, 2) conv2d_hs3x3_kernel(
           for (int rr = 0; rr < 2; ++rr) {
             const float y = accm[rr][half][r] + rs_[rr][r];            // scale 1, shift 0, no ReLU: what `finish` would store
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, y), yrsrc, voff[rr], cbase_o + cu * plane_ob, 0);
-            const bool keep = (rr == 0 ? val0 : val1) &&
-                              (mask_bits ? ((mb[rr][r >> 2] >> (r & 3)) & 1u) != 0u
-                                         : (mask_out ? ro_[rr][r] > 0.f : __builtin_fmaf(rw_[rr][r], msc, msh) > 0.f));
+            // all three forms of the consumer's ReLU mask evaluated, one SELECTED (the choice is uniform over the launch), the
+            // lane's validity folded in by `&`: as val && (bits ? .. : (out ? .. : ..)) it was four branches per value, 270 per tile
+            // (as integer masks: a select between booleans on a uniform condition is turned back into a branch)
+            const uint32_t on_bit = (mb[rr][r >> 2] >> (r & 3)) & 1u, on_out = ro_[rr][r] > 0.f ? 1u : 0u;
+            const uint32_t on_raw = __builtin_fmaf(rw_[rr][r], msc, msh) > 0.f ? 1u : 0u;
+            const bool keep = ((rr == 0 ? v0u : v1u) & ((on_bit & use_bit) | (on_out & use_out) | (on_raw & use_raw))) != 0u;
             p[rr] = keep ? y : 0.f;
             q[rr] = p[rr] * ((rw_[rr][r] - mu) * rsd);
             dmx = __builtin_fmaxf(dmx, __builtin_fabsf(p[rr]));
@@ -1270,6 +1275,15 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_stem_kernel(const Conv2dArgs
       const bool st = pr < PHo && (l31 & 1) == 0 && pq < PWo && tx >= tx_own;
       const uint32_t voff = st ? (uint32_t)(pr * PWo + pq) * 4u + (uint32_t)(4 * khalf) * plane_ob : kOutside;
       float mm[2][16];          // a.y_cells: the pooled values, stored as cells below
+      // the previous tile's last column (written by lane 31 one tile ago): all 32 values in flight at once, read by EVERY lane
+      // (a broadcast; only lane 0 of a 32-lane group uses them).  As `l31 == 0 ? cbuf[..] : up` each read sat in a branch of its
+      // own with a full LDS round trip behind it, 32 times per tile (round 6: 550 -> 516 us per launch at B = 64; stepping the
+      // staging geometry from cell to cell instead of dividing per cell, tried with it, costs +24 %: profiles/README.md)
+      float lf[2][16];
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lf[half][r] = cbuf[2 * (half * 16 + r)];
 #pragma unroll
       for (int half = 0; half < 2; ++half)
 #pragma unroll
@@ -1278,15 +1292,21 @@ __global__ void __launch_bounds__(256, 2) conv2d_hs_stem_kernel(const Conv2dArgs
           const int vi = __builtin_bit_cast(int, vm[half][r]);
           const float up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, vi, 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
           const float dn = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, vi, 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
-          const float left = l31 == 0 ? cbuf[2 * (half * 16 + r)] : up;     // written by lane 31 one tile ago
+          const float left = l31 == 0 ? lf[half][r] : up;
           const float right = l31 == 31 ? -INFINITY : dn;
           const float m = pool_max3(left, vm[half][r], right);
           cpark[2 * (half * 16 + r)] = vm[half][r];      // lane 31 parks its column for the next tile, the others hit a dummy row
-          const int cu = half * 32 + (r & 3) + 8 * (r >> 2);       // + 4 * khalf, which rides in voff
           mm[half][r] = m;
-          if (!a.y_cells) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, m), yrsrc, voff, cu * plane_ob, 0);
         }
-      if (a.y_cells) {          // the pooled map as a cell tensor (conv2d_hs3x3_kernel: XCELLS): layer1's first conv copies cells
+      if (!a.y_cells) {         // (one uniform branch around all 32 stores, not one per value)
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int cu = half * 32 + (r & 3) + 8 * (r >> 2);       // + 4 * khalf, which rides in voff
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, mm[half][r]), yrsrc, voff, cu * plane_ob, 0);
+          }
+      } else {          // the pooled map as a cell tensor (conv2d_hs3x3_kernel: XCELLS): layer1's first conv copies cells
         const uint32_t cplane = (uint32_t)(PHo * PWo) * 16u;
         const uint32_t vcell = st ? (uint32_t)(pr * PWo + pq) * 16u + (uint32_t)khalf * 2u * cplane : kOutside;
 #pragma unroll

@@ -338,6 +338,10 @@ __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs
       boff[rr] = valid[rr] ? (uint32_t)nl * (uint32_t)(a.Cout >> 3) * bplane + (uint32_t)(oy * a.OW + xl) + (uint32_t)(rw >> 1) * bplane : kOutside;
     }
     float dmx = 0.f;
+    // The ReLU mask of the consumer layer comes as bits or is recomputed from that layer's raw output; which, is uniform over the
+    // launch.  Both forms are evaluated and one is SELECTED, with the lane's validity folded in by `&`: as valid && (mask_bits ?
+    // bit : fma(raw, scale, shift) > 0) the compiler kept three branches per value and, on the recomputing side, an LDS round
+    // trip per value (the constants' reads sat inside the branch): 190 branches per tile.
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
       float sm[8], sq[8];
@@ -366,12 +370,14 @@ __global__ void __launch_bounds__(kQNT, 2) conv2d_hs3x3q_kernel(const Conv2dArgs
 #pragma unroll
         for (int c8 = 0; c8 < 8; ++c8) {
           const float* kc = bsw + 16 * cb + c8;
+          const float k_mu = kc[0], k_rs = kc[128], k_sc = kc[256], k_sh = kc[384];
           const float yv = o[c8] + (((mres >> c8) & 1u) ? res8[c8] : 0.f);
           __builtin_amdgcn_raw_buffer_store_b32(f2u(yv), yrsrc, voff[rr], (uint32_t)(cout0 + 16 * cb + c8) * plane_ob, 0);
-          const bool keep = valid[rr] && (mask_bits ? ((mbs >> c8) & 1u) != 0u : __builtin_fmaf(rw8[c8], kc[256], kc[384]) > 0.f);
+          const bool on_bit = ((mbs >> c8) & 1u) != 0u, on_raw = __builtin_fmaf(rw8[c8], k_sc, k_sh) > 0.f;
+          const bool keep = valid[rr] & (mask_bits ? on_bit : on_raw);
           const float pz = keep ? yv : 0.f;
           sm[c8] += pz;
-          sq[c8] = __builtin_fmaf(pz, (rw8[c8] - kc[0]) * kc[128], sq[c8]);
+          sq[c8] = __builtin_fmaf(pz, (rw8[c8] - k_mu) * k_rs, sq[c8]);
           dmx = __builtin_fmaxf(dmx, __builtin_fabsf(pz));
         }
       }
